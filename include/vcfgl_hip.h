@@ -1,0 +1,200 @@
+/*
+ * vcfgl_hip.h -- C ABI of the MI355X (gfx950) implementation of vcfgl's per-site
+ * genotype-likelihood simulation hot path.
+ *
+ * The reference (isinaltinkaya/vcfgl) has no plugin / FFI surface.  Its de-facto
+ * boundary for this path is
+ *
+ *     static int simulate_record_values(simRecord* sim)       vcfgl.cpp:327
+ *     void (*calculate_gls)(simRecord* sim)                   vcfgl.cpp:222, sole call :788
+ *
+ * whose inputs are the parsed flags (`argStruct* args`, io.h:40-148), the decoded true
+ * genotypes (`true_gts_acgt_int`, vcfgl.cpp:66, filled :132-147) and the RNG states, and
+ * whose outputs are the simRecord arrays consumed by simRecord::add_tags()
+ * (bcf_utils.cpp:426-507).  The entry points below are what a record loop calls IN PLACE
+ * of `simulate_record_values` (vcfgl.cpp:1522,1552,1611): it batches records into a tile,
+ * calls vgl_simulate_tile*, and feeds every site of the returned tile to add_tags().
+ *
+ * Everything is plain C: pointers, sizes, int error codes.  The library never calls
+ * exit(); the reference's ERROR()/ASSERT() exits (shared.h:292-327) become VGL_E_* codes
+ * plus a message retrievable with vgl_last_error().
+ *
+ * Tile layout (structure of arrays, sample index fastest so that one wavefront = 64
+ * consecutive samples of one site reads and writes contiguous 256-byte segments):
+ *
+ *     per (site, sample) scalar      x[site * n_samples + sample]
+ *     per (site, k, sample) plane    x[(site * K + k) * n_samples + sample]
+ *     per site vector                x[site * K + k]
+ */
+#ifndef VCFGL_HIP_H
+#define VCFGL_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VGL_ABI_VERSION 1
+
+/* ---- error codes (returned by every entry point; 0 = success) ----------------------- */
+#define VGL_OK              0
+#define VGL_E_ARG          (-1)  /* bad parameter value (reference: io.cpp:757-1000 range checks) */
+#define VGL_E_NODEVICE     (-2)  /* no HIP device / HIP runtime error                            */
+#define VGL_E_NOMEM        (-3)  /* allocation failure                                           */
+#define VGL_E_CAPACITY     (-4)  /* a per-sample read depth exceeded the staging capacity        */
+#define VGL_E_UNSUPPORTED  (-5)  /* flag combination not implemented on the device path          */
+#define VGL_E_QSBIN        (-6)  /* "Could not find a range for qs value" (vcfgl.cpp:63)         */
+
+/* ---- per-site status (reference: return value of simulate_record_values) ------------- */
+#define VGL_SITE_OK            0
+#define VGL_SITE_SKIP_INVAR  (-3) /* one simulated allele + --rm-invar-sites&4 (vcfgl.cpp:675-681) */
+#define VGL_SITE_SKIP_EMPTY  (-4) /* INFO/DP==0 + --rm-empty-sites 1           (vcfgl.cpp:400-402) */
+#define VGL_SITE_NO_READS      1  /* INFO/DP==0, site kept: simulate_site_with_no_reads (:228-315) */
+
+/* ---- missing / special values (htslib encodings that add_tags() expects) ------------- */
+#define VGL_FLOAT_MISSING_BITS 0x7F800001u  /* bcf_float_missing */
+#define VGL_INT32_MISSING      ((int32_t)0x80000000) /* bcf_int32_missing = INT32_MIN */
+#define VGL_GT_MISSING         0xF          /* allele nibble: missing true genotype */
+
+/* ---- RNG addressing modes ------------------------------------------------------------ */
+/* All uniform streams are the reference's own generator: glibc rand48,
+ * X <- (0x5DEECE66D * X + 0xB) mod 2^48, u = X * 2^-48, X0 = (seed << 16) | 0x330E
+ * (io.cpp:1054-1061, shared.h:17-22).  They differ in WHICH draw index a consumer uses. */
+#define VGL_RNG_TILE    0  /* counter addressed: each (site,sample) owns a private window      */
+#define VGL_RNG_SERIAL  1  /* the reference's serial consumption order (host oracle only; the
+                              device path returns VGL_E_UNSUPPORTED)                            */
+
+/* quality-score error sampler (rng.h:353-500) */
+#define VGL_BETA_RAND48 0  /* rng.h:426-446, reference built with -D__USE_STD_BETA__=0, rng2   */
+#define VGL_BETA_STD    1  /* rng.h:353-421, std::mt19937 + std::gamma_distribution (default
+                              reference build; one global stream => VGL_RNG_SERIAL only)       */
+
+/* Window layout of VGL_RNG_TILE.  Evaluation e = site_abs * n_samples + sample owns draws
+ * [e*block, (e+1)*block) of the rand48 sequence; stream k of that evaluation starts at
+ * e*block + off[k].  A consumer that needs more draws than its sub-window simply keeps
+ * stepping the generator (deterministic, only statistically overlapping).
+ *   k=0 depth        rng1, Poisson draws                  (vcfgl.cpp:364-368, rng.h:284-351)
+ *   k=1 haplotype    rng1, one draw per read              (vcfgl.cpp:473)
+ *   k=2 base/strand  rng0, error test, wrong base, strand (vcfgl.cpp:486-488,582)
+ *   k=3 qscore       rng2, beta deviates                  (vcfgl.cpp:428,495; rng.h:433-444)
+ * With --error-qs 1 the single per-site beta deviate uses stream 3 of sample 0. */
+typedef struct vgl_rng_layout {
+    uint64_t block;
+    uint64_t off[4];
+} vgl_rng_layout;
+
+/* ---- parameters = the subset of argStruct (io.h:40-148) the hot path reads ----------- */
+typedef struct vgl_params {
+    int32_t  abi_version;        /* VGL_ABI_VERSION */
+    int32_t  seed;               /* --seed                                   io.cpp:1047-1061 */
+    int32_t  n_samples;          /* bcf_hdr_nsamples                                         */
+    int32_t  rng_mode;           /* VGL_RNG_*                                                */
+    int32_t  beta_sampler;       /* VGL_BETA_*                                               */
+
+    double   depth;              /* --depth (mean)   ; ignored if depths != NULL             */
+    const double* depths;        /* --depths-file    ; [n_samples] per-sample means or NULL  */
+    double   error_rate;         /* --error-rate                                             */
+    int32_t  error_qs;           /* --error-qs 0|1|2                         io.h / README   */
+    double   beta_variance;      /* --beta-variance (error_qs != 0)                          */
+    int32_t  gl_model;           /* --gl-model 1|2                                           */
+    double   gl1_theta;          /* --gl1-theta (default 0.83)               io.cpp:455      */
+    int32_t  precise_gl;         /* --precise-gl 0|1 (usePreciseGlError)                     */
+    int32_t  adjust_qs;          /* --adjust-qs bitmask                      shared.h:103-117 */
+    double   adjust_by;          /* --adjust-by (default 0.499)                              */
+    int32_t  n_qs_bins;          /* --qs-bins: number of [start,end,value] triples           */
+    const int32_t* qs_bins;      /* [n_qs_bins][3]                           vcfgl.cpp:57-64 */
+    int32_t  i16_mapq;           /* --i16-mapq (default 20)                                  */
+
+    int32_t  do_unobserved;      /* -doUnobserved 0..5                       shared.h:70-89  */
+    int32_t  rm_invar_sites;     /* --rm-invar-sites bitmask (only bit 4 acts here)          */
+    int32_t  rm_empty_sites;     /* --rm-empty-sites                                         */
+    int32_t  do_gvcf;            /* -doGVCF (only affects the no-reads site, vcfgl.cpp:242)  */
+
+    int32_t  add_gl, add_gp, add_pl, add_i16, add_qs;              /* -addGL ... -addQS      */
+    int32_t  add_fmt_dp, add_info_dp;                              /* -addFormatDP/-addInfoDP */
+    int32_t  add_fmt_ad, add_info_ad;
+    int32_t  add_fmt_adf, add_info_adf;
+    int32_t  add_fmt_adr, add_info_adr;
+
+    vgl_rng_layout layout;       /* VGL_RNG_TILE window layout; block==0 => library default  */
+} vgl_params;
+
+/* ---- one tile of outputs = the simRecord arrays add_tags() reads (bcf_utils.h:157-211) -
+ * Any pointer may be NULL (that output is not produced / not copied back), except
+ * site_status, n_alleles and alleles2acgt which are always written.
+ * G = vgl_max_genotypes(params) (10 or 15), A = vgl_max_alleles(params) (4 or 5).        */
+typedef struct vgl_tile_out {
+    /* per site */
+    int32_t* site_status;    /* [n_sites]      VGL_SITE_*                                      */
+    int32_t* n_alleles;      /* [n_sites]      sim->nAlleles (incl. <*> / <NON_REF>)           */
+    int32_t* n_alleles_obs;  /* [n_sites]      sim->nAllelesObserved                           */
+    int8_t*  alleles2acgt;   /* [n_sites][5]   sim->alleles2acgt; 4 = unobserved allele, -1 = none */
+    int32_t* info_dp;        /* [n_sites]      INFO/DP                                         */
+    int32_t* info_ad;        /* [n_sites][A]   INFO/AD  (allele order)                         */
+    int32_t* info_adf;       /* [n_sites][A]                                                   */
+    int32_t* info_adr;       /* [n_sites][A]                                                   */
+    float*   qs;             /* [n_sites][A]   INFO/QS                                         */
+    float*   i16;            /* [n_sites][16]  INFO/I16 (fields 12-15, tail distance, use the
+                                               reference's unseeded rand(): host oracle only)  */
+    /* per (site, sample) */
+    int32_t* fmt_dp;         /* [n_sites][n_samples]          FORMAT/DP                        */
+    float*   gl;             /* [n_sites][G][n_samples]       FORMAT/GL, VCF genotype order;
+                                entries g >= nGenotypes(site) hold VGL_FLOAT_MISSING_BITS       */
+    int32_t* pl;             /* [n_sites][G][n_samples]       FORMAT/PL                        */
+    float*   gp;             /* [n_sites][G][n_samples]       FORMAT/GP                        */
+    int32_t* fmt_ad;         /* [n_sites][A][n_samples]       FORMAT/AD (allele order)         */
+    int32_t* fmt_adf;        /* [n_sites][A][n_samples]                                        */
+    int32_t* fmt_adr;        /* [n_sites][A][n_samples]                                        */
+    /* optional per-read staging dump (reference: -printPileup, vcfgl.cpp:616-634)            */
+    uint8_t* reads;          /* [read_capacity][n_sites][n_samples]  (qs << 2) | base           */
+    int32_t  read_capacity;  /* rows available in `reads` (0 = not requested)                  */
+} vgl_tile_out;
+
+typedef struct vgl_ctx vgl_ctx;
+
+/* Layout helpers (pure host arithmetic, usable without a GPU). */
+int32_t vgl_max_alleles(const vgl_params* p);      /* 4 or 5:  shared.h:148-152              */
+int32_t vgl_max_genotypes(const vgl_params* p);    /* 10 or 15: lut_nAlleles_to_nGenotypes    */
+int     vgl_default_rng_layout(const vgl_params* p, vgl_rng_layout* out);
+int     vgl_abi_version(void);
+const char* vgl_last_error(void);
+
+/* Replaces args_get()'s sampler/LUT construction (io.cpp:1036-1074,1276) and main()'s
+ * preCalc block (vcfgl.cpp:1661-1767): validates flags, builds the Poisson constants,
+ * beta shape parameters, fixed-qscore terms, GL1 error-model tables and rand48 jump
+ * tables, uploads them, and sizes the staging workspace for `max_sites_per_tile`.
+ * `device` is the HIP device ordinal.  Fails with VGL_E_NODEVICE when no GPU is present. */
+int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_sites_per_tile, vgl_ctx** out);
+int vgl_ctx_destroy(vgl_ctx* ctx);
+
+/* Replaces the call of simulate_record_values() (vcfgl.cpp:1522,1552,1611) for `n_sites`
+ * consecutive records whose absolute indices (in simulation order) start at `site0`.
+ *   gt : [n_sites][n_samples] one byte per sample, (allele1 << 4) | allele0, alleles in ACGT
+ *        space 0..3 exactly as check_rec_alleles() leaves them in true_gts_acgt_int
+ *        (vcfgl.cpp:132-147); VGL_GT_MISSING (0xF) in either nibble = missing genotype.
+ * Host variant: `gt` and every pointer in `out` are host memory; the call is synchronous. */
+int vgl_simulate_tile(vgl_ctx* ctx, int64_t site0, int32_t n_sites,
+                      const uint8_t* gt, vgl_tile_out* out);
+
+/* Device variant: `gt` and every pointer in `out` are device memory owned by the caller
+ * (hipMalloc / a torch tensor's data_ptr); work is enqueued on `hip_stream` (a hipStream_t
+ * cast to void*, NULL = default stream) and the call returns without synchronising. */
+int vgl_simulate_tile_device(vgl_ctx* ctx, int64_t site0, int32_t n_sites,
+                             const uint8_t* gt, vgl_tile_out* out, void* hip_stream);
+
+/* Sticky device-side error flags of the last tiles (capacity overflow, qs-bin miss):
+ * synchronises the stream, returns VGL_OK or the first VGL_E_* raised, and clears them. */
+int vgl_ctx_check(vgl_ctx* ctx, void* hip_stream);
+
+/* Kernel timing hook for bench.py: brackets the device work of every following
+ * vgl_simulate_tile_device call with hipEvents on its stream.  vgl_ctx_kernel_ms returns
+ * accumulated milliseconds and launch counts of the three kernels since the last reset. */
+int vgl_ctx_timing(vgl_ctx* ctx, int32_t enable);
+int vgl_ctx_kernel_ms(vgl_ctx* ctx, double ms[3], int64_t launches[3], int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VCFGL_HIP_H */

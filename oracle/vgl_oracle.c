@@ -1,0 +1,916 @@
+/*
+ * vgl_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C, single-threaded CPU restatement of vcfgl's per-site genotype-likelihood
+ * simulation (reference: /root/reference, isinaltinkaya/vcfgl v1.3.0).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the product
+ * (vcfgl_amd/, libvcfgl_hip.so) never does.
+ *
+ * Parity pin: tests/test_oracle_golden.py replays the reference's own golden VCFs
+ * (tests/golden/ref_vcf, copied data files of /root/reference/test/{data,reference}) through
+ * this file in VGL_RNG_SERIAL mode; tests/test_oracle_vs_ref.py checks the samplers
+ * against the reference's own rng.h/shared.cpp compiled from where they lie
+ * (oracle/_ref, built by oracle/Makefile when /root/reference is present).
+ * GL model 1 is the exception: its arithmetic lives in htslib (errmod.c, not in the
+ * reference tree; CI pins Ubuntu 22.04 libhts 1.13) and is restated here from the
+ * published algorithm; it is pinned only by the reference's depth<=3 goldens
+ * (test1/test3/test7) => "parity weakly pinned" for GL1 at larger depth.
+ *
+ * Every function cites the reference lines it follows.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/vcfgl_hip.h"   /* parameter / tile structs only (the interface) */
+
+#define MASK48 0xFFFFFFFFFFFFULL
+#define LCG_A  0x5DEECE66DULL
+#define LCG_C  0xBULL
+#define TWO_M48 (1.0 / 281474976710656.0)
+
+#define CAP_BASEQ 63            /* shared.h:241 */
+#define MAXPL 255               /* shared.h:208 */
+#define VGL_PI 3.141592654      /* shared.h:37 (NOT M_PI) */
+#define BASE_NONREF 4           /* shared.h:203 */
+
+static const int N_GT_OF_ALLELES[6] = {0, 1, 3, 6, 10, 15};   /* shared.cpp:29 */
+
+/* ------------------------------------------------------------------------------------ */
+/* rand48 (glibc drand48/erand48; rng.h:8-10).  state' = A*state + C mod 2^48, u = state'/2^48 */
+
+static inline double lcg_uniform(uint64_t* st) {
+    *st = (*st * LCG_A + LCG_C) & MASK48;
+    return (double)(*st) * TWO_M48;
+}
+
+/* state after n more steps (closed form by square-and-multiply of the affine map) */
+uint64_t vgl_oracle_rand48_jump(uint64_t st, uint64_t n) {
+    uint64_t a = LCG_A, c = LCG_C;      /* current power-of-two map  x -> a x + c */
+    uint64_t ra = 1, rc = 0;            /* accumulated map */
+    while (n) {
+        if (n & 1) { ra = (ra * a) & MASK48; rc = (rc * a + c) & MASK48; }
+        c = ((a + 1) * c) & MASK48;
+        a = (a * a) & MASK48;
+        n >>= 1;
+    }
+    return (ra * st + rc) & MASK48;
+}
+
+uint64_t vgl_oracle_rand48_seed(int32_t seed) {      /* io.cpp:1054-1061, shared.h:22 */
+    return ((((uint64_t)(uint32_t)seed) << 16) | 0x330EULL) & MASK48;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* gamma_ln: 6-coefficient Lanczos, rng.h:38-43,60-64 (__USE_PRECISE_GAMMA__ == 0) */
+double vgl_oracle_gamma_ln(double xx) {
+    static const double cof[6] = {76.18009172947146, -86.50532032941677, 24.01409824083091,
+                                  -1.231739572450155, 0.1208650973866179e-2, -0.5395239384953e-5};
+    double x, tmp, y, ser;
+    y = x = xx;
+    tmp = x + 5.5;
+    tmp -= (x + 0.5) * log(tmp);
+    ser = 1.000000000190015;
+    for (int j = 0; j <= 5; j++) ser += cof[j] / ++y;
+    return -tmp + log(2.5066282746310005 * ser / x);
+}
+
+/* PoissonSampler_init, rng.h:259-280 */
+typedef struct { double lm, sq, alxm, g; int st12; } poisson_t;
+
+static void poisson_init(poisson_t* p, double lambda) {
+    p->lm = lambda; p->sq = -1.0; p->alxm = -1.0; p->g = -1.0; p->st12 = 1;
+    if (lambda < 12.0) {
+        p->g = exp(-lambda);
+    } else {
+        p->st12 = 0;
+        p->sq = sqrt(2.0 * lambda);
+        p->alxm = log(lambda);
+        p->g = lambda * p->alxm - vgl_oracle_gamma_ln(lambda + 1.0);
+    }
+}
+
+/* one depth draw: body of poissonSampler_sample_depths_same_mean, rng.h:289-312 */
+static int poisson_sample(const poisson_t* p, uint64_t* st) {
+    double em, t;
+    if (p->st12) {
+        em = -1.0; t = 1.0;
+        do { ++em; t *= lcg_uniform(st); } while (t > p->g);
+    } else {
+        double y;
+        do {
+            do {
+                y = tan(VGL_PI * lcg_uniform(st));
+                em = p->sq * y + p->lm;
+            } while (em < 0.0);
+            em = floor(em);
+            t = 0.9 * (1.0 + y * y) * exp(em * p->alxm - vgl_oracle_gamma_ln(em + 1.0) - p->g);
+        } while (lcg_uniform(st) > t);
+    }
+    return (int)em;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* rand48 beta sampler: reference built with -D__USE_STD_BETA__=0                        */
+
+/* sample_NormalSampler_0_1_0, rng.h:70-80 (ratio of uniforms) */
+static double normal_rou(uint64_t* st) {
+    double u, v, x, y, q;
+    do {
+        u = lcg_uniform(st);
+        v = 1.7156 * (lcg_uniform(st) - 0.5);
+        x = u - 0.449871;
+        y = fabs(v) + 0.386595;
+        q = (x * x) + y * (0.19600 * y - 0.25472 * x);
+    } while ((q > 0.27597) && (q > 0.27846 || (v * v) > -4.0 * log(u) * (u * u)));
+    return v / u;
+}
+
+typedef struct { double alpha0, a1, a2; int changed; } gamma1_t;
+
+/* Gamma1Sampler_init, rng.h:155-173.  The reference never sets old_alpha (used at :148
+ * when alpha<1: reads uninitialised memory); the intended value, the original alpha, is
+ * used here. */
+static void gamma1_init(gamma1_t* g, double shape) {
+    double alpha = shape;
+    g->alpha0 = shape; g->changed = 0;
+    if (alpha < 1.0) { alpha += 1.0; g->changed = 1; }
+    g->a1 = alpha - 1.0 / 3.0;
+    g->a2 = 1.0 / sqrt(9. * g->a1);
+}
+
+/* Gamma1Sampler::sample, rng.h:133-152 (Marsaglia-Tsang) */
+static double gamma1_sample(const gamma1_t* g, uint64_t* st) {
+    double u, v, x, xsq;
+    do {
+        do {
+            x = normal_rou(st);
+            v = 1.0 + g->a2 * x;
+        } while (v <= 0.0);
+        v = v * v * v;
+        u = lcg_uniform(st);
+        xsq = x * x;
+    } while (u > 1.0 - 0.0331 * (xsq * xsq) && log(u) > 0.5 * xsq + g->a1 * (1.0 - v + log(v)));
+    if (g->changed) {
+        while ((u = lcg_uniform(st)) == 0.0);
+        return pow(u, 1.0 / g->alpha0) * g->a1 * v;
+    }
+    return g->a1 * v;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* std beta sampler: std::mt19937 + libstdc++ std::gamma_distribution (rng.h:353-421).
+ * The arithmetic is libstdc++'s (GCC 11, bits/random.h / random.tcc), restated. */
+
+typedef struct { uint32_t mt[624]; int idx; } mt19937_t;
+
+static void mt_seed(mt19937_t* m, uint32_t seed) {
+    m->mt[0] = seed;
+    for (int i = 1; i < 624; i++) m->mt[i] = 1812433253u * (m->mt[i - 1] ^ (m->mt[i - 1] >> 30)) + (uint32_t)i;
+    m->idx = 624;
+}
+
+static uint32_t mt_next(mt19937_t* m) {
+    if (m->idx >= 624) {
+        for (int i = 0; i < 624; i++) {
+            uint32_t y = (m->mt[i] & 0x80000000u) | (m->mt[(i + 1) % 624] & 0x7fffffffu);
+            m->mt[i] = m->mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        m->idx = 0;
+    }
+    uint32_t y = m->mt[m->idx++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+/* std::generate_canonical<double,53>(mt19937): two 32-bit words, low word first */
+static double mt_canonical(mt19937_t* m) {
+    double sum = 0.0, tmp = 1.0;
+    sum += (double)mt_next(m) * tmp; tmp *= 4294967296.0;
+    sum += (double)mt_next(m) * tmp; tmp *= 4294967296.0;
+    double r = sum / tmp;
+    if (r >= 1.0) r = nextafter(1.0, 0.0);
+    return r;
+}
+
+/* std::gamma_distribution<double>(alpha, 1.0)(gen) on a FRESH distribution object
+ * (rng.h:409-410 re-creates both distributions on every call, so the normal
+ * distribution's saved deviate lives only within one gamma draw). */
+static double std_gamma_fresh(mt19937_t* m, double alpha) {
+    const double malpha = alpha < 1.0 ? alpha + 1.0 : alpha;
+    const double a1 = malpha - 1.0 / 3.0;
+    const double a2 = 1.0 / sqrt(9.0 * a1);
+    int saved_avail = 0; double saved = 0.0;
+    double u, v, n;
+    do {
+        do {
+            /* std::normal_distribution<double>(0,1): Marsaglia polar, returns y*mult, saves x*mult */
+            if (saved_avail) { saved_avail = 0; n = saved; }
+            else {
+                double x, y, r2;
+                do {
+                    x = 2.0 * mt_canonical(m) - 1.0;
+                    y = 2.0 * mt_canonical(m) - 1.0;
+                    r2 = x * x + y * y;
+                } while (r2 > 1.0 || r2 == 0.0);
+                const double mult = sqrt(-2 * log(r2) / r2);
+                saved = x * mult; saved_avail = 1;
+                n = y * mult;
+            }
+            n = n * 1.0 + 0.0;
+            v = 1.0 + a2 * n;
+        } while (v <= 0.0);
+        v = v * v * v;
+        u = mt_canonical(m);
+    } while (u > 1.0 - 0.0331 * n * n * n * n && (log(u) > (0.5 * n * n + a1 * (1.0 - v + log(v)))));
+    if (alpha == malpha) return a1 * v * 1.0;
+    do u = mt_canonical(m); while (u == 0.0);
+    return pow(u, 1.0 / alpha) * a1 * v * 1.0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* qScore -> log10 GL terms.  shared.cpp:110-114 holds the table as 7-significant-digit
+ * literals printed by R (generator in the comment at shared.h:512-527); the same values
+ * are produced here by rounding the formula to 7 significant digits.
+ * tests/test_oracle_vs_ref.py checks all 3x257 entries against the reference's table. */
+static double g_q2gl[3][257];
+static int g_q2gl_ready = 0;
+
+static double round7(double v) {
+    if (isinf(v) || v == 0.0) return v;
+    char buf[64];
+    snprintf(buf, sizeof buf, "%.7g", v);
+    return strtod(buf, NULL);
+}
+
+static void q2gl_init(void) {
+    if (g_q2gl_ready) return;
+    for (int q = 0; q <= 256; q++) {
+        double p = pow(10.0, -q / 10.0);
+        g_q2gl[0][q] = round7(log10(1.0 - p));
+        g_q2gl[1][q] = round7(log10((1.0 - p) / 2.0 + p / 6.0));
+        g_q2gl[2][q] = round7(log10(p) - log10(3.0));
+    }
+    g_q2gl_ready = 1;
+}
+
+double vgl_oracle_q2gl(int row, int q) { q2gl_init(); return g_q2gl[row][q]; }
+
+/* QS_TO_QSSQ, shared.h:459 (lut_qs_to_qs2 = q*q, shared.cpp:21-27) */
+static inline int qs_to_qssq(int q) { return (0 == q) ? 0 : ((q < CAP_BASEQ) ? q * q : 3969); }
+
+/* ------------------------------------------------------------------------------------ */
+/* GL model 1: htslib errmod (errmod.c; NOT in the reference tree).  Restated from the
+ * published "revised MAQ" model as implemented by htslib >= 1.4 (log-space coefficients). */
+typedef struct {
+    double depcorr;
+    double fk[256];
+    double* beta;   /* [64][256][256] */
+    double* lhet;   /* [256][256] */
+} errmod_t;
+
+static errmod_t* errmod_make(double depcorr) {
+    const double eta = 0.03;
+    errmod_t* em = (errmod_t*)calloc(1, sizeof(errmod_t));
+    if (!em) return NULL;
+    em->depcorr = depcorr;
+    em->fk[0] = 1.0;
+    for (int n = 1; n != 256; ++n) em->fk[n] = pow(1. - depcorr, n) * (1.0 - eta) + eta;
+    em->beta = (double*)calloc(256 * 256 * 64, sizeof(double));
+    em->lhet = (double*)calloc(256 * 256, sizeof(double));
+    double* lC = (double*)calloc(256 * 256, sizeof(double));
+    if (!em->beta || !em->lhet || !lC) return NULL;
+    for (int n = 1; n <= 255; ++n)
+        for (int k = 1; k <= n; ++k)
+            lC[n << 8 | k] = lgamma(n + 1) - lgamma(k + 1) - lgamma(n - k + 1);
+    for (int q = 1; q < 64; ++q) {
+        double e = pow(10.0, -q / 10.0);
+        double le = log(e);
+        double le1 = log(1.0 - e);
+        for (int n = 1; n <= 255; ++n) {
+            double* beta = em->beta + (q << 16 | n << 8);
+            double sum, sum1 = lC[n << 8 | n] + n * le;
+            beta[n] = HUGE_VAL;
+            for (int k = n - 1; k >= 0; --k, sum1 = sum) {
+                sum = sum1 + log1p(exp(lC[n << 8 | k] + k * le + (n - k) * le1 - sum1));
+                beta[k] = -10. / M_LN10 * (sum1 - sum);
+            }
+        }
+    }
+    for (int n = 0; n < 256; ++n)
+        for (int k = 0; k < 256; ++k)
+            em->lhet[n << 8 | k] = lC[n << 8 | k] - M_LN2 * n;
+    free(lC);
+    return em;
+}
+
+static void errmod_free(errmod_t* em) { if (em) { free(em->beta); free(em->lhet); free(em); } }
+
+static int cmp_u16(const void* a, const void* b) {
+    return (int)*(const uint16_t*)a - (int)*(const uint16_t*)b;
+}
+
+/* errmod_cal(em, n, m=5, bases, q): bases[i] = qual<<5 | strand<<4 | base.
+ * Returns -1 for n > 255 (htslib then subsamples with ks_shuffle/drand48: not restated). */
+static int errmod_cal5(const errmod_t* em, int n, uint16_t* bases, float* q) {
+    const int m = 5;
+    double fsum[16], bsum[16];
+    uint32_t c[16];
+    int w[32];
+    memset(q, 0, m * m * sizeof(float));
+    if (n == 0) return 0;
+    if (n > 255) return -1;
+    qsort(bases, n, sizeof(uint16_t), cmp_u16);
+    memset(w, 0, sizeof w); memset(fsum, 0, sizeof fsum); memset(bsum, 0, sizeof bsum); memset(c, 0, sizeof c);
+    for (int j = n - 1; j >= 0; --j) {
+        uint16_t b = bases[j];
+        int qq = (b >> 5) < 4 ? 4 : (b >> 5);
+        if (qq > 63) qq = 63;
+        int k = b & 0x1f;
+        fsum[k & 0xf] += em->fk[w[k]];
+        bsum[k & 0xf] += em->fk[w[k]] * em->beta[qq << 16 | n << 8 | c[k & 0xf]];
+        ++c[k & 0xf];
+        ++w[k];
+    }
+    for (int j = 0; j != m; ++j) {
+        float tmp1; int tmp2, k;
+        for (k = 0, tmp1 = 0.0, tmp2 = 0; k != m; ++k) {
+            if (k == j) continue;
+            tmp1 += bsum[k]; tmp2 += c[k];
+        }
+        if (tmp2) q[j * m + j] = tmp1;
+        for (k = j + 1; k < m; ++k) {
+            int cjk = c[j] + c[k], i;
+            for (i = 0, tmp2 = 0, tmp1 = 0.0; i < m; ++i) {
+                if (i == j || i == k) continue;
+                tmp1 += bsum[i]; tmp2 += c[i];
+            }
+            if (tmp2) q[j * m + k] = q[k * m + j] = -4.343 * em->lhet[cjk << 8 | c[k]] + tmp1;
+            else q[j * m + k] = q[k * m + j] = -4.343 * em->lhet[cjk << 8 | c[k]];
+        }
+        for (k = 0; k != m; ++k) if (q[j * m + k] < 0.0) q[j * m + k] = 0.0;
+    }
+    return 0;
+}
+
+/* exported for unit tests */
+int vgl_oracle_errmod_cal(double depcorr, int n, const uint16_t* bases, float* q25) {
+    errmod_t* em = errmod_make(depcorr);
+    if (!em) return -3;
+    uint16_t* tmp = (uint16_t*)malloc(sizeof(uint16_t) * (n > 0 ? n : 1));
+    memcpy(tmp, bases, sizeof(uint16_t) * n);
+    int r = errmod_cal5(em, n, tmp, q25);
+    free(tmp); errmod_free(em);
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* oracle context */
+
+typedef struct vgl_oracle {
+    vgl_params p;
+    double* depths;            /* private copy */
+    int32_t* qs_bins;          /* private copy */
+    poisson_t* pois;           /* [1] or [n_samples]  (io.cpp:1063-1074) */
+    int n_pois;
+    /* beta (io.cpp:1036-1043; rng.h:370-371 / :459-460) */
+    double beta_a, beta_b;
+    gamma1_t gx, gy;
+    mt19937_t mt;
+    /* serial-mode stream states: rng0 (drand48), rng1, rng2 */
+    uint64_t x0, st0, st1, st2;
+    /* preCalc (vcfgl.cpp:1661-1743) */
+    int pre_q, pre_adjq;
+    double pre_homT, pre_het, pre_homF;
+    errmod_t* em;
+    vgl_rng_layout lay;
+    int A, G;                  /* max alleles / genotypes of the tile layout */
+    /* scratch */
+    int cap;                   /* reads capacity per sample */
+    int* bases; int* qsc; int* adjq; double* errp;   /* [n_samples][cap] */
+    int64_t n_draw_rand;       /* rand() draws consumed (I16) */
+} vgl_oracle;
+
+static char g_err[512];
+const char* vgl_oracle_last_error(void) { return g_err; }
+#define OFAIL(code, ...) do { snprintf(g_err, sizeof g_err, __VA_ARGS__); return (code); } while (0)
+
+static int max_alleles(const vgl_params* p) {     /* PROGRAM_WILL_ADD_UNOBSERVED, shared.h:151-152 */
+    int d = p->do_unobserved;
+    return (d == 1 || d == 2 || d == 4 || d == 5) ? 5 : 4;
+}
+
+int vgl_oracle_default_layout(const vgl_params* p, vgl_rng_layout* out) {
+    /* Must equal vgl_default_rng_layout() of the product; tests compare the two. */
+    double dmax = p->depth;
+    if (p->depths) { dmax = 0; for (int i = 0; i < p->n_samples; i++) if (p->depths[i] > dmax) dmax = p->depths[i]; }
+    if (!(dmax >= 0)) dmax = 0;
+    uint64_t d = (uint64_t)ceil(dmax);
+    uint64_t s0 = 64;
+    uint64_t s1 = 4 * d + 64;
+    uint64_t s2 = 3 * s1;
+    uint64_t s3 = (p->error_qs == 2) ? 32 * s1 : 64;
+    out->off[0] = 0; out->off[1] = s0; out->off[2] = s0 + s1; out->off[3] = s0 + s1 + s2;
+    out->block = (s0 + s1 + s2 + s3) | 1;   /* odd: the per-evaluation stride is a full-period multiplier power */
+    return 0;
+}
+
+/* apply_qs_bins, vcfgl.cpp:57-64 */
+static int apply_qs_bins(const vgl_oracle* o, int in_qs, int* out) {
+    for (int i = 0; i < o->p.n_qs_bins; ++i)
+        if (in_qs >= o->qs_bins[3 * i] && in_qs <= o->qs_bins[3 * i + 1]) { *out = o->qs_bins[3 * i + 2]; return 0; }
+    OFAIL(VGL_E_QSBIN, "Could not find a range for qs value %d", in_qs);
+}
+
+/* error probability -> (qScore, adjusted qScore): vcfgl.cpp:500-523 and :1668-1694 */
+static int errprob_to_qs(const vgl_oracle* o, double ep, int fixed, int* qs, int* adjqs) {
+    const int adj = o->p.adjust_qs != 0;
+    int q = -1, aq = -1;
+    if (0.0 == ep) { q = CAP_BASEQ; if (fixed) aq = CAP_BASEQ; }
+    else if (1.0 == ep) { q = 0; if (fixed) aq = 0; }
+    else if (0.0 < ep && ep < 1.0) {
+        double tmp = -10.0 * log10(ep);
+        q = (int)tmp;
+        if (adj) aq = (int)(tmp + o->p.adjust_by);
+    } else OFAIL(VGL_E_ARG, "Bad error probability value: %f", ep);
+    if (o->p.n_qs_bins != 0) {
+        int r = apply_qs_bins(o, q, &q); if (r) return r;
+        if (adj) { r = apply_qs_bins(o, aq, &aq); if (r) return r; }
+    } else {
+        q = (q > CAP_BASEQ) ? CAP_BASEQ : q;
+        if (adj) aq = (aq > CAP_BASEQ) ? CAP_BASEQ : aq;
+    }
+    *qs = q; *adjqs = aq;
+    return 0;
+}
+
+int vgl_oracle_destroy(vgl_oracle* o) {
+    if (!o) return 0;
+    free(o->depths); free(o->qs_bins); free(o->pois); errmod_free(o->em);
+    free(o->bases); free(o->qsc); free(o->adjq); free(o->errp);
+    free(o);
+    return 0;
+}
+
+int vgl_oracle_create(const vgl_params* p, vgl_oracle** out) {
+    if (!p || !out) OFAIL(VGL_E_ARG, "null argument");
+    if (p->abi_version != VGL_ABI_VERSION) OFAIL(VGL_E_ARG, "abi version mismatch");
+    if (p->n_samples <= 0) OFAIL(VGL_E_ARG, "n_samples must be positive");
+    if (p->gl_model != 1 && p->gl_model != 2) OFAIL(VGL_E_ARG, "gl_model must be 1 or 2");
+    if (p->error_qs < 0 || p->error_qs > 2) OFAIL(VGL_E_ARG, "error_qs must be 0, 1 or 2");
+    if (p->do_unobserved < 0 || p->do_unobserved > 5) OFAIL(VGL_E_ARG, "do_unobserved must be in [0,5]");
+    if (!(p->error_rate >= 0.0 && p->error_rate <= 1.0)) OFAIL(VGL_E_ARG, "error_rate must be in [0,1]");
+    if (p->rng_mode == VGL_RNG_TILE && p->error_qs != 0 && p->beta_sampler == VGL_BETA_STD)
+        OFAIL(VGL_E_UNSUPPORTED, "the mt19937 beta sampler is one global stream: VGL_RNG_SERIAL only");
+    q2gl_init();
+    vgl_oracle* o = (vgl_oracle*)calloc(1, sizeof(vgl_oracle));
+    if (!o) OFAIL(VGL_E_NOMEM, "out of memory");
+    o->p = *p;
+    const int N = p->n_samples;
+    if (p->depths) {
+        o->depths = (double*)malloc(sizeof(double) * N);
+        memcpy(o->depths, p->depths, sizeof(double) * N);
+        o->p.depths = o->depths;
+        o->n_pois = N;
+    } else o->n_pois = 1;
+    if (p->n_qs_bins > 0) {
+        o->qs_bins = (int32_t*)malloc(sizeof(int32_t) * 3 * p->n_qs_bins);
+        memcpy(o->qs_bins, p->qs_bins, sizeof(int32_t) * 3 * p->n_qs_bins);
+        o->p.qs_bins = o->qs_bins;
+    }
+    o->pois = (poisson_t*)malloc(sizeof(poisson_t) * o->n_pois);
+    for (int i = 0; i < o->n_pois; i++) {
+        double lam = p->depths ? p->depths[i] : p->depth;
+        if (!(lam >= 0.0)) { vgl_oracle_destroy(o); OFAIL(VGL_E_ARG, "depth must be >= 0"); }
+        poisson_init(&o->pois[i], lam);
+    }
+    if (p->error_qs != 0) {          /* rng.h:368-388 / :455-477 */
+        double mean = p->error_rate, var = p->beta_variance;
+        if (!(mean > 0.0 && mean < 1.0 && var > 0.0)) { vgl_oracle_destroy(o); OFAIL(VGL_E_ARG, "beta sampler needs 0<error_rate<1 and beta_variance>0"); }
+        double oom = 1.0 / mean;
+        o->beta_a = (((1.0 - mean) / var) - oom) * pow(mean, 2);
+        o->beta_b = o->beta_a * (oom - 1);
+        if (o->beta_a <= 0.0 || o->beta_b <= 0.0) { vgl_oracle_destroy(o); OFAIL(VGL_E_ARG, "beta shape parameters must be positive (alpha=%f beta=%f)", o->beta_a, o->beta_b); }
+        gamma1_init(&o->gx, o->beta_a);
+        gamma1_init(&o->gy, o->beta_b);
+        mt_seed(&o->mt, (uint32_t)p->seed);
+    }
+    o->x0 = vgl_oracle_rand48_seed(p->seed);
+    o->st0 = o->st1 = o->st2 = o->x0;
+    srand(1);                            /* the reference never seeds rand() (rng.h:12) */
+
+    o->pre_q = o->pre_adjq = -1;
+    if (p->error_qs == 0 || p->error_qs == 1) {            /* vcfgl.cpp:1661-1743 */
+        int r = errprob_to_qs(o, p->error_rate, 1, &o->pre_q, &o->pre_adjq);
+        if (r) { vgl_oracle_destroy(o); return r; }
+        if (!p->adjust_qs) o->pre_adjq = -1;
+        if (p->gl_model == 2) {
+            if (!p->precise_gl) {
+                int q = (p->adjust_qs & 1) ? o->pre_adjq : o->pre_q;
+                o->pre_homT = g_q2gl[0][q]; o->pre_het = g_q2gl[1][q]; o->pre_homF = g_q2gl[2][q];
+            } else {
+                double e = p->error_rate;
+                if (0.0 == e) { o->pre_homT = 0; o->pre_het = -0.3010299956639812; o->pre_homF = -INFINITY; }
+                else {
+                    o->pre_homT = log10(1.0 - e);
+                    o->pre_het = log10((1.0 - e) / 2.0 + e / 6.0);
+                    o->pre_homF = log10(e) - 0.47712125471966244;
+                }
+            }
+        }
+    }
+    if (p->gl_model == 1) {
+        o->em = errmod_make(1.0 - p->gl1_theta);          /* io.cpp:1276 */
+        if (!o->em) { vgl_oracle_destroy(o); OFAIL(VGL_E_NOMEM, "out of memory"); }
+    }
+    if (p->layout.block) o->lay = p->layout; else vgl_oracle_default_layout(p, &o->lay);
+    o->A = max_alleles(p);
+    o->G = N_GT_OF_ALLELES[o->A];
+    o->cap = 0;
+    *out = o;
+    return VGL_OK;
+}
+
+static int ensure_cap(vgl_oracle* o, int need) {      /* simRecord::expand_arrays, bcf_utils.cpp:618-648 */
+    if (need <= o->cap) return 0;
+    int cap = o->cap ? o->cap : 64;
+    while (cap < need) cap *= 2;
+    const size_t n = (size_t)o->p.n_samples * cap;
+    int* nb = (int*)malloc(n * sizeof(int)); int* nq = (int*)malloc(n * sizeof(int));
+    int* na = (int*)malloc(n * sizeof(int)); double* ne = (double*)malloc(n * sizeof(double));
+    if (!nb || !nq || !na || !ne) OFAIL(VGL_E_NOMEM, "out of memory");
+    free(o->bases); free(o->qsc); free(o->adjq); free(o->errp);
+    o->bases = nb; o->qsc = nq; o->adjq = na; o->errp = ne; o->cap = cap;
+    return 0;
+}
+
+static inline float f32_missing(void) { union { uint32_t i; float f; } u; u.i = VGL_FLOAT_MISSING_BITS; return u.f; }
+static inline int f32_is_missing(float f) { union { uint32_t i; float f; } u; u.f = f; return u.i == VGL_FLOAT_MISSING_BITS; }
+static inline int gt_index(int a, int b) { return a > b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; }  /* bcf_alleles2gt */
+
+/* beta deviate from whichever sampler is configured (rng.h:408-419 / :433-444) */
+static double beta_draw(vgl_oracle* o, uint64_t* st_qs) {
+    double x, y;
+    if (o->p.beta_sampler == VGL_BETA_STD) {
+        x = std_gamma_fresh(&o->mt, o->beta_a);
+        y = std_gamma_fresh(&o->mt, o->beta_b);
+    } else {
+        x = gamma1_sample(&o->gx, st_qs);
+        y = gamma1_sample(&o->gy, st_qs);
+    }
+    return x / (x + y);
+}
+
+/* GL model 2, one sample: gl_methods.cpp:22-59 / :94-139 / :171-220 */
+static void gl2_sample(const vgl_oracle* o, int s, int n, const int* acgt2alleles, int nAlleles, int nG, float* g) {
+    const vgl_params* p = &o->p;
+    const int per_read = (p->error_qs == 2);
+    for (int i = 0; i < nG; i++) g[i] = -0.0f;                  /* reset_rec_objects, bcf_utils.h:310 */
+    for (int r = 0; r < n; r++) {
+        double homT, het, homF;
+        if (!per_read) { homT = o->pre_homT; het = o->pre_het; homF = o->pre_homF; }
+        else if (!p->precise_gl) {
+            int qs = (p->adjust_qs & 1) ? o->adjq[(size_t)s * o->cap + r] : o->qsc[(size_t)s * o->cap + r];
+            homT = g_q2gl[0][qs]; het = g_q2gl[1][qs]; homF = g_q2gl[2][qs];
+        } else {
+            double e = o->errp[(size_t)s * o->cap + r];
+            if (0.0 == e) { homT = 0.0; het = -0.30103; homF = -INFINITY; }
+            else { homT = log10(1.0 - e); het = log10((1.0 - e) / 2.0 + e / 6.0); homF = log10(e / 3.0); }
+        }
+        const int ao = acgt2alleles[o->bases[(size_t)s * o->cap + r]];
+        g[gt_index(ao, ao)] += homT;
+        for (int a1 = 0; a1 < nAlleles; ++a1) {
+            if (a1 == ao) continue;
+            g[gt_index(a1, ao)] += het;
+            for (int a2 = a1; a2 < nAlleles; ++a2) if (a2 != ao) g[gt_index(a2, a1)] += homF;
+        }
+        float max = -INFINITY;
+        for (int i = 0; i < nG; ++i) if (g[i] > max) max = g[i];
+        for (int i = 0; i < nG; ++i) g[i] -= max;
+    }
+}
+
+/* GL model 1, one sample: gl_methods.cpp:256-290 / :325-357 */
+static int gl1_sample(const vgl_oracle* o, int s, int n, const int* alleles2acgt, int nAlleles, float* g) {
+    const vgl_params* p = &o->p;
+    uint16_t ub[256]; float fpls[25];
+    if (n > 255) OFAIL(VGL_E_UNSUPPORTED, "GL model 1 with depth > 255 (htslib subsamples with drand48): not restated");
+    for (int i = 0; i < n; i++) {
+        int qs;
+        if (p->error_qs == 2) qs = (p->adjust_qs & 1) ? o->adjq[(size_t)s * o->cap + i] : o->qsc[(size_t)s * o->cap + i];
+        else qs = (p->adjust_qs & 1) ? o->pre_adjq : o->pre_q;
+        ub[i] = (uint16_t)(qs << 5 | o->bases[(size_t)s * o->cap + i]);
+    }
+    errmod_cal5(o->em, n, ub, fpls);
+    float max = -INFINITY; int gi = 0;
+    for (int a2 = 0; a2 < nAlleles; ++a2) {
+        int b2 = alleles2acgt[a2];
+        for (int a1 = 0; a1 <= a2; ++a1) {
+            int b1 = alleles2acgt[a1];
+            g[gi] = ((-1.0 * fpls[b1 * 5 + b2]) / 10.0);
+            if (g[gi] > max) max = g[gi];
+            ++gi;
+        }
+    }
+    for (int i = 0; i < gi; ++i) g[i] -= max;
+    return 0;
+}
+
+#define PLANE(ptr, K, site, k, s) (ptr)[((size_t)(site) * (K) + (k)) * N + (s)]
+
+/* one site: simulate_record_values, vcfgl.cpp:327-1087 */
+static int simulate_site(vgl_oracle* o, int64_t site_abs, int32_t ls, int32_t n_sites, const uint8_t* gt, vgl_tile_out* out) {
+    const vgl_params* p = &o->p;
+    const int N = p->n_samples, A = o->A, G = o->G;
+    const int tile = (p->rng_mode == VGL_RNG_TILE);
+    const int sample_strand = p->add_i16 || p->add_fmt_adf || p->add_fmt_adr || p->add_info_adf || p->add_info_adr; /* shared.h:160-161 */
+    const float MISS = f32_missing();
+
+    int* dp = (int*)calloc(N, sizeof(int));
+    int* ad = (int*)calloc((size_t)4 * N, sizeof(int));
+    int* adf = (int*)calloc((size_t)4 * N, sizeof(int));
+    int* adr = (int*)calloc((size_t)4 * N, sizeof(int));
+    int* qsum = (int*)calloc((size_t)4 * N, sizeof(int));
+    int* qsumsq = (int*)calloc((size_t)4 * N, sizeof(int));
+    uint64_t* st_hap = (uint64_t*)calloc(N, sizeof(uint64_t));
+    uint64_t* st_base = (uint64_t*)calloc(N, sizeof(uint64_t));
+    uint64_t* st_qs = (uint64_t*)calloc(N, sizeof(uint64_t));
+    float* gl = (float*)malloc(sizeof(float) * (size_t)N * 15);
+    int rc = VGL_OK;
+    int info_dp = 0, info_acgt[4] = {0, 0, 0, 0}, nI16[8] = {0};
+    float taild[4] = {0}, taild_sq[4] = {0};
+    int acgt2alleles[5] = {-1, -1, -1, -1, -1}, alleles2acgt[5] = {-1, -1, -1, -1, -1};
+    int nAlleles = 0, nObs = 0, nG = 0, status = VGL_SITE_OK;
+    int r_base = -1;
+
+    /* ---- depths for ALL samples first (vcfgl.cpp:364-389); missing GT => DP 0 but the
+     *      draw is still consumed (:375-379) */
+    int maxdp = 0;
+    for (int s = 0; s < N; s++) {
+        uint64_t* st_depth;
+        uint64_t local_depth;
+        if (tile) {
+            uint64_t e = (uint64_t)site_abs * (uint64_t)N + (uint64_t)s;
+            uint64_t base = e * o->lay.block;
+            local_depth = vgl_oracle_rand48_jump(o->x0, base + o->lay.off[0]);
+            st_hap[s] = vgl_oracle_rand48_jump(o->x0, base + o->lay.off[1]);
+            st_base[s] = vgl_oracle_rand48_jump(o->x0, base + o->lay.off[2]);
+            st_qs[s] = vgl_oracle_rand48_jump(o->x0, base + o->lay.off[3]);
+            st_depth = &local_depth;
+        } else st_depth = &o->st1;
+        int n = poisson_sample(&o->pois[o->n_pois == 1 ? 0 : s], st_depth);
+        int a0 = gt[s] & 0xF, a1 = (gt[s] >> 4) & 0xF;
+        if (a0 == VGL_GT_MISSING || a1 == VGL_GT_MISSING) { dp[s] = 0; continue; }
+        dp[s] = n; info_dp += n;
+        if (n > maxdp) maxdp = n;
+    }
+    if ((rc = ensure_cap(o, maxdp))) goto done;
+
+    if (0 == info_dp) {                                    /* vcfgl.cpp:396-404, :228-315 */
+        if (p->rm_empty_sites) { status = VGL_SITE_SKIP_EMPTY; goto write_site; }
+        status = VGL_SITE_NO_READS;
+        switch (p->do_unobserved) {
+            case 0: nAlleles = 1; nObs = 0; break;
+            case 1: case 2: nAlleles = 1; nObs = 0; alleles2acgt[0] = BASE_NONREF; break;
+            case 3: nAlleles = 4; nObs = 4; for (int a = 0; a < 4; a++) alleles2acgt[a] = a; break;
+            default: nAlleles = 5; nObs = 4; for (int a = 0; a < 4; a++) alleles2acgt[a] = a; alleles2acgt[4] = BASE_NONREF; break;
+        }
+        nG = N_GT_OF_ALLELES[nAlleles];
+        goto write_site;
+    }
+
+    /* ---- per-site base-pick error (error_qs 1: one beta deviate, vcfgl.cpp:425-437) */
+    double base_pick_error_prob = p->error_rate;
+    if (1 == p->error_qs) base_pick_error_prob = beta_draw(o, tile ? &st_qs[0] : &o->st2);
+
+    /* ---- read loop (vcfgl.cpp:441-640) */
+    for (int s = 0; s < N; s++) {
+        const int n = dp[s];
+        if (0 == n) continue;
+        const int a0 = gt[s] & 0xF, a1 = (gt[s] >> 4) & 0xF;
+        uint64_t* sh = tile ? &st_hap[s] : &o->st1;
+        uint64_t* sb = tile ? &st_base[s] : &o->st0;
+        uint64_t* sq = tile ? &st_qs[s] : &o->st2;
+        for (int r = 0; r < n; r++) {
+            int true_base = (lcg_uniform(sh) < 0.5) ? a0 : a1;                       /* :473 */
+            r_base = true_base;
+            if (lcg_uniform(sb) < base_pick_error_prob)                              /* :486 */
+                while ((r_base = (int)floor(4 * lcg_uniform(sb))) == true_base);     /* :487 */
+            int q_i, aq_i;
+            if (2 == p->error_qs) {                                                  /* :494-565 */
+                double ep = beta_draw(o, sq);
+                if ((rc = errprob_to_qs(o, ep, 0, &q_i, &aq_i))) goto done;
+                o->qsc[(size_t)s * o->cap + r] = q_i;
+                o->adjq[(size_t)s * o->cap + r] = aq_i;
+                o->errp[(size_t)s * o->cap + r] = ep;
+            } else { q_i = o->pre_q; aq_i = o->pre_adjq; o->qsc[(size_t)s * o->cap + r] = q_i; o->adjq[(size_t)s * o->cap + r] = aq_i; }
+            const int qq = (p->adjust_qs & 2) ? aq_i : q_i;                          /* :557-575 */
+            qsum[s * 4 + r_base] += qq;
+            qsumsq[s * 4 + r_base] += qs_to_qssq(qq);
+            ad[s * 4 + r_base]++;
+            int strand = 0;
+            if (sample_strand) {                                                     /* :581-605 */
+                strand = (lcg_uniform(sb) < 0.5) ? 0 : 1;
+                if (strand == 0) adf[s * 4 + r_base]++; else adr[s * 4 + r_base]++;
+            } else adf[s * 4 + r_base]++;
+            nI16[2 * r_base + strand]++;
+            o->bases[(size_t)s * o->cap + r] = r_base;
+        }
+        for (int b = 0; b < 4; b++) info_acgt[b] += ad[s * 4 + b];
+    }
+
+    if (p->add_i16) {                                                                /* :647-663 */
+        for (int s = 0; s < N; s++)
+            for (int r = 0; r < dp[s]; r++) {
+                int td = 1 + rand() / (RAND_MAX / (50 - 1 + 1) + 1);                 /* rng.h:12 */
+                o->n_draw_rand++;
+                if (td > 25) td = 25;                                                /* CAP_TAIL_DIST */
+                taild[r_base] += td; taild_sq[r_base] += (td * td);                  /* stale r_base: reference quirk */
+            }
+    }
+
+    {
+        int nObservedBases = 0;
+        for (int b = 0; b < 4; b++) if (info_acgt[b] > 0) nObservedBases++;
+        if ((p->rm_invar_sites & 4) && 1 == nObservedBases) { status = VGL_SITE_SKIP_INVAR; goto write_site; }  /* :675-681 */
+    }
+
+    /* ---- allele order: stable descending insertion sort by INFO/AD (vcfgl.cpp:700-766) */
+    {
+        int sorted[4] = {0, 1, 2, 3};
+        for (int i = 1; i < 4; i++)
+            for (int j = i; j > 0 && info_acgt[sorted[j]] > info_acgt[sorted[j - 1]]; j--) {
+                int t = sorted[j]; sorted[j] = sorted[j - 1]; sorted[j - 1] = t;
+            }
+        for (int a = 0; a < 4; a++) { alleles2acgt[a] = sorted[a]; acgt2alleles[sorted[a]] = a; }
+        const int explode = (p->do_unobserved >= 3);
+        const int add_unobs = (A == 5);
+        for (int b = 0; b < 4; b++)
+            if (!(info_acgt[b] > 0) && !explode) { alleles2acgt[acgt2alleles[b]] = -1; acgt2alleles[b] = -1; }
+        int unobs = -1, n_all = 0;
+        for (int a = 0; a < 5; a++) {
+            if (-1 == alleles2acgt[a]) { if (add_unobs) unobs = a; break; }
+            ++n_all;
+        }
+        if (add_unobs) { alleles2acgt[unobs] = BASE_NONREF; acgt2alleles[BASE_NONREF] = unobs; }
+        nObs = n_all; nAlleles = n_all + (add_unobs ? 1 : 0);
+        nG = N_GT_OF_ALLELES[nAlleles];
+    }
+
+    /* ---- calculate_gls (vcfgl.cpp:788) */
+    for (int s = 0; s < N; s++) {
+        float* g = gl + (size_t)s * 15;
+        if (0 == dp[s]) { for (int i = 0; i < nG; i++) g[i] = MISS; continue; }
+        if (p->gl_model == 2) gl2_sample(o, s, dp[s], acgt2alleles, nAlleles, nG, g);
+        else if ((rc = gl1_sample(o, s, dp[s], alleles2acgt, nAlleles, g))) goto done;
+    }
+
+write_site:
+    out->site_status[ls] = status;
+    out->n_alleles[ls] = nAlleles;
+    if (out->n_alleles_obs) out->n_alleles_obs[ls] = nObs;
+    for (int a = 0; a < 5; a++) out->alleles2acgt[(size_t)ls * 5 + a] = (int8_t)alleles2acgt[a];
+    if (out->info_dp) out->info_dp[ls] = info_dp;
+    for (int s = 0; s < N; s++) if (out->fmt_dp) out->fmt_dp[(size_t)ls * N + s] = dp[s];
+
+    const int have = (status == VGL_SITE_OK);
+    /* AD remap (vcfgl.cpp:806-843) */
+    for (int a = 0; a < A; a++) {
+        int b = (have && a < nAlleles) ? alleles2acgt[a] : -1;
+        int tot = 0, totf = 0, totr = 0;
+        for (int s = 0; s < N; s++) {
+            int v = (b >= 0 && b < 4) ? ad[s * 4 + b] : 0, vf = (b >= 0 && b < 4) ? adf[s * 4 + b] : 0, vr = (b >= 0 && b < 4) ? adr[s * 4 + b] : 0;
+            if (out->fmt_ad) PLANE(out->fmt_ad, A, ls, a, s) = v;
+            if (out->fmt_adf) PLANE(out->fmt_adf, A, ls, a, s) = vf;
+            if (out->fmt_adr) PLANE(out->fmt_adr, A, ls, a, s) = vr;
+            tot += v; totf += vf; totr += vr;
+        }
+        if (out->info_ad) out->info_ad[(size_t)ls * A + a] = tot;
+        if (out->info_adf) out->info_adf[(size_t)ls * A + a] = totf;
+        if (out->info_adr) out->info_adr[(size_t)ls * A + a] = totr;
+    }
+    /* QS (vcfgl.cpp:845-898) */
+    if (out->qs) {
+        float qsv[5] = {0, 0, 0, 0, 0};
+        if (have)
+            for (int s = 0; s < N; s++) {
+                float sum = 0.0;
+                for (int b = 0; b < 4; b++) sum += qsum[s * 4 + b];
+                if (0.0 != sum)
+                    for (int b = 0; b < 4; b++) {
+                        int a = acgt2alleles[b];
+                        if (-1 == a) continue;
+                        qsv[a] += (float)((float)(qsum[s * 4 + b]) / sum);
+                    }
+            }
+        for (int a = 0; a < A; a++) out->qs[(size_t)ls * A + a] = qsv[a];
+    }
+    /* GL / PL / GP planes (vcfgl.cpp:907-970; no-reads site :297-305) */
+    for (int s = 0; s < N; s++) {
+        const float* g = gl + (size_t)s * 15;
+        float gpv[15]; float sum_gps = 0.0; int miss = 0;
+        for (int i = 0; i < G; i++) {
+            float v = (have && i < nG) ? g[i] : MISS;
+            if (out->gl) PLANE(out->gl, G, ls, i, s) = v;
+            if (out->pl) {
+                int32_t x;
+                if (f32_is_missing(v)) x = VGL_INT32_MISSING;
+                else if (v == -INFINITY) x = MAXPL;
+                else { x = (int32_t)lroundf(-10.0 * v); if (x > MAXPL) x = MAXPL; }
+                PLANE(out->pl, G, ls, i, s) = x;
+            }
+            if (i < nG && have) {
+                if (f32_is_missing(v)) { gpv[i] = MISS; miss = 1; }
+                else gpv[i] = pow(10, v);
+            }
+        }
+        if (out->gp) {
+            if (have && !miss) { for (int i = 0; i < nG; i++) sum_gps += gpv[i]; for (int i = 0; i < nG; i++) gpv[i] /= sum_gps; }
+            for (int i = 0; i < G; i++) PLANE(out->gp, G, ls, i, s) = (have && i < nG) ? gpv[i] : MISS;
+        }
+    }
+    /* I16 (vcfgl.cpp:982-1074) */
+    if (out->i16) {
+        float v[16] = {0};
+        if (have && p->add_i16 && nAlleles > 1) {
+            int refb = alleles2acgt[0];
+            v[0] = nI16[refb * 2 + 0]; v[1] = nI16[refb * 2 + 1];
+            for (int s = 0; s < N; s++) {
+                v[4] += qsum[s * 4 + refb]; v[5] += qsumsq[s * 4 + refb];
+                for (int a = 0; a < nAlleles; a++) {
+                    if (nObs == a) continue;
+                    int b = alleles2acgt[a];
+                    for (int i = 0; i < ad[s * 4 + b]; ++i) {
+                        if (0 == a) { v[8] += p->i16_mapq; v[9] += p->i16_mapq * p->i16_mapq; }
+                        else { v[10] += p->i16_mapq; v[11] += p->i16_mapq * p->i16_mapq; }
+                    }
+                }
+            }
+            v[12] = taild[refb]; v[13] = taild_sq[refb];
+            for (int a = 1; a < nAlleles; a++) {
+                if (nObs == a) continue;
+                int b = alleles2acgt[a];
+                v[2] += nI16[b * 2 + 0]; v[3] += nI16[b * 2 + 1];
+                for (int s = 0; s < N; s++) { v[6] += qsum[s * 4 + b]; v[7] += qsumsq[s * 4 + b]; }
+                v[14] += taild[b]; v[15] += taild_sq[b];
+            }
+        }
+        for (int i = 0; i < 16; i++) out->i16[(size_t)ls * 16 + i] = v[i];
+    }
+    /* per-read dump (pileup, vcfgl.cpp:616-634) */
+    if (out->reads && out->read_capacity > 0) {
+        for (int s = 0; s < N; s++)
+            for (int r = 0; r < out->read_capacity; r++) {
+                uint8_t v = 0xFF;
+                if (status != VGL_SITE_SKIP_EMPTY && status != VGL_SITE_NO_READS && r < dp[s])
+                    v = (uint8_t)((o->qsc[(size_t)s * o->cap + r] << 2) | o->bases[(size_t)s * o->cap + r]);
+                out->reads[((size_t)r * n_sites + ls) * N + s] = v;
+            }
+    }
+done:
+    free(dp); free(ad); free(adf); free(adr); free(qsum); free(qsumsq);
+    free(st_hap); free(st_base); free(st_qs); free(gl);
+    return rc;
+}
+
+int vgl_oracle_simulate(vgl_oracle* o, int64_t site0, int32_t n_sites, const uint8_t* gt, vgl_tile_out* out) {
+    if (!o || !gt || !out || !out->site_status || !out->n_alleles || !out->alleles2acgt) OFAIL(VGL_E_ARG, "null argument");
+    for (int32_t i = 0; i < n_sites; i++) {
+        int rc = simulate_site(o, site0 + i, i, n_sites, gt + (size_t)i * o->p.n_samples, out);
+        if (rc) return rc;
+    }
+    return VGL_OK;
+}
+
+/* -------- small exported probes used by unit tests (samplers driven from a given state) */
+int vgl_oracle_poisson_draws(double lambda, uint64_t* state, int n, int32_t* out) {
+    poisson_t p; poisson_init(&p, lambda);
+    for (int i = 0; i < n; i++) out[i] = poisson_sample(&p, state);
+    return 0;
+}
+
+int vgl_oracle_beta_rand48_draws(double mean, double var, uint64_t* state, int n, double* out) {
+    double oom = 1.0 / mean;
+    double a = (((1.0 - mean) / var) - oom) * pow(mean, 2), b = a * (oom - 1);
+    gamma1_t gx, gy; gamma1_init(&gx, a); gamma1_init(&gy, b);
+    for (int i = 0; i < n; i++) { double x = gamma1_sample(&gx, state); double y = gamma1_sample(&gy, state); out[i] = x / (x + y); }
+    return 0;
+}
+
+int vgl_oracle_beta_std_draws(double mean, double var, int32_t seed, int n, double* out) {
+    double oom = 1.0 / mean;
+    double a = (((1.0 - mean) / var) - oom) * pow(mean, 2), b = a * (oom - 1);
+    mt19937_t* m = (mt19937_t*)malloc(sizeof(mt19937_t));
+    mt_seed(m, (uint32_t)seed);
+    for (int i = 0; i < n; i++) { double x = std_gamma_fresh(m, a); double y = std_gamma_fresh(m, b); out[i] = x / (x + y); }
+    free(m);
+    return 0;
+}
+
+void vgl_oracle_stream_states(const vgl_oracle* o, uint64_t st[3]) { st[0] = o->st0; st[1] = o->st1; st[2] = o->st2; }

@@ -1,0 +1,105 @@
+"""ctypes view of include/vcfgl_hip.h (the C ABI of libvcfgl_hip.so).
+
+Pure declarations: no compute, no fallback.  `load_library()` raises if the HIP library has
+not been built -- the product path never falls back to a CPU implementation.
+"""
+import ctypes as C
+import os
+
+ABI_VERSION = 1
+
+VGL_OK = 0
+VGL_E_ARG, VGL_E_NODEVICE, VGL_E_NOMEM, VGL_E_CAPACITY, VGL_E_UNSUPPORTED, VGL_E_QSBIN = -1, -2, -3, -4, -5, -6
+VGL_SITE_OK, VGL_SITE_SKIP_INVAR, VGL_SITE_SKIP_EMPTY, VGL_SITE_NO_READS = 0, -3, -4, 1
+VGL_RNG_TILE, VGL_RNG_SERIAL = 0, 1
+VGL_BETA_RAND48, VGL_BETA_STD = 0, 1
+VGL_GT_MISSING = 0xF
+FLOAT_MISSING_BITS = 0x7F800001
+INT32_MISSING = -(2 ** 31)
+
+
+class RngLayout(C.Structure):
+    _fields_ = [("block", C.c_uint64), ("off", C.c_uint64 * 4)]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("seed", C.c_int32), ("n_samples", C.c_int32),
+        ("rng_mode", C.c_int32), ("beta_sampler", C.c_int32),
+        ("depth", C.c_double), ("depths", C.POINTER(C.c_double)),
+        ("error_rate", C.c_double), ("error_qs", C.c_int32), ("beta_variance", C.c_double),
+        ("gl_model", C.c_int32), ("gl1_theta", C.c_double), ("precise_gl", C.c_int32),
+        ("adjust_qs", C.c_int32), ("adjust_by", C.c_double),
+        ("n_qs_bins", C.c_int32), ("qs_bins", C.POINTER(C.c_int32)), ("i16_mapq", C.c_int32),
+        ("do_unobserved", C.c_int32), ("rm_invar_sites", C.c_int32), ("rm_empty_sites", C.c_int32),
+        ("do_gvcf", C.c_int32),
+        ("add_gl", C.c_int32), ("add_gp", C.c_int32), ("add_pl", C.c_int32), ("add_i16", C.c_int32),
+        ("add_qs", C.c_int32), ("add_fmt_dp", C.c_int32), ("add_info_dp", C.c_int32),
+        ("add_fmt_ad", C.c_int32), ("add_info_ad", C.c_int32),
+        ("add_fmt_adf", C.c_int32), ("add_info_adf", C.c_int32),
+        ("add_fmt_adr", C.c_int32), ("add_info_adr", C.c_int32),
+        ("layout", RngLayout),
+    ]
+
+
+class TileOut(C.Structure):
+    _fields_ = [
+        ("site_status", C.c_void_p), ("n_alleles", C.c_void_p), ("n_alleles_obs", C.c_void_p),
+        ("alleles2acgt", C.c_void_p), ("info_dp", C.c_void_p), ("info_ad", C.c_void_p),
+        ("info_adf", C.c_void_p), ("info_adr", C.c_void_p), ("qs", C.c_void_p), ("i16", C.c_void_p),
+        ("fmt_dp", C.c_void_p), ("gl", C.c_void_p), ("pl", C.c_void_p), ("gp", C.c_void_p),
+        ("fmt_ad", C.c_void_p), ("fmt_adf", C.c_void_p), ("fmt_adr", C.c_void_p),
+        ("reads", C.c_void_p), ("read_capacity", C.c_int32),
+    ]
+
+
+# (field, dtype, shape-kind): shape kinds resolved by tile.py
+TILE_FIELDS = [
+    ("site_status", "int32", "site"), ("n_alleles", "int32", "site"), ("n_alleles_obs", "int32", "site"),
+    ("alleles2acgt", "int8", "site5"), ("info_dp", "int32", "site"), ("info_ad", "int32", "siteA"),
+    ("info_adf", "int32", "siteA"), ("info_adr", "int32", "siteA"), ("qs", "float32", "siteA"),
+    ("i16", "float32", "site16"), ("fmt_dp", "int32", "eval"), ("gl", "float32", "planeG"),
+    ("pl", "int32", "planeG"), ("gp", "float32", "planeG"), ("fmt_ad", "int32", "planeA"),
+    ("fmt_adf", "int32", "planeA"), ("fmt_adr", "int32", "planeA"),
+]
+
+# every symbol include/vcfgl_hip.h declares
+EXPORTS = [
+    "vgl_max_alleles", "vgl_max_genotypes", "vgl_default_rng_layout", "vgl_abi_version",
+    "vgl_last_error", "vgl_ctx_create", "vgl_ctx_destroy", "vgl_simulate_tile",
+    "vgl_simulate_tile_device", "vgl_ctx_check", "vgl_ctx_timing", "vgl_ctx_kernel_ms",
+]
+
+_LIB = None
+
+
+def library_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libvcfgl_hip.so")
+
+
+def load_library():
+    """dlopen libvcfgl_hip.so and set prototypes.  Raises RuntimeError when it is not built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C vcfgl_amd/csrc`.  There is no CPU fallback.")
+    lib = C.CDLL(path)
+    lib.vgl_max_alleles.argtypes = [C.POINTER(Params)]
+    lib.vgl_max_genotypes.argtypes = [C.POINTER(Params)]
+    lib.vgl_default_rng_layout.argtypes = [C.POINTER(Params), C.POINTER(RngLayout)]
+    lib.vgl_last_error.restype = C.c_char_p
+    lib.vgl_ctx_create.argtypes = [C.POINTER(Params), C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.vgl_ctx_destroy.argtypes = [C.c_void_p]
+    lib.vgl_simulate_tile.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.POINTER(TileOut)]
+    lib.vgl_simulate_tile_device.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.POINTER(TileOut), C.c_void_p]
+    lib.vgl_ctx_check.argtypes = [C.c_void_p, C.c_void_p]
+    lib.vgl_ctx_timing.argtypes = [C.c_void_p, C.c_int32]
+    lib.vgl_ctx_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]
+    if lib.vgl_abi_version() != ABI_VERSION:
+        raise RuntimeError("libvcfgl_hip.so ABI version mismatch")
+    _LIB = lib
+    return lib
