@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- site-sample GL evaluations/s of the HIP hot path on N MI355X (one process per GPU).
+
+Workload (BASELINE.json configs[2], the depth-20 configuration the metric is quoted on):
+1M sites x 1000 samples, --depth 20 -e 0.01 --error-qs 2 --beta-variance 1e-5 -GL 2, default tag
+surface (GL + DP, -doUnobserved 1 => G = 15).  One step = one pass of the hot path over the whole
+1e9-evaluation batch, tile by tile, with the packed true genotypes already resident in HBM and the
+outputs written to HBM.  Sites shard across ranks (weak scaling: every rank simulates its own
+1M-site range, addressed by absolute site index); the only collective is the end-of-step gather of
+the per-site records' index fields (status / allele count) to the writer rank over RCCL.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import synth  # noqa: E402
+from vcfgl_amd import Simulator, VcfglArgs, _abi  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E vendor peak (MI355X_MICROARCH.md)
+
+
+def workload_args():
+    a = VcfglArgs(seed=42, depth=20.0, error_rate=0.01, error_qs=2, beta_variance=1e-5, gl_model=2)
+    a.rng_mode, a.beta_sampler = _abi.VGL_RNG_TILE, _abi.VGL_BETA_RAND48
+    return a
+
+
+def cpu_baseline(args, n_samples, budget_s=15.0):
+    """The CPU oracle (a port of the reference algorithm, same inputs, one core) on a bounded sample."""
+    import subprocess
+    so = os.path.join(ROOT, "oracle", "libvgl_oracle.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libvgl_oracle.so"])
+    import oracle_lib
+    o = oracle_lib.Oracle(args, n_samples)
+    fields = ["fmt_dp", "gl"]
+    n0 = 20
+    t0 = time.perf_counter(); o.simulate(0, synth.binary_sites(0, n0, n_samples), fields=fields); dt = time.perf_counter() - t0
+    n = int(max(n0, min(20000, budget_s / (dt / n0))))
+    gt = synth.binary_sites(0, n, n_samples)
+    t0 = time.perf_counter(); o.simulate(0, gt, fields=fields); dt = time.perf_counter() - t0
+    return {"value": n * n_samples / dt, "unit": "site-sample GL evals/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} sites x {n_samples} samples of the same workload, oracle/vgl_oracle.c (gcc -O2), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--sites", type=int, default=1_000_000)
+    ap.add_argument("--samples", type=int, default=1000)
+    ap.add_argument("--tile-sites", type=int, default=8192)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    opt = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    args = workload_args()
+    S, N, TS = opt.sites, opt.samples, opt.tile_sites
+    site_base = rank * S                                      # this rank's absolute site range
+    sim = Simulator(args, N, device=local_rank, max_sites_per_tile=TS)
+    G = sim.G
+
+    # ---- inputs resident in HBM before the timed region
+    gt = torch.empty((S, N), dtype=torch.uint8, device=dev)
+    for s0 in range(0, S, 65536):
+        n = min(65536, S - s0)
+        gt[s0:s0 + n] = synth.binary_sites_torch(site_base + s0, n, N, dev)
+    # ---- outputs: the whole job's tag arrays stay in HBM (65 B per evaluation)
+    out = {
+        "site_status": torch.empty((S,), dtype=torch.int32, device=dev),
+        "n_alleles": torch.empty((S,), dtype=torch.int32, device=dev),
+        "alleles2acgt": torch.empty((S, 5), dtype=torch.int8, device=dev),
+        "fmt_dp": torch.empty((S, N), dtype=torch.int32, device=dev),
+        "gl": torch.empty((S, G, N), dtype=torch.float32, device=dev),
+    }
+    structs = []
+    for s0 in range(0, S, TS):
+        n = min(TS, S - s0)
+        t = _abi.TileOut()
+        for k, v in out.items():
+            setattr(t, k, v[s0:s0 + n].data_ptr())
+        structs.append((s0, n, t))
+    stream = torch.cuda.Stream(device=dev)
+    import ctypes as C
+
+    def step():
+        for s0, n, t in structs:
+            sim._check(sim.lib.vgl_simulate_tile_device(sim.ctx, site_base + s0, n, gt[s0:s0 + n].data_ptr(), C.byref(t),
+                                                        C.c_void_p(stream.cuda_stream)))
+        if dist is not None:                                  # record-index gather to the writer rank
+            stream.synchronize()
+            idx = torch.stack([out["site_status"], out["n_alleles"]], dim=1)
+            bufs = [torch.empty_like(idx) for _ in range(world)] if rank == 0 else None
+            dist.gather(idx, bufs, dst=0)
+
+    def barrier():
+        stream.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(opt.warmup):
+        step()
+    barrier()
+    sim.check(stream.cuda_stream)
+    sim.timing(True)
+    sim.kernel_ms(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(opt.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    sim.check(stream.cuda_stream)
+    kms, klaunch = sim.kernel_ms(reset=True)
+    sim.timing(False)
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    evals_total = float(S) * N * world * opt.steps
+    value = evals_total / dt
+    if rank == 0:
+        b_eval = 1 + 4 + 4 * G                               # packed GT in + DP out + GL out
+        names = ["k_sample", "k_site", "k_gl"]
+        dom = int(np.argmax(kms))
+        avg_ms = kms[dom] / max(klaunch[dom], 1)
+        evals_per_launch = float(min(TS, S)) * N
+        achieved = b_eval * evals_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(names[dom], {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "site-sample GL evals/s at depth 20", "value": value, "unit": "site-sample GL evals/s",
+            "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": dt / opt.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64+f32 (rand48 u48)",
+            "data": "synthetic",
+            "config": {"workload": f"{S} sites x {N} samples per GPU, --depth 20 -e 0.01 --error-qs 2 --beta-variance 1e-5 -GL 2, "
+                                   f"tags GL+DP (G={G}), rng tile mode, rand48 beta sampler", "tile_sites": TS,
+                       "parallelism": f"site-sharded x{world}"},
+            "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_eval": b_eval,
+                         "kernel_ms_total": dict(zip(names, kms)), "launches": dict(zip(names, klaunch))},
+        }
+        if not opt.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args, N)
+        print(json.dumps(line))
+    sim.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,88 @@
+"""CPU-side checks of the C ABI library: it loads, exports every symbol include/vcfgl_hip.h
+declares, its pure-host helpers agree with the oracle, and -- without a GPU -- it fails
+loudly instead of computing anything on the CPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from vcfgl_amd import _abi
+from vcfgl_amd.params import VcfglArgs, VcfglArgError
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _have_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def test_header_symbols_exported():
+    hdr = open(os.path.join(ROOT, "include", "vcfgl_hip.h")).read()
+    declared = set(re.findall(r"\b(vgl_[a-z0-9_]+)\s*\(", hdr)) - {"vgl_simulate_tile_"}
+    assert declared == set(_abi.EXPORTS), declared ^ set(_abi.EXPORTS)
+    lib = _abi.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.vgl_abi_version() == _abi.ABI_VERSION
+
+
+def test_struct_sizes_match_header():
+    """The ctypes mirror must lay out vgl_params / vgl_tile_out like the C compiler does."""
+    import subprocess, tempfile
+    src = '#include "vcfgl_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu\\n",sizeof(vgl_params),sizeof(vgl_tile_out),sizeof(vgl_rng_layout));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(d, "t"), os.path.join(d, "t.c")])
+        a, b, c = map(int, subprocess.check_output([os.path.join(d, "t")]).split())
+    assert (a, b, c) == (C.sizeof(_abi.Params), C.sizeof(_abi.TileOut), C.sizeof(_abi.RngLayout))
+
+
+@pytest.mark.parametrize("du,A,G", [(0, 4, 10), (1, 5, 15), (2, 5, 15), (3, 4, 10), (4, 5, 15), (5, 5, 15)])
+def test_layout_helpers(du, A, G):
+    lib = _abi.load_library()
+    args = VcfglArgs(seed=1, depth=3, error_rate=0.01, do_unobserved=du)
+    p, _ = args.to_struct(7)
+    assert lib.vgl_max_alleles(C.byref(p)) == A == args.max_alleles
+    assert lib.vgl_max_genotypes(C.byref(p)) == G == args.max_genotypes
+
+
+@pytest.mark.parametrize("depth,eqs", [(0.0, 0), (1.5, 0), (20, 2), (100, 1), (500, 2)])
+def test_default_rng_layout_matches_oracle(oracle, depth, eqs):
+    lib = _abi.load_library()
+    args = VcfglArgs(seed=1, depth=depth, error_rate=0.01, error_qs=eqs, beta_variance=1e-5 if eqs else -1.0)
+    p, _ = args.to_struct(5)
+    a, b = _abi.RngLayout(), _abi.RngLayout()
+    assert lib.vgl_default_rng_layout(C.byref(p), C.byref(a)) == 0
+    assert oracle.lib().vgl_oracle_default_layout(C.byref(p), C.byref(b)) == 0
+    assert a.block == b.block and list(a.off) == list(b.off)
+    assert a.block % 2 == 1 and a.off[0] == 0
+
+
+@pytest.mark.skipif(_have_gpu(), reason="needs a machine WITHOUT a GPU")
+def test_no_gpu_fails_loudly():
+    lib = _abi.load_library()
+    args = VcfglArgs(seed=1, depth=3, error_rate=0.01)
+    p, _ = args.to_struct(4)
+    ctx = C.c_void_p()
+    rc = lib.vgl_ctx_create(C.byref(p), 0, 16, C.byref(ctx))
+    assert rc == _abi.VGL_E_NODEVICE and not ctx.value
+    assert b"no CPU path" in lib.vgl_last_error() or b"hip" in lib.vgl_last_error().lower()
+
+
+def test_flag_parser_matches_reference_surface():
+    a = VcfglArgs.from_argv("--seed 42 -d 4 -e 0.01 -GL 1 -doUnobserved 2 -addPL 1 -addFormatAD 1 --adjust-qs 1".split()).validate()
+    assert (a.seed, a.depth, a.error_rate, a.gl_model, a.do_unobserved, a.add_pl, a.add_fmt_ad) == (42, 4.0, 0.01, 1, 2, 1, 1)
+    assert a.add_gl == 1 and a.add_fmt_dp == 1 and a.gl1_theta == 0.83 and a.adjust_by == 0.499   # io.cpp:428-526 defaults
+    with pytest.raises(VcfglArgError):
+        VcfglArgs.from_argv("--seed 1 -d 4".split()).validate()                      # error rate required
+    with pytest.raises(VcfglArgError):
+        VcfglArgs.from_argv("-d 4 -e 0.1 --gl-model 1 --precise-gl 1".split()).validate()
+    with pytest.raises(VcfglArgError):
+        VcfglArgs.from_argv("-d 4 -e 0.1 --error-qs 2".split()).validate()           # beta variance required
+    with pytest.raises(VcfglArgError):
+        VcfglArgs.from_argv("-d 4 -e 1.0".split()).validate()                        # [0,1)

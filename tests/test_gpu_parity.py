@@ -1,0 +1,210 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle on identical seeded inputs,
+VGL_RNG_TILE addressing.  Integer fields must be bit-exact.  GL is bit-exact wherever the
+per-read terms come from constants or the qScore LUT; where a per-read log10()/pow() is
+evaluated on the device (precise-gl 1, GP) the north-star tolerance of 1e-6 applies."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+import synth
+from vcfgl_amd import Simulator, VcfglArgs, _abi
+
+pytestmark = pytest.mark.gpu
+
+INT_FIELDS = ["site_status", "n_alleles", "n_alleles_obs", "alleles2acgt", "info_dp", "info_ad", "info_adf",
+              "info_adr", "fmt_dp", "pl", "fmt_ad", "fmt_adf", "fmt_adr"]
+TOL = 1e-6
+
+
+def run_both(oracle, args, gt, site0=0, read_capacity=0, max_sites=None):
+    args.rng_mode, args.beta_sampler = _abi.VGL_RNG_TILE, _abi.VGL_BETA_RAND48
+    n_sites, N = gt.shape
+    o = oracle.Oracle(args, N)
+    want = o.simulate(site0, gt, read_capacity=read_capacity)
+    sim = Simulator(args, N, device=0, max_sites_per_tile=max_sites or max(n_sites, 1))
+    got = sim.simulate(site0, gt, read_capacity=read_capacity)
+    sim.close()
+    return want, got
+
+
+def assert_parity(want, got, exact_gl=True, i16=False, qs=True, check_gp=True):
+    for f in INT_FIELDS:
+        assert np.array_equal(want.numpy(f), got.numpy(f)), f
+    wgl, ggl = want.numpy("gl"), got.numpy("gl")
+    wb, gb = wgl.view(np.uint32), ggl.view(np.uint32)
+    miss = wb == _abi.FLOAT_MISSING_BITS
+    assert np.array_equal(miss, gb == _abi.FLOAT_MISSING_BITS), "GL missing pattern"
+    if exact_gl:
+        assert np.array_equal(wb, gb), f"GL not bit-exact: {np.sum(wb != gb)} of {wb.size} differ"
+    else:
+        a, b = wgl[~miss].astype(np.float64), ggl[~miss].astype(np.float64)
+        fin = np.isfinite(a)
+        assert np.array_equal(fin, np.isfinite(b)) and np.array_equal(a[~fin], b[~fin])
+        assert np.all(np.abs(a[fin] - b[fin]) <= TOL * np.maximum(1.0, np.abs(a[fin])))
+    if check_gp:
+        wgp, ggp = want.numpy("gp"), got.numpy("gp")
+        m = wgp.view(np.uint32) == _abi.FLOAT_MISSING_BITS
+        assert np.array_equal(m, ggp.view(np.uint32) == _abi.FLOAT_MISSING_BITS)
+        assert np.all(np.abs(wgp[~m].astype(np.float64) - ggp[~m].astype(np.float64)) <= TOL)
+    if qs:
+        assert np.array_equal(want.numpy("qs").view(np.uint32), got.numpy("qs").view(np.uint32)), "QS"
+    if i16:
+        assert np.array_equal(want.numpy("i16")[:, :12], got.numpy("i16")[:, :12]), "I16[0..11]"
+
+
+ALLTAGS = dict(add_gp=1, add_pl=1, add_qs=1, add_info_dp=1, add_fmt_ad=1, add_info_ad=1)
+STRAND = dict(add_i16=1, add_fmt_adf=1, add_info_adf=1, add_fmt_adr=1, add_info_adr=1)
+
+
+@pytest.mark.parametrize("N,n_sites", [(1, 5), (2, 7), (63, 9), (64, 9), (65, 9), (100, 40), (257, 11), (1000, 6)])
+def test_gl2_fixed_q_shapes(oracle, N, n_sites):
+    """ragged shapes: N below / at / above the 64-lane wavefront, single sample, many waves per site"""
+    args = VcfglArgs(seed=42, depth=10, error_rate=0.01, **ALLTAGS)
+    want, got = run_both(oracle, args, synth.binary_sites(3, n_sites, N), site0=3)
+    assert_parity(want, got)
+
+
+@pytest.mark.parametrize("depth", [0.0, 0.1, 2, 11.99, 12, 20, 30, 100])
+def test_depth_branches(oracle, depth):
+    """Poisson product branch (<12), rejection branch (>=12), empty sites (depth 0)"""
+    args = VcfglArgs(seed=7, depth=depth, error_rate=0.002, **ALLTAGS)
+    want, got = run_both(oracle, args, synth.binary_sites(0, 24, 130))
+    assert_parity(want, got)
+    if depth == 0.0:
+        assert (got.numpy("site_status") == _abi.VGL_SITE_NO_READS).all()
+
+
+@pytest.mark.parametrize("du", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("rm", [(0, 0), (4, 1)])
+def test_unobserved_and_skip_modes(oracle, du, rm):
+    args = VcfglArgs(seed=11, depth=1.2, error_rate=0.05, do_unobserved=du, rm_invar_sites=rm[0], rm_empty_sites=rm[1], **ALLTAGS)
+    want, got = run_both(oracle, args, synth.acgt_sites(60, 5, seed=du, missing=0.1))
+    assert_parity(want, got)
+
+
+@pytest.mark.parametrize("e", [0.0, 0.2, 0.9])
+def test_error_rates_incl_low_qscore(oracle, e):
+    """e=0 -> q 63; e=0.9 -> q 0 (homT = -inf in the LUT)"""
+    args = VcfglArgs(seed=5, depth=6, error_rate=e, **ALLTAGS)
+    want, got = run_both(oracle, args, synth.acgt_sites(40, 70, seed=3))
+    assert_parity(want, got, check_gp=(e != 0.9))
+
+
+def test_strand_i16_adf_adr(oracle):
+    args = VcfglArgs(seed=42, depth=5, error_rate=0.02, adjust_qs=3, **ALLTAGS, **STRAND)
+    want, got = run_both(oracle, args, synth.acgt_sites(50, 66, seed=9, missing=0.05))
+    assert_parity(want, got, i16=True)
+
+
+@pytest.mark.parametrize("precise", [0, 1])
+@pytest.mark.parametrize("adj", [0, 3])
+def test_error_qs2_beta_quality_scores(oracle, precise, adj):
+    if precise and (adj & 1):
+        pytest.skip("--adjust-qs 1 requires --precise-gl 0 (io.cpp)")
+    args = VcfglArgs(seed=42, depth=8, error_rate=0.01, error_qs=2, beta_variance=1e-5, precise_gl=precise,
+                     adjust_qs=adj, **ALLTAGS)
+    want, got = run_both(oracle, args, synth.binary_sites(0, 30, 100), read_capacity=40)
+    assert np.array_equal(want.numpy("reads"), got.numpy("reads")), "per-read base / qscore dump"
+    assert_parity(want, got, exact_gl=not precise)
+
+
+def test_error_qs2_alpha_below_one(oracle):
+    """beta(0.4, 0.1): alpha < 1 branch of the gamma sampler (pow)"""
+    args = VcfglArgs(seed=3, depth=4, error_rate=0.4, error_qs=2, beta_variance=0.1, **ALLTAGS)
+    want, got = run_both(oracle, args, synth.binary_sites(0, 20, 64), read_capacity=24)
+    assert np.mean(want.numpy("reads") == got.numpy("reads")) > 0.999
+    assert np.array_equal(want.numpy("fmt_dp"), got.numpy("fmt_dp"))
+
+
+def test_error_qs1_site_level_beta(oracle):
+    args = VcfglArgs(seed=42, depth=6, error_rate=0.05, error_qs=1, beta_variance=1e-3, **ALLTAGS)
+    want, got = run_both(oracle, args, synth.binary_sites(0, 40, 90))
+    assert_parity(want, got)
+
+
+def test_qs_bins(oracle):
+    bins = [(0, 2, 2), (3, 14, 12), (15, 30, 23), (31, 40, 37)]
+    args = VcfglArgs(seed=42, depth=8, error_rate=0.01, error_qs=2, beta_variance=1e-5, qs_bins=bins, adjust_qs=3, **ALLTAGS)
+    want, got = run_both(oracle, args, synth.binary_sites(0, 20, 100))
+    assert_parity(want, got)
+
+
+def test_per_sample_depths(oracle):
+    N = 70
+    depths = [0.1, 10, 25, 3] * 17 + [0.0, 40.0]
+    args = VcfglArgs(seed=42, depths=depths, error_rate=0.01, **ALLTAGS)
+    want, got = run_both(oracle, args, synth.binary_sites(0, 30, N))
+    assert_parity(want, got)
+
+
+@pytest.mark.parametrize("depth,du", [(1, 1), (10, 2), (30, 3)])
+def test_gl_model1_fixed_q(oracle, depth, du):
+    """config C2 family: -GL 1 (errmod) with one fixed qScore"""
+    args = VcfglArgs(seed=42, depth=depth, error_rate=0.01, gl_model=1, do_unobserved=du, adjust_qs=1, **ALLTAGS)
+    want, got = run_both(oracle, args, synth.binary_sites(0, 50, 100))
+    assert_parity(want, got)
+
+
+def test_site_index_invariance(oracle):
+    """tiles are addressed by absolute site index: splitting a run into tiles (or shards)
+    does not change any value"""
+    args = VcfglArgs(seed=42, depth=10, error_rate=0.01, **ALLTAGS)
+    gt = synth.binary_sites(0, 64, 100)
+    N = 100
+    sim = Simulator(args, N, max_sites_per_tile=64)
+    whole = sim.simulate(0, gt)
+    a = sim.simulate(0, gt[:20])
+    b = sim.simulate(20, gt[20:])
+    sim.close()
+    for f in ["fmt_dp", "gl", "pl", "fmt_ad", "info_ad", "alleles2acgt"]:
+        assert np.array_equal(whole.numpy(f), np.concatenate([a.numpy(f), b.numpy(f)])), f
+
+
+@pytest.mark.parametrize("name", ["test2", "test5", "test12", "test14", "test17", "test18"])
+def test_reference_inputs_tile_mode(oracle, name):
+    """the reference's own test inputs and flags (error-qs 0 cases), counter-addressed streams"""
+    args, vcf, sites, gold = gu.load_case(name, rng_mode=_abi.VGL_RNG_TILE, beta_sampler=_abi.VGL_BETA_RAND48)
+    gt = np.stack([s.gt for s in sites])
+    want, got = run_both(oracle, args, gt)
+    assert_parity(want, got, i16=bool(args.add_i16), qs=bool(args.add_qs), check_gp=bool(args.add_gp))
+
+
+def test_first_evaluation_equals_reference_stream(oracle):
+    """site 0 / sample 0 starts every stream at the reference's initial state, so its depth
+    equals the reference's first depth draw: 85 for --depth 100 --seed 42 (test/reference/test18)."""
+    args = VcfglArgs(seed=42, depth=100, error_rate=0.0, do_unobserved=5)
+    sim = Simulator(args, 2, max_sites_per_tile=4)
+    t = sim.simulate(0, np.zeros((1, 2), np.uint8))
+    sim.close()
+    assert t.numpy("fmt_dp")[0, 0] == 85
+
+
+def test_device_buffers_and_stream(oracle):
+    """device variant of the ABI: torch owns GT / outputs, launch on a side stream"""
+    import torch
+    args = VcfglArgs(seed=42, depth=10, error_rate=0.01, add_pl=1)
+    args.rng_mode = _abi.VGL_RNG_TILE
+    N, S = 200, 33
+    gt = synth.binary_sites(0, S, N)
+    sim = Simulator(args, N, max_sites_per_tile=S)
+    tile = sim.new_tile(S, fields=["fmt_dp", "gl", "pl"], device="cuda:0")
+    st = torch.cuda.Stream()
+    dgt = torch.from_numpy(gt).to("cuda:0")
+    torch.cuda.synchronize()
+    sim.simulate_device(0, dgt, tile, stream=st.cuda_stream)
+    sim.check(stream=st.cuda_stream)
+    host = sim.simulate(0, gt, fields=["fmt_dp", "gl", "pl"])
+    sim.close()
+    for f in ["fmt_dp", "gl", "pl", "n_alleles"]:
+        assert np.array_equal(tile.numpy(f), host.numpy(f)), f
+
+
+def test_capacity_overflow_is_reported(oracle):
+    """a depth beyond the staging capacity must surface as VGL_E_CAPACITY, not as wrong data"""
+    from vcfgl_amd import VglError
+    args = VcfglArgs(seed=42, depths=[0.0, 400.0], error_rate=0.01)
+    sim = Simulator(args, 2, max_sites_per_tile=4)
+    sim.dp_cap = None
+    t = sim.simulate(0, np.zeros((2, 2), np.uint8))
+    assert t.numpy("fmt_dp")[:, 1].min() > 300        # capacity is sized from the largest mean
+    sim.close()

@@ -1,0 +1,103 @@
+// vgl_device.h -- structures shared by the host side of the C ABI (vgl_host.cpp) and the
+// gfx950 kernels (vgl_kernels.hip).
+#pragma once
+#include <stdint.h>
+
+#define VGL_MASK48 0xFFFFFFFFFFFFULL
+#define VGL_LCG_A  0x5DEECE66DULL
+#define VGL_LCG_C  0xBULL
+#define VGL_WAVE   64
+#define VGL_MAX_QS_BINS 32
+
+// x -> a*x + c (mod 2^48): a power of the rand48 step
+struct VglAffine { uint64_t a, c; };
+
+// PoissonSampler (rng.h:249-280), one per run or one per sample
+struct VglPois { double lm, sq, alxm, g; int32_t st12; int32_t pad; };
+
+// Gamma1Sampler (rng.h:122-173)
+struct VglGamma1 { double alpha0, a1, a2; int32_t changed; int32_t pad; };
+
+// Device error flag bits (sticky, OR-ed by kernels)
+#define VGL_DEVERR_CAPACITY 1u
+#define VGL_DEVERR_QSBIN    2u
+#define VGL_DEVERR_GL1DEPTH 4u
+
+// per-site accumulator layout (int32 x 16): [0] INFO/DP, [1..4] ACGT depth,
+// [5..8] forward-strand ACGT depth, [9..12] reverse-strand ACGT depth
+#define VGL_ACC_STRIDE 16
+
+// per-site record produced by k_site for k_gl (one 16-byte row)
+struct VglSiteInfo {
+    int32_t status;
+    int32_t n_alleles;
+    uint32_t acgt2alleles;   // 5 nibbles (A,C,G,T,NONREF), 0xF = not present
+    uint32_t alleles2acgt;   // 5 nibbles, 0xF = none, 4 = NONREF
+};
+
+struct VglDevParams {
+    // geometry
+    int32_t n_samples;       // N
+    int32_t chunks;          // ceil(N / 64): wavefronts per site
+    int32_t A, G;            // max alleles / genotypes of the tile layout
+    int32_t read_cap;        // staged reads per (site,sample)
+    // flags
+    int32_t error_qs, gl_model, precise_gl, adjust_qs, n_qs_bins, do_unobserved;
+    int32_t rm_invar_sites, rm_empty_sites, sample_strand, per_sample_depth;
+    int32_t need_qsum, need_qsumsq, need_adf, i16_mapq;
+    int32_t add_i16;
+    int32_t pre_q, pre_adjq;           // preCalc qScore / adj_qScore (vcfgl.cpp:1697-1702)
+    double  adjust_by;
+    double  pre_homT, pre_het, pre_homF;
+    uint64_t err_thresh;               // ceil(error_rate * 2^48): u < e  <=>  X < err_thresh
+    // rand48 addressing
+    uint64_t x0;
+    VglAffine off[4];                  // J^(off[k])
+    VglAffine site_pow[40];            // J^(block * N * 2^b)
+    const VglAffine* samp_tab;         // [N] J^(block * s)
+    // samplers
+    VglPois pois0;
+    const VglPois* pois;               // [N] when per_sample_depth
+    VglGamma1 gx, gy;
+    int32_t qs_bins[VGL_MAX_QS_BINS * 3];
+    // tables
+    const double* q2gl;                // [3][257]
+    const double* gl1_bsum;            // [256][256]  sum_{i<c} fk[i]*beta[q][n][i]   (fixed qScore)
+    const double* gl1_lhet;            // [256][256]
+};
+
+// per-tile pointers
+struct VglTilePtrs {
+    int64_t site0;
+    int32_t n_sites;
+    const uint8_t* gt;
+    // staging / scratch (ctx owned)
+    uint8_t* reads;          // [read_cap][n_sites][N]
+    double*  errp;           // [read_cap][n_sites][N]   (precise_gl with error_qs 2)
+    uint64_t* ad4;           // [n_sites][N]  4 x u16 ACGT depth
+    uint64_t* adf4;          // [n_sites][N]  4 x u16 forward-strand depth
+    uint32_t* qsum;          // [n_sites][4][N]
+    uint32_t* qsumsq;        // [n_sites][4][N]
+    int32_t*  acc;           // [n_sites][16]
+    VglSiteInfo* sinfo;      // [n_sites]
+    uint32_t* errflag;
+    // outputs (caller owned device memory; may be null)
+    int32_t* site_status; int32_t* n_alleles; int32_t* n_alleles_obs; int8_t* alleles2acgt;
+    int32_t* info_dp; int32_t* info_ad; int32_t* info_adf; int32_t* info_adr;
+    float* qs; float* i16;
+    int32_t* fmt_dp; float* gl; int32_t* pl; float* gp;
+    int32_t* fmt_ad; int32_t* fmt_adf; int32_t* fmt_adr;
+    uint8_t* reads_out; int32_t reads_out_cap;
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+// launch wrappers implemented in vgl_kernels.hip (stream = hipStream_t)
+int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, void* stream);
+int vgl_launch_site(const VglDevParams* p, const VglTilePtrs* t, void* stream);
+int vgl_launch_gl(const VglDevParams* p, const VglTilePtrs* t, void* stream);
+int vgl_launch_siteagg(const VglDevParams* p, const VglTilePtrs* t, void* stream);
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,481 @@
+// vgl_host.cpp -- host side of the C ABI declared in include/vcfgl_hip.h.
+// Builds the constant tables a run needs (Poisson constants, beta shape parameters,
+// fixed-qscore terms, qScore LUT, GL-model-1 error-model tables, rand48 jump tables),
+// owns the device workspace, and enqueues the gfx950 kernels of vgl_kernels.hip.
+// There is no CPU compute path in this library.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/vcfgl_hip.h"
+#include "vgl_device.h"
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+    return code;
+}
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? VGL_E_NOMEM : VGL_E_NODEVICE, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
+
+extern "C" const char* vgl_last_error(void) { return g_err; }
+extern "C" int vgl_abi_version(void) { return VGL_ABI_VERSION; }
+
+// PROGRAM_WILL_ADD_UNOBSERVED (shared.h:151-152): <*> / <NON_REF> appended => 5 alleles
+extern "C" int32_t vgl_max_alleles(const vgl_params* p) {
+    const int d = p->do_unobserved;
+    return (d == 1 || d == 2 || d == 4 || d == 5) ? 5 : 4;
+}
+extern "C" int32_t vgl_max_genotypes(const vgl_params* p) { return vgl_max_alleles(p) == 5 ? 15 : 10; }
+
+static double max_depth(const vgl_params* p) {
+    double dmax = p->depth;
+    if (p->depths) { dmax = 0; for (int i = 0; i < p->n_samples; i++) if (p->depths[i] > dmax) dmax = p->depths[i]; }
+    if (!(dmax >= 0)) dmax = 0;
+    return dmax;
+}
+
+extern "C" int vgl_default_rng_layout(const vgl_params* p, vgl_rng_layout* out) {
+    if (!p || !out) return fail(VGL_E_ARG, "null argument");
+    const uint64_t d = (uint64_t)ceil(max_depth(p));
+    const uint64_t s0 = 64;                                   // depth draws (Poisson)
+    const uint64_t s1 = 4 * d + 64;                           // one haplotype draw per read
+    const uint64_t s2 = 3 * s1;                               // error test + wrong base + strand
+    const uint64_t s3 = (p->error_qs == 2) ? 32 * s1 : 64;    // beta deviates
+    out->off[0] = 0; out->off[1] = s0; out->off[2] = s0 + s1; out->off[3] = s0 + s1 + s2;
+    out->block = (s0 + s1 + s2 + s3) | 1;
+    return VGL_OK;
+}
+
+// ---- rand48 affine powers ---------------------------------------------------------------
+static VglAffine aff_compose(VglAffine f, VglAffine g) {      // f after g
+    VglAffine r; r.a = (f.a * g.a) & VGL_MASK48; r.c = (f.a * g.c + f.c) & VGL_MASK48; return r;
+}
+static VglAffine aff_pow(uint64_t n) {                        // J^n, J = one rand48 step
+    VglAffine base = {VGL_LCG_A, VGL_LCG_C}, r = {1, 0};
+    while (n) { if (n & 1) r = aff_compose(base, r); base = aff_compose(base, base); n >>= 1; }
+    return r;
+}
+static VglAffine aff_pow_of(VglAffine base, uint64_t n) {
+    VglAffine r = {1, 0};
+    while (n) { if (n & 1) r = aff_compose(base, r); base = aff_compose(base, base); n >>= 1; }
+    return r;
+}
+
+// ---- qScore -> log10 GL terms: shared.cpp:110-114 lists them with 7 significant digits
+// (generator: shared.h:512-527); the same doubles are obtained by rounding the formula.
+static double round7(double v) {
+    if (isinf(v) || v == 0.0) return v;
+    char buf[64]; snprintf(buf, sizeof buf, "%.7g", v);
+    return strtod(buf, NULL);
+}
+static void build_q2gl(double* t /*[3][257]*/) {
+    for (int q = 0; q <= 256; q++) {
+        const double p = pow(10.0, -q / 10.0);
+        t[q] = round7(log10(1.0 - p));
+        t[257 + q] = round7(log10((1.0 - p) / 2.0 + p / 6.0));
+        t[514 + q] = round7(log10(p) - log10(3.0));
+    }
+}
+
+// ---- GL model 1 tables (htslib errmod.c cal_coef(), restated from the published model) --
+// For one fixed qScore q the per-base sums of errmod_cal() depend only on (n, count):
+//   bsum[n][c] = sum_{i<c} fk[i] * beta[q][n][i],   lhet[n][k] = lC[n][k] - n ln 2
+static void build_gl1_tables(double depcorr, int q, std::vector<double>& bsum, std::vector<double>& lhet) {
+    const double eta = 0.03;
+    double fk[256];
+    fk[0] = 1.0;
+    for (int n = 1; n != 256; ++n) fk[n] = pow(1. - depcorr, n) * (1.0 - eta) + eta;
+    std::vector<double> lC(256 * 256, 0.0), beta(256, 0.0);
+    for (int n = 1; n <= 255; ++n)
+        for (int k = 1; k <= n; ++k)
+            lC[n << 8 | k] = lgamma(n + 1) - lgamma(k + 1) - lgamma(n - k + 1);
+    bsum.assign(256 * 256, 0.0);
+    lhet.assign(256 * 256, 0.0);
+    int qq = q < 4 ? 4 : q; if (qq > 63) qq = 63;              // errmod_cal clamps qual to [4,63]
+    const double e = pow(10.0, -qq / 10.0), le = log(e), le1 = log(1.0 - e);
+    for (int n = 1; n <= 255; ++n) {
+        double sum, sum1 = lC[n << 8 | n] + n * le;
+        beta[n] = HUGE_VAL;
+        for (int k = n - 1; k >= 0; --k, sum1 = sum) {
+            sum = sum1 + log1p(exp(lC[n << 8 | k] + k * le + (n - k) * le1 - sum1));
+            beta[k] = -10. / M_LN10 * (sum1 - sum);
+        }
+        double acc = 0.0;
+        bsum[n * 256 + 0] = 0.0;
+        for (int c = 1; c <= n; ++c) { acc += fk[c - 1] * beta[c - 1]; bsum[n * 256 + c] = acc; }
+    }
+    for (int n = 0; n < 256; ++n)
+        for (int k = 0; k < 256; ++k) lhet[n << 8 | k] = lC[n << 8 | k] - M_LN2 * n;
+}
+
+// ---- context ---------------------------------------------------------------------------
+struct vgl_ctx {
+    vgl_params p;
+    int device;
+    int max_sites;
+    VglDevParams dp;
+    // device tables
+    VglAffine* d_samp_tab = nullptr; VglPois* d_pois = nullptr;
+    double* d_q2gl = nullptr; double* d_gl1_bsum = nullptr; double* d_gl1_lhet = nullptr;
+    // workspace
+    uint8_t* d_reads = nullptr; double* d_errp = nullptr; uint64_t* d_ad4 = nullptr; uint64_t* d_adf4 = nullptr;
+    uint32_t* d_qsum = nullptr; uint32_t* d_qsumsq = nullptr; int32_t* d_acc = nullptr; VglSiteInfo* d_sinfo = nullptr;
+    uint32_t* d_errflag = nullptr;
+    // host-variant mirrors
+    uint8_t* d_gt = nullptr; void* d_out[17] = {nullptr}; size_t d_out_bytes[17] = {0};
+    uint8_t* d_reads_out = nullptr; size_t d_reads_out_bytes = 0;
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev;     // groups of 4
+    double ms[3] = {0, 0, 0}; int64_t launches[3] = {0, 0, 0};
+};
+
+static int errprob_to_qs_fixed(const vgl_params* p, double ep, int* qs, int* adjqs) {
+    // vcfgl.cpp:1668-1694
+    const int adj = p->adjust_qs != 0;
+    int q = -1, aq = -1;
+    if (0.0 == ep) { q = 63; aq = 63; }
+    else if (1.0 == ep) { q = 0; aq = 0; }
+    else if (0.0 < ep && ep < 1.0) {
+        const double tmp = -10.0 * log10(ep);
+        q = (int)tmp;
+        if (adj) aq = (int)(tmp + p->adjust_by);
+    } else return fail(VGL_E_ARG, "Bad error probability value: %f", ep);
+    auto bins = [&](int in, int* out) -> int {
+        for (int i = 0; i < p->n_qs_bins; ++i)
+            if (in >= p->qs_bins[3 * i] && in <= p->qs_bins[3 * i + 1]) { *out = p->qs_bins[3 * i + 2]; return 0; }
+        return fail(VGL_E_QSBIN, "Could not find a range for qs value %d", in);
+    };
+    if (p->n_qs_bins != 0) {
+        int r = bins(q, &q); if (r) return r;
+        if (adj) { r = bins(aq, &aq); if (r) return r; }
+    } else {
+        q = q > 63 ? 63 : q;
+        if (adj) aq = aq > 63 ? 63 : aq;
+    }
+    if (!adj) aq = -1;
+    *qs = q; *adjqs = aq;
+    return VGL_OK;
+}
+
+static void pois_init(VglPois* o, double lambda) {            // PoissonSampler_init, rng.h:259-280
+    o->lm = lambda; o->sq = -1.0; o->alxm = -1.0; o->g = -1.0; o->st12 = 1; o->pad = 0;
+    if (lambda < 12.0) o->g = exp(-lambda);
+    else {
+        o->st12 = 0; o->sq = sqrt(2.0 * lambda); o->alxm = log(lambda);
+        // gamma_ln (rng.h:60-64)
+        static const double cof[6] = {76.18009172947146, -86.50532032941677, 24.01409824083091,
+                                      -1.231739572450155, 0.1208650973866179e-2, -0.5395239384953e-5};
+        double x = lambda + 1.0, y = x, tmp = x + 5.5;
+        tmp -= (x + 0.5) * log(tmp);
+        double ser = 1.000000000190015;
+        for (int j = 0; j <= 5; j++) ser += cof[j] / ++y;
+        o->g = lambda * o->alxm - (-tmp + log(2.5066282746310005 * ser / x));
+    }
+}
+
+static void gamma1_init(VglGamma1* g, double shape) {         // Gamma1Sampler_init, rng.h:155-173
+    double alpha = shape;
+    g->alpha0 = shape; g->changed = 0; g->pad = 0;
+    if (alpha < 1.0) { alpha += 1.0; g->changed = 1; }
+    g->a1 = alpha - 1.0 / 3.0;
+    g->a2 = 1.0 / sqrt(9. * g->a1);
+}
+
+template <typename T> static int dmalloc(T** p, size_t n) {
+    if (n == 0) n = 1;
+    HIPCHK(hipMalloc((void**)p, n * sizeof(T)));
+    return VGL_OK;
+}
+
+extern "C" int vgl_ctx_destroy(vgl_ctx* c) {
+    if (!c) return VGL_OK;
+    (void)hipSetDevice(c->device);
+    void* ptrs[] = {c->d_samp_tab, c->d_pois, c->d_q2gl, c->d_gl1_bsum, c->d_gl1_lhet, c->d_reads, c->d_errp, c->d_ad4,
+                    c->d_adf4, c->d_qsum, c->d_qsumsq, c->d_acc, c->d_sinfo, c->d_errflag, c->d_gt, c->d_reads_out};
+    for (void* q : ptrs) if (q) (void)hipFree(q);
+    for (void* q : c->d_out) if (q) (void)hipFree(q);
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    delete c;
+    return VGL_OK;
+}
+
+extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_sites, vgl_ctx** out) {
+    if (!p || !out) return fail(VGL_E_ARG, "null argument");
+    *out = nullptr;
+    if (p->abi_version != VGL_ABI_VERSION) return fail(VGL_E_ARG, "abi version mismatch");
+    if (p->n_samples <= 0) return fail(VGL_E_ARG, "n_samples must be positive");
+    if (max_sites <= 0) return fail(VGL_E_ARG, "max_sites_per_tile must be positive");
+    if (p->gl_model != 1 && p->gl_model != 2) return fail(VGL_E_ARG, "[Bad argument value: '--gl-model %d'] Allowed range is [1,2]", p->gl_model);
+    if (p->error_qs < 0 || p->error_qs > 2) return fail(VGL_E_ARG, "[Bad argument value: '--error-qs %d'] Allowed range is [0,2]", p->error_qs);
+    if (p->do_unobserved < 0 || p->do_unobserved > 5) return fail(VGL_E_ARG, "[Bad argument value: '-doUnobserved %d'] Allowed range is [0,5]", p->do_unobserved);
+    if (!(p->error_rate >= 0.0 && p->error_rate < 1.0)) return fail(VGL_E_ARG, "[Bad argument value: '--error-rate %f'] Allowed range is [0,1)", p->error_rate);
+    if (p->n_qs_bins < 0 || p->n_qs_bins > VGL_MAX_QS_BINS) return fail(VGL_E_ARG, "at most %d qs bins are supported", VGL_MAX_QS_BINS);
+    if (p->gl_model == 1 && p->precise_gl) return fail(VGL_E_ARG, "Precise genotype likelihood error (--precise-gl 1) is not supported with genotype likelihood model 1 (--gl-model 1).");
+    if (p->rng_mode != VGL_RNG_TILE) return fail(VGL_E_UNSUPPORTED, "the device path implements VGL_RNG_TILE (counter-addressed windows) only");
+    if (p->error_qs != 0 && p->beta_sampler != VGL_BETA_RAND48) return fail(VGL_E_UNSUPPORTED, "the mt19937 beta sampler is one global serial stream; the device path uses the rand48 sampler (VGL_BETA_RAND48)");
+    if (p->gl_model == 1 && p->error_qs == 2) return fail(VGL_E_UNSUPPORTED, "GL model 1 with per-read quality scores is not implemented on the device yet");
+    const double dmax = max_depth(p);
+    if (p->depths) { for (int i = 0; i < p->n_samples; i++) if (!(p->depths[i] >= 0.0)) return fail(VGL_E_ARG, "depths must be >= 0"); }
+    else if (!(p->depth >= 0.0)) return fail(VGL_E_ARG, "[Bad argument value: '--depth %f'] Allowed range is [0,500]", p->depth);
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(VGL_E_NODEVICE, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(VGL_E_NODEVICE, "device %d out of range (%d devices)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+
+    vgl_ctx* c = new vgl_ctx();
+    c->p = *p; c->p.depths = nullptr; c->p.qs_bins = nullptr;
+    c->device = device; c->max_sites = max_sites;
+    VglDevParams& D = c->dp;
+    memset(&D, 0, sizeof D);
+    const int N = p->n_samples;
+    D.n_samples = N; D.chunks = (N + 63) / 64;
+    D.A = vgl_max_alleles(p); D.G = vgl_max_genotypes(p);
+    int cap = (int)ceil(dmax + 8.0 * sqrt(dmax) + 16.0);
+    D.read_cap = (cap + 3) & ~3;
+    D.error_qs = p->error_qs; D.gl_model = p->gl_model; D.precise_gl = p->precise_gl; D.adjust_qs = p->adjust_qs;
+    D.n_qs_bins = p->n_qs_bins; D.do_unobserved = p->do_unobserved; D.rm_invar_sites = p->rm_invar_sites;
+    D.rm_empty_sites = p->rm_empty_sites;
+    D.sample_strand = (p->add_i16 || p->add_fmt_adf || p->add_fmt_adr || p->add_info_adf || p->add_info_adr) ? 1 : 0;  // shared.h:160-161
+    D.per_sample_depth = p->depths ? 1 : 0;
+    D.need_qsum = (p->add_qs || p->add_i16) ? 1 : 0; D.need_qsumsq = p->add_i16 ? 1 : 0; D.need_adf = D.sample_strand;
+    D.i16_mapq = p->i16_mapq; D.add_i16 = p->add_i16;
+    D.adjust_by = p->adjust_by;
+    for (int i = 0; i < p->n_qs_bins * 3; i++) D.qs_bins[i] = p->qs_bins[i];
+    D.err_thresh = (uint64_t)ceil(ldexp(p->error_rate, 48));
+
+    int rc = VGL_OK;
+    std::vector<double> q2gl(3 * 257);
+    build_q2gl(q2gl.data());
+    D.pre_q = D.pre_adjq = -1;
+    if (p->error_qs == 0 || p->error_qs == 1) {                  // preCalc, vcfgl.cpp:1661-1743
+        if ((rc = errprob_to_qs_fixed(p, p->error_rate, &D.pre_q, &D.pre_adjq))) { vgl_ctx_destroy(c); return rc; }
+        if (p->gl_model == 2) {
+            if (!p->precise_gl) {
+                const int q = (p->adjust_qs & 1) ? D.pre_adjq : D.pre_q;
+                D.pre_homT = q2gl[q]; D.pre_het = q2gl[257 + q]; D.pre_homF = q2gl[514 + q];
+            } else {
+                const double e = p->error_rate;
+                if (0.0 == e) { D.pre_homT = 0; D.pre_het = -0.3010299956639812; D.pre_homF = -INFINITY; }
+                else { D.pre_homT = log10(1.0 - e); D.pre_het = log10((1.0 - e) / 2.0 + e / 6.0); D.pre_homF = log10(e) - 0.47712125471966244; }
+            }
+        }
+    }
+    if (p->error_qs != 0) {                                       // rng.h:455-477
+        const double mean = p->error_rate, var = p->beta_variance;
+        if (!(mean > 0.0 && mean < 1.0 && var > 0.0)) { vgl_ctx_destroy(c); return fail(VGL_E_ARG, "--error-qs 1 or 2 requires 0 < --error-rate < 1 and --beta-variance > 0"); }
+        const double oom = 1.0 / mean;
+        const double a = (((1.0 - mean) / var) - oom) * pow(mean, 2), b = a * (oom - 1);
+        if (a <= 0.0 || b <= 0.0) { vgl_ctx_destroy(c); return fail(VGL_E_ARG, "Beta shape parameters must be positive (alpha=%f beta=%f); use different --error-rate / --beta-variance", a, b); }
+        gamma1_init(&D.gx, a); gamma1_init(&D.gy, b);
+    }
+    pois_init(&D.pois0, p->depths ? 0.0 : p->depth);
+
+    // rand48 addressing
+    vgl_rng_layout lay;
+    if (p->layout.block) lay = p->layout; else vgl_default_rng_layout(p, &lay);
+    c->p.layout = lay;
+    D.x0 = ((((uint64_t)(uint32_t)p->seed) << 16) | 0x330EULL) & VGL_MASK48;   // io.cpp:1054-1061
+    for (int k = 0; k < 4; k++) D.off[k] = aff_pow(lay.off[k]);
+    const VglAffine jb = aff_pow(lay.block);                       // one evaluation block
+    VglAffine js = aff_pow_of(jb, (uint64_t)N);                    // one site = N blocks
+    for (int b = 0; b < 40; b++) { D.site_pow[b] = js; js = aff_compose(js, js); }
+    std::vector<VglAffine> samp(N);
+    { VglAffine cur = {1, 0}; for (int s = 0; s < N; s++) { samp[s] = cur; cur = aff_compose(jb, cur); } }
+
+#define TRY(x) do { if ((rc = (x))) { vgl_ctx_destroy(c); return rc; } } while (0)
+#define TRYHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { vgl_ctx_destroy(c); return fail(e_ == hipErrorOutOfMemory ? VGL_E_NOMEM : VGL_E_NODEVICE, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
+    TRY(dmalloc(&c->d_samp_tab, (size_t)N));
+    TRYHIP(hipMemcpy(c->d_samp_tab, samp.data(), sizeof(VglAffine) * N, hipMemcpyHostToDevice));
+    D.samp_tab = c->d_samp_tab;
+    if (p->depths) {
+        std::vector<VglPois> pv(N);
+        for (int s = 0; s < N; s++) pois_init(&pv[s], p->depths[s]);
+        TRY(dmalloc(&c->d_pois, (size_t)N));
+        TRYHIP(hipMemcpy(c->d_pois, pv.data(), sizeof(VglPois) * N, hipMemcpyHostToDevice));
+        D.pois = c->d_pois;
+    }
+    TRY(dmalloc(&c->d_q2gl, (size_t)3 * 257));
+    TRYHIP(hipMemcpy(c->d_q2gl, q2gl.data(), sizeof(double) * 3 * 257, hipMemcpyHostToDevice));
+    D.q2gl = c->d_q2gl;
+    if (p->gl_model == 1) {
+        std::vector<double> bsum, lhet;
+        build_gl1_tables(1.0 - p->gl1_theta, (p->adjust_qs & 1) ? D.pre_adjq : D.pre_q, bsum, lhet);   // io.cpp:1276, gl_methods.cpp:318
+        TRY(dmalloc(&c->d_gl1_bsum, bsum.size())); TRY(dmalloc(&c->d_gl1_lhet, lhet.size()));
+        TRYHIP(hipMemcpy(c->d_gl1_bsum, bsum.data(), sizeof(double) * bsum.size(), hipMemcpyHostToDevice));
+        TRYHIP(hipMemcpy(c->d_gl1_lhet, lhet.data(), sizeof(double) * lhet.size(), hipMemcpyHostToDevice));
+        D.gl1_bsum = c->d_gl1_bsum; D.gl1_lhet = c->d_gl1_lhet;
+    }
+    const size_t E = (size_t)max_sites * N;
+    TRY(dmalloc(&c->d_reads, E * D.read_cap));
+    if (p->precise_gl && p->error_qs == 2) TRY(dmalloc(&c->d_errp, E * D.read_cap));
+    TRY(dmalloc(&c->d_ad4, E));
+    if (D.need_adf) TRY(dmalloc(&c->d_adf4, E));
+    if (D.need_qsum) TRY(dmalloc(&c->d_qsum, E * 4));
+    if (D.need_qsumsq) TRY(dmalloc(&c->d_qsumsq, E * 4));
+    TRY(dmalloc(&c->d_acc, (size_t)max_sites * VGL_ACC_STRIDE));
+    TRY(dmalloc(&c->d_sinfo, (size_t)max_sites));
+    TRY(dmalloc(&c->d_errflag, (size_t)1));
+    TRYHIP(hipMemset(c->d_errflag, 0, sizeof(uint32_t)));
+    *out = c;
+    return VGL_OK;
+}
+
+static int resolve_timing(vgl_ctx* c) {
+    for (size_t i = 0; i + 3 < c->ev.size(); i += 4) {
+        HIPCHK(hipEventSynchronize(c->ev[i + 3]));
+        for (int k = 0; k < 3; k++) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, c->ev[i + k], c->ev[i + k + 1]));
+            c->ms[k] += ms; c->launches[k] += 1;
+        }
+    }
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    c->ev.clear();
+    return VGL_OK;
+}
+
+extern "C" int vgl_ctx_timing(vgl_ctx* c, int32_t enable) {
+    if (!c) return fail(VGL_E_ARG, "null ctx");
+    c->timing = enable != 0;
+    return VGL_OK;
+}
+
+extern "C" int vgl_ctx_kernel_ms(vgl_ctx* c, double ms[3], int64_t launches[3], int32_t reset) {
+    if (!c) return fail(VGL_E_ARG, "null ctx");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = resolve_timing(c);
+    if (rc) return rc;
+    for (int k = 0; k < 3; k++) { ms[k] = c->ms[k]; launches[k] = c->launches[k]; }
+    if (reset) for (int k = 0; k < 3; k++) { c->ms[k] = 0; c->launches[k] = 0; }
+    return VGL_OK;
+}
+
+extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sites, const uint8_t* gt,
+                                        vgl_tile_out* o, void* stream) {
+    if (!c || !o) return fail(VGL_E_ARG, "null argument");
+    if (n_sites < 0 || n_sites > c->max_sites) return fail(VGL_E_ARG, "n_sites %d exceeds max_sites_per_tile %d", n_sites, c->max_sites);
+    if (n_sites == 0) return VGL_OK;
+    if (!gt || !o->site_status || !o->n_alleles || !o->alleles2acgt) return fail(VGL_E_ARG, "gt, site_status, n_alleles and alleles2acgt are required");
+    if (site0 < 0) return fail(VGL_E_ARG, "site0 must be >= 0");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const VglDevParams& D = c->dp;
+    VglTilePtrs T;
+    memset(&T, 0, sizeof T);
+    T.site0 = site0; T.n_sites = n_sites; T.gt = gt;
+    T.reads = c->d_reads; T.errp = c->d_errp; T.ad4 = c->d_ad4; T.adf4 = c->d_adf4; T.qsum = c->d_qsum; T.qsumsq = c->d_qsumsq;
+    T.acc = c->d_acc; T.sinfo = c->d_sinfo; T.errflag = c->d_errflag;
+    T.site_status = o->site_status; T.n_alleles = o->n_alleles; T.n_alleles_obs = o->n_alleles_obs; T.alleles2acgt = o->alleles2acgt;
+    T.info_dp = o->info_dp; T.info_ad = o->info_ad; T.info_adf = o->info_adf; T.info_adr = o->info_adr;
+    T.qs = o->qs; T.i16 = o->i16; T.fmt_dp = o->fmt_dp; T.gl = o->gl; T.pl = o->pl; T.gp = o->gp;
+    T.fmt_ad = o->fmt_ad; T.fmt_adf = o->fmt_adf; T.fmt_adr = o->fmt_adr;
+    T.reads_out = o->read_capacity > 0 ? o->reads : nullptr;
+    T.reads_out_cap = o->read_capacity > 0 ? (o->read_capacity < D.read_cap ? o->read_capacity : D.read_cap) : 0;
+    if (o->read_capacity > D.read_cap && o->reads)
+        HIPCHK(hipMemsetAsync(o->reads + (size_t)D.read_cap * n_sites * D.n_samples, 0xFF,
+                              (size_t)(o->read_capacity - D.read_cap) * n_sites * D.n_samples, st));
+    if ((o->qs && !D.need_qsum) || (o->i16 && !D.need_qsumsq))
+        return fail(VGL_E_ARG, "qs / i16 outputs need -addQS / -addI16 in the context parameters");
+
+    hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (c->timing) for (int k = 0; k < 4; k++) HIPCHK(hipEventCreate(&e[k]));
+    HIPCHK(hipMemsetAsync(c->d_acc, 0, sizeof(int32_t) * VGL_ACC_STRIDE * (size_t)n_sites, st));
+    if (c->timing) HIPCHK(hipEventRecord(e[0], st));
+    if (vgl_launch_sample(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_sample launch failed: %s", hipGetErrorString(hipGetLastError()));
+    if (c->timing) HIPCHK(hipEventRecord(e[1], st));
+    if (vgl_launch_site(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_site launch failed");
+    if (c->timing) HIPCHK(hipEventRecord(e[2], st));
+    if (vgl_launch_gl(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_gl launch failed");
+    if (c->timing) HIPCHK(hipEventRecord(e[3], st));
+    if (o->qs || o->i16) if (vgl_launch_siteagg(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_siteagg launch failed");
+    if (c->timing) for (int k = 0; k < 4; k++) c->ev.push_back(e[k]);
+    return VGL_OK;
+}
+
+extern "C" int vgl_ctx_check(vgl_ctx* c, void* stream) {
+    if (!c) return fail(VGL_E_ARG, "null ctx");
+    HIPCHK(hipSetDevice(c->device));
+    uint32_t flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, c->d_errflag, sizeof flag, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (flag) HIPCHK(hipMemsetAsync(c->d_errflag, 0, sizeof flag, (hipStream_t)stream));
+    if (flag & VGL_DEVERR_CAPACITY) return fail(VGL_E_CAPACITY, "a simulated read depth exceeded the staging capacity of %d reads per sample", c->dp.read_cap);
+    if (flag & VGL_DEVERR_QSBIN) return fail(VGL_E_QSBIN, "Could not find a range for a simulated qs value in --qs-bins");
+    if (flag & VGL_DEVERR_GL1DEPTH) return fail(VGL_E_UNSUPPORTED, "GL model 1 with depth > 255 (htslib subsamples with drand48) is not supported");
+    return VGL_OK;
+}
+
+// field table of vgl_tile_out in declaration order: element size and per-tile element count
+struct FieldDesc { size_t off; size_t esz; int kind; };
+enum { K_SITE, K_SITE5, K_SITEA, K_SITE16, K_EVAL, K_PLANEG, K_PLANEA };
+static const FieldDesc FIELDS[17] = {
+    {offsetof(vgl_tile_out, site_status), 4, K_SITE}, {offsetof(vgl_tile_out, n_alleles), 4, K_SITE},
+    {offsetof(vgl_tile_out, n_alleles_obs), 4, K_SITE}, {offsetof(vgl_tile_out, alleles2acgt), 1, K_SITE5},
+    {offsetof(vgl_tile_out, info_dp), 4, K_SITE}, {offsetof(vgl_tile_out, info_ad), 4, K_SITEA},
+    {offsetof(vgl_tile_out, info_adf), 4, K_SITEA}, {offsetof(vgl_tile_out, info_adr), 4, K_SITEA},
+    {offsetof(vgl_tile_out, qs), 4, K_SITEA}, {offsetof(vgl_tile_out, i16), 4, K_SITE16},
+    {offsetof(vgl_tile_out, fmt_dp), 4, K_EVAL}, {offsetof(vgl_tile_out, gl), 4, K_PLANEG},
+    {offsetof(vgl_tile_out, pl), 4, K_PLANEG}, {offsetof(vgl_tile_out, gp), 4, K_PLANEG},
+    {offsetof(vgl_tile_out, fmt_ad), 4, K_PLANEA}, {offsetof(vgl_tile_out, fmt_adf), 4, K_PLANEA},
+    {offsetof(vgl_tile_out, fmt_adr), 4, K_PLANEA},
+};
+static size_t field_count(const vgl_ctx* c, int kind, size_t n_sites) {
+    const size_t N = c->dp.n_samples, A = c->dp.A, G = c->dp.G;
+    switch (kind) {
+        case K_SITE: return n_sites; case K_SITE5: return n_sites * 5; case K_SITEA: return n_sites * A;
+        case K_SITE16: return n_sites * 16; case K_EVAL: return n_sites * N; case K_PLANEG: return n_sites * G * N;
+        default: return n_sites * A * N;
+    }
+}
+
+extern "C" int vgl_simulate_tile(vgl_ctx* c, int64_t site0, int32_t n_sites, const uint8_t* gt, vgl_tile_out* o) {
+    if (!c || !o) return fail(VGL_E_ARG, "null argument");
+    if (n_sites < 0 || n_sites > c->max_sites) return fail(VGL_E_ARG, "n_sites %d exceeds max_sites_per_tile %d", n_sites, c->max_sites);
+    if (n_sites == 0) return VGL_OK;
+    if (!gt) return fail(VGL_E_ARG, "null gt");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t N = c->dp.n_samples;
+    if (!c->d_gt) HIPCHK(hipMalloc((void**)&c->d_gt, (size_t)c->max_sites * N));
+    HIPCHK(hipMemcpy(c->d_gt, gt, (size_t)n_sites * N, hipMemcpyHostToDevice));
+    vgl_tile_out d;
+    memset(&d, 0, sizeof d);
+    for (int f = 0; f < 17; f++) {
+        void* host = *(void**)((char*)o + FIELDS[f].off);
+        if (!host) continue;
+        const size_t need = field_count(c, FIELDS[f].kind, (size_t)c->max_sites) * FIELDS[f].esz;
+        if (c->d_out_bytes[f] < need) {
+            if (c->d_out[f]) (void)hipFree(c->d_out[f]);
+            c->d_out[f] = nullptr; c->d_out_bytes[f] = 0;
+            HIPCHK(hipMalloc(&c->d_out[f], need));
+            c->d_out_bytes[f] = need;
+        }
+        *(void**)((char*)&d + FIELDS[f].off) = c->d_out[f];
+    }
+    if (o->reads && o->read_capacity > 0) {
+        const size_t need = (size_t)o->read_capacity * c->max_sites * N;
+        if (c->d_reads_out_bytes < need) {
+            if (c->d_reads_out) (void)hipFree(c->d_reads_out);
+            c->d_reads_out = nullptr; c->d_reads_out_bytes = 0;
+            HIPCHK(hipMalloc((void**)&c->d_reads_out, need));
+            c->d_reads_out_bytes = need;
+        }
+        d.reads = c->d_reads_out; d.read_capacity = o->read_capacity;
+    }
+    int rc = vgl_simulate_tile_device(c, site0, n_sites, c->d_gt, &d, nullptr);
+    if (rc) return rc;
+    if ((rc = vgl_ctx_check(c, nullptr))) return rc;
+    for (int f = 0; f < 17; f++) {
+        void* host = *(void**)((char*)o + FIELDS[f].off);
+        if (!host) continue;
+        HIPCHK(hipMemcpy(host, c->d_out[f], field_count(c, FIELDS[f].kind, (size_t)n_sites) * FIELDS[f].esz, hipMemcpyDeviceToHost));
+    }
+    if (d.reads) HIPCHK(hipMemcpy(o->reads, d.reads, (size_t)o->read_capacity * n_sites * N, hipMemcpyDeviceToHost));
+    return VGL_OK;
+}

@@ -1,0 +1,576 @@
+// vgl_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the vcfgl genotype-likelihood
+// simulation hot path.  Written for wave64 only; no other target is supported.
+//
+// Work decomposition: one LANE owns one evaluation = one (site, sample); one WAVEFRONT
+// owns 64 consecutive samples of one site, so every per-evaluation global access of a
+// wave is one contiguous segment (structure-of-arrays tiles, sample index fastest).
+//
+//   k_sample   Poisson depth -> per-read haplotype / base-call error / quality score /
+//              strand draws -> per-evaluation ACGT depth; reads staged as 1 byte each in
+//              [read][site][sample] planes; per-site depth sums by DPP wave reduction +
+//              one integer atomic per wave.     (vcfgl.cpp:364-389, 441-640; rng.h)
+//   k_site     per-site allele order / status.  (vcfgl.cpp:396-404, 665-766)
+//   k_gl       genotype likelihoods from the staged reads in the site's allele order,
+//              accumulators in VGPRs, then PL / GP / AD epilogue.
+//                                               (gl_methods.cpp:4-369, vcfgl.cpp:806-970)
+//   k_siteagg  order-dependent per-site float sums (QS, I16).  (vcfgl.cpp:845-898, 982-1074)
+//
+// The float32 accumulation order of the reference is kept exactly (double add rounded to
+// float per genotype per read, float max, float subtract): build with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "vgl_device.h"
+
+#define VGL_PI 3.141592654            // shared.h:37 (not M_PI)
+#define CAP_BASEQ 63                  // shared.h:241
+#define MAXPL 255                     // shared.h:208
+#define F32_MISSING_BITS 0x7F800001u  // bcf_float_missing
+#define I32_MISSING ((int32_t)0x80000000)
+
+#define SITE_OK 0
+#define SITE_SKIP_INVAR (-3)
+#define SITE_SKIP_EMPTY (-4)
+#define SITE_NO_READS 1
+
+// ------------------------------------------------------------------------------------
+// rand48: X <- (A X + C) mod 2^48, u = X 2^-48   (glibc drand48/erand48; rng.h:8-10)
+__device__ __forceinline__ uint64_t lcg_next(uint64_t x) { return (x * VGL_LCG_A + VGL_LCG_C) & VGL_MASK48; }
+__device__ __forceinline__ uint64_t aff(const VglAffine m, uint64_t x) { return (m.a * x + m.c) & VGL_MASK48; }
+__device__ __forceinline__ double u01(uint64_t x) {
+    // exact: x < 2^48
+    return ((double)(uint32_t)(x >> 32) * 4294967296.0 + (double)(uint32_t)x) * (1.0 / 281474976710656.0);
+}
+__device__ __forceinline__ double next_u(uint64_t& st) { st = lcg_next(st); return u01(st); }
+
+// gamma_ln, rng.h:38-43,60-64
+__device__ double gamma_ln_dev(const double xx) {
+    const double cof[6] = {76.18009172947146, -86.50532032941677, 24.01409824083091,
+                           -1.231739572450155, 0.1208650973866179e-2, -0.5395239384953e-5};
+    double x, tmp, y, ser;
+    y = x = xx;
+    tmp = x + 5.5;
+    tmp -= (x + 0.5) * log(tmp);
+    ser = 1.000000000190015;
+#pragma unroll
+    for (int j = 0; j <= 5; j++) ser += cof[j] / ++y;
+    return -tmp + log(2.5066282746310005 * ser / x);
+}
+
+// one depth draw, rng.h:289-312
+__device__ int poisson_draw(const VglPois& p, uint64_t& st) {
+    double em, t;
+    if (p.st12) {
+        em = -1.0; t = 1.0;
+        do { ++em; t *= next_u(st); } while (t > p.g);
+    } else {
+        double y;
+        do {
+            do {
+                y = tan(VGL_PI * next_u(st));
+                em = p.sq * y + p.lm;
+            } while (em < 0.0);
+            em = floor(em);
+            t = 0.9 * (1.0 + y * y) * exp(em * p.alxm - gamma_ln_dev(em + 1.0) - p.g);
+        } while (next_u(st) > t);
+    }
+    return (int)em;
+}
+
+// sample_NormalSampler_0_1_0, rng.h:70-80
+__device__ double normal_rou(uint64_t& st) {
+    double u, v, x, y, q;
+    do {
+        u = next_u(st);
+        v = 1.7156 * (next_u(st) - 0.5);
+        x = u - 0.449871;
+        y = fabs(v) + 0.386595;
+        q = (x * x) + y * (0.19600 * y - 0.25472 * x);
+    } while ((q > 0.27597) && (q > 0.27846 || (v * v) > -4.0 * log(u) * (u * u)));
+    return v / u;
+}
+
+// Gamma1Sampler::sample, rng.h:133-152
+__device__ double gamma1_draw(const VglGamma1& g, uint64_t& st) {
+    double u, v, x, xsq;
+    do {
+        do {
+            x = normal_rou(st);
+            v = 1.0 + g.a2 * x;
+        } while (v <= 0.0);
+        v = v * v * v;
+        u = next_u(st);
+        xsq = x * x;
+    } while (u > 1.0 - 0.0331 * (xsq * xsq) && log(u) > 0.5 * xsq + g.a1 * (1.0 - v + log(v)));
+    if (g.changed) {
+        while ((u = next_u(st)) == 0.0);
+        return pow(u, 1.0 / g.alpha0) * g.a1 * v;
+    }
+    return g.a1 * v;
+}
+
+// BetaSampler::sample, rng.h:433-444
+__device__ __forceinline__ double beta_draw(const VglDevParams& P, uint64_t& st) {
+    double x = gamma1_draw(P.gx, st);
+    double y = gamma1_draw(P.gy, st);
+    return x / (x + y);
+}
+
+// apply_qs_bins, vcfgl.cpp:57-64
+__device__ int apply_bins(const VglDevParams& P, int q, uint32_t* errflag) {
+    for (int i = 0; i < P.n_qs_bins; ++i)
+        if (q >= P.qs_bins[3 * i] && q <= P.qs_bins[3 * i + 1]) return P.qs_bins[3 * i + 2];
+    atomicOr(errflag, VGL_DEVERR_QSBIN);
+    return 0;
+}
+
+// error probability -> qScore / adjusted qScore, vcfgl.cpp:500-523
+__device__ void errprob_to_qs(const VglDevParams& P, double ep, int& q, int& aq, uint32_t* errflag) {
+    q = -1; aq = -1;
+    if (0.0 == ep) q = CAP_BASEQ;
+    else if (1.0 == ep) q = 0;
+    else {
+        double tmp = -10.0 * log10(ep);
+        q = (int)tmp;
+        if (P.adjust_qs) aq = (int)(tmp + P.adjust_by);
+    }
+    if (P.n_qs_bins != 0) {
+        q = apply_bins(P, q, errflag);
+        if (P.adjust_qs) aq = apply_bins(P, aq, errflag);
+    } else {
+        q = (q > CAP_BASEQ) ? CAP_BASEQ : q;
+        if (P.adjust_qs) aq = (aq > CAP_BASEQ) ? CAP_BASEQ : aq;
+    }
+}
+
+__device__ __forceinline__ int qs_to_qssq(int q) { return (0 == q) ? 0 : ((q < CAP_BASEQ) ? q * q : 3969); }  // shared.h:459
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// wave -> (local site, 64-sample chunk); everything here is wave-uniform (SGPRs)
+struct WavePos { int ls; int chunk; bool valid; };
+__device__ __forceinline__ WavePos wave_pos(const VglDevParams& P, const VglTilePtrs& T) {
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t w = (int64_t)blockIdx.x * (blockDim.x >> 6) + wib;
+    WavePos r;
+    r.valid = w < (int64_t)T.n_sites * P.chunks;
+    r.ls = (int)(w / P.chunks);
+    r.chunk = (int)(w - (int64_t)r.ls * P.chunks);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sample(const VglDevParams P, const VglTilePtrs T) {
+    const WavePos wp = wave_pos(P, T);
+    if (!wp.valid) return;
+    const int lane = threadIdx.x & 63;
+    const int N = P.n_samples;
+    const int ls = wp.ls;
+    const int s = wp.chunk * 64 + lane;
+    const bool active = s < N;
+    const size_t ev = (size_t)ls * N + (active ? s : 0);
+
+    int dp = 0;
+    uint64_t ad4 = 0, adf4 = 0;
+    uint32_t qs0 = 0, qs1 = 0, qs2 = 0, qs3 = 0, qq0 = 0, qq1 = 0, qq2 = 0, qq3 = 0;
+
+    if (active) {
+        // ---- stream states of this evaluation: J^(off_k) . J^(block*s) . J^(block*N*site) (x0)
+        const uint64_t site_abs = (uint64_t)(T.site0 + ls);
+        uint64_t xb = P.x0;
+#pragma unroll 1
+        for (int b = 0; b < 40; ++b)
+            if ((site_abs >> b) & 1) xb = aff(P.site_pow[b], xb);
+        const VglAffine ms = P.samp_tab[s];
+        const uint64_t xe = aff(ms, xb);
+        uint64_t st_depth = aff(P.off[0], xe);
+        uint64_t st_hap = aff(P.off[1], xe);
+        uint64_t st_base = aff(P.off[2], xe);
+        uint64_t st_qs = aff(P.off[3], xe);
+
+        // ---- depth (vcfgl.cpp:364-389): drawn even when the genotype is missing
+        int n;
+        if (P.per_sample_depth) { const VglPois pc = P.pois[s]; n = poisson_draw(pc, st_depth); }
+        else n = poisson_draw(P.pois0, st_depth);
+        const uint32_t g = T.gt[ev];
+        const int a0 = g & 0xF, a1 = (g >> 4) & 0xF;
+        dp = (a0 == 0xF || a1 == 0xF) ? 0 : n;
+        if (dp > P.read_cap) { atomicOr(T.errflag, VGL_DEVERR_CAPACITY); dp = P.read_cap; }
+
+        // ---- per-site base-pick error probability (error_qs 1: one beta deviate per site,
+        //      stream 3 of sample 0; vcfgl.cpp:425-437)
+        uint64_t err_thresh = P.err_thresh;
+        if (P.error_qs == 1) {
+            uint64_t st_site = aff(P.off[3], aff(P.samp_tab[0], xb));
+            const double pe = beta_draw(P, st_site);
+            err_thresh = (uint64_t)ceil(ldexp(pe, 48));
+        }
+
+        // ---- read loop (vcfgl.cpp:469-613)
+        const size_t plane = (size_t)T.n_sites * N;
+        for (int r = 0; r < dp; ++r) {
+            st_hap = lcg_next(st_hap);
+            const int true_base = (st_hap < (1ULL << 47)) ? a0 : a1;                 // u < 0.5
+            int r_base = true_base;
+            st_base = lcg_next(st_base);
+            if (st_base < err_thresh) {                                             // u < e
+                do { st_base = lcg_next(st_base); r_base = (int)(st_base >> 46); }   // floor(4u)
+                while (r_base == true_base);
+            }
+            int q_i = P.pre_q, aq_i = P.pre_adjq;
+            if (P.error_qs == 2) {
+                const double ep = beta_draw(P, st_qs);
+                errprob_to_qs(P, ep, q_i, aq_i, T.errflag);
+                if (P.precise_gl) T.errp[(size_t)r * plane + ev] = ep;
+            }
+            const int q_gl = (P.adjust_qs & 1) ? aq_i : q_i;
+            T.reads[(size_t)r * plane + ev] = (uint8_t)((q_gl << 2) | r_base);
+            if (T.reads_out && r < T.reads_out_cap) T.reads_out[(size_t)r * plane + ev] = (uint8_t)((q_i << 2) | r_base);
+            if (P.need_qsum) {
+                const uint32_t qq = (uint32_t)((P.adjust_qs & 2) ? aq_i : q_i);
+                const uint32_t q2 = (uint32_t)qs_to_qssq((int)qq);
+                qs0 += (r_base == 0) ? qq : 0u; qs1 += (r_base == 1) ? qq : 0u;
+                qs2 += (r_base == 2) ? qq : 0u; qs3 += (r_base == 3) ? qq : 0u;
+                qq0 += (r_base == 0) ? q2 : 0u; qq1 += (r_base == 1) ? q2 : 0u;
+                qq2 += (r_base == 2) ? q2 : 0u; qq3 += (r_base == 3) ? q2 : 0u;
+            }
+            const uint64_t one = 1ULL << (16 * r_base);
+            ad4 += one;
+            if (P.sample_strand) {
+                st_base = lcg_next(st_base);
+                if (st_base < (1ULL << 47)) adf4 += one;                             // forward
+            }
+        }
+        if (!P.sample_strand) adf4 = ad4;
+
+        if (T.fmt_dp) T.fmt_dp[ev] = dp;
+        T.ad4[ev] = ad4;
+        if (P.need_adf) T.adf4[ev] = adf4;
+        if (P.need_qsum) {
+            uint32_t* q = T.qsum + (size_t)ls * 4 * N + s;
+            q[0] = qs0; q[(size_t)N] = qs1; q[(size_t)2 * N] = qs2; q[(size_t)3 * N] = qs3;
+            if (P.need_qsumsq) {
+                uint32_t* qq = T.qsumsq + (size_t)ls * 4 * N + s;
+                qq[0] = qq0; qq[(size_t)N] = qq1; qq[(size_t)2 * N] = qq2; qq[(size_t)3 * N] = qq3;
+            }
+        }
+        if (T.reads_out) for (int r = dp; r < T.reads_out_cap; ++r) T.reads_out[(size_t)r * plane + ev] = 0xFF;
+    }
+
+    // ---- per-site sums: wave reduction, one atomic per wave and counter
+    int v[9];
+    v[0] = dp;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { v[1 + b] = (int)((ad4 >> (16 * b)) & 0xFFFF); v[5 + b] = (int)((adf4 >> (16 * b)) & 0xFFFF); }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) v[k] = wave_sum(v[k]);
+    if (lane == 0) {
+        int32_t* acc = T.acc + (size_t)ls * VGL_ACC_STRIDE;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) if (v[k]) atomicAdd(&acc[k], v[k]);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// one lane per site: status + allele order (vcfgl.cpp:396-404, 665-766; no-reads :228-315)
+__global__ __launch_bounds__(256) void k_site(const VglDevParams P, const VglTilePtrs T) {
+    const int ls = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ls >= T.n_sites) return;
+    const int32_t* acc = T.acc + (size_t)ls * VGL_ACC_STRIDE;
+    const int A = P.A;
+    const int info_dp = acc[0];
+    int ad[4] = {acc[1], acc[2], acc[3], acc[4]};
+    int a2b[5] = {-1, -1, -1, -1, -1}, b2a[5] = {-1, -1, -1, -1, -1};
+    int status = SITE_OK, nAll = 0, nObs = 0;
+
+    if (0 == info_dp) {
+        if (P.rm_empty_sites) status = SITE_SKIP_EMPTY;
+        else {
+            status = SITE_NO_READS;
+            switch (P.do_unobserved) {
+                case 0: nAll = 1; nObs = 0; break;
+                case 1: case 2: nAll = 1; nObs = 0; a2b[0] = 4; break;
+                case 3: nAll = 4; nObs = 4; for (int a = 0; a < 4; a++) a2b[a] = a; break;
+                default: nAll = 5; nObs = 4; for (int a = 0; a < 4; a++) a2b[a] = a; a2b[4] = 4; break;
+            }
+        }
+    } else {
+        int nObservedBases = 0;
+        for (int b = 0; b < 4; b++) if (ad[b] > 0) nObservedBases++;
+        if ((P.rm_invar_sites & 4) && 1 == nObservedBases) status = SITE_SKIP_INVAR;
+        else {
+            int sorted[4] = {0, 1, 2, 3};
+            for (int i = 1; i < 4; i++)
+                for (int j = i; j > 0 && ad[sorted[j]] > ad[sorted[j - 1]]; j--) { int t = sorted[j]; sorted[j] = sorted[j - 1]; sorted[j - 1] = t; }
+            for (int a = 0; a < 4; a++) { a2b[a] = sorted[a]; b2a[sorted[a]] = a; }
+            const bool explode = P.do_unobserved >= 3, add_unobs = (A == 5);
+            for (int b = 0; b < 4; b++)
+                if (!(ad[b] > 0) && !explode) { a2b[b2a[b]] = -1; b2a[b] = -1; }
+            int unobs = -1, n_all = 0;
+            for (int a = 0; a < 5; a++) { if (-1 == a2b[a]) { if (add_unobs) unobs = a; break; } ++n_all; }
+            if (add_unobs) { a2b[unobs] = 4; b2a[4] = unobs; }
+            nObs = n_all; nAll = n_all + (add_unobs ? 1 : 0);
+        }
+    }
+    VglSiteInfo si;
+    si.status = status; si.n_alleles = nAll;
+    uint32_t pa = 0, pb = 0;
+    for (int k = 0; k < 5; k++) { pa |= (uint32_t)(b2a[k] & 0xF) << (4 * k); pb |= (uint32_t)(a2b[k] & 0xF) << (4 * k); }
+    si.acgt2alleles = pa; si.alleles2acgt = pb;
+    T.sinfo[ls] = si;
+
+    T.site_status[ls] = status;
+    T.n_alleles[ls] = nAll;
+    if (T.n_alleles_obs) T.n_alleles_obs[ls] = nObs;
+    for (int k = 0; k < 5; k++) T.alleles2acgt[(size_t)ls * 5 + k] = (int8_t)a2b[k];
+    if (T.info_dp) T.info_dp[ls] = info_dp;
+    const bool have = (status == SITE_OK);
+    for (int a = 0; a < A; a++) {
+        const int b = (have && a < nAll) ? a2b[a] : -1;
+        const bool real = (b >= 0 && b < 4);
+        const int tot = real ? acc[1 + b] : 0;
+        const int totf = real ? acc[5 + b] : 0;
+        if (T.info_ad) T.info_ad[(size_t)ls * A + a] = tot;
+        if (T.info_adf) T.info_adf[(size_t)ls * A + a] = totf;
+        if (T.info_adr) T.info_adr[(size_t)ls * A + a] = tot - totf;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float f32_missing() { return __uint_as_float(F32_MISSING_BITS); }
+__device__ __forceinline__ int nib(uint32_t v, int k) { return (int)((v >> (4 * k)) & 0xF); }
+__device__ __forceinline__ int cnt_of(uint64_t ad4, int b) { return b < 4 ? (int)((ad4 >> (16 * b)) & 0xFFFF) : 0; }
+
+template <int A>
+__global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTilePtrs T) {
+    constexpr int NG = A * (A + 1) / 2;
+    const WavePos wp = wave_pos(P, T);
+    if (!wp.valid) return;
+    const int lane = threadIdx.x & 63;
+    const int N = P.n_samples;
+    const int ls = wp.ls;
+    const int s = wp.chunk * 64 + lane;
+    if (s >= N) return;
+    const size_t ev = (size_t)ls * N + s;
+    const size_t plane = (size_t)T.n_sites * N;
+    const VglSiteInfo si = T.sinfo[ls];
+    const int nA = si.n_alleles;
+    const int nG = nA * (nA + 1) / 2;
+    const bool have = (si.status == SITE_OK);
+    const float MISS = f32_missing();
+
+    const uint64_t ad4 = T.ad4[ev];
+    const int dp = have ? (int)((ad4 & 0xFFFF) + ((ad4 >> 16) & 0xFFFF) + ((ad4 >> 32) & 0xFFFF) + ((ad4 >> 48) & 0xFFFF)) : 0;
+
+    float acc[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) acc[i] = -0.0f;                                     // bcf_utils.h:310
+
+    if (dp > 0) {
+        if (P.gl_model == 2) {
+            // gl_methods.cpp:22-59 / :94-139 / :171-220
+            const bool per_read = (P.error_qs == 2);
+            double homT = P.pre_homT, het = P.pre_het, homF = P.pre_homF;
+            for (int r = 0; r < dp; ++r) {
+                const uint32_t rb = T.reads[(size_t)r * plane + ev];
+                const int ao = nib(si.acgt2alleles, (int)(rb & 3));
+                if (per_read) {
+                    if (!P.precise_gl) {
+                        const int q = (int)(rb >> 2);
+                        homT = P.q2gl[q]; het = P.q2gl[257 + q]; homF = P.q2gl[514 + q];
+                    } else {
+                        const double e = T.errp[(size_t)r * plane + ev];
+                        if (0.0 == e) { homT = 0.0; het = -0.30103; homF = -INFINITY; }
+                        else { homT = log10(1.0 - e); het = log10((1.0 - e) / 2.0 + e / 6.0); homF = log10(e / 3.0); }
+                    }
+                }
+                float mx = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < A; ++i) {
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) {
+                        const int idx = i * (i + 1) / 2 + j;                         // bcf_alleles2gt
+                        const double t = (i == j) ? ((ao == i) ? homT : homF) : ((ao == i || ao == j) ? het : homF);
+                        const float v = (float)((double)acc[idx] + t);
+                        acc[idx] = v;
+                        if (i < nA) mx = (v > mx) ? v : mx;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NG; ++i) acc[i] -= mx;
+            }
+        } else {
+            // GL model 1 with one fixed qScore: errmod_cal() reduces to table lookups on the
+            // per-base depths (gl_methods.cpp:304-369; htslib errmod.c restated in vgl_host.cpp)
+            int n = dp;
+            if (n > 255) { atomicOr(T.errflag, VGL_DEVERR_GL1DEPTH); n = 255; }
+            int c[5]; double bs[5];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { c[b] = (int)((ad4 >> (16 * b)) & 0xFFFF); if (c[b] > 255) c[b] = 255; bs[b] = P.gl1_bsum[n * 256 + c[b]]; }
+            c[4] = 0; bs[4] = 0.0;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < A; ++i) {
+#pragma unroll
+                for (int j = 0; j <= i; ++j) {
+                    const int idx = i * (i + 1) / 2 + j;
+                    const int b1 = nib(si.alleles2acgt, j), b2 = nib(si.alleles2acgt, i);
+                    float tmp1 = 0.0f; int tmp2 = 0;
+#pragma unroll
+                    for (int k = 0; k < 5; ++k)
+                        if (k != b1 && k != b2) { tmp1 = (float)((double)tmp1 + bs[k]); tmp2 += c[k]; }
+                    float q;
+                    if (b1 == b2) q = tmp2 ? tmp1 : 0.0f;
+                    else {
+                        const int lo = b1 < b2 ? b1 : b2, hi = b1 < b2 ? b2 : b1;
+                        const int chi = cnt_of(ad4, hi) > 255 ? 255 : cnt_of(ad4, hi);
+                        int cjk = cnt_of(ad4, lo) + cnt_of(ad4, hi); if (cjk > 255) cjk = 255;
+                        const double lh = P.gl1_lhet[cjk << 8 | chi];
+                        q = tmp2 ? (float)(-4.343 * lh + (double)tmp1) : (float)(-4.343 * lh);
+                    }
+                    if (q < 0.0f) q = 0.0f;
+                    const float v = (float)((-1.0 * (double)q) / 10.0);
+                    acc[idx] = v;
+                    if (i < nA) mx = (v > mx) ? v : mx;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NG; ++i) acc[i] -= mx;
+        }
+    }
+
+    // ---- GL / PL / GP planes (vcfgl.cpp:907-970; no-reads site :297-305)
+    float gp[NG]; float sum_gps = 0.0f;
+    const bool sample_ok = have && dp > 0;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const bool valid = sample_ok && i < nG;
+        const float v = valid ? acc[i] : MISS;
+        const size_t o = ((size_t)ls * NG + i) * N + s;
+        if (T.gl) T.gl[o] = v;
+        if (T.pl) {
+            int32_t x;
+            if (!valid) x = I32_MISSING;
+            else if (v == -INFINITY) x = MAXPL;
+            else { x = (int32_t)lroundf((float)(-10.0 * (double)v)); if (x > MAXPL) x = MAXPL; }
+            T.pl[o] = x;
+        }
+        if (T.gp) { gp[i] = valid ? (float)pow(10.0, (double)v) : 0.0f; if (valid) sum_gps += gp[i]; }
+    }
+    if (T.gp) {
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const bool valid = sample_ok && i < nG;
+            T.gp[((size_t)ls * NG + i) * N + s] = valid ? gp[i] / sum_gps : MISS;
+        }
+    }
+    // ---- FORMAT/AD, ADF, ADR in allele order (vcfgl.cpp:806-843)
+    if (T.fmt_ad || T.fmt_adf || T.fmt_adr) {
+        const uint64_t adf4 = P.need_adf ? T.adf4[ev] : ad4;
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            const int b = (have && a < nA) ? nib(si.alleles2acgt, a) : 0xF;
+            const int v = cnt_of(ad4, b), vf = cnt_of(adf4, b);
+            const size_t o = ((size_t)ls * A + a) * N + s;
+            if (T.fmt_ad) T.fmt_ad[o] = v;
+            if (T.fmt_adf) T.fmt_adf[o] = vf;
+            if (T.fmt_adr) T.fmt_adr[o] = v - vf;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// one lane per site, samples in order: the reference accumulates these in float32 in sample
+// order (vcfgl.cpp:875-897, 997-1066), which a tree reduction would not reproduce bit for bit.
+__global__ __launch_bounds__(64) void k_siteagg(const VglDevParams P, const VglTilePtrs T) {
+    const int ls = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ls >= T.n_sites) return;
+    const int N = P.n_samples, A = P.A;
+    const VglSiteInfo si = T.sinfo[ls];
+    const bool have = (si.status == SITE_OK);
+    const int nA = si.n_alleles;
+    const uint32_t* qsum = T.qsum + (size_t)ls * 4 * N;
+    if (T.qs) {
+        float qsv[5] = {0, 0, 0, 0, 0};
+        if (have && P.need_qsum)
+            for (int s = 0; s < N; ++s) {
+                float sum = 0.0f;
+                uint32_t q[4];
+                for (int b = 0; b < 4; ++b) { q[b] = qsum[(size_t)b * N + s]; sum += (float)(int)q[b]; }
+                if (0.0f != sum)
+                    for (int b = 0; b < 4; ++b) {
+                        const int a = nib(si.acgt2alleles, b);
+                        if (a == 0xF) continue;
+                        const float add = (float)((float)(int)q[b] / sum);
+                        qsv[0] += (a == 0) ? add : 0.0f; qsv[1] += (a == 1) ? add : 0.0f; qsv[2] += (a == 2) ? add : 0.0f;
+                        qsv[3] += (a == 3) ? add : 0.0f; qsv[4] += (a == 4) ? add : 0.0f;
+                    }
+            }
+        for (int a = 0; a < A; ++a) T.qs[(size_t)ls * A + a] = qsv[a];
+    }
+    if (T.i16) {
+        float v[16];
+        for (int k = 0; k < 16; ++k) v[k] = 0.0f;
+        if (have && P.add_i16 && nA > 1) {
+            const int32_t* acc = T.acc + (size_t)ls * VGL_ACC_STRIDE;
+            const uint32_t* qsq = T.qsumsq + (size_t)ls * 4 * N;
+            const int refb = nib(si.alleles2acgt, 0);
+            const int nObs = (A == 5) ? nA - 1 : nA;
+            v[0] = (float)acc[5 + refb]; v[1] = (float)(acc[1 + refb] - acc[5 + refb]);
+            const float mq = (float)P.i16_mapq, mq2 = (float)(P.i16_mapq * P.i16_mapq);
+            for (int s = 0; s < N; ++s) {
+                v[4] += (float)(int)qsum[(size_t)refb * N + s];
+                v[5] += (float)(int)qsq[(size_t)refb * N + s];
+                const uint64_t ad4 = T.ad4[(size_t)ls * N + s];
+                for (int a = 0; a < nA; ++a) {
+                    if (a == nObs) continue;
+                    const int cnt = cnt_of(ad4, nib(si.alleles2acgt, a));
+                    for (int i = 0; i < cnt; ++i) {
+                        if (0 == a) { v[8] += mq; v[9] += mq2; } else { v[10] += mq; v[11] += mq2; }
+                    }
+                }
+            }
+            for (int a = 1; a < nA; ++a) {
+                if (a == nObs) continue;
+                const int b = nib(si.alleles2acgt, a);
+                v[2] += (float)acc[5 + b]; v[3] += (float)(acc[1 + b] - acc[5 + b]);
+                for (int s = 0; s < N; ++s) { v[6] += (float)(int)qsum[(size_t)b * N + s]; v[7] += (float)(int)qsq[(size_t)b * N + s]; }
+            }
+            // v[12..15] (tail distance) come from the reference's unseeded libc rand(): not produced on the device
+        }
+        for (int k = 0; k < 16; ++k) T.i16[(size_t)ls * 16 + k] = v[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------
+extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
+    const int64_t waves = (int64_t)t->n_sites * p->chunks;
+    if (waves == 0) return 0;
+    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    hipLaunchKernelGGL(k_sample, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, *t);
+    return (int)hipGetLastError();
+}
+
+extern "C" int vgl_launch_site(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
+    if (t->n_sites == 0) return 0;
+    hipLaunchKernelGGL(k_site, dim3((t->n_sites + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p, *t);
+    return (int)hipGetLastError();
+}
+
+extern "C" int vgl_launch_gl(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
+    const int64_t waves = (int64_t)t->n_sites * p->chunks;
+    if (waves == 0) return 0;
+    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    if (p->A == 5) hipLaunchKernelGGL(k_gl<5>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, *t);
+    else hipLaunchKernelGGL(k_gl<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, *t);
+    return (int)hipGetLastError();
+}
+
+extern "C" int vgl_launch_siteagg(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
+    if (t->n_sites == 0) return 0;
+    hipLaunchKernelGGL(k_siteagg, dim3((t->n_sites + 63) / 64), dim3(64), 0, (hipStream_t)stream, *p, *t);
+    return (int)hipGetLastError();
+}
