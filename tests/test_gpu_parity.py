@@ -16,12 +16,17 @@ INT_FIELDS = ["site_status", "n_alleles", "n_alleles_obs", "alleles2acgt", "info
 TOL = 1e-6
 
 
+def bits(a):
+    """missing floats are NaN patterns (bcf_float_missing): compare raw bits"""
+    return a.view(np.uint32) if a.dtype == np.float32 else a
+
+
 def run_both(oracle, args, gt, site0=0, read_capacity=0, max_sites=None):
     args.rng_mode, args.beta_sampler = _abi.VGL_RNG_TILE, _abi.VGL_BETA_RAND48
     n_sites, N = gt.shape
     o = oracle.Oracle(args, N)
-    want = o.simulate(site0, gt, read_capacity=read_capacity)
     sim = Simulator(args, N, device=0, max_sites_per_tile=max_sites or max(n_sites, 1))
+    want = o.simulate(site0, gt, fields=sim.default_fields(), read_capacity=read_capacity)
     got = sim.simulate(site0, gt, read_capacity=read_capacity)
     sim.close()
     return want, got
@@ -46,9 +51,9 @@ def assert_parity(want, got, exact_gl=True, i16=False, qs=True, check_gp=True):
         m = wgp.view(np.uint32) == _abi.FLOAT_MISSING_BITS
         assert np.array_equal(m, ggp.view(np.uint32) == _abi.FLOAT_MISSING_BITS)
         assert np.all(np.abs(wgp[~m].astype(np.float64) - ggp[~m].astype(np.float64)) <= TOL)
-    if qs:
+    if qs and "qs" in got.arrays:
         assert np.array_equal(want.numpy("qs").view(np.uint32), got.numpy("qs").view(np.uint32)), "QS"
-    if i16:
+    if i16 and "i16" in got.arrays:
         assert np.array_equal(want.numpy("i16")[:, :12], got.numpy("i16")[:, :12]), "I16[0..11]"
 
 
@@ -157,7 +162,7 @@ def test_site_index_invariance(oracle):
     b = sim.simulate(20, gt[20:])
     sim.close()
     for f in ["fmt_dp", "gl", "pl", "fmt_ad", "info_ad", "alleles2acgt"]:
-        assert np.array_equal(whole.numpy(f), np.concatenate([a.numpy(f), b.numpy(f)])), f
+        assert np.array_equal(bits(whole.numpy(f)), bits(np.concatenate([a.numpy(f), b.numpy(f)]))), f
 
 
 @pytest.mark.parametrize("name", ["test2", "test5", "test12", "test14", "test17", "test18"])
@@ -196,7 +201,7 @@ def test_device_buffers_and_stream(oracle):
     host = sim.simulate(0, gt, fields=["fmt_dp", "gl", "pl"])
     sim.close()
     for f in ["fmt_dp", "gl", "pl", "n_alleles"]:
-        assert np.array_equal(tile.numpy(f), host.numpy(f)), f
+        assert np.array_equal(bits(tile.numpy(f)), bits(host.numpy(f))), f
 
 
 def test_capacity_overflow_is_reported(oracle):

@@ -87,6 +87,13 @@ def load_library():
         raise RuntimeError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C vcfgl_amd/csrc`.  There is no CPU fallback.")
+    try:
+        # torch wheels bundle their own libamdhip64.so.7; the first copy loaded serves the whole
+        # process, so load torch's first: device pointers of torch tensors and this library's
+        # launches must go through one HIP runtime.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     lib.vgl_max_alleles.argtypes = [C.POINTER(Params)]
     lib.vgl_max_genotypes.argtypes = [C.POINTER(Params)]

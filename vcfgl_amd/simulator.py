@@ -47,7 +47,19 @@ class Simulator:
         if rc != _abi.VGL_OK:
             raise VglError(rc, self.lib.vgl_last_error().decode())
 
+    def default_fields(self):
+        """Every output the context can produce: QS / I16 need -addQS / -addI16 (their inputs,
+        the per-base quality sums, are only accumulated when asked for)."""
+        skip = set()
+        if not (self.args.add_qs or self.args.add_i16):
+            skip.add("qs")
+        if not self.args.add_i16:
+            skip.add("i16")
+        return [f for f, _, _ in _abi.TILE_FIELDS if f not in skip]
+
     def new_tile(self, n_sites, fields=None, device=None, read_capacity=0):
+        if fields is None:
+            fields = self.default_fields()
         return Tile(n_sites, self.n_samples, self.A, self.G, fields=fields, device=device, read_capacity=read_capacity)
 
     def simulate(self, site0, gt, fields=None, read_capacity=0):
