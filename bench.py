@@ -24,6 +24,7 @@ import torch  # noqa: E402
 
 import synth  # noqa: E402
 from vcfgl_amd import Simulator, VcfglArgs, _abi  # noqa: E402
+from vcfgl_amd.shard import gather_site_index  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E vendor peak (MI355X_MICROARCH.md)
 
@@ -109,9 +110,7 @@ def main():
                                                         C.c_void_p(stream.cuda_stream)))
         if dist is not None:                                  # record-index gather to the writer rank
             stream.synchronize()
-            idx = torch.stack([out["site_status"], out["n_alleles"]], dim=1)
-            bufs = [torch.empty_like(idx) for _ in range(world)] if rank == 0 else None
-            dist.gather(idx, bufs, dst=0)
+            gather_site_index(out["site_status"], out["n_alleles"], world, rank, S * world)
 
     def barrier():
         stream.synchronize()
