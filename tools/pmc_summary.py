@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc counter_collection CSVs (one pass per counter group, as the MI355X
+guide prescribes) into profiles/<tag>_pmc_summary.json and profiles/pmc_traffic.json.
+
+HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE/WRITE_SIZE are in KiB and on
+gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced streaming read (MI355X_MICROARCH.md,
+section HBM).  The raw (uncorrected) fetch figure is kept beside it: this path's loads are 1-8 bytes
+per lane, a width the guide marks as uncalibrated.
+usage: tools/pmc_summary.py <dir with FETCH_SIZE/ WRITE_SIZE/ SQ/ subdirs> <tag>"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+root, tag = sys.argv[1], sys.argv[2]
+out = collections.defaultdict(dict)
+for f in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if k.startswith("k_"):
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            out[k]["vgpr"] = int(r["VGPR_Count"]); out[k]["sgpr"] = int(r["SGPR_Count"])
+            out[k]["grid"] = int(r["Grid_Size"]); out[k]["lds"] = int(r["LDS_Block_Size"])
+    for k, v in agg.items():
+        for c, vals in v.items():
+            out[k][c] = sum(vals) / len(vals)
+            out[k]["launches_" + c] = len(vals)
+traffic = {}
+for k, v in out.items():
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        v["hbm_bytes_per_launch"] = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
+        v["hbm_bytes_per_launch_raw_fetch"] = (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
+        traffic[k.split("<")[0]] = {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"],
+                                    "raw_fetch_variant": v["hbm_bytes_per_launch_raw_fetch"], "source": tag}
+    if "SQ_INSTS_VALU" in v and "SQ_WAVES" in v:
+        v["valu_insts_per_wave"] = v["SQ_INSTS_VALU"] / v["SQ_WAVES"]
+        v["active_lanes_per_valu_inst"] = v.get("SQ_THREAD_CYCLES_VALU", 0) / v["SQ_INSTS_VALU"]
+here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+json.dump(out, open(os.path.join(here, "profiles", f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+json.dump(traffic, open(os.path.join(here, "profiles", "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+print(json.dumps(out, indent=1, sort_keys=True))
