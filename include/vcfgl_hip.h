@@ -79,10 +79,14 @@ extern "C" {
  *   k=1 haplotype    rng1, one draw per read              (vcfgl.cpp:473)
  *   k=2 base/strand  rng0, error test, wrong base, strand (vcfgl.cpp:486-488,582)
  *   k=3 qscore       rng2, beta deviates                  (vcfgl.cpp:428,495; rng.h:433-444)
- * With --error-qs 1 the single per-site beta deviate uses stream 3 of sample 0. */
+ * Stream 3 is further divided per read: the beta deviate of read r starts at
+ * e*block + off[3] + r*qs_read_stride, so the quality scores of one wavefront's reads are
+ * independent work items that the device balances across lanes.  With --error-qs 1 the single
+ * per-site beta deviate uses stream 3 of sample 0, read 0. */
 typedef struct vgl_rng_layout {
     uint64_t block;
     uint64_t off[4];
+    uint64_t qs_read_stride;
 } vgl_rng_layout;
 
 /* ---- parameters = the subset of argStruct (io.h:40-148) the hot path reads ----------- */

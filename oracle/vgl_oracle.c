@@ -415,7 +415,9 @@ int vgl_oracle_default_layout(const vgl_params* p, vgl_rng_layout* out) {
     uint64_t s0 = 64;
     uint64_t s1 = 4 * d + 64;
     uint64_t s2 = 3 * s1;
-    uint64_t s3 = (p->error_qs == 2) ? 32 * s1 : 64;
+    const uint64_t qstride = 32;
+    uint64_t s3 = (p->error_qs == 2) ? qstride * s1 : 64;
+    out->qs_read_stride = qstride;
     out->off[0] = 0; out->off[1] = s0; out->off[2] = s0 + s1; out->off[3] = s0 + s1 + s2;
     out->block = (s0 + s1 + s2 + s3) | 1;   /* odd: the per-evaluation stride is a full-period multiplier power */
     return 0;
@@ -704,6 +706,8 @@ static int simulate_site(vgl_oracle* o, int64_t site_abs, int32_t ls, int32_t n_
                 while ((r_base = (int)floor(4 * lcg_uniform(sb))) == true_base);     /* :487 */
             int q_i, aq_i;
             if (2 == p->error_qs) {                                                  /* :494-565 */
+                uint64_t st_read = 0;
+                if (tile) { st_read = vgl_oracle_rand48_jump(st_qs[s], (uint64_t)r * o->lay.qs_read_stride); sq = &st_read; }
                 double ep = beta_draw(o, sq);
                 if ((rc = errprob_to_qs(o, ep, 0, &q_i, &aq_i))) goto done;
                 o->qsc[(size_t)s * o->cap + r] = q_i;

@@ -59,7 +59,7 @@ def test_default_rng_layout_matches_oracle(oracle, depth, eqs):
     a, b = _abi.RngLayout(), _abi.RngLayout()
     assert lib.vgl_default_rng_layout(C.byref(p), C.byref(a)) == 0
     assert oracle.lib().vgl_oracle_default_layout(C.byref(p), C.byref(b)) == 0
-    assert a.block == b.block and list(a.off) == list(b.off)
+    assert a.block == b.block and list(a.off) == list(b.off) and a.qs_read_stride == b.qs_read_stride == 32
     assert a.block % 2 == 1 and a.off[0] == 0
 
 

@@ -1,0 +1,20 @@
+import sys; sys.path.insert(0,'/root/repo')
+import torch, numpy as np, ctypes as C
+from vcfgl_amd import _abi
+lib=_abi.load_library()
+lib.vgl_dbg_vlog.argtypes=[C.c_void_p,C.c_void_p,C.c_int]
+rng=np.random.default_rng(1)
+parts=[rng.random(4_000_000).astype(np.float32), (1-rng.random(2_000_000)*1e-3).astype(np.float32), (1+ (rng.random(2_000_000)-0.5)*0.2).astype(np.float32),
+       np.exp(rng.uniform(-33,3,4_000_000)).astype(np.float32), np.float32(2.0)**rng.integers(-48,2,1000), (1-2.0**-np.arange(1,25)).astype(np.float32), (1+2.0**-np.arange(1,24)).astype(np.float32)]
+x=np.concatenate(parts).astype(np.float32); x=x[x>0]
+xi=torch.from_numpy(x).cuda(); xo=torch.empty_like(xi)
+assert lib.vgl_dbg_vlog(xi.data_ptr(), xo.data_ptr(), x.size)==0
+y=xo.cpu().numpy().astype(np.float64)
+t=np.log2(x.astype(np.float64))
+err=np.abs(y-t)
+rel=err/np.maximum(np.abs(t),1e-300)
+print("n",x.size,"max abs err",err.max(),"max rel err (|t|>1e-3)",rel[np.abs(t)>1e-3].max(), "ulps:", (rel[np.abs(t)>1e-3].max()/2**-24))
+near=np.abs(x-1)<0.1
+print("near 1: max abs err", err[near].max(), "max err/|x-1|", (err[near]/np.maximum(np.abs(x[near].astype(np.float64)-1),1e-30)).max())
+b=np.abs(t)*2.0**-21+2.0**-23
+print("bound violated:", np.sum(err>b))

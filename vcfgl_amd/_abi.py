@@ -19,7 +19,7 @@ INT32_MISSING = -(2 ** 31)
 
 
 class RngLayout(C.Structure):
-    _fields_ = [("block", C.c_uint64), ("off", C.c_uint64 * 4)]
+    _fields_ = [("block", C.c_uint64), ("off", C.c_uint64 * 4), ("qs_read_stride", C.c_uint64)]
 
 
 class Params(C.Structure):

@@ -41,11 +41,14 @@ struct VglDevParams {
     int32_t chunks;          // ceil(N / 64): wavefronts per site
     int32_t A, G;            // max alleles / genotypes of the tile layout
     int32_t read_cap;        // staged reads per (site,sample)
+    int32_t pool_cap;        // quality-score work items per wavefront and LDS segment
+    int32_t pool_lds_bytes;  // LDS bytes per wavefront of k_sample<2>: 512 + 5 * pool_cap
     // flags
     int32_t error_qs, gl_model, precise_gl, adjust_qs, n_qs_bins, do_unobserved;
     int32_t rm_invar_sites, rm_empty_sites, sample_strand, per_sample_depth;
     int32_t need_qsum, need_qsumsq, need_adf, i16_mapq;
     int32_t add_i16;
+    int32_t dbg_phase;       // diagnostic (VGL_DEBUG_PHASE=n): k_sample returns after phase n; 0 = off
     int32_t pre_q, pre_adjq;           // preCalc qScore / adj_qScore (vcfgl.cpp:1697-1702)
     double  adjust_by;
     double  pre_homT, pre_het, pre_homF;
@@ -55,6 +58,7 @@ struct VglDevParams {
     VglAffine off[4];                  // J^(off[k])
     VglAffine site_pow[40];            // J^(block * N * 2^b)
     const VglAffine* samp_tab;         // [N] J^(block * s)
+    const VglAffine* qs_read_tab;      // [read_cap] J^(qs_read_stride * r)
     // samplers
     VglPois pois0;
     const VglPois* pois;               // [N] when per_sample_depth
@@ -62,6 +66,8 @@ struct VglDevParams {
     int32_t qs_bins[VGL_MAX_QS_BINS * 3];
     // tables
     const double* q2gl;                // [3][257]
+    const double* gamma_ln_tab;        // [gamma_ln_n] gamma_ln(k), k >= 1 (entry 0 unused)
+    int32_t gamma_ln_n;
     const double* gl1_bsum;            // [256][256]  sum_{i<c} fk[i]*beta[q][n][i]   (fixed qScore)
     const double* gl1_lhet;            // [256][256]
 };
@@ -88,6 +94,7 @@ struct VglTilePtrs {
     int32_t* fmt_dp; float* gl; int32_t* pl; float* gp;
     int32_t* fmt_ad; int32_t* fmt_adf; int32_t* fmt_adr;
     uint8_t* reads_out; int32_t reads_out_cap;
+    unsigned long long* dbg;  // diagnostic cycle stamps (VGL_DEBUG_STAMPS=1), else null
 };
 
 #ifdef __cplusplus

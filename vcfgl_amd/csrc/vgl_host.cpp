@@ -45,7 +45,9 @@ extern "C" int vgl_default_rng_layout(const vgl_params* p, vgl_rng_layout* out) 
     const uint64_t s0 = 64;                                   // depth draws (Poisson)
     const uint64_t s1 = 4 * d + 64;                           // one haplotype draw per read
     const uint64_t s2 = 3 * s1;                               // error test + wrong base + strand
-    const uint64_t s3 = (p->error_qs == 2) ? 32 * s1 : 64;    // beta deviates
+    const uint64_t qstride = 32;                              // draws reserved per beta deviate
+    const uint64_t s3 = (p->error_qs == 2) ? qstride * s1 : 64;
+    out->qs_read_stride = qstride;
     out->off[0] = 0; out->off[1] = s0; out->off[2] = s0 + s1; out->off[3] = s0 + s1 + s2;
     out->block = (s0 + s1 + s2 + s3) | 1;
     return VGL_OK;
@@ -120,12 +122,13 @@ struct vgl_ctx {
     int max_sites;
     VglDevParams dp;
     // device tables
-    VglAffine* d_samp_tab = nullptr; VglPois* d_pois = nullptr;
-    double* d_q2gl = nullptr; double* d_gl1_bsum = nullptr; double* d_gl1_lhet = nullptr;
+    VglAffine* d_samp_tab = nullptr; VglAffine* d_qs_read_tab = nullptr; VglPois* d_pois = nullptr;
+    double* d_q2gl = nullptr; double* d_gamma_ln = nullptr; double* d_gl1_bsum = nullptr; double* d_gl1_lhet = nullptr;
     // workspace
     uint8_t* d_reads = nullptr; double* d_errp = nullptr; uint64_t* d_ad4 = nullptr; uint64_t* d_adf4 = nullptr;
     uint32_t* d_qsum = nullptr; uint32_t* d_qsumsq = nullptr; int32_t* d_acc = nullptr; VglSiteInfo* d_sinfo = nullptr;
     uint32_t* d_errflag = nullptr;
+    unsigned long long* d_dbg = nullptr;   // VGL_DEBUG_STAMPS=1 diagnostic counters
     // host-variant mirrors
     uint8_t* d_gt = nullptr; void* d_out[17] = {nullptr}; size_t d_out_bytes[17] = {0};
     uint8_t* d_reads_out = nullptr; size_t d_reads_out_bytes = 0;
@@ -163,6 +166,16 @@ static int errprob_to_qs_fixed(const vgl_params* p, double ep, int* qs, int* adj
     return VGL_OK;
 }
 
+static double gamma_ln_host(double xx) {                      // gamma_ln, rng.h:38-43,60-64
+    static const double cof[6] = {76.18009172947146, -86.50532032941677, 24.01409824083091,
+                                  -1.231739572450155, 0.1208650973866179e-2, -0.5395239384953e-5};
+    double x = xx, y = xx, tmp = x + 5.5;
+    tmp -= (x + 0.5) * log(tmp);
+    double ser = 1.000000000190015;
+    for (int j = 0; j <= 5; j++) ser += cof[j] / ++y;
+    return -tmp + log(2.5066282746310005 * ser / x);
+}
+
 static void pois_init(VglPois* o, double lambda) {            // PoissonSampler_init, rng.h:259-280
     o->lm = lambda; o->sq = -1.0; o->alxm = -1.0; o->g = -1.0; o->st12 = 1; o->pad = 0;
     if (lambda < 12.0) o->g = exp(-lambda);
@@ -196,8 +209,8 @@ template <typename T> static int dmalloc(T** p, size_t n) {
 extern "C" int vgl_ctx_destroy(vgl_ctx* c) {
     if (!c) return VGL_OK;
     (void)hipSetDevice(c->device);
-    void* ptrs[] = {c->d_samp_tab, c->d_pois, c->d_q2gl, c->d_gl1_bsum, c->d_gl1_lhet, c->d_reads, c->d_errp, c->d_ad4,
-                    c->d_adf4, c->d_qsum, c->d_qsumsq, c->d_acc, c->d_sinfo, c->d_errflag, c->d_gt, c->d_reads_out};
+    void* ptrs[] = {c->d_gamma_ln, c->d_samp_tab, c->d_qs_read_tab, c->d_pois, c->d_q2gl, c->d_gl1_bsum, c->d_gl1_lhet, c->d_reads, c->d_errp, c->d_ad4,
+                    c->d_adf4, c->d_qsum, c->d_qsumsq, c->d_acc, c->d_sinfo, c->d_errflag, c->d_gt, c->d_reads_out, c->d_dbg};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     for (void* q : c->d_out) if (q) (void)hipFree(q);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -239,6 +252,20 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     D.A = vgl_max_alleles(p); D.G = vgl_max_genotypes(p);
     int cap = (int)ceil(dmax + 8.0 * sqrt(dmax) + 16.0);
     D.read_cap = (cap + 3) & ~3;
+    if (D.read_cap > 1023) { delete c; return fail(VGL_E_ARG, "mean depth too large for the staging layout"); }
+    {   // quality-score pool of one wavefront: the summed depth of its (up to) 64 samples
+        double lmax = 0.0;
+        for (int c0 = 0; c0 < N; c0 += 64) {
+            double l = 0.0;
+            for (int s = c0; s < N && s < c0 + 64; s++) l += p->depths ? p->depths[s] : p->depth;
+            if (l > lmax) lmax = l;
+        }
+        int pc = (int)ceil(lmax + 8.0 * sqrt(lmax) + 64.0);
+        pc = (pc + 63) & ~63;
+        if (pc > 6144) pc = 6144;                      // larger pools run in several LDS segments
+        D.pool_cap = pc;
+        D.pool_lds_bytes = 512 + 5 * pc;
+    }
     D.error_qs = p->error_qs; D.gl_model = p->gl_model; D.precise_gl = p->precise_gl; D.adjust_qs = p->adjust_qs;
     D.n_qs_bins = p->n_qs_bins; D.do_unobserved = p->do_unobserved; D.rm_invar_sites = p->rm_invar_sites;
     D.rm_empty_sites = p->rm_empty_sites;
@@ -247,6 +274,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     D.need_qsum = (p->add_qs || p->add_i16) ? 1 : 0; D.need_qsumsq = p->add_i16 ? 1 : 0; D.need_adf = D.sample_strand;
     D.i16_mapq = p->i16_mapq; D.add_i16 = p->add_i16;
     D.adjust_by = p->adjust_by;
+    D.dbg_phase = getenv("VGL_DEBUG_PHASE") ? atoi(getenv("VGL_DEBUG_PHASE")) : 0;
     for (int i = 0; i < p->n_qs_bins * 3; i++) D.qs_bins[i] = p->qs_bins[i];
     D.err_thresh = (uint64_t)ceil(ldexp(p->error_rate, 48));
 
@@ -294,12 +322,30 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     TRY(dmalloc(&c->d_samp_tab, (size_t)N));
     TRYHIP(hipMemcpy(c->d_samp_tab, samp.data(), sizeof(VglAffine) * N, hipMemcpyHostToDevice));
     D.samp_tab = c->d_samp_tab;
+    if (p->error_qs == 2) {
+        if (lay.qs_read_stride == 0) { vgl_ctx_destroy(c); return fail(VGL_E_ARG, "layout.qs_read_stride must be > 0 with --error-qs 2"); }
+        std::vector<VglAffine> rt(D.read_cap);
+        const VglAffine jr = aff_pow(lay.qs_read_stride);
+        VglAffine cur = {1, 0};
+        for (int r = 0; r < D.read_cap; r++) { rt[r] = cur; cur = aff_compose(jr, cur); }
+        TRY(dmalloc(&c->d_qs_read_tab, (size_t)D.read_cap));
+        TRYHIP(hipMemcpy(c->d_qs_read_tab, rt.data(), sizeof(VglAffine) * D.read_cap, hipMemcpyHostToDevice));
+        D.qs_read_tab = c->d_qs_read_tab;
+    }
     if (p->depths) {
         std::vector<VglPois> pv(N);
         for (int s = 0; s < N; s++) pois_init(&pv[s], p->depths[s]);
         TRY(dmalloc(&c->d_pois, (size_t)N));
         TRYHIP(hipMemcpy(c->d_pois, pv.data(), sizeof(VglPois) * N, hipMemcpyHostToDevice));
         D.pois = c->d_pois;
+    }
+    {
+        const int n = 2048;
+        std::vector<double> gl(n, 0.0);
+        for (int k = 1; k < n; k++) gl[k] = gamma_ln_host((double)k);
+        TRY(dmalloc(&c->d_gamma_ln, (size_t)n));
+        TRYHIP(hipMemcpy(c->d_gamma_ln, gl.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+        D.gamma_ln_tab = c->d_gamma_ln; D.gamma_ln_n = n;
     }
     TRY(dmalloc(&c->d_q2gl, (size_t)3 * 257));
     TRYHIP(hipMemcpy(c->d_q2gl, q2gl.data(), sizeof(double) * 3 * 257, hipMemcpyHostToDevice));
@@ -323,6 +369,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     TRY(dmalloc(&c->d_sinfo, (size_t)max_sites));
     TRY(dmalloc(&c->d_errflag, (size_t)1));
     TRYHIP(hipMemset(c->d_errflag, 0, sizeof(uint32_t)));
+    if (getenv("VGL_DEBUG_STAMPS")) { TRY(dmalloc(&c->d_dbg, (size_t)16)); TRYHIP(hipMemset(c->d_dbg, 0, 128)); }
     *out = c;
     return VGL_OK;
 }
@@ -371,7 +418,7 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     memset(&T, 0, sizeof T);
     T.site0 = site0; T.n_sites = n_sites; T.gt = gt;
     T.reads = c->d_reads; T.errp = c->d_errp; T.ad4 = c->d_ad4; T.adf4 = c->d_adf4; T.qsum = c->d_qsum; T.qsumsq = c->d_qsumsq;
-    T.acc = c->d_acc; T.sinfo = c->d_sinfo; T.errflag = c->d_errflag;
+    T.acc = c->d_acc; T.sinfo = c->d_sinfo; T.errflag = c->d_errflag; T.dbg = c->d_dbg;
     T.site_status = o->site_status; T.n_alleles = o->n_alleles; T.n_alleles_obs = o->n_alleles_obs; T.alleles2acgt = o->alleles2acgt;
     T.info_dp = o->info_dp; T.info_ad = o->info_ad; T.info_adf = o->info_adf; T.info_adr = o->info_adr;
     T.qs = o->qs; T.i16 = o->i16; T.fmt_dp = o->fmt_dp; T.gl = o->gl; T.pl = o->pl; T.gp = o->gp;
@@ -396,6 +443,15 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     if (c->timing) HIPCHK(hipEventRecord(e[3], st));
     if (o->qs || o->i16) if (vgl_launch_siteagg(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_siteagg launch failed");
     if (c->timing) for (int k = 0; k < 4; k++) c->ev.push_back(e[k]);
+    return VGL_OK;
+}
+
+// diagnostic (not in the public header): read and clear the VGL_DEBUG_STAMPS counters
+extern "C" int vgl_dbg_stamps(vgl_ctx* c, unsigned long long out[16]) {
+    if (!c || !c->d_dbg) return fail(VGL_E_ARG, "context was not created with VGL_DEBUG_STAMPS=1");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, c->d_dbg, 128, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(c->d_dbg, 0, 128));
     return VGL_OK;
 }
 

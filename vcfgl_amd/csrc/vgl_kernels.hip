@@ -37,8 +37,8 @@
 __device__ __forceinline__ uint64_t lcg_next(uint64_t x) { return (x * VGL_LCG_A + VGL_LCG_C) & VGL_MASK48; }
 __device__ __forceinline__ uint64_t aff(const VglAffine m, uint64_t x) { return (m.a * x + m.c) & VGL_MASK48; }
 __device__ __forceinline__ double u01(uint64_t x) {
-    // exact: x < 2^48
-    return ((double)(uint32_t)(x >> 32) * 4294967296.0 + (double)(uint32_t)x) * (1.0 / 281474976710656.0);
+    // exact for x < 2^48: the 48 bits become the top of the mantissa of 1.xxx (what glibc's erand48 does)
+    return __longlong_as_double((long long)(0x3FF0000000000000ULL | (x << 4))) - 1.0;
 }
 __device__ __forceinline__ double next_u(uint64_t& st) { st = lcg_next(st); return u01(st); }
 
@@ -56,8 +56,9 @@ __device__ double gamma_ln_dev(const double xx) {
     return -tmp + log(2.5066282746310005 * ser / x);
 }
 
-// one depth draw, rng.h:289-312
-__device__ int poisson_draw(const VglPois& p, uint64_t& st) {
+// one depth draw, rng.h:289-312.  gamma_ln(em + 1) of the integer em comes from a table the host
+// fills with the same formula (rng.h:60-64); larger arguments are evaluated here.
+__device__ int poisson_draw(const VglPois& p, uint64_t& st, const double* __restrict__ glt, const int glt_n) {
     double em, t;
     if (p.st12) {
         em = -1.0; t = 1.0;
@@ -70,7 +71,8 @@ __device__ int poisson_draw(const VglPois& p, uint64_t& st) {
                 em = p.sq * y + p.lm;
             } while (em < 0.0);
             em = floor(em);
-            t = 0.9 * (1.0 + y * y) * exp(em * p.alxm - gamma_ln_dev(em + 1.0) - p.g);
+            const double gl = (em < (double)(glt_n - 1)) ? glt[(int)em + 1] : gamma_ln_dev(em + 1.0);
+            t = 0.9 * (1.0 + y * y) * exp(em * p.alxm - gl - p.g);
         } while (next_u(st) > t);
     }
     return (int)em;
@@ -151,19 +153,134 @@ __device__ __forceinline__ int wave_sum(int v) {
 }
 
 // wave -> (local site, 64-sample chunk); everything here is wave-uniform (SGPRs)
-struct WavePos { int ls; int chunk; bool valid; };
+struct WavePos { int ls; int chunk; int wib; bool valid; };
 __device__ __forceinline__ WavePos wave_pos(const VglDevParams& P, const VglTilePtrs& T) {
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t w = (int64_t)blockIdx.x * (blockDim.x >> 6) + wib;
     WavePos r;
+    r.wib = wib;
     r.valid = w < (int64_t)T.n_sites * P.chunks;
     r.ls = (int)(w / P.chunks);
     r.chunk = (int)(w - (int64_t)r.ls * P.chunks);
     return r;
 }
 
+// ---- decisions of the rejection samplers without a float64 logarithm ---------------------
+// The reference compares expressions that contain log() in double.  The hardware float32
+// log2 (v_log_f32) with an explicit error bound decides the comparison unless the two sides
+// are closer than that bound; only then is the exact double expression evaluated, so the
+// decision is always the one the exact expression gives.
+// Bound: for normal float x, |v_log_f32(x) - log2(x)| <= 2^-22.9 |log2 x| (measured on MI355X
+// over 1.2e7 inputs incl. a dense set around 1: tools/vlogcheck.py; relative to |x-1| near 1);
+// with the double->float rounding of the argument and the multiplication by ln 2:
+//     |fast_ln(x) - ln(x)| <= |fast_ln(x)| 2^-21 + 2^-22
+#define VGL_LN2 0.6931471805599453
+__device__ __forceinline__ double fast_ln(const float xf) { return (double)__builtin_amdgcn_logf(xf) * VGL_LN2; }
+__device__ __forceinline__ double fast_ln_err(const double l) { return fabs(l) * 0x1p-21 + 0x1p-22; }
+
+// (v*v) > -4.0*log(u)*(u*u)                                              rng.h:78
+// `need` = lanes whose result is used; only those can force the exact evaluation.
+__device__ __forceinline__ bool normal_slow_test(const double v, const double u, const bool need) {
+    const double lhs = v * v;
+    const float uf = (float)u;
+    const double l = fast_ln(uf);
+    const double uu = u * u;
+    const double rhs = -4.0 * l * uu;
+    const double m = 4.0 * uu * fast_ln_err(l);
+    const bool hi = lhs > rhs + m, lo = lhs < rhs - m;
+    bool res = hi;
+    if (need & !((hi | lo) & (uf > 0.0f))) {
+        res = lhs > -4.0 * log(u) * (u * u);
+    }
+    return res;
+}
+
+// log(u) > 0.5*xsq + a1*(1.0 - v + log(v)),  v = fl(fl(w*w)*w), w = fl(1 + a2 x)    rng.h:139-145
+// With s = a2 x and a2^2 = 1/(9 a1) the quadratic terms cancel analytically:
+//     0.5 x^2 + a1 (1 - (1+s)^3 + 3 ln(1+s)) = -3 a1 s^4 (1/4 - s/5 + s^2/6 - s^3/7 + ...)
+// a well-conditioned series (no cancellation), so float32 is enough for the bounded decision:
+// |s| <= 1/3 => 11 terms leave < 2e-7 relative truncation; float32 evaluation < 1e-6 relative;
+// the reference's own double rounding of its expression is < 1e-12.  Outside the band (or for
+// |s| > 1/3) the exact double expression is evaluated.
+__device__ __forceinline__ bool gamma_slow_test(const double u, const double xsq, const double a1, const double v,
+                                                const double s, const bool need) {
+    const float uf = (float)u, sf = (float)s, a1f = (float)a1;
+    const float lu = __builtin_amdgcn_logf(uf) * 0.69314718f;
+    float p = 1.0f / 14.0f;
+    p = 1.0f / 13.0f - sf * p; p = 1.0f / 12.0f - sf * p; p = 1.0f / 11.0f - sf * p; p = 1.0f / 10.0f - sf * p;
+    p = 1.0f / 9.0f - sf * p; p = 1.0f / 8.0f - sf * p; p = 1.0f / 7.0f - sf * p; p = 1.0f / 6.0f - sf * p;
+    p = 1.0f / 5.0f - sf * p; p = 1.0f / 4.0f - sf * p;
+    const float s2 = sf * sf;
+    const float g = 3.0f * a1f * (s2 * s2) * p;                 // = -(rhs of the reference), >= 0
+    const float d = lu + g;                                     // log(u) - rhs
+    const float m = fabsf(lu) * 0x1p-20f + 0x1p-21f + g * 4e-6f + 1e-10f;
+    const bool ok = (fabsf(d) > m) & (fabsf(sf) <= 0.3333f) & (uf > 0.0f);
+    bool res = d > 0.0f;
+    if (need & !ok) {
+        res = log(u) > 0.5 * xsq + a1 * (1.0 - v + log(v));
+    }
+    return res;
+}
+
+// error probability -> qScore / adjusted qScore (vcfgl.cpp:500-523); (int)(-10*log10(p)) is
+// taken from the float32 log2 unless p sits within its error bound of an integer boundary
+__device__ __forceinline__ void errprob_to_qs_fast(const VglDevParams& P, const double ep, int& q, int& aq, uint32_t* errflag) {
+    // float32: tf = -10 log10(p) within |tf| 2^-20 + 1e-6 (v_log_f32 bound + argument rounding)
+    const float pf = (float)ep;
+    const float tf = -3.0103f * __builtin_amdgcn_logf(pf);
+    const float m = tf * 0x1p-19f + 2e-6f;
+    const float fl = floorf(tf);
+    const float t2 = tf + (float)P.adjust_by;
+    const float fl2 = floorf(t2);
+    bool ok = (pf > 1.0e-37f) && (pf < 1.0f) && (tf - fl > m) && (fl + 1.0f - tf > m);
+    if (P.adjust_qs) ok = ok && (t2 > m) && (t2 - fl2 > m) && (fl2 + 1.0f - t2 > m);
+    q = (int)fl; aq = P.adjust_qs ? (int)fl2 : -1;
+    if (!ok) {                                         // exact: vcfgl.cpp:500-507
+        q = -1; aq = -1;
+        if (0.0 == ep) q = CAP_BASEQ;
+        else if (1.0 == ep) q = 0;
+        else {
+            const double tmp = -10.0 * log10(ep);
+            q = (int)tmp;
+            if (P.adjust_qs) aq = (int)(tmp + P.adjust_by);
+        }
+    }
+    if (P.n_qs_bins != 0) {
+        q = apply_bins(P, q, errflag);
+        if (P.adjust_qs) aq = apply_bins(P, aq, errflag);
+    } else {
+        q = (q > CAP_BASEQ) ? CAP_BASEQ : q;
+        if (P.adjust_qs) aq = (aq > CAP_BASEQ) ? CAP_BASEQ : aq;
+    }
+}
+
+// one read: haplotype pick, base-call error, strand (vcfgl.cpp:473,486-488,581-586); all compares
+// are exact integer restatements on the 48-bit state: u<0.5 <=> X<2^47, u<e <=> X<ceil(e 2^48),
+// floor(4u) = X>>46
+__device__ __forceinline__ int sample_read_base(uint64_t& st_hap, uint64_t& st_base, const int a0, const int a1,
+                                                const uint64_t err_thresh, const bool sample_strand, bool& fwd) {
+    st_hap = lcg_next(st_hap);
+    const int true_base = (st_hap < (1ULL << 47)) ? a0 : a1;
+    int r_base = true_base;
+    st_base = lcg_next(st_base);
+    if (st_base < err_thresh) {
+        do { st_base = lcg_next(st_base); r_base = (int)(st_base >> 46); } while (r_base == true_base);
+    }
+    fwd = true;
+    if (sample_strand) { st_base = lcg_next(st_base); fwd = st_base < (1ULL << 47); }
+    return r_base;
+}
+
 // ------------------------------------------------------------------------------------
+// EQS = --error-qs.  EQS 2 (a beta deviate per read) runs the quality-score sampling as a
+// wavefront-wide pool: the reads of the wave's 64 evaluations are independent work items
+// (stream 3 is addressed per read), staged in LDS and dealt round-robin to the lanes, so a
+// lane's work does not depend on its own evaluation's depth; each lane runs the nested
+// rejection loops of the gamma sampler as one flat state machine (one normal-deviate attempt
+// per iteration) so that lanes at different stages share every iteration.
+template <int EQS>
 __global__ __launch_bounds__(256) void k_sample(const VglDevParams P, const VglTilePtrs T) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const WavePos wp = wave_pos(P, T);
     if (!wp.valid) return;
     const int lane = threadIdx.x & 63;
@@ -171,81 +288,218 @@ __global__ __launch_bounds__(256) void k_sample(const VglDevParams P, const VglT
     const int ls = wp.ls;
     const int s = wp.chunk * 64 + lane;
     const bool active = s < N;
-    const size_t ev = (size_t)ls * N + (active ? s : 0);
+    const size_t ev0 = (size_t)ls * N + (size_t)wp.chunk * 64;      // evaluation of lane 0
+    const size_t ev = ev0 + (active ? lane : 0);
+    const size_t plane = (size_t)T.n_sites * N;
 
-    int dp = 0;
+    int dp = 0, a0 = 0, a1 = 0;
     uint64_t ad4 = 0, adf4 = 0;
     uint32_t qs0 = 0, qs1 = 0, qs2 = 0, qs3 = 0, qq0 = 0, qq1 = 0, qq2 = 0, qq3 = 0;
+    uint64_t st_hap = 0, st_base = 0, st_qs = 0;
+    // diagnostic build only (T.dbg != null): per-phase cycle stamps, never in a timed run
+    unsigned long long c_t0 = 0, c_pois = 0, c_owner = 0, c_pool = 0, c_flush = 0, c_iter = 0, c_items = 0, c_tmp = 0;
+    if (T.dbg) c_t0 = clock64();
+    uint64_t err_thresh = P.err_thresh;
+
+    // ---- stream states of this evaluation: J^(off_k) . J^(block*s) . J^(block*N*site) (x0)
+    const uint64_t site_abs = (uint64_t)(T.site0 + ls);
+    uint64_t xb = P.x0;
+#pragma unroll 1
+    for (int b = 0; b < 40; ++b)
+        if ((site_abs >> b) & 1) xb = aff(P.site_pow[b], xb);
 
     if (active) {
-        // ---- stream states of this evaluation: J^(off_k) . J^(block*s) . J^(block*N*site) (x0)
-        const uint64_t site_abs = (uint64_t)(T.site0 + ls);
-        uint64_t xb = P.x0;
-#pragma unroll 1
-        for (int b = 0; b < 40; ++b)
-            if ((site_abs >> b) & 1) xb = aff(P.site_pow[b], xb);
         const VglAffine ms = P.samp_tab[s];
         const uint64_t xe = aff(ms, xb);
         uint64_t st_depth = aff(P.off[0], xe);
-        uint64_t st_hap = aff(P.off[1], xe);
-        uint64_t st_base = aff(P.off[2], xe);
-        uint64_t st_qs = aff(P.off[3], xe);
+        st_hap = aff(P.off[1], xe);
+        st_base = aff(P.off[2], xe);
+        st_qs = aff(P.off[3], xe);
 
         // ---- depth (vcfgl.cpp:364-389): drawn even when the genotype is missing
         int n;
-        if (P.per_sample_depth) { const VglPois pc = P.pois[s]; n = poisson_draw(pc, st_depth); }
-        else n = poisson_draw(P.pois0, st_depth);
+        if (P.per_sample_depth) { const VglPois pc = P.pois[s]; n = poisson_draw(pc, st_depth, P.gamma_ln_tab, P.gamma_ln_n); }
+        else n = poisson_draw(P.pois0, st_depth, P.gamma_ln_tab, P.gamma_ln_n);
         const uint32_t g = T.gt[ev];
-        const int a0 = g & 0xF, a1 = (g >> 4) & 0xF;
+        a0 = g & 0xF; a1 = (g >> 4) & 0xF;
         dp = (a0 == 0xF || a1 == 0xF) ? 0 : n;
         if (dp > P.read_cap) { atomicOr(T.errflag, VGL_DEVERR_CAPACITY); dp = P.read_cap; }
+    }
 
-        // ---- per-site base-pick error probability (error_qs 1: one beta deviate per site,
-        //      stream 3 of sample 0; vcfgl.cpp:425-437)
-        uint64_t err_thresh = P.err_thresh;
-        if (P.error_qs == 1) {
+    if (T.dbg) c_pois = clock64() - c_t0;
+    if (P.dbg_phase == 1) return;
+    if (EQS == 1) {
+        // one beta deviate per site: stream 3 of sample 0, read 0 (vcfgl.cpp:425-437); lane 0 draws it
+        uint32_t lo = 0, hi = 0;
+        if (lane == 0) {
             uint64_t st_site = aff(P.off[3], aff(P.samp_tab[0], xb));
             const double pe = beta_draw(P, st_site);
-            err_thresh = (uint64_t)ceil(ldexp(pe, 48));
+            const uint64_t th = (uint64_t)ceil(ldexp(pe, 48));
+            lo = (uint32_t)th; hi = (uint32_t)(th >> 32);
         }
+        lo = __shfl(lo, 0, 64); hi = __shfl(hi, 0, 64);
+        err_thresh = ((uint64_t)hi << 32) | lo;
+    }
 
-        // ---- read loop (vcfgl.cpp:469-613)
-        const size_t plane = (size_t)T.n_sites * N;
+    if (EQS != 2) {
+        // ---- read loop (vcfgl.cpp:469-613), fixed quality score
+        const int q_i = P.pre_q, aq_i = P.pre_adjq;
+        const uint32_t q_gl = (uint32_t)((P.adjust_qs & 1) ? aq_i : q_i);
+        const uint32_t qq = (uint32_t)((P.adjust_qs & 2) ? aq_i : q_i);
+        const uint32_t q2 = (uint32_t)qs_to_qssq((int)qq);
         for (int r = 0; r < dp; ++r) {
-            st_hap = lcg_next(st_hap);
-            const int true_base = (st_hap < (1ULL << 47)) ? a0 : a1;                 // u < 0.5
-            int r_base = true_base;
-            st_base = lcg_next(st_base);
-            if (st_base < err_thresh) {                                             // u < e
-                do { st_base = lcg_next(st_base); r_base = (int)(st_base >> 46); }   // floor(4u)
-                while (r_base == true_base);
-            }
-            int q_i = P.pre_q, aq_i = P.pre_adjq;
-            if (P.error_qs == 2) {
-                const double ep = beta_draw(P, st_qs);
-                errprob_to_qs(P, ep, q_i, aq_i, T.errflag);
-                if (P.precise_gl) T.errp[(size_t)r * plane + ev] = ep;
-            }
-            const int q_gl = (P.adjust_qs & 1) ? aq_i : q_i;
+            bool fwd;
+            const int r_base = sample_read_base(st_hap, st_base, a0, a1, err_thresh, P.sample_strand != 0, fwd);
             T.reads[(size_t)r * plane + ev] = (uint8_t)((q_gl << 2) | r_base);
             if (T.reads_out && r < T.reads_out_cap) T.reads_out[(size_t)r * plane + ev] = (uint8_t)((q_i << 2) | r_base);
-            if (P.need_qsum) {
-                const uint32_t qq = (uint32_t)((P.adjust_qs & 2) ? aq_i : q_i);
-                const uint32_t q2 = (uint32_t)qs_to_qssq((int)qq);
-                qs0 += (r_base == 0) ? qq : 0u; qs1 += (r_base == 1) ? qq : 0u;
-                qs2 += (r_base == 2) ? qq : 0u; qs3 += (r_base == 3) ? qq : 0u;
-                qq0 += (r_base == 0) ? q2 : 0u; qq1 += (r_base == 1) ? q2 : 0u;
-                qq2 += (r_base == 2) ? q2 : 0u; qq3 += (r_base == 3) ? q2 : 0u;
-            }
             const uint64_t one = 1ULL << (16 * r_base);
             ad4 += one;
-            if (P.sample_strand) {
-                st_base = lcg_next(st_base);
-                if (st_base < (1ULL << 47)) adf4 += one;                             // forward
-            }
+            if (fwd) adf4 += one;
         }
-        if (!P.sample_strand) adf4 = ad4;
+        if (P.need_qsum) {
+            qs0 = qq * (uint32_t)(ad4 & 0xFFFF); qs1 = qq * (uint32_t)((ad4 >> 16) & 0xFFFF);
+            qs2 = qq * (uint32_t)((ad4 >> 32) & 0xFFFF); qs3 = qq * (uint32_t)((ad4 >> 48) & 0xFFFF);
+            qq0 = q2 * (uint32_t)(ad4 & 0xFFFF); qq1 = q2 * (uint32_t)((ad4 >> 16) & 0xFFFF);
+            qq2 = q2 * (uint32_t)((ad4 >> 32) & 0xFFFF); qq3 = q2 * (uint32_t)((ad4 >> 48) & 0xFFFF);
+        }
+    } else {
+        // ---- LDS of this wave: [64] u64 qscore-stream bases | [cap] u16 item->(read,owner) |
+        //      [cap] u8 base | [cap] u8 qScore | [cap] u8 adjusted qScore
+        const int cap = P.pool_cap;
+        uint8_t* wl = lds_raw + (size_t)wp.wib * P.pool_lds_bytes;
+        uint64_t* l_stq = (uint64_t*)wl;
+        uint16_t* l_map = (uint16_t*)(wl + 512);
+        uint8_t* l_pb = wl + 512 + 2 * (size_t)cap;
+        uint8_t* l_pq = l_pb + cap;
+        uint8_t* l_paq = l_pq + cap;
 
+        // exclusive prefix sum of the depths = first pool index of each owner
+        int incl = dp;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        const int offs = incl - dp;
+        const int total = __shfl(incl, 63, 64);
+        l_stq[lane] = st_qs;
+        int rdone = 0;
+
+        for (int seg0 = 0; seg0 < total; seg0 += cap) {                 // normally one segment
+            const int segT = (total - seg0 < cap) ? (total - seg0) : cap;
+            // -- owners: bases of their reads that fall into this segment
+            if (T.dbg) c_tmp = clock64();
+            int r_end = seg0 + segT - offs; r_end = r_end > dp ? dp : r_end; r_end = r_end < rdone ? rdone : r_end;
+            for (int r = rdone; r < r_end; ++r) {
+                bool fwd;
+                const int r_base = sample_read_base(st_hap, st_base, a0, a1, err_thresh, P.sample_strand != 0, fwd);
+                const uint64_t one = 1ULL << (16 * r_base);
+                ad4 += one;
+                if (fwd) adf4 += one;
+                const int k = offs + r - seg0;
+                l_map[k] = (uint16_t)((r << 6) | lane);
+                l_pb[k] = (uint8_t)r_base;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+            // -- pool: item k -> lane k % 64.  One iteration = one normal-deviate attempt
+            //    (rng.h:72-78) + the gamma step it feeds (rng.h:139-145), computed for every lane
+            //    without branches; lane state (stream, stage, first gamma) advances by selects, so
+            //    lanes in different stages of different reads share every instruction.  Real
+            //    branches remain only around the rare bounded-log tests and the per-read epilogue.
+            if (T.dbg) { const unsigned long long c = clock64(); c_owner += c - c_tmp; c_tmp = c; c_items += segT; }
+            if (P.dbg_phase == 2) return;
+            {
+                int k = lane;
+                bool have = k < segT;
+                uint64_t st = 0; int stage = 0; double gx = 0.0; int it_o = 0, it_r = 0;
+                if (have) { const uint32_t m = l_map[k]; it_o = m & 63; it_r = m >> 6; st = aff(P.qs_read_tab[it_r], l_stq[it_o]); }
+                const bool any_changed = (P.gx.changed | P.gy.changed) != 0;
+                while (__ballot(have)) {
+                    if (T.dbg) c_iter++;
+                    const double ga1 = stage ? P.gy.a1 : P.gx.a1;
+                    const double ga2 = stage ? P.gy.a2 : P.gx.a2;
+                    // normal attempt
+                    const uint64_t st1 = lcg_next(st);
+                    const uint64_t st2 = lcg_next(st1);
+                    const uint64_t st3 = lcg_next(st2);
+                    const double u = u01(st1);
+                    const double v = 1.7156 * (u01(st2) - 0.5);
+                    const double x = u - 0.449871;
+                    const double y = fabs(v) + 0.386595;
+                    const double q = (x * x) + y * (0.19600 * y - 0.25472 * x);
+                    const bool q_lo = q > 0.27597, q_hi = q > 0.27846;
+                    bool slow_n = false;
+                    if (__ballot(have & q_lo & !q_hi)) slow_n = normal_slow_test(v, u, have & q_lo & !q_hi);
+                    const bool acc_n = !(q_lo & (q_hi | slow_n));
+                    // gamma step on the accepted deviate
+                    const double xn = v / u;
+                    const double w = 1.0 + ga2 * xn;
+                    const bool w_pos = w > 0.0;
+                    const double vv = w * w * w;
+                    const double u2 = u01(st3);
+                    const double xsq = xn * xn;
+                    const bool sq_fail = u2 > 1.0 - 0.0331 * (xsq * xsq);
+                    const bool g_try = have & acc_n & w_pos;
+                    bool slow_g = false;
+                    if (__ballot(g_try & sq_fail)) slow_g = gamma_slow_test(u2, xsq, ga1, vv, ga2 * xn, g_try & sq_fail);
+                    const bool acc_g = g_try & !(sq_fail & slow_g);
+                    st = g_try ? st3 : st2;                  // u2 is drawn only when w > 0 (rng.h:140-142)
+                    double val = ga1 * vv;
+                    if (any_changed) {                       // alpha < 1 (rng.h:146-148)
+                        if (acc_g && (stage ? P.gy.changed : P.gx.changed)) {
+                            double u3;
+                            do { st = lcg_next(st); u3 = u01(st); } while (u3 == 0.0);
+                            val = pow(u3, 1.0 / (stage ? P.gy.alpha0 : P.gx.alpha0)) * ga1 * vv;
+                        }
+                    }
+                    const bool fin = acc_g & (stage == 1);
+                    gx = (acc_g & (stage == 0)) ? val : gx;
+                    stage = acc_g ? (stage ^ 1) : stage;
+                    if (fin) {
+                        const double ep = gx / (gx + val);                         // rng.h:438
+                        int q_i, aq_i;
+                        errprob_to_qs_fast(P, ep, q_i, aq_i, T.errflag);
+                        l_pq[k] = (uint8_t)q_i;
+                        l_paq[k] = (uint8_t)aq_i;
+                        if (P.precise_gl) T.errp[(size_t)it_r * plane + ev0 + it_o] = ep;
+                        k += 64; have = k < segT;
+                        if (have) { const uint32_t m = l_map[k]; it_o = m & 63; it_r = m >> 6; st = aff(P.qs_read_tab[it_r], l_stq[it_o]); }
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+            // -- owners: combine base + quality score, stage the read, quality sums (vcfgl.cpp:525-564)
+            if (T.dbg) { const unsigned long long c = clock64(); c_pool += c - c_tmp; c_tmp = c; }
+            if (P.dbg_phase == 3) return;
+            for (int r = rdone; r < r_end; ++r) {
+                const int k = offs + r - seg0;
+                const int r_base = l_pb[k];
+                const int q_i = l_pq[k];
+                const int aq_i = P.adjust_qs ? (int)l_paq[k] : -1;
+                const int q_gl = (P.adjust_qs & 1) ? aq_i : q_i;
+                T.reads[(size_t)r * plane + ev] = (uint8_t)((q_gl << 2) | r_base);
+                if (T.reads_out && r < T.reads_out_cap) T.reads_out[(size_t)r * plane + ev] = (uint8_t)((q_i << 2) | r_base);
+                if (P.need_qsum) {
+                    const uint32_t qq = (uint32_t)((P.adjust_qs & 2) ? aq_i : q_i);
+                    const uint32_t q2 = (uint32_t)qs_to_qssq((int)qq);
+                    qs0 += (r_base == 0) ? qq : 0u; qs1 += (r_base == 1) ? qq : 0u;
+                    qs2 += (r_base == 2) ? qq : 0u; qs3 += (r_base == 3) ? qq : 0u;
+                    qq0 += (r_base == 0) ? q2 : 0u; qq1 += (r_base == 1) ? q2 : 0u;
+                    qq2 += (r_base == 2) ? q2 : 0u; qq3 += (r_base == 3) ? q2 : 0u;
+                }
+            }
+            rdone = r_end;
+            __builtin_amdgcn_wave_barrier();
+            if (T.dbg) c_flush += clock64() - c_tmp;
+            if (P.dbg_phase == 4) return;
+        }
+    }
+
+    if (active) {
+        if (!P.sample_strand) adf4 = ad4;
         if (T.fmt_dp) T.fmt_dp[ev] = dp;
         T.ad4[ev] = ad4;
         if (P.need_adf) T.adf4[ev] = adf4;
@@ -271,6 +525,11 @@ __global__ __launch_bounds__(256) void k_sample(const VglDevParams P, const VglT
         int32_t* acc = T.acc + (size_t)ls * VGL_ACC_STRIDE;
 #pragma unroll
         for (int k = 0; k < 9; ++k) if (v[k]) atomicAdd(&acc[k], v[k]);
+        if (T.dbg) {
+            atomicAdd(&T.dbg[0], 1ULL); atomicAdd(&T.dbg[1], clock64() - c_t0); atomicAdd(&T.dbg[2], c_pois);
+            atomicAdd(&T.dbg[3], c_owner); atomicAdd(&T.dbg[4], c_pool); atomicAdd(&T.dbg[5], c_flush);
+            atomicAdd(&T.dbg[6], c_iter); atomicAdd(&T.dbg[7], c_items);
+        }
     }
 }
 
@@ -550,7 +809,9 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
     const int64_t waves = (int64_t)t->n_sites * p->chunks;
     if (waves == 0) return 0;
     const unsigned blocks = (unsigned)((waves + 3) / 4);
-    hipLaunchKernelGGL(k_sample, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, *t);
+    if (p->error_qs == 2) hipLaunchKernelGGL(k_sample<2>, dim3(blocks), dim3(256), (size_t)4 * p->pool_lds_bytes, (hipStream_t)stream, *p, *t);
+    else if (p->error_qs == 1) hipLaunchKernelGGL(k_sample<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, *t);
+    else hipLaunchKernelGGL(k_sample<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, *t);
     return (int)hipGetLastError();
 }
 
@@ -573,4 +834,16 @@ extern "C" int vgl_launch_siteagg(const VglDevParams* p, const VglTilePtrs* t, v
     if (t->n_sites == 0) return 0;
     hipLaunchKernelGGL(k_siteagg, dim3((t->n_sites + 63) / 64), dim3(64), 0, (hipStream_t)stream, *p, *t);
     return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// debug hook (not part of the C ABI): raw v_log_f32 over a buffer, used by
+// tests/test_gpu_parity.py to check the error bound the fast decision paths assume
+__global__ void k_dbg_vlog(const float* in, float* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = __builtin_amdgcn_logf(in[i]);
+}
+extern "C" int vgl_dbg_vlog(const float* d_in, float* d_out, int n) {
+    hipLaunchKernelGGL(k_dbg_vlog, dim3((n + 255) / 256), dim3(256), 0, 0, d_in, d_out, n);
+    return (int)hipDeviceSynchronize();
 }
