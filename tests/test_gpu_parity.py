@@ -150,6 +150,14 @@ def test_gl_model1_fixed_q(oracle, depth, du):
     assert_parity(want, got)
 
 
+@pytest.mark.parametrize("depth,adj", [(2, 0), (12, 1), (40, 3)])
+def test_gl_model1_per_read_q(oracle, depth, adj):
+    """-GL 1 --error-qs 2: errmod over per-read quality scores (LDS histogram instead of a sort)"""
+    args = VcfglArgs(seed=42, depth=depth, error_rate=0.01, error_qs=2, beta_variance=1e-5, gl_model=1, adjust_qs=adj, **ALLTAGS)
+    want, got = run_both(oracle, args, synth.binary_sites(0, 30, 100))
+    assert_parity(want, got)
+
+
 def test_site_index_invariance(oracle):
     """tiles are addressed by absolute site index: splitting a run into tiles (or shards)
     does not change any value"""

@@ -70,6 +70,8 @@ struct VglDevParams {
     int32_t gamma_ln_n;
     const double* gl1_bsum;            // [256][256]  sum_{i<c} fk[i]*beta[q][n][i]   (fixed qScore)
     const double* gl1_lhet;            // [256][256]
+    const double* gl1_fk;              // [256]            (per-read qScores only)
+    const double* gl1_beta;            // [64][256][256]   (per-read qScores only)
 };
 
 // per-tile pointers

@@ -87,7 +87,9 @@ static void build_q2gl(double* t /*[3][257]*/) {
 // ---- GL model 1 tables (htslib errmod.c cal_coef(), restated from the published model) --
 // For one fixed qScore q the per-base sums of errmod_cal() depend only on (n, count):
 //   bsum[n][c] = sum_{i<c} fk[i] * beta[q][n][i],   lhet[n][k] = lC[n][k] - n ln 2
-static void build_gl1_tables(double depcorr, int q, std::vector<double>& bsum, std::vector<double>& lhet) {
+// With per-read qScores (q < 0) the full fk[256] and beta[64][256][256] tables are returned instead.
+static void build_gl1_tables(double depcorr, int q, std::vector<double>& bsum, std::vector<double>& lhet,
+                             std::vector<double>* fk_out = nullptr, std::vector<double>* beta_out = nullptr) {
     const double eta = 0.03;
     double fk[256];
     fk[0] = 1.0;
@@ -98,6 +100,25 @@ static void build_gl1_tables(double depcorr, int q, std::vector<double>& bsum, s
             lC[n << 8 | k] = lgamma(n + 1) - lgamma(k + 1) - lgamma(n - k + 1);
     bsum.assign(256 * 256, 0.0);
     lhet.assign(256 * 256, 0.0);
+    for (int n = 0; n < 256; ++n)
+        for (int k = 0; k < 256; ++k) lhet[n << 8 | k] = lC[n << 8 | k] - M_LN2 * n;
+    if (fk_out && beta_out) {
+        fk_out->assign(fk, fk + 256);
+        beta_out->assign((size_t)64 * 256 * 256, 0.0);
+        for (int qv = 1; qv < 64; ++qv) {
+            const double e = pow(10.0, -qv / 10.0), le = log(e), le1 = log(1.0 - e);
+            for (int n = 1; n <= 255; ++n) {
+                double* b = beta_out->data() + ((size_t)qv << 16 | (size_t)n << 8);
+                double sum, sum1 = lC[n << 8 | n] + n * le;
+                b[n] = HUGE_VAL;
+                for (int k = n - 1; k >= 0; --k, sum1 = sum) {
+                    sum = sum1 + log1p(exp(lC[n << 8 | k] + k * le + (n - k) * le1 - sum1));
+                    b[k] = -10. / M_LN10 * (sum1 - sum);
+                }
+            }
+        }
+        return;
+    }
     int qq = q < 4 ? 4 : q; if (qq > 63) qq = 63;              // errmod_cal clamps qual to [4,63]
     const double e = pow(10.0, -qq / 10.0), le = log(e), le1 = log(1.0 - e);
     for (int n = 1; n <= 255; ++n) {
@@ -111,8 +132,6 @@ static void build_gl1_tables(double depcorr, int q, std::vector<double>& bsum, s
         bsum[n * 256 + 0] = 0.0;
         for (int c = 1; c <= n; ++c) { acc += fk[c - 1] * beta[c - 1]; bsum[n * 256 + c] = acc; }
     }
-    for (int n = 0; n < 256; ++n)
-        for (int k = 0; k < 256; ++k) lhet[n << 8 | k] = lC[n << 8 | k] - M_LN2 * n;
 }
 
 // ---- context ---------------------------------------------------------------------------
@@ -123,7 +142,7 @@ struct vgl_ctx {
     VglDevParams dp;
     // device tables
     VglAffine* d_samp_tab = nullptr; VglAffine* d_qs_read_tab = nullptr; VglPois* d_pois = nullptr;
-    double* d_q2gl = nullptr; double* d_gamma_ln = nullptr; double* d_gl1_bsum = nullptr; double* d_gl1_lhet = nullptr;
+    double* d_q2gl = nullptr; double* d_gamma_ln = nullptr; double* d_gl1_fk = nullptr; double* d_gl1_beta = nullptr; double* d_gl1_bsum = nullptr; double* d_gl1_lhet = nullptr;
     // workspace
     uint8_t* d_reads = nullptr; double* d_errp = nullptr; uint64_t* d_ad4 = nullptr; uint64_t* d_adf4 = nullptr;
     uint32_t* d_qsum = nullptr; uint32_t* d_qsumsq = nullptr; int32_t* d_acc = nullptr; VglSiteInfo* d_sinfo = nullptr;
@@ -209,7 +228,7 @@ template <typename T> static int dmalloc(T** p, size_t n) {
 extern "C" int vgl_ctx_destroy(vgl_ctx* c) {
     if (!c) return VGL_OK;
     (void)hipSetDevice(c->device);
-    void* ptrs[] = {c->d_gamma_ln, c->d_samp_tab, c->d_qs_read_tab, c->d_pois, c->d_q2gl, c->d_gl1_bsum, c->d_gl1_lhet, c->d_reads, c->d_errp, c->d_ad4,
+    void* ptrs[] = {c->d_gl1_fk, c->d_gl1_beta, c->d_gamma_ln, c->d_samp_tab, c->d_qs_read_tab, c->d_pois, c->d_q2gl, c->d_gl1_bsum, c->d_gl1_lhet, c->d_reads, c->d_errp, c->d_ad4,
                     c->d_adf4, c->d_qsum, c->d_qsumsq, c->d_acc, c->d_sinfo, c->d_errflag, c->d_gt, c->d_reads_out, c->d_dbg};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     for (void* q : c->d_out) if (q) (void)hipFree(q);
@@ -232,7 +251,6 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     if (p->gl_model == 1 && p->precise_gl) return fail(VGL_E_ARG, "Precise genotype likelihood error (--precise-gl 1) is not supported with genotype likelihood model 1 (--gl-model 1).");
     if (p->rng_mode != VGL_RNG_TILE) return fail(VGL_E_UNSUPPORTED, "the device path implements VGL_RNG_TILE (counter-addressed windows) only");
     if (p->error_qs != 0 && p->beta_sampler != VGL_BETA_RAND48) return fail(VGL_E_UNSUPPORTED, "the mt19937 beta sampler is one global serial stream; the device path uses the rand48 sampler (VGL_BETA_RAND48)");
-    if (p->gl_model == 1 && p->error_qs == 2) return fail(VGL_E_UNSUPPORTED, "GL model 1 with per-read quality scores is not implemented on the device yet");
     const double dmax = max_depth(p);
     if (p->depths) { for (int i = 0; i < p->n_samples; i++) if (!(p->depths[i] >= 0.0)) return fail(VGL_E_ARG, "depths must be >= 0"); }
     else if (!(p->depth >= 0.0)) return fail(VGL_E_ARG, "[Bad argument value: '--depth %f'] Allowed range is [0,500]", p->depth);
@@ -351,7 +369,14 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     TRYHIP(hipMemcpy(c->d_q2gl, q2gl.data(), sizeof(double) * 3 * 257, hipMemcpyHostToDevice));
     D.q2gl = c->d_q2gl;
     if (p->gl_model == 1) {
-        std::vector<double> bsum, lhet;
+        std::vector<double> bsum, lhet, fkv, betav;
+        if (p->error_qs == 2) {                                    // gl_methods.cpp:233-302: per-read qScores
+            build_gl1_tables(1.0 - p->gl1_theta, -1, bsum, lhet, &fkv, &betav);
+            TRY(dmalloc(&c->d_gl1_fk, fkv.size())); TRY(dmalloc(&c->d_gl1_beta, betav.size()));
+            TRYHIP(hipMemcpy(c->d_gl1_fk, fkv.data(), sizeof(double) * fkv.size(), hipMemcpyHostToDevice));
+            TRYHIP(hipMemcpy(c->d_gl1_beta, betav.data(), sizeof(double) * betav.size(), hipMemcpyHostToDevice));
+            D.gl1_fk = c->d_gl1_fk; D.gl1_beta = c->d_gl1_beta;
+        } else
         build_gl1_tables(1.0 - p->gl1_theta, (p->adjust_qs & 1) ? D.pre_adjq : D.pre_q, bsum, lhet);   // io.cpp:1276, gl_methods.cpp:318
         TRY(dmalloc(&c->d_gl1_bsum, bsum.size())); TRY(dmalloc(&c->d_gl1_lhet, lhet.size()));
         TRYHIP(hipMemcpy(c->d_gl1_bsum, bsum.data(), sizeof(double) * bsum.size(), hipMemcpyHostToDevice));

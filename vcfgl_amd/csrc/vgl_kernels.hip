@@ -605,6 +605,7 @@ __device__ __forceinline__ int cnt_of(uint64_t ad4, int b) { return b < 4 ? (int
 
 template <int A>
 __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTilePtrs T) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     constexpr int NG = A * (A + 1) / 2;
     const WavePos wp = wave_pos(P, T);
     if (!wp.valid) return;
@@ -668,8 +669,33 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
             if (n > 255) { atomicOr(T.errflag, VGL_DEVERR_GL1DEPTH); n = 255; }
             int c[5]; double bs[5];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) { c[b] = (int)((ad4 >> (16 * b)) & 0xFFFF); if (c[b] > 255) c[b] = 255; bs[b] = P.gl1_bsum[n * 256 + c[b]]; }
+            for (int b = 0; b < 4; ++b) { c[b] = (int)((ad4 >> (16 * b)) & 0xFFFF); if (c[b] > 255) c[b] = 255; }
             c[4] = 0; bs[4] = 0.0;
+            if (P.error_qs != 2) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) bs[b] = P.gl1_bsum[n * 256 + c[b]];
+            } else {
+                // per-read qScores (gl_methods.cpp:233-302): errmod_cal() walks the reads in descending
+                // (qual, base) order, so each base accumulates fk[i]*beta[q][n][i] over its own reads in
+                // descending quality: a per-lane (base, qual) histogram in LDS replaces the sort
+                uint8_t* h = lds_raw + (size_t)wp.wib * 16384 + lane;
+                for (int bin = 0; bin < 256; ++bin) h[bin * 64] = 0;
+                for (int r = 0; r < n; ++r) {
+                    const uint32_t rb = T.reads[(size_t)r * plane + ev];
+                    const int bin = (int)(((rb & 3) << 6) | (rb >> 2));
+                    h[bin * 64] = (uint8_t)(h[bin * 64] + 1);
+                }
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    double acc_b = 0.0; int i = 0;
+                    for (int q = 63; q >= 0; --q) {
+                        const int cnt = h[(b * 64 + q) * 64];
+                        const int qq = q < 4 ? 4 : q;                          // errmod_cal clamps qual to [4,63]
+                        for (int j = 0; j < cnt; ++j) { acc_b += P.gl1_fk[i] * P.gl1_beta[((size_t)qq << 16) | ((size_t)n << 8) | (size_t)i]; ++i; }
+                    }
+                    bs[b] = acc_b;
+                }
+            }
             float mx = -INFINITY;
 #pragma unroll
             for (int i = 0; i < A; ++i) {
@@ -825,8 +851,9 @@ extern "C" int vgl_launch_gl(const VglDevParams* p, const VglTilePtrs* t, void* 
     const int64_t waves = (int64_t)t->n_sites * p->chunks;
     if (waves == 0) return 0;
     const unsigned blocks = (unsigned)((waves + 3) / 4);
-    if (p->A == 5) hipLaunchKernelGGL(k_gl<5>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, *t);
-    else hipLaunchKernelGGL(k_gl<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, *t);
+    const size_t lds = (p->gl_model == 1 && p->error_qs == 2) ? (size_t)4 * 16384 : 0;   // (base,qual) histograms
+    if (p->A == 5) hipLaunchKernelGGL(k_gl<5>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, *p, *t);
+    else hipLaunchKernelGGL(k_gl<4>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, *p, *t);
     return (int)hipGetLastError();
 }
 
