@@ -63,8 +63,10 @@ extern "C" {
  * X <- (0x5DEECE66D * X + 0xB) mod 2^48, u = X * 2^-48, X0 = (seed << 16) | 0x330E
  * (io.cpp:1054-1061, shared.h:17-22).  They differ in WHICH draw index a consumer uses. */
 #define VGL_RNG_TILE    0  /* counter addressed: each (site,sample) owns a private window      */
-#define VGL_RNG_SERIAL  1  /* the reference's serial consumption order (host oracle only; the
-                              device path returns VGL_E_UNSUPPORTED)                            */
+#define VGL_RNG_SERIAL  1  /* the reference's serial consumption order: reproduces the reference
+                              program bit for bit.  On the device a sequential scout records the
+                              stream states per (site,sample), everything else runs in parallel;
+                              tiles must be submitted in site order (site0 = sites done so far). */
 
 /* quality-score error sampler (rng.h:353-500) */
 #define VGL_BETA_RAND48 0  /* rng.h:426-446, reference built with -D__USE_STD_BETA__=0, rng2   */

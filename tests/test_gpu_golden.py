@@ -1,0 +1,64 @@
+"""The HIP path itself, in VGL_RNG_SERIAL mode (sequential scout + parallel kernels), run on the
+reference's own test inputs with the reference's flags, against the reference's golden VCFs
+(tests/golden/ref_vcf = data files of /root/reference/test).  I16 fields 13-16 (tail distance)
+come from the reference's unseeded libc rand() and are not produced on the device."""
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+from vcfgl_amd import Simulator, _abi
+
+pytestmark = pytest.mark.gpu
+CASES = sorted(gu.REF_TESTS, key=lambda s: int(s[4:]))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_device_reproduces_reference_golden_vcf(name):
+    args, vcf, sites, gold = gu.load_case(name, rng_mode=_abi.VGL_RNG_SERIAL, beta_sampler=_abi.VGL_BETA_STD)
+    gt = np.stack([s.gt for s in sites])
+    sim = Simulator(args, len(vcf.samples), max_sites_per_tile=len(sites))
+    tile = sim.simulate(0, gt)
+    sim.close()
+    errs = gu.compare_with_golden(args, sites, tile, gold, check_i16_tail=False)
+    assert not errs, "\n".join(errs[:40])
+
+
+def test_device_reproduces_reference_pileup():
+    args, vcf, sites, gold = gu.load_case("test10", rng_mode=_abi.VGL_RNG_SERIAL, beta_sampler=_abi.VGL_BETA_STD)
+    gt = np.stack([s.gt for s in sites])
+    sim = Simulator(args, len(vcf.samples), max_sites_per_tile=len(sites))
+    tile = sim.simulate(0, gt, read_capacity=16)
+    sim.close()
+    rows = gu.read_pileup(os.path.join(gu.REFVCF, "reference", "test10", "test10.pileup.gz"))
+    reads, dp = tile.numpy("reads"), tile.numpy("fmt_dp")
+    for i, (chrom, pos, ref, smp) in enumerate(rows):
+        for s, (n, bases, quals) in enumerate(smp):
+            assert n == dp[i, s]
+            if n:
+                assert "".join("ACGT"[reads[r, i, s] & 3] for r in range(n)) == bases
+                assert "".join(chr((reads[r, i, s] >> 2) + 33) for r in range(n)) == quals
+
+
+def test_serial_streams_continue_across_tiles(oracle):
+    """two consecutive tiles == one tile: the generator states are carried in the context;
+    also equals the CPU oracle's serial mode on a larger random input"""
+    import synth
+    from vcfgl_amd import VcfglArgs, VglError
+    args = VcfglArgs(seed=7, depth=3, error_rate=0.02, error_qs=2, beta_variance=1e-5, add_pl=1, add_fmt_ad=1, add_qs=1)
+    args.rng_mode, args.beta_sampler = _abi.VGL_RNG_SERIAL, _abi.VGL_BETA_STD
+    N, S = 37, 50
+    gt = synth.acgt_sites(S, N, seed=5, missing=0.05)
+    sim = Simulator(args, N, max_sites_per_tile=S)
+    a = sim.simulate(0, gt[:20])
+    b = sim.simulate(20, gt[20:])
+    with pytest.raises(VglError):
+        sim.simulate(0, gt[:5])                      # out of order: refused, not silently different
+    sim.close()
+    want = oracle.Oracle(args, N).simulate(0, gt, fields=sim.default_fields())
+    for f in ["fmt_dp", "fmt_ad", "pl", "alleles2acgt", "site_status"]:
+        assert np.array_equal(np.concatenate([a.numpy(f), b.numpy(f)]), want.numpy(f)), f
+    got_gl = np.concatenate([a.numpy("gl"), b.numpy("gl")]).view(np.uint32)
+    assert np.array_equal(got_gl, want.numpy("gl").view(np.uint32))
+    assert np.array_equal(np.concatenate([a.numpy("qs"), b.numpy("qs")]).view(np.uint32), want.numpy("qs").view(np.uint32))

@@ -48,6 +48,9 @@ struct VglDevParams {
     int32_t rm_invar_sites, rm_empty_sites, sample_strand, per_sample_depth;
     int32_t need_qsum, need_qsumsq, need_adf, i16_mapq;
     int32_t add_i16;
+    int32_t serial;          // VGL_RNG_SERIAL
+    int32_t beta_std;        // VGL_BETA_STD (serial only)
+    double  beta_a, beta_b;  // beta shape parameters (std sampler)
     int32_t dbg_phase;       // diagnostic (VGL_DEBUG_PHASE=n): k_sample returns after phase n; 0 = off
     int32_t pre_q, pre_adjq;           // preCalc qScore / adj_qScore (vcfgl.cpp:1697-1702)
     double  adjust_by;
@@ -97,6 +100,18 @@ struct VglTilePtrs {
     int32_t* fmt_ad; int32_t* fmt_adf; int32_t* fmt_adr;
     uint8_t* reads_out; int32_t reads_out_cap;
     unsigned long long* dbg;  // diagnostic cycle stamps (VGL_DEBUG_STAMPS=1), else null
+    // VGL_RNG_SERIAL: per-evaluation stream states found by the sequential scout (k_scout)
+    uint64_t* sst_depth; uint64_t* sst_hap; uint64_t* sst_base;   // [n_sites][N]
+    uint64_t* site_thresh;   // [n_sites] per-site base-pick error threshold (error_qs 1)
+    int32_t*  scout_dp;      // [N] scratch of the scout
+};
+
+// persistent serial-mode generator states (device memory, carried from tile to tile)
+struct VglSerialState {
+    uint64_t st0, st1, st2;  // rng0 (drand48), rng1, rng2
+    uint32_t mt[624];        // std::mt19937 of the default beta sampler
+    int32_t  mt_idx;
+    int32_t  pad;
 };
 
 #ifdef __cplusplus
@@ -107,6 +122,7 @@ int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, void* stream)
 int vgl_launch_site(const VglDevParams* p, const VglTilePtrs* t, void* stream);
 int vgl_launch_gl(const VglDevParams* p, const VglTilePtrs* t, void* stream);
 int vgl_launch_siteagg(const VglDevParams* p, const VglTilePtrs* t, void* stream);
+int vgl_launch_scout(const VglDevParams* p, const VglTilePtrs* t, struct VglSerialState* st, void* stream);
 #ifdef __cplusplus
 }
 #endif

@@ -147,7 +147,10 @@ struct vgl_ctx {
     uint8_t* d_reads = nullptr; double* d_errp = nullptr; uint64_t* d_ad4 = nullptr; uint64_t* d_adf4 = nullptr;
     uint32_t* d_qsum = nullptr; uint32_t* d_qsumsq = nullptr; int32_t* d_acc = nullptr; VglSiteInfo* d_sinfo = nullptr;
     uint32_t* d_errflag = nullptr;
-    unsigned long long* d_dbg = nullptr;   // VGL_DEBUG_STAMPS=1 diagnostic counters
+    unsigned long long* d_dbg = nullptr;
+    // VGL_RNG_SERIAL
+    VglSerialState* d_serial = nullptr; uint64_t* d_sst = nullptr; uint64_t* d_site_thresh = nullptr; int32_t* d_scout_dp = nullptr;
+    int64_t serial_next_site = 0;   // VGL_DEBUG_STAMPS=1 diagnostic counters
     // host-variant mirrors
     uint8_t* d_gt = nullptr; void* d_out[17] = {nullptr}; size_t d_out_bytes[17] = {0};
     uint8_t* d_reads_out = nullptr; size_t d_reads_out_bytes = 0;
@@ -229,7 +232,8 @@ extern "C" int vgl_ctx_destroy(vgl_ctx* c) {
     if (!c) return VGL_OK;
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_gl1_fk, c->d_gl1_beta, c->d_gamma_ln, c->d_samp_tab, c->d_qs_read_tab, c->d_pois, c->d_q2gl, c->d_gl1_bsum, c->d_gl1_lhet, c->d_reads, c->d_errp, c->d_ad4,
-                    c->d_adf4, c->d_qsum, c->d_qsumsq, c->d_acc, c->d_sinfo, c->d_errflag, c->d_gt, c->d_reads_out, c->d_dbg};
+                    c->d_adf4, c->d_qsum, c->d_qsumsq, c->d_acc, c->d_sinfo, c->d_errflag, c->d_gt, c->d_reads_out, c->d_dbg,
+                    c->d_serial, c->d_sst, c->d_site_thresh, c->d_scout_dp};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     for (void* q : c->d_out) if (q) (void)hipFree(q);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -249,8 +253,9 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     if (!(p->error_rate >= 0.0 && p->error_rate < 1.0)) return fail(VGL_E_ARG, "[Bad argument value: '--error-rate %f'] Allowed range is [0,1)", p->error_rate);
     if (p->n_qs_bins < 0 || p->n_qs_bins > VGL_MAX_QS_BINS) return fail(VGL_E_ARG, "at most %d qs bins are supported", VGL_MAX_QS_BINS);
     if (p->gl_model == 1 && p->precise_gl) return fail(VGL_E_ARG, "Precise genotype likelihood error (--precise-gl 1) is not supported with genotype likelihood model 1 (--gl-model 1).");
-    if (p->rng_mode != VGL_RNG_TILE) return fail(VGL_E_UNSUPPORTED, "the device path implements VGL_RNG_TILE (counter-addressed windows) only");
-    if (p->error_qs != 0 && p->beta_sampler != VGL_BETA_RAND48) return fail(VGL_E_UNSUPPORTED, "the mt19937 beta sampler is one global serial stream; the device path uses the rand48 sampler (VGL_BETA_RAND48)");
+    if (p->rng_mode != VGL_RNG_TILE && p->rng_mode != VGL_RNG_SERIAL) return fail(VGL_E_ARG, "rng_mode must be VGL_RNG_TILE or VGL_RNG_SERIAL");
+    if (p->rng_mode == VGL_RNG_TILE && p->error_qs != 0 && p->beta_sampler != VGL_BETA_RAND48)
+        return fail(VGL_E_UNSUPPORTED, "the mt19937 beta sampler is one global serial stream: use VGL_RNG_SERIAL, or VGL_BETA_RAND48 with VGL_RNG_TILE");
     const double dmax = max_depth(p);
     if (p->depths) { for (int i = 0; i < p->n_samples; i++) if (!(p->depths[i] >= 0.0)) return fail(VGL_E_ARG, "depths must be >= 0"); }
     else if (!(p->depth >= 0.0)) return fail(VGL_E_ARG, "[Bad argument value: '--depth %f'] Allowed range is [0,500]", p->depth);
@@ -292,6 +297,8 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     D.need_qsum = (p->add_qs || p->add_i16) ? 1 : 0; D.need_qsumsq = p->add_i16 ? 1 : 0; D.need_adf = D.sample_strand;
     D.i16_mapq = p->i16_mapq; D.add_i16 = p->add_i16;
     D.adjust_by = p->adjust_by;
+    D.serial = (p->rng_mode == VGL_RNG_SERIAL) ? 1 : 0;
+    D.beta_std = (p->beta_sampler == VGL_BETA_STD) ? 1 : 0;
     D.dbg_phase = getenv("VGL_DEBUG_PHASE") ? atoi(getenv("VGL_DEBUG_PHASE")) : 0;
     for (int i = 0; i < p->n_qs_bins * 3; i++) D.qs_bins[i] = p->qs_bins[i];
     D.err_thresh = (uint64_t)ceil(ldexp(p->error_rate, 48));
@@ -320,6 +327,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
         const double a = (((1.0 - mean) / var) - oom) * pow(mean, 2), b = a * (oom - 1);
         if (a <= 0.0 || b <= 0.0) { vgl_ctx_destroy(c); return fail(VGL_E_ARG, "Beta shape parameters must be positive (alpha=%f beta=%f); use different --error-rate / --beta-variance", a, b); }
         gamma1_init(&D.gx, a); gamma1_init(&D.gy, b);
+        D.beta_a = a; D.beta_b = b;
     }
     pois_init(&D.pois0, p->depths ? 0.0 : p->depth);
 
@@ -385,7 +393,17 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     }
     const size_t E = (size_t)max_sites * N;
     TRY(dmalloc(&c->d_reads, E * D.read_cap));
-    if (p->precise_gl && p->error_qs == 2) TRY(dmalloc(&c->d_errp, E * D.read_cap));
+    if ((p->precise_gl || D.serial) && p->error_qs == 2) TRY(dmalloc(&c->d_errp, E * D.read_cap));
+    if (D.serial) {
+        TRY(dmalloc(&c->d_sst, E * 3)); TRY(dmalloc(&c->d_site_thresh, (size_t)max_sites)); TRY(dmalloc(&c->d_scout_dp, (size_t)N));
+        TRY(dmalloc(&c->d_serial, (size_t)1));
+        VglSerialState hs; memset(&hs, 0, sizeof hs);
+        hs.st0 = hs.st1 = hs.st2 = D.x0;                         // io.cpp:1054-1061: all three streams start equal
+        hs.mt[0] = (uint32_t)p->seed;                            // io.cpp:1039, rng.h:400
+        for (int i = 1; i < 624; i++) hs.mt[i] = 1812433253u * (hs.mt[i - 1] ^ (hs.mt[i - 1] >> 30)) + (uint32_t)i;
+        hs.mt_idx = 624;
+        TRYHIP(hipMemcpy(c->d_serial, &hs, sizeof hs, hipMemcpyHostToDevice));
+    }
     TRY(dmalloc(&c->d_ad4, E));
     if (D.need_adf) TRY(dmalloc(&c->d_adf4, E));
     if (D.need_qsum) TRY(dmalloc(&c->d_qsum, E * 4));
@@ -444,6 +462,13 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     T.site0 = site0; T.n_sites = n_sites; T.gt = gt;
     T.reads = c->d_reads; T.errp = c->d_errp; T.ad4 = c->d_ad4; T.adf4 = c->d_adf4; T.qsum = c->d_qsum; T.qsumsq = c->d_qsumsq;
     T.acc = c->d_acc; T.sinfo = c->d_sinfo; T.errflag = c->d_errflag; T.dbg = c->d_dbg;
+    if (D.serial) {
+        const size_t E = (size_t)c->max_sites * D.n_samples;
+        T.sst_depth = c->d_sst; T.sst_hap = c->d_sst + E; T.sst_base = c->d_sst + 2 * E;
+        T.site_thresh = c->d_site_thresh; T.scout_dp = c->d_scout_dp;
+        if (site0 != c->serial_next_site)
+            return fail(VGL_E_ARG, "VGL_RNG_SERIAL consumes the streams in call order: expected site0 %lld, got %lld", (long long)c->serial_next_site, (long long)site0);
+    }
     T.site_status = o->site_status; T.n_alleles = o->n_alleles; T.n_alleles_obs = o->n_alleles_obs; T.alleles2acgt = o->alleles2acgt;
     T.info_dp = o->info_dp; T.info_ad = o->info_ad; T.info_adf = o->info_adf; T.info_adr = o->info_adr;
     T.qs = o->qs; T.i16 = o->i16; T.fmt_dp = o->fmt_dp; T.gl = o->gl; T.pl = o->pl; T.gp = o->gp;
@@ -459,6 +484,10 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
     if (c->timing) for (int k = 0; k < 4; k++) HIPCHK(hipEventCreate(&e[k]));
     HIPCHK(hipMemsetAsync(c->d_acc, 0, sizeof(int32_t) * VGL_ACC_STRIDE * (size_t)n_sites, st));
+    if (D.serial) {
+        if (vgl_launch_scout(&D, &T, c->d_serial, st)) return fail(VGL_E_NODEVICE, "k_scout launch failed");
+        c->serial_next_site = site0 + n_sites;
+    }
     if (c->timing) HIPCHK(hipEventRecord(e[0], st));
     if (vgl_launch_sample(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_sample launch failed: %s", hipGetErrorString(hipGetLastError()));
     if (c->timing) HIPCHK(hipEventRecord(e[1], st));

@@ -534,6 +534,187 @@ __global__ __launch_bounds__(256) void k_sample(const VglDevParams P, const VglT
 }
 
 // ------------------------------------------------------------------------------------
+// VGL_RNG_SERIAL: the reference's own stream order.  The three rand48 streams
+// and the mt19937 of the default beta sampler are consumed in a data-dependent serial order, so a
+// sequential scout (one lane) walks the tile once and records, per evaluation, the state of each
+// stream at the point the reference reaches it; the per-read beta deviates (one global mt19937 /
+// rng2 stream) are recorded too.  All the remaining work (Poisson evaluation, reads, likelihoods)
+// then runs in parallel from those recorded states and reproduces the serial program exactly.
+
+// std::mt19937 (libstdc++) -- default BetaSampler, rng.h:353-421
+__device__ uint32_t mt_next(VglSerialState* S) {
+    if (S->mt_idx >= 624) {
+        for (int i = 0; i < 624; i++) {
+            const uint32_t y = (S->mt[i] & 0x80000000u) | (S->mt[(i + 1) % 624] & 0x7fffffffu);
+            S->mt[i] = S->mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        S->mt_idx = 0;
+    }
+    uint32_t y = S->mt[S->mt_idx++];
+    y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= (y >> 18);
+    return y;
+}
+// std::generate_canonical<double,53>
+__device__ double mt_canonical(VglSerialState* S) {
+    double sum = 0.0, tmp = 1.0;
+    sum += (double)mt_next(S) * tmp; tmp *= 4294967296.0;
+    sum += (double)mt_next(S) * tmp; tmp *= 4294967296.0;
+    double r = sum / tmp;
+    if (r >= 1.0) r = 0x1.fffffffffffffp-1;
+    return r;
+}
+// std::gamma_distribution<double>(alpha,1)(gen) on a fresh distribution object (rng.h:409-412)
+__device__ double std_gamma_fresh(VglSerialState* S, const double alpha) {
+    const double malpha = alpha < 1.0 ? alpha + 1.0 : alpha;
+    const double a1 = malpha - 1.0 / 3.0;
+    const double a2 = 1.0 / sqrt(9.0 * a1);
+    bool saved_avail = false; double saved = 0.0;
+    double u, v, n;
+    do {
+        do {
+            if (saved_avail) { saved_avail = false; n = saved; }
+            else {
+                double x, y, r2;
+                do {
+                    x = 2.0 * mt_canonical(S) - 1.0;
+                    y = 2.0 * mt_canonical(S) - 1.0;
+                    r2 = x * x + y * y;
+                } while (r2 > 1.0 || r2 == 0.0);
+                const double mult = sqrt(-2 * log(r2) / r2);
+                saved = x * mult; saved_avail = true;
+                n = y * mult;
+            }
+            v = 1.0 + a2 * n;
+        } while (v <= 0.0);
+        v = v * v * v;
+        u = mt_canonical(S);
+    } while (u > 1.0 - 0.0331 * n * n * n * n && (log(u) > (0.5 * n * n + a1 * (1.0 - v + log(v)))));
+    if (alpha == malpha) return a1 * v;
+    do u = mt_canonical(S); while (u == 0.0);
+    return pow(u, 1.0 / alpha) * a1 * v;
+}
+__device__ double serial_beta(const VglDevParams& P, VglSerialState* S) {
+    if (P.beta_std) {
+        const double x = std_gamma_fresh(S, P.beta_a);
+        const double y = std_gamma_fresh(S, P.beta_b);
+        return x / (x + y);
+    }
+    return beta_draw(P, S->st2);
+}
+
+__global__ __launch_bounds__(64) void k_scout(const VglDevParams P, const VglTilePtrs T, VglSerialState* S) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int N = P.n_samples;
+    const size_t plane = (size_t)T.n_sites * N;
+    uint64_t st0 = S->st0, st1 = S->st1;
+    for (int ls = 0; ls < T.n_sites; ++ls) {
+        const size_t e0 = (size_t)ls * N;
+        // depths of all samples first (vcfgl.cpp:364-389)
+        long long info_dp = 0;
+        for (int s = 0; s < N; ++s) {
+            T.sst_depth[e0 + s] = st1;
+            int n;
+            if (P.per_sample_depth) { const VglPois pc = P.pois[s]; n = poisson_draw(pc, st1, P.gamma_ln_tab, P.gamma_ln_n); }
+            else n = poisson_draw(P.pois0, st1, P.gamma_ln_tab, P.gamma_ln_n);
+            const uint32_t g = T.gt[e0 + s];
+            if ((g & 0xF) == 0xF || ((g >> 4) & 0xF) == 0xF) n = 0;
+            if (n > P.read_cap) n = P.read_cap;                    // flagged by k_sample_serial
+            T.scout_dp[s] = n;
+            info_dp += n;
+        }
+        uint64_t thresh = P.err_thresh;
+        if (info_dp == 0) { if (P.error_qs == 1) T.site_thresh[ls] = thresh; continue; }   // nothing else is drawn (vcfgl.cpp:396-404)
+        if (P.error_qs == 1) {                                     // vcfgl.cpp:425-437
+            const double pe = serial_beta(P, S);
+            thresh = (uint64_t)ceil(ldexp(pe, 48));
+            T.site_thresh[ls] = thresh;
+        }
+        for (int s = 0; s < N; ++s) {
+            const int dp = T.scout_dp[s];
+            T.sst_hap[e0 + s] = st1;
+            T.sst_base[e0 + s] = st0;
+            if (dp == 0) continue;
+            const uint32_t g = T.gt[e0 + s];
+            const int a0 = g & 0xF, a1 = (g >> 4) & 0xF;
+            for (int r = 0; r < dp; ++r) {                          // vcfgl.cpp:469-613
+                bool fwd;
+                (void)sample_read_base(st1, st0, a0, a1, thresh, P.sample_strand != 0, fwd);
+                if (P.error_qs == 2) T.errp[(size_t)r * plane + e0 + s] = serial_beta(P, S);
+            }
+        }
+    }
+    S->st0 = st0; S->st1 = st1;
+}
+
+// parallel evaluation from the recorded states: same per-read code as k_sample
+__global__ __launch_bounds__(256) void k_sample_serial(const VglDevParams P, const VglTilePtrs T) {
+    const WavePos wp = wave_pos(P, T);
+    if (!wp.valid) return;
+    const int lane = threadIdx.x & 63;
+    const int N = P.n_samples;
+    const int ls = wp.ls;
+    const int s = wp.chunk * 64 + lane;
+    const bool active = s < N;
+    const size_t ev = (size_t)ls * N + (size_t)wp.chunk * 64 + (active ? lane : 0);
+    const size_t plane = (size_t)T.n_sites * N;
+    int dp = 0;
+    uint64_t ad4 = 0, adf4 = 0;
+    uint32_t qs[4] = {0, 0, 0, 0}, qq[4] = {0, 0, 0, 0};
+    if (active) {
+        uint64_t st_depth = T.sst_depth[ev], st_hap = T.sst_hap[ev], st_base = T.sst_base[ev];
+        int n;
+        if (P.per_sample_depth) { const VglPois pc = P.pois[s]; n = poisson_draw(pc, st_depth, P.gamma_ln_tab, P.gamma_ln_n); }
+        else n = poisson_draw(P.pois0, st_depth, P.gamma_ln_tab, P.gamma_ln_n);
+        const uint32_t g = T.gt[ev];
+        const int a0 = g & 0xF, a1 = (g >> 4) & 0xF;
+        dp = (a0 == 0xF || a1 == 0xF) ? 0 : n;
+        if (dp > P.read_cap) { atomicOr(T.errflag, VGL_DEVERR_CAPACITY); dp = P.read_cap; }
+        const uint64_t err_thresh = (P.error_qs == 1) ? T.site_thresh[ls] : P.err_thresh;
+        for (int r = 0; r < dp; ++r) {
+            bool fwd;
+            const int r_base = sample_read_base(st_hap, st_base, a0, a1, err_thresh, P.sample_strand != 0, fwd);
+            int q_i = P.pre_q, aq_i = P.pre_adjq;
+            if (P.error_qs == 2) errprob_to_qs(P, T.errp[(size_t)r * plane + ev], q_i, aq_i, T.errflag);
+            const int q_gl = (P.adjust_qs & 1) ? aq_i : q_i;
+            T.reads[(size_t)r * plane + ev] = (uint8_t)((q_gl << 2) | r_base);
+            if (T.reads_out && r < T.reads_out_cap) T.reads_out[(size_t)r * plane + ev] = (uint8_t)((q_i << 2) | r_base);
+            if (P.need_qsum) {
+                const uint32_t qv = (uint32_t)((P.adjust_qs & 2) ? aq_i : q_i);
+                const uint32_t q2 = (uint32_t)qs_to_qssq((int)qv);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) { qs[b] += (r_base == b) ? qv : 0u; qq[b] += (r_base == b) ? q2 : 0u; }
+            }
+            const uint64_t one = 1ULL << (16 * r_base);
+            ad4 += one;
+            if (fwd) adf4 += one;
+        }
+        if (!P.sample_strand) adf4 = ad4;
+        if (T.fmt_dp) T.fmt_dp[ev] = dp;
+        T.ad4[ev] = ad4;
+        if (P.need_adf) T.adf4[ev] = adf4;
+        if (P.need_qsum) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                T.qsum[((size_t)ls * 4 + b) * N + s] = qs[b];
+                if (P.need_qsumsq) T.qsumsq[((size_t)ls * 4 + b) * N + s] = qq[b];
+            }
+        }
+        if (T.reads_out) for (int r = dp; r < T.reads_out_cap; ++r) T.reads_out[(size_t)r * plane + ev] = 0xFF;
+    }
+    int v[9];
+    v[0] = dp;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { v[1 + b] = (int)((ad4 >> (16 * b)) & 0xFFFF); v[5 + b] = (int)((adf4 >> (16 * b)) & 0xFFFF); }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) v[k] = wave_sum(v[k]);
+    if (lane == 0) {
+        int32_t* acc = T.acc + (size_t)ls * VGL_ACC_STRIDE;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) if (v[k]) atomicAdd(&acc[k], v[k]);
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // one lane per site: status + allele order (vcfgl.cpp:396-404, 665-766; no-reads :228-315)
 __global__ __launch_bounds__(256) void k_site(const VglDevParams P, const VglTilePtrs T) {
     const int ls = blockIdx.x * blockDim.x + threadIdx.x;
@@ -831,10 +1012,20 @@ __global__ __launch_bounds__(64) void k_siteagg(const VglDevParams P, const VglT
 }
 
 // ------------------------------------------------------------------------------------
+extern "C" int vgl_launch_scout(const VglDevParams* p, const VglTilePtrs* t, VglSerialState* st, void* stream) {
+    if (t->n_sites == 0) return 0;
+    hipLaunchKernelGGL(k_scout, dim3(1), dim3(64), 0, (hipStream_t)stream, *p, *t, st);
+    return (int)hipGetLastError();
+}
+
 extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
     const int64_t waves = (int64_t)t->n_sites * p->chunks;
     if (waves == 0) return 0;
     const unsigned blocks = (unsigned)((waves + 3) / 4);
+    if (p->serial) {
+        hipLaunchKernelGGL(k_sample_serial, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, *t);
+        return (int)hipGetLastError();
+    }
     if (p->error_qs == 2) hipLaunchKernelGGL(k_sample<2>, dim3(blocks), dim3(256), (size_t)4 * p->pool_lds_bytes, (hipStream_t)stream, *p, *t);
     else if (p->error_qs == 1) hipLaunchKernelGGL(k_sample<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, *t);
     else hipLaunchKernelGGL(k_sample<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, *t);
