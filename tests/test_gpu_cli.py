@@ -1,0 +1,77 @@
+"""End-to-end runs of the C++ front end (vcfgl_amd/bin/vcfgl_hip: the reference's flags, VCF text in,
+VCF text out, GPU simulation through the C ABI) in serial RNG mode against the reference's golden
+VCFs, the way test/runTests.sh does it: `diff -I '^##'`.  Records must match as TEXT (this pins the
+htslib-style float formatting); the only masked tokens are I16 fields 13-16 (libc rand())."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "vcfgl_amd", "bin", "vcfgl_hip")
+CASES = sorted(gu.REF_TESTS, key=lambda s: int(s[4:]))
+
+
+def _mask_i16(line):
+    f = line.split("\t")
+    if len(f) > 7 and "I16=" in f[7]:
+        parts = f[7].split(";")
+        for k, p in enumerate(parts):
+            if p.startswith("I16="):
+                v = p[4:].split(",")
+                parts[k] = "I16=" + ",".join(v[:12] + ["*"] * 4)
+        f[7] = ";".join(parts)
+    return "\t".join(f)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_cli_diff_against_reference_golden(name, tmp_path):
+    t = gu.REF_TESTS[name]
+    data = os.path.join(gu.REFVCF, "data")
+    argv = []
+    toks = t["args"].split()
+    for i in range(0, len(toks), 2):
+        flag, val = toks[i], toks[i + 1]
+        if flag in ("--depths-file", "--qs-bins"):
+            val = os.path.join(data, os.path.basename(val))
+        if flag == "-printTruth":
+            continue                                   # truth VCF is outside the hot path
+        argv += [flag, val]
+    out = str(tmp_path / name)
+    cmd = [BIN, "-i", os.path.join(data, t["input"]), "-o", out, "--rng-mode", "1"] + argv
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ours = [l.rstrip("\n") for l in open(out + ".vcf") if not l.startswith("##")]
+    gold = [l.rstrip("\n") for l in open(os.path.join(gu.REFVCF, "reference", name, name + ".vcf")) if not l.startswith("##")]
+    assert len(ours) == len(gold)
+    for a, b in zip(ours, gold):
+        assert _mask_i16(a) == _mask_i16(b)
+    if t.get("pileup"):
+        a = gzip.open(out + ".pileup.gz", "rt").read()
+        b = gzip.open(os.path.join(gu.REFVCF, "reference", name, name + ".pileup.gz"), "rt").read()
+        assert a == b
+
+
+def test_cli_errors_like_the_reference(tmp_path):
+    data = os.path.join(gu.REFVCF, "data")
+    r = subprocess.run([BIN, "-i", os.path.join(data, "data2.vcf"), "-d", "2"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Error rate is not specified" in r.stderr
+    r = subprocess.run([BIN, "-i", os.path.join(data, "data2.vcf"), "-d", "2", "-e", "0.1", "--gl-model", "1", "--precise-gl", "1"],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "not supported with genotype likelihood model 1" in r.stderr
+
+
+def test_cli_tile_mode_independent_of_tile_size(tmp_path):
+    data = os.path.join(gu.REFVCF, "data")
+    outs = []
+    for ts in (1, 3, 4096):
+        out = str(tmp_path / f"t{ts}")
+        r = subprocess.run([BIN, "-i", os.path.join(data, "data3.vcf"), "-o", out, "--seed", "42", "-d", "5", "-e", "0.01", "-explode", "1",
+                            "-addPL", "1", "-addFormatAD", "1", "--tile-sites", str(ts)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in open(out + ".vcf") if not l.startswith("##")])
+    assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 5

@@ -1,0 +1,481 @@
+// vcfgl_hip -- command-line front end with vcfgl's flag surface (io.cpp:538-752) over the C ABI
+// of libvcfgl_hip.so.  It restates, on the host, what surrounds the hot path in the reference:
+//   * the flag parser / defaults / range checks          io.cpp:428-526, 538-752, 757-1000
+//   * the record loop incl. -explode and input filters   vcfgl.cpp:75-163, 1456-1639
+//   * tag formatting of add_tags()                       bcf_utils.cpp:426-507
+//   * VCF text in / out (neither box has htslib): float printing follows htslib's kputd()
+//     (6 significant digits, %g outside [1e-4, 999999]), so `diff -I '^##'` against the
+//     reference's golden VCFs is empty in --rng-mode 1 (serial) runs.
+// Records are batched into tiles and simulated on the GPU by vgl_simulate_tile(); there is no
+// CPU simulation path here.  Not provided: BCF / bgzip output (-O b|u|z), gVCF blocks
+// (-doGVCF 1), --depth inf, -printTruth.
+#include <math.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../../include/vcfgl_hip.h"
+
+[[noreturn]] static void die(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt);
+    fprintf(stderr, "\n\n*******\n[ERROR] "); vfprintf(stderr, fmt, ap); fprintf(stderr, "\n*******\n");
+    va_end(ap);
+    exit(1);                                   // shared.h:292-299
+}
+
+// ---------------------------------------------------------------------------------------
+struct Args {
+    int seed = -1, source = 0, error_qs = 0, gl_model = 2, precise_gl = 0, i16_mapq = 20, adjust_qs = 0;
+    int explode = 0, rm_invar = 0, rm_empty = 0, do_unobserved = 1, do_gvcf = 0, print_pileup = 0, print_truth = 0;
+    int add_gl = 1, add_gp = 0, add_pl = 0, add_i16 = 0, add_qs = 0, add_fmt_dp = 1, add_info_dp = 0;
+    int add_fmt_ad = 0, add_info_ad = 0, add_fmt_adf = 0, add_info_adf = 0, add_fmt_adr = 0, add_info_adr = 0;
+    int rng_mode = VGL_RNG_TILE, beta_sampler = -1, tile_sites = 4096, device = 0, verbose = 0, threads = 1;
+    double depth = -1.0, error_rate = -1.0, beta_variance = -1.0, gl1_theta = 0.83, adjust_by = 0.499;
+    bool have_depth = false;
+    std::string in_fn, out_prefix = "output", output_mode = "v", depths_fn, qs_bins_fn, command;
+    std::vector<double> depths;
+    std::vector<int32_t> qs_bins;
+};
+
+static Args parse_args(int argc, char** argv) {
+    Args a;
+    a.command = "Command: vcfgl_hip";
+    for (int i = 1; i < argc; i++) { a.command += " "; a.command += argv[i]; }
+    auto I = [&](const char* v) { return atoi(v); };
+    auto D = [&](const char* v) { return atof(v); };
+    for (int i = 1; i < argc; i += 2) {
+        const std::string f = argv[i];
+        if (f == "-h" || f == "--help") { printf("vcfgl_hip: vcfgl flag surface over libvcfgl_hip.so; see README of vcfgl for the flags.\n"); exit(0); }
+        if (i + 1 >= argc) die("Argument %s requires a value", argv[i]);
+        const char* v = argv[i + 1];
+        if (f == "--seed" || f == "-s") a.seed = I(v);
+        else if (f == "--input" || f == "-i") a.in_fn = v;
+        else if (f == "--source") a.source = I(v);
+        else if (f == "--output" || f == "-o") a.out_prefix = v;
+        else if (f == "--output-mode" || f == "-O") a.output_mode = v;
+        else if (f == "--depth" || f == "-d") {
+            if (!strcmp(v, "inf")) die("--depth inf (true-value output, vcfgl.cpp:1089-1262) is outside the simulation hot path");
+            a.depth = D(v); a.have_depth = true;
+        } else if (f == "--depths-file" || f == "-df") a.depths_fn = v;
+        else if (f == "--error-rate" || f == "-e") a.error_rate = D(v);
+        else if (f == "--error-qs" || f == "-eq") a.error_qs = I(v);
+        else if (f == "--beta-variance" || f == "-bv") a.beta_variance = D(v);
+        else if (f == "--gl-model" || f == "-GL") a.gl_model = I(v);
+        else if (f == "--gl1-theta") a.gl1_theta = D(v);
+        else if (f == "--qs-bins") a.qs_bins_fn = v;
+        else if (f == "--precise-gl") a.precise_gl = I(v);
+        else if (f == "--i16-mapq") a.i16_mapq = I(v);
+        else if (f == "--gvcf-dps") {}
+        else if (f == "--adjust-qs") a.adjust_qs = I(v);
+        else if (f == "--adjust-by") a.adjust_by = D(v);
+        else if (f == "-explode") a.explode = I(v);
+        else if (f == "--rm-invar-sites") a.rm_invar = I(v);
+        else if (f == "--rm-empty-sites") a.rm_empty = I(v);
+        else if (f == "-doUnobserved") a.do_unobserved = I(v);
+        else if (f == "-doGVCF") a.do_gvcf = I(v);
+        else if (f == "-printPileup") a.print_pileup = I(v);
+        else if (f == "-printTruth") a.print_truth = I(v);
+        else if (f == "-printBasePickError" || f == "-printQsError" || f == "-printGlError" || f == "-printQScores") { if (I(v)) die("%s is not provided", f.c_str()); }
+        else if (f == "-addGL" || f == "-addFormatGL") a.add_gl = I(v);
+        else if (f == "-addGP" || f == "-addFormatGP") a.add_gp = I(v);
+        else if (f == "-addPL" || f == "-addFormatPL") a.add_pl = I(v);
+        else if (f == "-addI16" || f == "-addFormatI16") a.add_i16 = I(v);
+        else if (f == "-addQS" || f == "-addFormatQS") a.add_qs = I(v);
+        else if (f == "-addFormatDP") a.add_fmt_dp = I(v);
+        else if (f == "-addInfoDP") a.add_info_dp = I(v);
+        else if (f == "-addFormatAD") a.add_fmt_ad = I(v);
+        else if (f == "-addInfoAD") a.add_info_ad = I(v);
+        else if (f == "-addFormatADF") a.add_fmt_adf = I(v);
+        else if (f == "-addInfoADF") a.add_info_adf = I(v);
+        else if (f == "-addFormatADR") a.add_fmt_adr = I(v);
+        else if (f == "-addInfoADR") a.add_info_adr = I(v);
+        else if (f == "--verbose" || f == "-V") a.verbose = I(v);
+        else if (f == "--threads" || f == "-@") a.threads = I(v);
+        // extensions of this implementation
+        else if (f == "--rng-mode") a.rng_mode = I(v);
+        else if (f == "--beta-sampler") a.beta_sampler = I(v);
+        else if (f == "--tile-sites") a.tile_sites = I(v);
+        else if (f == "--device") a.device = I(v);
+        else die("Unknown argument: %s", argv[i]);
+    }
+    // ---- validation (io.cpp:757-1000, the rules that concern the hot path)
+    auto range = [&](double v, double lo, double hi, const char* s) { if (v < lo || v > hi) die("[Bad argument value: '%s %g'] Allowed range is [%g,%g]", s, v, lo, hi); };
+    if (a.in_fn.empty()) die("Input file is not specified. Please use -i/--input option to specify the input file.");
+    if (!a.have_depth && a.depths_fn.empty()) die("Average per-site read depth value is required. Please set it using --depth or --depths-file and re-run.");
+    if (a.depths_fn.empty()) range(a.depth, 0.0, 500.0, "--depth");
+    if (a.error_rate < 0) die("Error rate is not specified. Please use --error-rate option to specify the error rate. Allowed range: [0.0, 1.0]");
+    if (a.error_rate >= 1.0) die("[Bad argument value: '--error-rate %f'] Allowed range is [0.0,1.0]", a.error_rate);
+    range(a.source, 0, 1, "--source"); range(a.error_qs, 0, 2, "--error-qs"); range(a.gl_model, 1, 2, "--gl-model");
+    range(a.gl1_theta, 0, 1, "--gl1-theta"); range(a.precise_gl, 0, 1, "--precise-gl"); range(a.i16_mapq, 0, 60, "--i16-mapq");
+    range(a.adjust_qs, 0, 31, "--adjust-qs"); range(a.do_unobserved, 0, 5, "-doUnobserved"); range(a.rm_invar, 0, 7, "--rm-invar-sites");
+    if (a.adjust_qs && a.adjust_by == 0.0) die("--adjust-qs %d requires a non-zero value for --adjust-by. Please set --adjust-by and rerun.", a.adjust_qs);
+    if ((a.adjust_qs & 1) && a.precise_gl) die("--adjust-qs 1 requires --precise-gl 0. Please set --precise-gl 0 and rerun.");
+    if ((a.adjust_qs & 2) && !a.add_qs) die("--adjust-qs 2 requires -addQS 1. Please set -addQS 1 and rerun.");
+    if (a.gl_model == 1 && a.precise_gl) die("Precise genotype likelihood error (--precise-gl 1) is not supported with genotype likelihood model 1 (--gl-model 1).");
+    if (a.error_qs == 0 && a.beta_variance >= 0) die("--beta-variance %e requires --error-qs 1 or 2.", a.beta_variance);
+    if (a.error_qs != 0 && !(a.error_rate > 0)) die("--error-qs 1 or 2 requires --error-rate > 0 (found %f).", a.error_rate);
+    if (a.error_qs != 0 && !(a.beta_variance > 0)) die("--error-qs 1 or 2 requires --beta-variance > 0 (found %e).", a.beta_variance);
+    if (a.do_gvcf) die("-doGVCF 1 (gVCF block output, bcf_utils.cpp:662-1003) is not provided by this front end");
+    if (a.print_truth) die("-printTruth 1 is not provided by this front end");
+    if (a.output_mode != "v") die("--output-mode %s: only uncompressed VCF text (v) is provided (no htslib on this platform)", a.output_mode.c_str());
+    if (a.seed == -1) { a.seed = (int)time(NULL); fprintf(stderr, "\n-> No seed was given. Setting the random seed to the randomly chosen value: %d\n", a.seed); }
+    if (a.beta_sampler < 0) a.beta_sampler = (a.rng_mode == VGL_RNG_SERIAL) ? VGL_BETA_STD : VGL_BETA_RAND48;
+    if (!a.depths_fn.empty()) {
+        FILE* fp = fopen(a.depths_fn.c_str(), "r"); if (!fp) die("Could not open file: %s", a.depths_fn.c_str());
+        double d; while (fscanf(fp, "%lf", &d) == 1) a.depths.push_back(d);
+        fclose(fp);
+    }
+    if (!a.qs_bins_fn.empty()) {
+        FILE* fp = fopen(a.qs_bins_fn.c_str(), "r"); if (!fp) die("Could not open file: %s", a.qs_bins_fn.c_str());
+        int x, y, z; while (fscanf(fp, "%d,%d,%d", &x, &y, &z) == 3) { a.qs_bins.push_back(x); a.qs_bins.push_back(y); a.qs_bins.push_back(z); }
+        fclose(fp);
+    }
+    return a;
+}
+
+// ---------------------------------------------------------------------------------------
+// htslib kputd(): floats of VCF text.  0 -> "0"; outside [1e-4, 999999] -> "%g"; otherwise
+// trunc(d*1e10) plus half a unit of the 6th significant digit, cut to 6 significant digits,
+// trailing zeros removed.
+static void put_float(std::string& s, float f) {
+    uint32_t bits; memcpy(&bits, &f, 4);
+    if (bits == VGL_FLOAT_MISSING_BITS) { s += '.'; return; }
+    double d = f;
+    if (isnan(d)) { s += "nan"; return; }
+    if (d == 0) { s += signbit(d) ? "-0" : "0"; return; }
+    if (d < 0) { s += '-'; d = -d; }
+    char buf[64];
+    if (!(d >= 0.0001 && d <= 999999)) { snprintf(buf, sizeof buf, "%g", d); s += buf; return; }
+    uint64_t i = (uint64_t)(d * 10000000000LL);
+    if (d < .0001) i += 0; else if (d < 0.001) i += 5; else if (d < 0.01) i += 50; else if (d < 0.1) i += 500;
+    else if (d < 1) i += 5000; else if (d < 10) i += 50000; else if (d < 100) i += 500000; else if (d < 1000) i += 5000000;
+    else if (d < 10000) i += 50000000; else if (d < 100000) i += 500000000; else i += 5000000000LL;
+    char dig[32]; int n = snprintf(dig, sizeof dig, "%llu", (unsigned long long)i);   // d*1e10 as an integer
+    std::string out;
+    if (n <= 10) {                       // d < 1: "0." + leading zeros + 6 significant digits
+        out = "0.";
+        out.append(10 - n, '0');
+        out.append(dig, n < 6 ? n : 6);
+    } else {                             // integer part has n-10 digits; 6 significant digits in all
+        const int ip = n - 10;
+        out.append(dig, ip);
+        if (ip < 6) { out += '.'; out.append(dig + ip, 6 - ip); }
+    }
+    if (out.find('.') != std::string::npos) {
+        while (out.back() == '0') out.pop_back();
+        if (out.back() == '.') out.pop_back();
+    }
+    s += out;
+}
+
+static void put_int(std::string& s, int32_t v) {
+    if (v == VGL_INT32_MISSING) { s += '.'; return; }
+    char buf[16]; snprintf(buf, sizeof buf, "%d", v); s += buf;
+}
+
+// ---------------------------------------------------------------------------------------
+struct Rec {
+    std::string chrom, id, qual, filt, info;
+    long pos0;
+    std::vector<std::string> alleles;
+    std::vector<int8_t> gt;            // 2 per sample, allele index or -1
+    char ref_char;
+};
+
+struct Vcf {
+    std::vector<std::string> header;   // '##' lines
+    std::vector<std::string> samples;
+    std::map<std::string, long> contig_len;
+    std::vector<Rec> recs;
+};
+
+static void split(const std::string& s, char c, std::vector<std::string>& out) {
+    out.clear(); size_t b = 0;
+    while (true) { size_t e = s.find(c, b); if (e == std::string::npos) { out.push_back(s.substr(b)); break; } out.push_back(s.substr(b, e - b)); b = e + 1; }
+}
+
+static Vcf read_vcf(const std::string& fn, int n_expected = -1) {
+    gzFile fp = gzopen(fn.c_str(), "r");               // plain text or gzip
+    if (!fp) die("Could not open file: %s", fn.c_str());
+    Vcf v;
+    std::string line; char buf[1 << 16];
+    std::vector<std::string> f, g, fmt;
+    auto getline = [&]() -> bool {
+        line.clear();
+        while (gzgets(fp, buf, sizeof buf)) { line += buf; if (!line.empty() && line.back() == '\n') { line.pop_back(); return true; } }
+        return !line.empty();
+    };
+    while (getline()) {
+        if (line.empty()) continue;
+        if (line.compare(0, 2, "##") == 0) {
+            v.header.push_back(line);
+            if (line.compare(0, 10, "##contig=<") == 0) {
+                size_t a = line.find("ID="), l = line.find("length=");
+                if (a != std::string::npos) {
+                    std::string id = line.substr(a + 3, line.find_first_of(",>", a) - a - 3);
+                    v.contig_len[id] = (l != std::string::npos) ? atol(line.c_str() + l + 7) : -1;
+                }
+            }
+            continue;
+        }
+        split(line, '\t', f);
+        if (line[0] == '#') { for (size_t i = 9; i < f.size(); i++) v.samples.push_back(f[i]); continue; }
+        if (f.size() < 10) die("VCF record with fewer than 10 columns (a FORMAT/GT column is required)");
+        Rec r;
+        r.chrom = f[0]; r.pos0 = atol(f[1].c_str()) - 1; r.id = f[2]; r.qual = f[5]; r.filt = f[6]; r.info = f[7];
+        r.alleles.push_back(f[3]);
+        if (f[4] != ".") { split(f[4], ',', g); for (auto& x : g) r.alleles.push_back(x); }
+        r.ref_char = f[3][0];
+        split(f[8], ':', fmt);
+        int gti = -1; for (size_t i = 0; i < fmt.size(); i++) if (fmt[i] == "GT") gti = (int)i;
+        if (gti < 0) die("Could not find GT tag at position %ld.", r.pos0 + 1);
+        const size_t n = f.size() - 9;
+        r.gt.assign(2 * n, -1);
+        for (size_t s = 0; s < n; s++) {
+            split(f[9 + s], ':', g);
+            const std::string& t = g[gti];
+            size_t sep = t.find_first_of("|/");
+            std::string x = t.substr(0, sep), y = (sep == std::string::npos) ? x : t.substr(sep + 1);
+            r.gt[2 * s] = (x == "." || x.empty()) ? -1 : (int8_t)atoi(x.c_str());
+            r.gt[2 * s + 1] = (y == "." || y.empty()) ? -1 : (int8_t)atoi(y.c_str());
+        }
+        v.recs.push_back(std::move(r));
+    }
+    gzclose(fp);
+    (void)n_expected;
+    return v;
+}
+
+// allele_char_to_int, vcfgl.cpp:20-50
+static int allele_to_int(const std::string& a) {
+    if (a.size() > 1) return (a == "<*>" || a == "<NON_REF>") ? 4 : -1;
+    switch (a[0]) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return -1; }
+}
+
+struct Site { const Rec* rec; long pos0; std::string chrom; std::vector<uint8_t> gt; char ref_char; };
+
+// check_rec_alleles (vcfgl.cpp:75-163) + the n_allele==1 filter (vcfgl.cpp:335-338); false = skipped
+static bool make_site(const Args& a, const Rec& rec, long pos0, bool blank, int N, Site& out) {
+    const int n_alleles = (int)rec.alleles.size();
+    if (n_alleles > 5) die("Multiallelic sites with more than 4 alleles are not supported.");
+    int ra[5] = {-1, -1, -1, -1, -1};
+    for (int i = 0; i < n_alleles; i++) {
+        if (a.source == 1) { ra[i] = allele_to_int(rec.alleles[i]); if (ra[i] == -1) die("Allele '%s' at position %ld is not a valid base.", rec.alleles[i].c_str(), pos0 + 1); }
+        else {
+            const int x = rec.alleles[i][0] - '0';
+            if (x != 0 && x != 1) die("[--source %d] Found allele '%s' at position %ld. Only 0 and 1 are allowed when using binary GT source.", a.source, rec.alleles[i].c_str(), pos0 + 1);
+            ra[i] = x;
+        }
+    }
+    if (a.source == 0 && n_alleles > 2) die("Multiallelic sites are not supported when using binary GT source.");
+    long allelesum = 0;
+    out.gt.assign(N, 0);
+    for (int s = 0; s < N; s++) {
+        int g0 = blank ? 0 : rec.gt[2 * s], g1 = blank ? 0 : rec.gt[2 * s + 1];
+        int b0 = 0xF, b1 = 0xF;
+        if (g0 >= 0) { if (g0 >= n_alleles) die("GT allele index out of range at position %ld", pos0 + 1); allelesum += g0; b0 = ra[g0] & 0xF; }
+        if (g1 >= 0) { if (g1 >= n_alleles) die("GT allele index out of range at position %ld", pos0 + 1); allelesum += g1; b1 = ra[g1] & 0xF; }
+        out.gt[s] = (uint8_t)(b0 | (b1 << 4));
+    }
+    if ((a.rm_invar & 1) && allelesum == 0) return false;
+    if (a.rm_invar & 2) for (int k = 1; k < n_alleles; k++) if ((long)k * N * 2 == allelesum) return false;
+    if ((a.rm_invar & 3) && n_alleles == 1) return false;
+    out.rec = &rec; out.pos0 = pos0; out.chrom = rec.chrom; out.ref_char = (a.source == 0) ? 'A' : rec.ref_char;
+    return true;
+}
+
+// main_simulate_record_values (vcfgl.cpp:1456-1639): sites in simulation order
+static std::vector<Site> build_sites(const Args& a, const Vcf& v) {
+    std::vector<Site> sites;
+    const int N = (int)v.samples.size();
+    const Rec* tpl = nullptr;
+    std::string last; long n_in = 0;
+    Site s;
+    for (const Rec& r : v.recs) {
+        if (r.chrom != last) { n_in = 0; last = r.chrom; }
+        while (a.explode == 1 && n_in != r.pos0) {
+            if (!tpl) tpl = &r;                                      // bcf_copy(explode_rec, in_rec): keeps its contig (reference quirk)
+            if (make_site(a, *tpl, n_in, true, N, s)) sites.push_back(s);
+            n_in++;
+        }
+        if (make_site(a, r, r.pos0, false, N, s)) sites.push_back(s);
+        n_in++;
+    }
+    if (a.explode == 1 && !v.recs.empty()) {
+        const Rec& r = v.recs.back();
+        auto it = v.contig_len.find(r.chrom);
+        const long size = (it == v.contig_len.end()) ? -1 : it->second;
+        while (size >= 0 && n_in != size) {
+            if (!tpl) tpl = &r;
+            if (make_site(a, *tpl, n_in, true, N, s)) sites.push_back(s);
+            n_in++;
+        }
+    }
+    return sites;
+}
+
+// ---------------------------------------------------------------------------------------
+int main(int argc, char** argv) {
+    Args a = parse_args(argc, argv);
+    Vcf vcf = read_vcf(a.in_fn);
+    const int N = (int)vcf.samples.size();
+    if (N <= 0) die("no samples in %s", a.in_fn.c_str());
+    if (!a.depths.empty() && (int)a.depths.size() != N) die("--depths-file must hold one depth per sample (%zu given, %d samples)", a.depths.size(), N);
+    std::vector<Site> sites = build_sites(a, vcf);
+
+    vgl_params p; memset(&p, 0, sizeof p);
+    p.abi_version = VGL_ABI_VERSION; p.seed = a.seed; p.n_samples = N; p.rng_mode = a.rng_mode; p.beta_sampler = a.beta_sampler;
+    p.depth = a.depth; p.depths = a.depths.empty() ? nullptr : a.depths.data();
+    p.error_rate = a.error_rate; p.error_qs = a.error_qs; p.beta_variance = a.beta_variance; p.gl_model = a.gl_model;
+    p.gl1_theta = a.gl1_theta; p.precise_gl = a.precise_gl; p.adjust_qs = a.adjust_qs; p.adjust_by = a.adjust_by;
+    p.n_qs_bins = (int)a.qs_bins.size() / 3; p.qs_bins = a.qs_bins.empty() ? nullptr : a.qs_bins.data(); p.i16_mapq = a.i16_mapq;
+    p.do_unobserved = a.do_unobserved; p.rm_invar_sites = a.rm_invar; p.rm_empty_sites = a.rm_empty; p.do_gvcf = 0;
+    p.add_gl = a.add_gl; p.add_gp = a.add_gp; p.add_pl = a.add_pl; p.add_i16 = a.add_i16; p.add_qs = a.add_qs;
+    p.add_fmt_dp = a.add_fmt_dp; p.add_info_dp = a.add_info_dp; p.add_fmt_ad = a.add_fmt_ad; p.add_info_ad = a.add_info_ad;
+    p.add_fmt_adf = a.add_fmt_adf; p.add_info_adf = a.add_info_adf; p.add_fmt_adr = a.add_fmt_adr; p.add_info_adr = a.add_info_adr;
+    int TS = a.tile_sites > 0 ? a.tile_sites : 4096;
+    if (a.print_pileup) TS = std::max(1, std::min(TS, (int)((64u << 20) / ((size_t)1024 * (size_t)std::max(N, 1)) + 1)));
+    vgl_ctx* ctx = nullptr;
+    if (vgl_ctx_create(&p, a.device, TS, &ctx) != VGL_OK) die("%s", vgl_last_error());
+    const int A = vgl_max_alleles(&p), G = vgl_max_genotypes(&p);
+
+    // ---- output header (set_hdr, bcf_utils.cpp:511-615): input header minus FORMAT/GT, plus our tags
+    const std::string out_fn = a.out_prefix + ".vcf";
+    FILE* out = fopen(out_fn.c_str(), "w");
+    if (!out) die("Could not open file: %s", out_fn.c_str());
+    for (const std::string& h : vcf.header) if (h.find("##FORMAT=<ID=GT,") == std::string::npos) fprintf(out, "%s\n", h.c_str());
+    fprintf(out, "##source=vcfgl_hip (libvcfgl_hip ABI %d, gfx950)\n##source=%s\n", vgl_abi_version(), a.command.c_str());
+    if (a.do_unobserved == 1 || a.do_unobserved == 4) fprintf(out, "##ALT=<ID=*,Description=\"Any other alternative allele (unobserved)\">\n");
+    if (a.do_unobserved == 2 || a.do_unobserved == 5) fprintf(out, "##ALT=<ID=NON_REF,Description=\"Any other alternative allele (unobserved)\">\n");
+    if (a.add_fmt_dp) fprintf(out, "##FORMAT=<ID=DP,Number=1,Type=Integer,Description=\"Simulated read depth of the sample\">\n");
+    if (a.add_info_dp) fprintf(out, "##INFO=<ID=DP,Number=1,Type=Integer,Description=\"Read depth summed over samples\">\n");
+    if (a.add_gl) fprintf(out, "##FORMAT=<ID=GL,Number=G,Type=Float,Description=\"log10 genotype likelihoods, best = 0\">\n");
+    if (a.add_pl) fprintf(out, "##FORMAT=<ID=PL,Number=G,Type=Integer,Description=\"Phred-scaled genotype likelihoods\">\n");
+    if (a.add_gp) fprintf(out, "##FORMAT=<ID=GP,Number=G,Type=Float,Description=\"Genotype probabilities\">\n");
+    if (a.add_qs) fprintf(out, "##INFO=<ID=QS,Number=R,Type=Float,Description=\"Normalised per-allele base quality sum\">\n");
+    if (a.add_i16) fprintf(out, "##INFO=<ID=I16,Number=16,Type=Float,Description=\"bcftools call auxiliary tag (fields 13-16 not simulated on the device)\">\n");
+    if (a.add_fmt_ad) fprintf(out, "##FORMAT=<ID=AD,Number=R,Type=Integer,Description=\"Allelic depths\">\n");
+    if (a.add_fmt_adf) fprintf(out, "##FORMAT=<ID=ADF,Number=R,Type=Integer,Description=\"Allelic depths, forward strand\">\n");
+    if (a.add_fmt_adr) fprintf(out, "##FORMAT=<ID=ADR,Number=R,Type=Integer,Description=\"Allelic depths, reverse strand\">\n");
+    if (a.add_info_ad) fprintf(out, "##INFO=<ID=AD,Number=R,Type=Integer,Description=\"Total allelic depths\">\n");
+    if (a.add_info_adf) fprintf(out, "##INFO=<ID=ADF,Number=R,Type=Integer,Description=\"Total allelic depths, forward strand\">\n");
+    if (a.add_info_adr) fprintf(out, "##INFO=<ID=ADR,Number=R,Type=Integer,Description=\"Total allelic depths, reverse strand\">\n");
+    fprintf(out, "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT");
+    for (const std::string& s : vcf.samples) fprintf(out, "\t%s", s.c_str());
+    fprintf(out, "\n");
+    gzFile pile = nullptr;
+    if (a.print_pileup) { pile = gzopen((a.out_prefix + ".pileup.gz").c_str(), "wb"); if (!pile) die("Could not open pileup output"); }
+
+    // ---- tile buffers (host side of vgl_tile_out)
+    const size_t E = (size_t)TS * N;
+    std::vector<int32_t> st(TS), na(TS), nobs(TS), idp(TS), iad((size_t)TS * A), iadf((size_t)TS * A), iadr((size_t)TS * A);
+    std::vector<int8_t> a2b((size_t)TS * 5);
+    std::vector<float> qs((size_t)TS * A), i16((size_t)TS * 16);
+    std::vector<int32_t> dp(E), pl(a.add_pl ? E * G : 0), ad(E * A), adf(E * A), adr(E * A);
+    std::vector<float> gl(E * G), gp(a.add_gp ? E * G : 0);
+    // per-read dump rows: the library's own staging capacity (vgl_host.cpp: depth + 8 sqrt(depth) + 16)
+    double dmax = a.depth; for (double d : a.depths) dmax = std::max(dmax, d); if (!(dmax >= 0)) dmax = 0;
+    const int pile_cap = (((int)ceil(dmax + 8.0 * sqrt(dmax) + 16.0)) + 3) & ~3;
+    std::vector<uint8_t> reads, gt_tile(E);
+    vgl_tile_out o; memset(&o, 0, sizeof o);
+    o.site_status = st.data(); o.n_alleles = na.data(); o.n_alleles_obs = nobs.data(); o.alleles2acgt = a2b.data();
+    o.info_dp = idp.data(); o.info_ad = iad.data(); o.info_adf = iadf.data(); o.info_adr = iadr.data();
+    if (a.add_qs) o.qs = qs.data();
+    if (a.add_i16) o.i16 = i16.data();
+    o.fmt_dp = dp.data(); o.gl = gl.data(); if (a.add_pl) o.pl = pl.data(); if (a.add_gp) o.gp = gp.data();
+    o.fmt_ad = ad.data(); o.fmt_adf = adf.data(); o.fmt_adr = adr.data();
+    const char* nonref = (a.do_unobserved == 1 || a.do_unobserved == 4) ? "<*>" : "<NON_REF>";
+
+    long n_out = 0, n_skipped = 0;
+    std::string line;
+    for (size_t t0 = 0; t0 < sites.size(); t0 += TS) {
+        const int ns = (int)std::min((size_t)TS, sites.size() - t0);
+        for (int i = 0; i < ns; i++) memcpy(&gt_tile[(size_t)i * N], sites[t0 + i].gt.data(), N);
+        if (pile) {
+            // capacity of the per-read dump: the library stages at most read_cap reads; ask generously
+            reads.assign((size_t)pile_cap * ns * N, 0xFF);
+            o.reads = reads.data(); o.read_capacity = pile_cap;
+        }
+        if (vgl_simulate_tile(ctx, (int64_t)t0, ns, gt_tile.data(), &o) != VGL_OK) die("%s", vgl_last_error());
+        for (int i = 0; i < ns; i++) {
+            const Site& S = sites[t0 + i];
+            if (pile && st[i] != VGL_SITE_SKIP_EMPTY) {              // vcfgl.cpp:414-416, 616-634 (printed before skip decisions)
+                line.clear();
+                char hb[64]; snprintf(hb, sizeof hb, "\t%ld\t%c", S.pos0 + 1, S.ref_char);
+                line += S.chrom; line += hb;
+                for (int s = 0; s < N; s++) {
+                    const int n = dp[(size_t)i * N + s];
+                    if (n == 0) { line += "\t0\t*\t*"; continue; }
+                    snprintf(hb, sizeof hb, "\t%d\t", n); line += hb;
+                    for (int r = 0; r < n; r++) line += "ACGT"[reads[((size_t)r * ns + i) * N + s] & 3];
+                    line += '\t';
+                    for (int r = 0; r < n; r++) line += (char)((reads[((size_t)r * ns + i) * N + s] >> 2) + 33);
+                }
+                line += '\n';
+                gzwrite(pile, line.data(), (unsigned)line.size());
+            }
+            if (st[i] < 0) { n_skipped++; continue; }
+            const int nA = na[i], nG = nA * (nA + 1) / 2;
+            line.clear();
+            char hb[64];
+            line += S.chrom; snprintf(hb, sizeof hb, "\t%ld\t", S.pos0 + 1); line += hb;
+            line += S.rec->id; line += '\t';
+            // alleles (vcfgl.cpp:739-762; no-reads site :250-280)
+            std::vector<std::string> al;
+            for (int k = 0; k < nA; k++) { const int b = a2b[(size_t)i * 5 + k]; al.push_back(b == 4 ? nonref : (b >= 0 ? std::string(1, "ACGT"[b]) : ".")); }
+            if (al.empty()) al.push_back(".");
+            line += al[0]; line += '\t';
+            if (al.size() == 1) line += '.';
+            else for (size_t k = 1; k < al.size(); k++) { if (k > 1) line += ','; line += al[k]; }
+            line += '\t'; line += S.rec->qual; line += '\t'; line += S.rec->filt; line += '\t';
+            // INFO in add_tags() order: DP, QS, I16, AD, ADF, ADR (after the input record's own INFO)
+            std::string info = (S.rec->info == ".") ? "" : S.rec->info;
+            auto add_key = [&](const char* k) { if (!info.empty()) info += ';'; info += k; info += '='; };
+            if (a.add_info_dp) { add_key("DP"); put_int(info, idp[i]); }
+            if (a.add_qs) { add_key("QS"); for (int k = 0; k < nA; k++) { if (k) info += ','; put_float(info, qs[(size_t)i * A + k]); } }
+            if (a.add_i16) { add_key("I16"); for (int k = 0; k < 16; k++) { if (k) info += ','; put_float(info, i16[(size_t)i * 16 + k]); } }
+            if (a.add_info_ad) { add_key("AD"); for (int k = 0; k < nA; k++) { if (k) info += ','; put_int(info, iad[(size_t)i * A + k]); } }
+            if (a.add_info_adf) { add_key("ADF"); for (int k = 0; k < nA; k++) { if (k) info += ','; put_int(info, iadf[(size_t)i * A + k]); } }
+            if (a.add_info_adr) { add_key("ADR"); for (int k = 0; k < nA; k++) { if (k) info += ','; put_int(info, iadr[(size_t)i * A + k]); } }
+            line += info.empty() ? "." : info;
+            // FORMAT keys: DP, GL, PL, GP, AD, ADF, ADR
+            std::string fmt;
+            auto add_fmt = [&](const char* k) { if (!fmt.empty()) fmt += ':'; fmt += k; };
+            if (a.add_fmt_dp) add_fmt("DP"); if (a.add_gl) add_fmt("GL"); if (a.add_pl) add_fmt("PL"); if (a.add_gp) add_fmt("GP");
+            if (a.add_fmt_ad) add_fmt("AD"); if (a.add_fmt_adf) add_fmt("ADF"); if (a.add_fmt_adr) add_fmt("ADR");
+            line += '\t'; line += fmt.empty() ? "." : fmt;
+            for (int s = 0; s < N; s++) {
+                line += '\t';
+                bool first = true;
+                auto sep = [&]() { if (!first) line += ':'; first = false; };
+                if (a.add_fmt_dp) { sep(); put_int(line, dp[(size_t)i * N + s]); }
+                if (a.add_gl) { sep(); for (int g = 0; g < nG; g++) { if (g) line += ','; put_float(line, gl[((size_t)i * G + g) * N + s]); } }
+                if (a.add_pl) { sep(); for (int g = 0; g < nG; g++) { if (g) line += ','; put_int(line, pl[((size_t)i * G + g) * N + s]); } }
+                if (a.add_gp) { sep(); for (int g = 0; g < nG; g++) { if (g) line += ','; put_float(line, gp[((size_t)i * G + g) * N + s]); } }
+                if (a.add_fmt_ad) { sep(); for (int k = 0; k < nA; k++) { if (k) line += ','; put_int(line, ad[((size_t)i * A + k) * N + s]); } }
+                if (a.add_fmt_adf) { sep(); for (int k = 0; k < nA; k++) { if (k) line += ','; put_int(line, adf[((size_t)i * A + k) * N + s]); } }
+                if (a.add_fmt_adr) { sep(); for (int k = 0; k < nA; k++) { if (k) line += ','; put_int(line, adr[((size_t)i * A + k) * N + s]); } }
+                if (first) line += '.';
+            }
+            line += '\n';
+            fwrite(line.data(), 1, line.size(), out);
+            n_out++;
+        }
+    }
+    fclose(out);
+    if (pile) gzclose(pile);
+    vgl_ctx_destroy(ctx);
+    fprintf(stderr, "\n\n-> Simulation finished successfully.\n\nSummary:\n\tNumber of samples: %d\n\tTotal number of sites simulated: %zu\n"
+                    "\tNumber of sites included in simulation output file: %ld\n\tNumber of sites skipped: %ld\n",
+            N, sites.size(), n_out, n_skipped);
+    return 0;
+}
