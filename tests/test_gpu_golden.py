@@ -11,7 +11,7 @@ import golden_util as gu
 from vcfgl_amd import Simulator, _abi
 
 pytestmark = pytest.mark.gpu
-CASES = sorted(gu.REF_TESTS, key=lambda s: int(s[4:]))
+CASES = sorted((k for k, v in gu.REF_TESTS.items() if not v.get("cli_only")), key=lambda s: int(s[4:]))
 
 
 @pytest.mark.parametrize("name", CASES)

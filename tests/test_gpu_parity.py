@@ -158,6 +158,25 @@ def test_gl_model1_per_read_q(oracle, depth, adj):
     assert_parity(want, got)
 
 
+def test_config_c4_flags(oracle):
+    """BASELINE.json configs[3] flags at its sample count: 2000 samples, depth 30, --error-qs 2 with the
+    rta3 quality-score bins (32 wavefronts per site)"""
+    bins = [(0, 2, 2), (3, 14, 12), (15, 30, 23), (31, 40, 37)]
+    args = VcfglArgs(seed=42, depth=30, error_rate=0.01, error_qs=2, beta_variance=1e-5, qs_bins=bins, **ALLTAGS)
+    want, got = run_both(oracle, args, synth.binary_sites(123456, 6, 2000), site0=123456)
+    assert_parity(want, got)
+
+
+def test_config_c5_flags(oracle):
+    """BASELINE.json configs[4] simulation flags: exploded (all hom-ref) sites, -doUnobserved 2, PL,
+    depth 5, 500 samples; site indices near the end of a 50M-site job"""
+    args = VcfglArgs(seed=42, depth=5, error_rate=0.01, do_unobserved=2, add_pl=1)
+    gt = np.zeros((40, 500), np.uint8)
+    want, got = run_both(oracle, args, gt, site0=49_999_000)
+    assert_parity(want, got, check_gp=False, qs=False)
+    assert (got.numpy("n_alleles") >= 2).all()
+
+
 def test_site_index_invariance(oracle):
     """tiles are addressed by absolute site index: splitting a run into tiles (or shards)
     does not change any value"""

@@ -7,8 +7,8 @@
 //     (6 significant digits, %g outside [1e-4, 999999]), so `diff -I '^##'` against the
 //     reference's golden VCFs is empty in --rng-mode 1 (serial) runs.
 // Records are batched into tiles and simulated on the GPU by vgl_simulate_tile(); there is no
-// CPU simulation path here.  Not provided: BCF / bgzip output (-O b|u|z), gVCF blocks
-// (-doGVCF 1), --depth inf, -printTruth.
+//   * the gVCF block builder prepare_gvcf_block()         bcf_utils.cpp:662-942
+// CPU simulation path here.  Not provided: BCF / bgzip output (-O b|u|z), --depth inf, -printTruth.
 #include <math.h>
 #include <stdarg.h>
 #include <stdint.h>
@@ -44,6 +44,8 @@ struct Args {
     std::string in_fn, out_prefix = "output", output_mode = "v", depths_fn, qs_bins_fn, command;
     std::vector<double> depths;
     std::vector<int32_t> qs_bins;
+    std::string gvcf_dps_str;
+    std::vector<int> gvcf_dps;
 };
 
 static Args parse_args(int argc, char** argv) {
@@ -74,7 +76,7 @@ static Args parse_args(int argc, char** argv) {
         else if (f == "--qs-bins") a.qs_bins_fn = v;
         else if (f == "--precise-gl") a.precise_gl = I(v);
         else if (f == "--i16-mapq") a.i16_mapq = I(v);
-        else if (f == "--gvcf-dps") {}
+        else if (f == "--gvcf-dps") a.gvcf_dps_str = v;
         else if (f == "--adjust-qs") a.adjust_qs = I(v);
         else if (f == "--adjust-by") a.adjust_by = D(v);
         else if (f == "-explode") a.explode = I(v);
@@ -124,7 +126,18 @@ static Args parse_args(int argc, char** argv) {
     if (a.error_qs == 0 && a.beta_variance >= 0) die("--beta-variance %e requires --error-qs 1 or 2.", a.beta_variance);
     if (a.error_qs != 0 && !(a.error_rate > 0)) die("--error-qs 1 or 2 requires --error-rate > 0 (found %f).", a.error_rate);
     if (a.error_qs != 0 && !(a.beta_variance > 0)) die("--error-qs 1 or 2 requires --beta-variance > 0 (found %e).", a.beta_variance);
-    if (a.do_gvcf) die("-doGVCF 1 (gVCF block output, bcf_utils.cpp:662-1003) is not provided by this front end");
+    if (a.do_gvcf == 1) {                                                       // io.cpp:958-985
+        if (!a.add_fmt_dp) die("[-doGVCF 1] -addFormatDP 1 is required for gVCF output. Please set -addFormatDP 1 and rerun.");
+        if (a.rm_invar != 0) die("-> [-doGVCF 1] --rm-invar-sites 0 is required. Please set --rm-invar-sites 0 and rerun.");
+        if (a.gvcf_dps_str.empty()) die("-> [-doGVCF 1] --gvcf-dps is required. Please set --gvcf-dps and rerun.");
+        if (!(a.do_unobserved == 1 || a.do_unobserved == 2 || a.do_unobserved == 4 || a.do_unobserved == 5))
+            die("-> [-doGVCF 1] Adding unobserved alleles is required for gVCF output. Please set -doUnobserved to 1 or 2 and rerun.");
+        if (!a.add_pl) die("-> [-doGVCF 1] -addPL 1 is required for gVCF output. Please set -addPL 1 and rerun.");
+        std::vector<std::string> parts; std::string cur;                          // gvcfData_init, bcf_utils.cpp:946-985
+        for (char ch : a.gvcf_dps_str) { if (ch == ',') { parts.push_back(cur); cur.clear(); } else cur += ch; }
+        parts.push_back(cur);
+        for (auto& x : parts) { if (x.empty()) die("Could not parse --gvcf-dps %s", a.gvcf_dps_str.c_str()); const int d = atoi(x.c_str()); if (d < 1) die("Invalid DP range: %d", d); a.gvcf_dps.push_back(d); }
+    } else if (!a.gvcf_dps_str.empty()) die("-> [--gvcf-dps] --gvcf-dps requires -doGVCF 1. Please set -doGVCF 1 and rerun.");
     if (a.print_truth) die("-printTruth 1 is not provided by this front end");
     if (a.output_mode != "v") die("--output-mode %s: only uncompressed VCF text (v) is provided (no htslib on this platform)", a.output_mode.c_str());
     if (a.seed == -1) { a.seed = (int)time(NULL); fprintf(stderr, "\n-> No seed was given. Setting the random seed to the randomly chosen value: %d\n", a.seed); }
@@ -324,6 +337,86 @@ static std::vector<Site> build_sites(const Args& a, const Vcf& v) {
 }
 
 // ---------------------------------------------------------------------------------------
+// gVCF blocks: prepare_gvcf_block(), bcf_utils.cpp:662-942.  Invariant records (one observed
+// allele) whose minimum per-sample depth falls in the same --gvcf-dps range are merged into one
+// record with END / MIN_DP, per-sample minimum DP and the smallest (REF,ALT),(ALT,ALT) PLs.
+struct SiteView {
+    const std::string* chrom; long pos0; int n_obs, n_alleles, N, G;
+    const int32_t* dp;        // [N]
+    const int32_t* pl;        // [G][N] planes of this site
+    const float* qs;          // [n_alleles] or null
+    std::string alleles;      // "A,<NON_REF>"
+};
+struct GvcfBlocker {
+    enum { NO_WRITE = 0, FLUSH_BLOCK = 1, WRITE_SIMREC = 2 };
+    std::vector<int> block_dps;
+    int current_dpr = 0;
+    std::vector<int32_t> dp, pl;
+    std::vector<float> qsum;
+    std::string chrom, alleles;
+    long start_pos = -1, end_pos = -1;
+    int32_t min_dp = 0;
+
+    int prepare(const SiteView* sv) {
+        if (!sv) return current_dpr == 0 ? NO_WRITE : FLUSH_BLOCK;
+        if (current_dpr == 0) { if (sv->n_obs != 1) return WRITE_SIMREC; }
+        else {
+            if (sv->n_obs != 1) return FLUSH_BLOCK;                       // broken by a variant site
+            if (*sv->chrom != chrom) return FLUSH_BLOCK;                  // other contig
+            if (sv->pos0 > end_pos + 1) return FLUSH_BLOCK;               // gap
+        }
+        int32_t mdp = sv->dp[0];
+        for (int s = 1; s < sv->N; ++s) if (mdp > sv->dp[s]) mdp = sv->dp[s];
+        int r = 0;
+        for (r = 0; r < (int)block_dps.size(); ++r) if (mdp < block_dps[r]) break;
+        const int dp_range = r;
+        if (!dp_range) return current_dpr == 0 ? WRITE_SIMREC : FLUSH_BLOCK;
+        if (current_dpr != 0 && current_dpr != dp_range) return FLUSH_BLOCK;
+        if (current_dpr == 0) {                                           // founder of a new block
+            dp.assign(sv->dp, sv->dp + sv->N);
+            const int nG = sv->n_alleles * (sv->n_alleles + 1) / 2;
+            pl.assign((size_t)sv->N * nG, 0);
+            for (int s = 0; s < sv->N; ++s) for (int g = 0; g < nG; ++g) pl[(size_t)s * nG + g] = sv->pl[(size_t)g * sv->N + s];
+            qsum.clear(); if (sv->qs) qsum.assign(sv->qs, sv->qs + sv->n_alleles);
+            chrom = *sv->chrom; start_pos = sv->pos0; alleles = sv->alleles; min_dp = mdp; current_dpr = dp_range;
+        } else {
+            if (min_dp > mdp) min_dp = mdp;
+            for (int s = 0; s < sv->N; ++s) if (dp[s] > sv->dp[s]) dp[s] = sv->dp[s];
+            if (sv->n_alleles != 2 || pl.size() != (size_t)sv->N * 3) die("Unexpected number of PL values: %d", sv->N * sv->n_alleles * (sv->n_alleles + 1) / 2);
+            for (int s = 0; s < sv->N; ++s) {
+                const int32_t p1 = sv->pl[(size_t)1 * sv->N + s], p2 = sv->pl[(size_t)2 * sv->N + s];
+                if (pl[3 * s + 1] > p1) { pl[3 * s + 1] = p1; pl[3 * s + 2] = p2; }
+                else if (pl[3 * s + 1] == p1 && pl[3 * s + 2] > p2) pl[3 * s + 2] = p2;
+            }
+        }
+        end_pos = sv->pos0;
+        return NO_WRITE;
+    }
+
+    void emit(FILE* out, int N) {
+        const long end1 = end_pos + 1;                                    // 0-based -> 1-based
+        std::string line = chrom;
+        char hb[64]; snprintf(hb, sizeof hb, "\t%ld\t.\t", start_pos + 1); line += hb;
+        const size_t c = alleles.find(',');
+        line += alleles.substr(0, c); line += '\t'; line += (c == std::string::npos) ? "." : alleles.substr(c + 1);
+        line += "\t.\t.\t";
+        if (end1 - start_pos >= 2) { snprintf(hb, sizeof hb, "END=%ld;", end1); line += hb; }
+        snprintf(hb, sizeof hb, "MIN_DP=%d", min_dp); line += hb;
+        if (!qsum.empty()) { line += ";QS="; for (size_t k = 0; k < qsum.size(); k++) { if (k) line += ','; put_float(line, qsum[k]); } }
+        line += "\tPL:DP";
+        const size_t nG = pl.size() / (size_t)N;
+        for (int s = 0; s < N; ++s) {
+            line += '\t';
+            for (size_t g = 0; g < nG; ++g) { if (g) line += ','; put_int(line, pl[(size_t)s * nG + g]); }
+            line += ':'; put_int(line, dp[s]);
+        }
+        line += '\n';
+        fwrite(line.data(), 1, line.size(), out);
+        current_dpr = 0; chrom.clear();
+    }
+};
+
+// ---------------------------------------------------------------------------------------
 int main(int argc, char** argv) {
     Args a = parse_args(argc, argv);
     Vcf vcf = read_vcf(a.in_fn);
@@ -338,7 +431,7 @@ int main(int argc, char** argv) {
     p.error_rate = a.error_rate; p.error_qs = a.error_qs; p.beta_variance = a.beta_variance; p.gl_model = a.gl_model;
     p.gl1_theta = a.gl1_theta; p.precise_gl = a.precise_gl; p.adjust_qs = a.adjust_qs; p.adjust_by = a.adjust_by;
     p.n_qs_bins = (int)a.qs_bins.size() / 3; p.qs_bins = a.qs_bins.empty() ? nullptr : a.qs_bins.data(); p.i16_mapq = a.i16_mapq;
-    p.do_unobserved = a.do_unobserved; p.rm_invar_sites = a.rm_invar; p.rm_empty_sites = a.rm_empty; p.do_gvcf = 0;
+    p.do_unobserved = a.do_unobserved; p.rm_invar_sites = a.rm_invar; p.rm_empty_sites = a.rm_empty; p.do_gvcf = a.do_gvcf;
     p.add_gl = a.add_gl; p.add_gp = a.add_gp; p.add_pl = a.add_pl; p.add_i16 = a.add_i16; p.add_qs = a.add_qs;
     p.add_fmt_dp = a.add_fmt_dp; p.add_info_dp = a.add_info_dp; p.add_fmt_ad = a.add_fmt_ad; p.add_info_ad = a.add_info_ad;
     p.add_fmt_adf = a.add_fmt_adf; p.add_info_adf = a.add_info_adf; p.add_fmt_adr = a.add_fmt_adr; p.add_info_adr = a.add_info_adr;
@@ -356,6 +449,8 @@ int main(int argc, char** argv) {
     fprintf(out, "##source=vcfgl_hip (libvcfgl_hip ABI %d, gfx950)\n##source=%s\n", vgl_abi_version(), a.command.c_str());
     if (a.do_unobserved == 1 || a.do_unobserved == 4) fprintf(out, "##ALT=<ID=*,Description=\"Any other alternative allele (unobserved)\">\n");
     if (a.do_unobserved == 2 || a.do_unobserved == 5) fprintf(out, "##ALT=<ID=NON_REF,Description=\"Any other alternative allele (unobserved)\">\n");
+    if (a.do_gvcf) fprintf(out, "##INFO=<ID=END,Number=1,Type=Integer,Description=\"Last position of the non-variant block\">\n"
+                                "##INFO=<ID=MIN_DP,Number=1,Type=Integer,Description=\"Smallest per-sample depth within the block\">\n");
     if (a.add_fmt_dp) fprintf(out, "##FORMAT=<ID=DP,Number=1,Type=Integer,Description=\"Simulated read depth of the sample\">\n");
     if (a.add_info_dp) fprintf(out, "##INFO=<ID=DP,Number=1,Type=Integer,Description=\"Read depth summed over samples\">\n");
     if (a.add_gl) fprintf(out, "##FORMAT=<ID=GL,Number=G,Type=Float,Description=\"log10 genotype likelihoods, best = 0\">\n");
@@ -397,6 +492,8 @@ int main(int argc, char** argv) {
 
     long n_out = 0, n_skipped = 0;
     std::string line;
+    GvcfBlocker gv;
+    gv.block_dps = a.gvcf_dps;
     for (size_t t0 = 0; t0 < sites.size(); t0 += TS) {
         const int ns = (int)std::min((size_t)TS, sites.size() - t0);
         for (int i = 0; i < ns; i++) memcpy(&gt_tile[(size_t)i * N], sites[t0 + i].gt.data(), N);
@@ -467,10 +564,21 @@ int main(int argc, char** argv) {
                 if (first) line += '.';
             }
             line += '\n';
+            if (a.do_gvcf) {                                             // write_record_values, vcfgl.cpp:167-206
+                SiteView sv;
+                sv.chrom = &S.chrom; sv.pos0 = S.pos0; sv.n_obs = nobs[i]; sv.n_alleles = nA; sv.N = N; sv.G = G;
+                sv.dp = &dp[(size_t)i * N]; sv.pl = &pl[(size_t)i * G * N]; sv.qs = a.add_qs ? &qs[(size_t)i * A] : nullptr;
+                sv.alleles = al[0]; for (size_t k = 1; k < al.size(); k++) { sv.alleles += ','; sv.alleles += al[k]; }
+                int ret = gv.prepare(&sv);
+                if (ret == GvcfBlocker::FLUSH_BLOCK) { gv.emit(out, N); n_out++; ret = gv.prepare(&sv); }
+                if (ret == GvcfBlocker::WRITE_SIMREC) { fwrite(line.data(), 1, line.size(), out); n_out++; }
+                continue;
+            }
             fwrite(line.data(), 1, line.size(), out);
             n_out++;
         }
     }
+    if (a.do_gvcf && gv.prepare(nullptr) == GvcfBlocker::FLUSH_BLOCK) { gv.emit(out, N); n_out++; }
     fclose(out);
     if (pile) gzclose(pile);
     vgl_ctx_destroy(ctx);
