@@ -189,8 +189,11 @@ __device__ __forceinline__ bool normal_slow_test(const double v, const double u,
     const double m = 4.0 * uu * fast_ln_err(l);
     const bool hi = lhs > rhs + m, lo = lhs < rhs - m;
     bool res = hi;
-    if (need & !((hi | lo) & (uf > 0.0f))) {
-        res = lhs > -4.0 * log(u) * (u * u);
+    const bool amb = need & !((hi | lo) & (uf > 0.0f));
+    if (__builtin_expect(__ballot(amb) != 0, 0)) {          // wave-uniform and rare: a real branch
+        asm volatile("" ::: "memory");                      // (keeps the compiler from speculating the double log)
+        const bool ex = lhs > -4.0 * log(u) * (u * u);
+        res = amb ? ex : res;
     }
     return res;
 }
@@ -216,15 +219,18 @@ __device__ __forceinline__ bool gamma_slow_test(const double u, const double xsq
     const float m = fabsf(lu) * 0x1p-20f + 0x1p-21f + g * 4e-6f + 1e-10f;
     const bool ok = (fabsf(d) > m) & (fabsf(sf) <= 0.3333f) & (uf > 0.0f);
     bool res = d > 0.0f;
-    if (need & !ok) {
-        res = log(u) > 0.5 * xsq + a1 * (1.0 - v + log(v));
+    const bool amb = need & !ok;
+    if (__builtin_expect(__ballot(amb) != 0, 0)) {          // wave-uniform and rare: a real branch
+        asm volatile("" ::: "memory");
+        const bool ex = log(u) > 0.5 * xsq + a1 * (1.0 - v + log(v));
+        res = amb ? ex : res;
     }
     return res;
 }
 
 // error probability -> qScore / adjusted qScore (vcfgl.cpp:500-523); (int)(-10*log10(p)) is
 // taken from the float32 log2 unless p sits within its error bound of an integer boundary
-__device__ __forceinline__ void errprob_to_qs_fast(const VglDevParams& P, const double ep, int& q, int& aq, uint32_t* errflag) {
+__device__ __forceinline__ void errprob_to_qs_fast(const VglDevParams& P, const double ep, int& q, int& aq, uint32_t* errflag, const bool need) {
     // float32: tf = -10 log10(p) within |tf| 2^-20 + 1e-6 (v_log_f32 bound + argument rounding)
     const float pf = (float)ep;
     const float tf = -3.0103f * __builtin_amdgcn_logf(pf);
@@ -235,19 +241,24 @@ __device__ __forceinline__ void errprob_to_qs_fast(const VglDevParams& P, const 
     bool ok = (pf > 1.0e-37f) && (pf < 1.0f) && (tf - fl > m) && (fl + 1.0f - tf > m);
     if (P.adjust_qs) ok = ok && (t2 > m) && (t2 - fl2 > m) && (fl2 + 1.0f - t2 > m);
     q = (int)fl; aq = P.adjust_qs ? (int)fl2 : -1;
-    if (!ok) {                                         // exact: vcfgl.cpp:500-507
-        q = -1; aq = -1;
-        if (0.0 == ep) q = CAP_BASEQ;
-        else if (1.0 == ep) q = 0;
+    ok = ok | !need;
+    if (__builtin_expect(__ballot(!ok) != 0, 0)) {     // exact: vcfgl.cpp:500-507 (rare: a real branch)
+        asm volatile("" ::: "memory");
+        int qe = -1, aqe = -1;
+        if (0.0 == ep) qe = CAP_BASEQ;
+        else if (1.0 == ep) qe = 0;
         else {
             const double tmp = -10.0 * log10(ep);
-            q = (int)tmp;
-            if (P.adjust_qs) aq = (int)(tmp + P.adjust_by);
+            qe = (int)tmp;
+            if (P.adjust_qs) aqe = (int)(tmp + P.adjust_by);
         }
+        q = ok ? q : qe; aq = ok ? aq : aqe;
     }
     if (P.n_qs_bins != 0) {
-        q = apply_bins(P, q, errflag);
-        if (P.adjust_qs) aq = apply_bins(P, aq, errflag);
+        if (need) {
+            q = apply_bins(P, q, errflag);
+            if (P.adjust_qs) aq = apply_bins(P, aq, errflag);
+        }
     } else {
         q = (q > CAP_BASEQ) ? CAP_BASEQ : q;
         if (P.adjust_qs) aq = (aq > CAP_BASEQ) ? CAP_BASEQ : aq;
@@ -416,6 +427,15 @@ __global__ __launch_bounds__(256) void k_sample(const VglDevParams P, const VglT
                 const bool any_changed = (P.gx.changed | P.gy.changed) != 0;
                 while (__ballot(have)) {
                     if (T.dbg) c_iter++;
+                    // operands of this lane's NEXT item, fetched at the top of the iteration and consumed
+                    // at the bottom (unconditional, clamped index: no divergent control flow in the loop)
+                    const int kn = k + 64;
+                    const bool hn = kn < segT;
+                    const uint32_t m_n = l_map[have ? (hn ? kn : k) : 0];
+                    const int o_n = m_n & 63, r_n = m_n >> 6;
+                    const VglAffine tab_n = P.qs_read_tab[r_n];
+                    const uint64_t base_n = l_stq[o_n];
+
                     const double ga1 = stage ? P.gy.a1 : P.gx.a1;
                     const double ga2 = stage ? P.gy.a2 : P.gx.a2;
                     // normal attempt
@@ -445,7 +465,7 @@ __global__ __launch_bounds__(256) void k_sample(const VglDevParams P, const VglT
                     const bool acc_g = g_try & !(sq_fail & slow_g);
                     st = g_try ? st3 : st2;                  // u2 is drawn only when w > 0 (rng.h:140-142)
                     double val = ga1 * vv;
-                    if (any_changed) {                       // alpha < 1 (rng.h:146-148)
+                    if (any_changed) {                       // alpha < 1 (rng.h:146-148); wave-uniform guard
                         if (acc_g && (stage ? P.gy.changed : P.gx.changed)) {
                             double u3;
                             do { st = lcg_next(st); u3 = u01(st); } while (u3 == 0.0);
@@ -453,18 +473,23 @@ __global__ __launch_bounds__(256) void k_sample(const VglDevParams P, const VglT
                         }
                     }
                     const bool fin = acc_g & (stage == 1);
-                    gx = (acc_g & (stage == 0)) ? val : gx;
-                    stage = acc_g ? (stage ^ 1) : stage;
+                    // per-read epilogue, computed for every lane, committed where fin (rng.h:438, vcfgl.cpp:500-531)
+                    const double ep = gx / (gx + val);
+                    int q_i, aq_i;
+                    errprob_to_qs_fast(P, ep, q_i, aq_i, T.errflag, fin);
                     if (fin) {
-                        const double ep = gx / (gx + val);                         // rng.h:438
-                        int q_i, aq_i;
-                        errprob_to_qs_fast(P, ep, q_i, aq_i, T.errflag);
                         l_pq[k] = (uint8_t)q_i;
                         l_paq[k] = (uint8_t)aq_i;
                         if (P.precise_gl) T.errp[(size_t)it_r * plane + ev0 + it_o] = ep;
-                        k += 64; have = k < segT;
-                        if (have) { const uint32_t m = l_map[k]; it_o = m & 63; it_r = m >> 6; st = aff(P.qs_read_tab[it_r], l_stq[it_o]); }
                     }
+                    gx = (acc_g & (stage == 0)) ? val : gx;
+                    stage = acc_g ? (stage ^ 1) : stage;
+                    // advance to the next item by selects
+                    const uint64_t st_n = aff(tab_n, base_n);
+                    st = fin ? st_n : st;
+                    it_o = fin ? o_n : it_o; it_r = fin ? r_n : it_r;
+                    k = fin ? kn : k;
+                    have = have & (!fin | hn);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
