@@ -78,6 +78,61 @@ __device__ int poisson_draw(const VglPois& p, uint64_t& st, const double* __rest
     return (int)em;
 }
 
+// The same draw with the transcendental work in float32 (rng.h:300-312 otherwise unchanged).
+// tan() only feeds (1) em = floor(sq*y + lm) and (2) the acceptance bound t, exp() only (2): both are
+// decisions, so float32 values with explicit error bounds decide them and the exact double
+// expressions are evaluated only inside the error band.  Bounds measured on MI355X
+// (tools/vlogcheck.py): |tanf(x) - tan(x)| <= 1.2 ulp, v_exp_f32 <= 0.71 ulp; 4x margins used.
+// Flat loop: one attempt per iteration for every lane that has not accepted yet.
+__device__ int poisson_draw_fast(const VglPois& p, uint64_t& st, const double* __restrict__ glt, const int glt_n) {
+    if (p.st12) {
+        double em = -1.0, t = 1.0;
+        do { ++em; t *= next_u(st); } while (t > p.g);
+        return (int)em;
+    }
+    bool done = false;
+    double em_res = 0.0;
+    while (__ballot(!done)) {
+        const uint64_t st1 = lcg_next(st);
+        const uint64_t st2 = lcg_next(st1);
+        const double a = VGL_PI * u01(st1);
+        const float af = (float)a;
+        const float yf = tanf(af);
+        const float y2 = yf * yf;
+        const float dy = fabsf(yf) * 0x1p-21f + (1.0f + y2) * af * 0x1p-23f;      // |yf - tan(a)|
+        const double e0 = p.sq * (double)yf + p.lm;
+        const double derr = p.sq * (double)dy + 1e-9;
+        double em = floor(e0);
+        const bool amb_em = (e0 - em < derr) | (em + 1.0 - e0 < derr) | !(fabs(e0) < 1.0e6);
+        bool neg = e0 < 0.0;
+        const bool in_tab = (em >= 0.0) & (em < (double)(glt_n - 1));
+        const double gl = glt[in_tab ? (int)em + 1 : 1];
+        const double z = em * p.alxm - gl - p.g;
+        const float ex = __builtin_amdgcn_exp2f((float)(z * 1.4426950408889634));
+        const float tt = 0.9f * (1.0f + y2) * ex;
+        const float rel_t = 2.0f * fabsf(yf) * dy / (1.0f + y2) + fabsf((float)z) * 0x1p-22f + 0x1p-19f;
+        const double u2 = u01(st2);
+        bool reject = u2 > (double)tt;
+        const bool amb_t = fabs(u2 - (double)tt) <= (double)(tt * rel_t) + 1e-30;
+        const bool amb = !done & (amb_em | (!neg & (amb_t | !in_tab)));
+        if (__builtin_expect(__ballot(amb) != 0, 0)) {               // exact evaluation (rare, wave-uniform branch)
+            asm volatile("" ::: "memory");
+            const double y = tan(a);
+            double eme = p.sq * y + p.lm;
+            const bool nege = eme < 0.0;
+            eme = floor(eme);
+            const double t = 0.9 * (1.0 + y * y) * exp(eme * p.alxm - ((eme >= 0.0 && eme < (double)(glt_n - 1)) ? glt[(int)eme + 1] : gamma_ln_dev(eme + 1.0)) - p.g);
+            const bool reje = u2 > t;
+            neg = amb ? nege : neg; em = amb ? eme : em; reject = amb ? reje : reject;
+        }
+        const bool acc = !done & !neg & !reject;
+        st = done ? st : (neg ? st1 : st2);                          // em < 0 consumes one draw, an attempt two
+        em_res = acc ? em : em_res;
+        done = done | acc;
+    }
+    return (int)em_res;
+}
+
 // sample_NormalSampler_0_1_0, rng.h:70-80
 __device__ double normal_rou(uint64_t& st) {
     double u, v, x, y, q;
@@ -329,8 +384,8 @@ __global__ __launch_bounds__(256) void k_sample(const VglDevParams P, const VglT
 
         // ---- depth (vcfgl.cpp:364-389): drawn even when the genotype is missing
         int n;
-        if (P.per_sample_depth) { const VglPois pc = P.pois[s]; n = poisson_draw(pc, st_depth, P.gamma_ln_tab, P.gamma_ln_n); }
-        else n = poisson_draw(P.pois0, st_depth, P.gamma_ln_tab, P.gamma_ln_n);
+        if (P.per_sample_depth) { const VglPois pc = P.pois[s]; n = poisson_draw_fast(pc, st_depth, P.gamma_ln_tab, P.gamma_ln_n); }
+        else n = poisson_draw_fast(P.pois0, st_depth, P.gamma_ln_tab, P.gamma_ln_n);
         const uint32_t g = T.gt[ev];
         a0 = g & 0xF; a1 = (g >> 4) & 0xF;
         dp = (a0 == 0xF || a1 == 0xF) ? 0 : n;
@@ -688,8 +743,8 @@ __global__ __launch_bounds__(256) void k_sample_serial(const VglDevParams P, con
     if (active) {
         uint64_t st_depth = T.sst_depth[ev], st_hap = T.sst_hap[ev], st_base = T.sst_base[ev];
         int n;
-        if (P.per_sample_depth) { const VglPois pc = P.pois[s]; n = poisson_draw(pc, st_depth, P.gamma_ln_tab, P.gamma_ln_n); }
-        else n = poisson_draw(P.pois0, st_depth, P.gamma_ln_tab, P.gamma_ln_n);
+        if (P.per_sample_depth) { const VglPois pc = P.pois[s]; n = poisson_draw_fast(pc, st_depth, P.gamma_ln_tab, P.gamma_ln_n); }
+        else n = poisson_draw_fast(P.pois0, st_depth, P.gamma_ln_tab, P.gamma_ln_n);
         const uint32_t g = T.gt[ev];
         const int a0 = g & 0xF, a1 = (g >> 4) & 0xF;
         dp = (a0 == 0xF || a1 == 0xF) ? 0 : n;
@@ -1082,11 +1137,14 @@ extern "C" int vgl_launch_siteagg(const VglDevParams* p, const VglTilePtrs* t, v
 // ------------------------------------------------------------------------------------
 // debug hook (not part of the C ABI): raw v_log_f32 over a buffer, used by
 // tests/test_gpu_parity.py to check the error bound the fast decision paths assume
-__global__ void k_dbg_vlog(const float* in, float* out, int n) {
+__global__ void k_dbg_vlog(const float* in, float* out, int n, int mode) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = __builtin_amdgcn_logf(in[i]);
+    if (i >= n) return;
+    if (mode == 0) out[i] = __builtin_amdgcn_logf(in[i]);          // v_log_f32
+    else if (mode == 1) out[i] = tanf(in[i]);                      // ocml tanf
+    else out[i] = __builtin_amdgcn_exp2f(in[i]);                   // v_exp_f32
 }
-extern "C" int vgl_dbg_vlog(const float* d_in, float* d_out, int n) {
-    hipLaunchKernelGGL(k_dbg_vlog, dim3((n + 255) / 256), dim3(256), 0, 0, d_in, d_out, n);
+extern "C" int vgl_dbg_vlog(const float* d_in, float* d_out, int n, int mode) {
+    hipLaunchKernelGGL(k_dbg_vlog, dim3((n + 255) / 256), dim3(256), 0, 0, d_in, d_out, n, mode);
     return (int)hipDeviceSynchronize();
 }
