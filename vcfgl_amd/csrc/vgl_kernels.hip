@@ -864,16 +864,60 @@ __device__ __forceinline__ float f32_missing() { return __uint_as_float(F32_MISS
 __device__ __forceinline__ int nib(uint32_t v, int k) { return (int)((v >> (4 * k)) & 0xF); }
 __device__ __forceinline__ int cnt_of(uint64_t ad4, int b) { return b < 4 ? (int)((ad4 >> (16 * b)) & 0xFFFF) : 0; }
 
+// Evaluations differ in depth, and the likelihood loop runs once per read: a wavefront is busy for
+// its deepest evaluation.  The 256 evaluations of a workgroup are therefore re-dealt to the lanes in
+// depth order (LDS counting sort of the thread ids), so each wavefront works on evaluations of
+// similar depth; loads and stores stay inside the workgroup's 256-evaluation window of each plane.
 template <int A>
 __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTilePtrs T) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    __shared__ uint32_t s_hist[1026];
+    __shared__ uint16_t s_perm[256];
     constexpr int NG = A * (A + 1) / 2;
-    const WavePos wp = wave_pos(P, T);
-    if (!wp.valid) return;
-    const int lane = threadIdx.x & 63;
     const int N = P.n_samples;
-    const int ls = wp.ls;
-    const int s = wp.chunk * 64 + lane;
+    const int tid = threadIdx.x;
+    const int64_t nwaves = (int64_t)T.n_sites * P.chunks;
+    // ---- depth of the evaluation this thread would own in natural order
+    int dp0 = -1;                                                      // -1: no evaluation (padding lane)
+    {
+        const int64_t w = (int64_t)blockIdx.x * 4 + (tid >> 6);
+        if (w < nwaves) {
+            const int ls0 = (int)(w / P.chunks);
+            const int s0 = (int)(w - (int64_t)ls0 * P.chunks) * 64 + (tid & 63);
+            if (s0 < N) {
+                const uint64_t a = T.ad4[(size_t)ls0 * N + s0];
+                dp0 = (int)((a & 0xFFFF) + ((a >> 16) & 0xFFFF) + ((a >> 32) & 0xFFFF) + ((a >> 48) & 0xFFFF));
+                if (dp0 > 1023) dp0 = 1023;
+            }
+        }
+    }
+    for (int i = tid; i < 1026; i += 256) s_hist[i] = 0;
+    __syncthreads();
+    const int key = 1024 - dp0;                                        // deepest first; padding (dp0 = -1) last
+    atomicAdd(&s_hist[key], 1u);
+    __syncthreads();
+    if (tid < 64) {                                                    // exclusive scan of 1026 bins by one wavefront
+        uint32_t run = 0;
+        for (int base = 0; base < 1026; base += 64) {
+            const int i = base + tid;
+            const uint32_t v = (i < 1026) ? s_hist[i] : 0u;
+            uint32_t incl = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d, 64); if (tid >= d) incl += t; }
+            if (i < 1026) s_hist[i] = run + incl - v;
+            run += __shfl(incl, 63, 64);
+        }
+    }
+    __syncthreads();
+    s_perm[atomicAdd(&s_hist[key], 1u)] = (uint16_t)tid;
+    __syncthreads();
+    const int otid = s_perm[tid];                                      // thread id whose evaluation this lane processes
+    const int lane = tid & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t w = (int64_t)blockIdx.x * 4 + (otid >> 6);
+    if (w >= nwaves) return;
+    const int ls = (int)(w / P.chunks);
+    const int s = (int)(w - (int64_t)ls * P.chunks) * 64 + (otid & 63);
     if (s >= N) return;
     const size_t ev = (size_t)ls * N + s;
     const size_t plane = (size_t)T.n_sites * N;
@@ -939,7 +983,7 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
                 // per-read qScores (gl_methods.cpp:233-302): errmod_cal() walks the reads in descending
                 // (qual, base) order, so each base accumulates fk[i]*beta[q][n][i] over its own reads in
                 // descending quality: a per-lane (base, qual) histogram in LDS replaces the sort
-                uint8_t* h = lds_raw + (size_t)wp.wib * 16384 + lane;
+                uint8_t* h = lds_raw + (size_t)wib * 16384 + lane;
                 for (int bin = 0; bin < 256; ++bin) h[bin * 64] = 0;
                 for (int r = 0; r < n; ++r) {
                     const uint32_t rb = T.reads[(size_t)r * plane + ev];
