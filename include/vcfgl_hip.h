@@ -142,8 +142,9 @@ typedef struct vgl_tile_out {
     int32_t* info_adf;       /* [n_sites][A]                                                   */
     int32_t* info_adr;       /* [n_sites][A]                                                   */
     float*   qs;             /* [n_sites][A]   INFO/QS                                         */
-    float*   i16;            /* [n_sites][16]  INFO/I16 (fields 12-15, tail distance, use the
-                                               reference's unseeded rand(): host oracle only)  */
+    float*   i16;            /* [n_sites][16]  INFO/I16; fields 12-15 (tail distance: the reference draws
+                                               them from the never-seeded libc rand()) are produced in
+                                               VGL_RNG_SERIAL mode and are 0 in VGL_RNG_TILE mode */
     /* per (site, sample) */
     int32_t* fmt_dp;         /* [n_sites][n_samples]          FORMAT/DP                        */
     float*   gl;             /* [n_sites][G][n_samples]       FORMAT/GL, VCF genotype order;

@@ -457,7 +457,7 @@ int main(int argc, char** argv) {
     if (a.add_pl) fprintf(out, "##FORMAT=<ID=PL,Number=G,Type=Integer,Description=\"Phred-scaled genotype likelihoods\">\n");
     if (a.add_gp) fprintf(out, "##FORMAT=<ID=GP,Number=G,Type=Float,Description=\"Genotype probabilities\">\n");
     if (a.add_qs) fprintf(out, "##INFO=<ID=QS,Number=R,Type=Float,Description=\"Normalised per-allele base quality sum\">\n");
-    if (a.add_i16) fprintf(out, "##INFO=<ID=I16,Number=16,Type=Float,Description=\"bcftools call auxiliary tag (fields 13-16 not simulated on the device)\">\n");
+    if (a.add_i16) fprintf(out, "##INFO=<ID=I16,Number=16,Type=Float,Description=\"bcftools call auxiliary tag (fields 13-16 only in --rng-mode 1)\">\n");
     if (a.add_fmt_ad) fprintf(out, "##FORMAT=<ID=AD,Number=R,Type=Integer,Description=\"Allelic depths\">\n");
     if (a.add_fmt_adf) fprintf(out, "##FORMAT=<ID=ADF,Number=R,Type=Integer,Description=\"Allelic depths, forward strand\">\n");
     if (a.add_fmt_adr) fprintf(out, "##FORMAT=<ID=ADR,Number=R,Type=Integer,Description=\"Allelic depths, reverse strand\">\n");

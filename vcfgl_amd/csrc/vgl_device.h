@@ -77,6 +77,10 @@ struct VglDevParams {
     const double* gl1_beta;            // [64][256][256]   (per-read qScores only)
 };
 
+// per-site I16 tail-distance sums (vcfgl.cpp:647-663): all of a site's draws are credited to the base of
+// its last simulated read (the reference's stale r_base)
+struct VglSiteTail { float sum, sumsq; int32_t base; int32_t pad; };
+
 // per-tile pointers
 struct VglTilePtrs {
     int64_t site0;
@@ -104,6 +108,7 @@ struct VglTilePtrs {
     uint64_t* sst_depth; uint64_t* sst_hap; uint64_t* sst_base;   // [n_sites][N]
     uint64_t* site_thresh;   // [n_sites] per-site base-pick error threshold (error_qs 1)
     int32_t*  scout_dp;      // [N] scratch of the scout
+    VglSiteTail* site_tail;  // [n_sites] (serial mode with -addI16)
 };
 
 // persistent serial-mode generator states (device memory, carried from tile to tile)
@@ -111,8 +116,11 @@ struct VglSerialState {
     uint64_t st0, st1, st2;  // rng0 (drand48), rng1, rng2
     uint32_t mt[624];        // std::mt19937 of the default beta sampler
     int32_t  mt_idx;
+    int32_t  rand_f, rand_r; // glibc rand() (TYPE_3 additive feedback, degree 31, separation 3)
+    uint32_t rand_state[31]; // the reference draws I16 tail distances from the never-seeded rand() (rng.h:12)
     int32_t  pad;
 };
+
 
 #ifdef __cplusplus
 extern "C" {

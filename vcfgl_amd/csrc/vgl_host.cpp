@@ -149,7 +149,7 @@ struct vgl_ctx {
     uint32_t* d_errflag = nullptr;
     unsigned long long* d_dbg = nullptr;
     // VGL_RNG_SERIAL
-    VglSerialState* d_serial = nullptr; uint64_t* d_sst = nullptr; uint64_t* d_site_thresh = nullptr; int32_t* d_scout_dp = nullptr;
+    VglSerialState* d_serial = nullptr; uint64_t* d_sst = nullptr; uint64_t* d_site_thresh = nullptr; int32_t* d_scout_dp = nullptr; VglSiteTail* d_site_tail = nullptr;
     int64_t serial_next_site = 0;   // VGL_DEBUG_STAMPS=1 diagnostic counters
     // host-variant mirrors
     uint8_t* d_gt = nullptr; void* d_out[17] = {nullptr}; size_t d_out_bytes[17] = {0};
@@ -233,7 +233,7 @@ extern "C" int vgl_ctx_destroy(vgl_ctx* c) {
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_gl1_fk, c->d_gl1_beta, c->d_gamma_ln, c->d_samp_tab, c->d_qs_read_tab, c->d_pois, c->d_q2gl, c->d_gl1_bsum, c->d_gl1_lhet, c->d_reads, c->d_errp, c->d_ad4,
                     c->d_adf4, c->d_qsum, c->d_qsumsq, c->d_acc, c->d_sinfo, c->d_errflag, c->d_gt, c->d_reads_out, c->d_dbg,
-                    c->d_serial, c->d_sst, c->d_site_thresh, c->d_scout_dp};
+                    c->d_serial, c->d_sst, c->d_site_thresh, c->d_scout_dp, c->d_site_tail};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     for (void* q : c->d_out) if (q) (void)hipFree(q);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -402,6 +402,16 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
         hs.mt[0] = (uint32_t)p->seed;                            // io.cpp:1039, rng.h:400
         for (int i = 1; i < 624; i++) hs.mt[i] = 1812433253u * (hs.mt[i - 1] ^ (hs.mt[i - 1] >> 30)) + (uint32_t)i;
         hs.mt_idx = 624;
+        {   // glibc srandom_r(1) + the 310 discarded outputs: the state a process that never calls srand() starts from
+            int32_t word = 1; hs.rand_state[0] = 1;
+            for (int i = 1; i < 31; i++) { const long hi = word / 127773, lo = word % 127773; long w = 16807 * lo - 2836 * hi; if (w < 0) w += 2147483647; word = (int32_t)w; hs.rand_state[i] = (uint32_t)word; }
+            hs.rand_f = 3; hs.rand_r = 0;
+            for (int k = 0; k < 310; k++) {
+                hs.rand_state[hs.rand_f] += hs.rand_state[hs.rand_r];
+                if (++hs.rand_f >= 31) { hs.rand_f = 0; ++hs.rand_r; } else if (++hs.rand_r >= 31) hs.rand_r = 0;
+            }
+        }
+        if (p->add_i16) TRY(dmalloc(&c->d_site_tail, (size_t)max_sites));
         TRYHIP(hipMemcpy(c->d_serial, &hs, sizeof hs, hipMemcpyHostToDevice));
     }
     TRY(dmalloc(&c->d_ad4, E));
@@ -465,7 +475,7 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     if (D.serial) {
         const size_t E = (size_t)c->max_sites * D.n_samples;
         T.sst_depth = c->d_sst; T.sst_hap = c->d_sst + E; T.sst_base = c->d_sst + 2 * E;
-        T.site_thresh = c->d_site_thresh; T.scout_dp = c->d_scout_dp;
+        T.site_thresh = c->d_site_thresh; T.scout_dp = c->d_scout_dp; T.site_tail = c->d_site_tail;
         if (site0 != c->serial_next_site)
             return fail(VGL_E_ARG, "VGL_RNG_SERIAL consumes the streams in call order: expected site0 %lld, got %lld", (long long)c->serial_next_site, (long long)site0);
     }

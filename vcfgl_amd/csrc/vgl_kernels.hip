@@ -682,6 +682,14 @@ __device__ double serial_beta(const VglDevParams& P, VglSerialState* S) {
     return beta_draw(P, S->st2);
 }
 
+// glibc rand(): random_r() TYPE_3
+__device__ int glibc_rand(VglSerialState* S) {
+    const uint32_t val = (S->rand_state[S->rand_f] += S->rand_state[S->rand_r]);
+    if (++S->rand_f >= 31) { S->rand_f = 0; ++S->rand_r; }
+    else if (++S->rand_r >= 31) S->rand_r = 0;
+    return (int)(val >> 1);
+}
+
 __global__ __launch_bounds__(64) void k_scout(const VglDevParams P, const VglTilePtrs T, VglSerialState* S) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int N = P.n_samples;
@@ -703,6 +711,8 @@ __global__ __launch_bounds__(64) void k_scout(const VglDevParams P, const VglTil
             info_dp += n;
         }
         uint64_t thresh = P.err_thresh;
+        int last_base = -1;
+        if (T.site_tail) { VglSiteTail z; z.sum = 0.0f; z.sumsq = 0.0f; z.base = -1; z.pad = 0; T.site_tail[ls] = z; }
         if (info_dp == 0) { if (P.error_qs == 1) T.site_thresh[ls] = thresh; continue; }   // nothing else is drawn (vcfgl.cpp:396-404)
         if (P.error_qs == 1) {                                     // vcfgl.cpp:425-437
             const double pe = serial_beta(P, S);
@@ -718,9 +728,18 @@ __global__ __launch_bounds__(64) void k_scout(const VglDevParams P, const VglTil
             const int a0 = g & 0xF, a1 = (g >> 4) & 0xF;
             for (int r = 0; r < dp; ++r) {                          // vcfgl.cpp:469-613
                 bool fwd;
-                (void)sample_read_base(st1, st0, a0, a1, thresh, P.sample_strand != 0, fwd);
+                last_base = sample_read_base(st1, st0, a0, a1, thresh, P.sample_strand != 0, fwd);
                 if (P.error_qs == 2) T.errp[(size_t)r * plane + e0 + s] = serial_beta(P, S);
             }
+        }
+        if (P.add_i16 && T.site_tail) {                             // vcfgl.cpp:647-663
+            VglSiteTail t; t.sum = 0.0f; t.sumsq = 0.0f; t.base = last_base; t.pad = 0;
+            for (long long i = 0; i < info_dp; ++i) {
+                int td = 1 + glibc_rand(S) / (2147483647 / (50 - 1 + 1) + 1);       // sample_from_range_rng_rand(1,50)
+                if (td > 25) td = 25;                                            // CAP_TAIL_DIST
+                t.sum += td; t.sumsq += (td * td);
+            }
+            T.site_tail[ls] = t;
         }
     }
     S->st0 = st0; S->st1 = st1;
@@ -1129,7 +1148,15 @@ __global__ __launch_bounds__(64) void k_siteagg(const VglDevParams P, const VglT
                 v[2] += (float)acc[5 + b]; v[3] += (float)(acc[1 + b] - acc[5 + b]);
                 for (int s = 0; s < N; ++s) { v[6] += (float)(int)qsum[(size_t)b * N + s]; v[7] += (float)(int)qsq[(size_t)b * N + s]; }
             }
-            // v[12..15] (tail distance) come from the reference's unseeded libc rand(): not produced on the device
+            // tail distance (vcfgl.cpp:1029-1071): drawn from libc rand() by the serial-mode scout; zero in tile mode
+            if (T.site_tail) {
+                const VglSiteTail tl = T.site_tail[ls];
+                if (tl.base == refb) { v[12] = tl.sum; v[13] = tl.sumsq; }
+                for (int a = 1; a < nA; ++a) {
+                    if (a == nObs) continue;
+                    if (nib(si.alleles2acgt, a) == tl.base) { v[14] += tl.sum; v[15] += tl.sumsq; }
+                }
+            }
         }
         for (int k = 0; k < 16; ++k) T.i16[(size_t)ls * 16 + k] = v[k];
     }
