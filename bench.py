@@ -175,7 +175,7 @@ def main():
         line = {
             "metric": "site-sample GL evals/s at depth 20" if opt.workload != "c2" else "site-sample GL evals/s at depth 10", "value": value, "unit": "site-sample GL evals/s",
             "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": dt / opt.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64+f32 (rand48 u48)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{opt.workload}: {S} sites x {N} samples per GPU, {wl['desc']}, "
                                    f"tags GL+DP (G={G}), rng tile mode, rand48 beta sampler", "tile_sites": TS,

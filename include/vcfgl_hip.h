@@ -187,7 +187,9 @@ int vgl_simulate_tile(vgl_ctx* ctx, int64_t site0, int32_t n_sites,
 
 /* Device variant: `gt` and every pointer in `out` are device memory owned by the caller
  * (hipMalloc / a torch tensor's data_ptr); work is enqueued on `hip_stream` (a hipStream_t
- * cast to void*, NULL = default stream) and the call returns without synchronising. */
+ * cast to void*, NULL = default stream) and the call returns without synchronising.  A context owns
+ * one staging workspace: tiles of one context must be enqueued on one stream (or otherwise ordered);
+ * use one context per stream / per GPU for concurrent tiles. */
 int vgl_simulate_tile_device(vgl_ctx* ctx, int64_t site0, int32_t n_sites,
                              const uint8_t* gt, vgl_tile_out* out, void* hip_stream);
 

@@ -231,12 +231,23 @@ def test_device_buffers_and_stream(oracle):
         assert np.array_equal(bits(tile.numpy(f)), bits(host.numpy(f))), f
 
 
-def test_capacity_overflow_is_reported(oracle):
-    """a depth beyond the staging capacity must surface as VGL_E_CAPACITY, not as wrong data"""
-    from vcfgl_amd import VglError
+def test_capacity_sized_from_largest_mean(oracle):
     args = VcfglArgs(seed=42, depths=[0.0, 400.0], error_rate=0.01)
     sim = Simulator(args, 2, max_sites_per_tile=4)
-    sim.dp_cap = None
     t = sim.simulate(0, np.zeros((2, 2), np.uint8))
-    assert t.numpy("fmt_dp")[:, 1].min() > 300        # capacity is sized from the largest mean
+    assert t.numpy("fmt_dp")[:, 1].min() > 300
+    sim.close()
+
+
+@pytest.mark.parametrize("eqs", [0, 2])
+def test_capacity_overflow_is_reported(oracle, eqs, monkeypatch):
+    """a depth beyond the staging capacity must surface as VGL_E_CAPACITY, never as wrong data
+    (VGL_DEBUG_READ_CAP shrinks the capacity so the path can be exercised)"""
+    from vcfgl_amd import VglError
+    monkeypatch.setenv("VGL_DEBUG_READ_CAP", "8")
+    args = VcfglArgs(seed=42, depth=20, error_rate=0.01, error_qs=eqs, beta_variance=1e-5 if eqs else -1.0)
+    sim = Simulator(args, 100, max_sites_per_tile=8)
+    with pytest.raises(VglError) as ei:
+        sim.simulate(0, synth.binary_sites(0, 8, 100))
+    assert ei.value.code == _abi.VGL_E_CAPACITY
     sim.close()

@@ -418,6 +418,11 @@ struct GvcfBlocker {
 
 // ---------------------------------------------------------------------------------------
 int main(int argc, char** argv) {
+    if (argc >= 2 && !strcmp(argv[1], "--format-floats")) {
+        // self-test hook of the VCF float formatter: hex float32 bit patterns in, formatted text out
+        for (int i = 2; i < argc; i++) { uint32_t b = (uint32_t)strtoul(argv[i], NULL, 16); float f; memcpy(&f, &b, 4); std::string s; put_float(s, f); printf("%s\n", s.c_str()); }
+        return 0;
+    }
     Args a = parse_args(argc, argv);
     Vcf vcf = read_vcf(a.in_fn);
     const int N = (int)vcf.samples.size();
