@@ -413,10 +413,11 @@ __global__ __launch_bounds__(256) void k_sample(const VglDevParams P, const VglT
         const uint32_t q_gl = (uint32_t)((P.adjust_qs & 1) ? aq_i : q_i);
         const uint32_t qq = (uint32_t)((P.adjust_qs & 2) ? aq_i : q_i);
         const uint32_t q2 = (uint32_t)qs_to_qssq((int)qq);
+        const bool stage = (P.gl_model != 1);      // GL model 1 with one fixed qScore needs only the per-base depths
         for (int r = 0; r < dp; ++r) {
             bool fwd;
             const int r_base = sample_read_base(st_hap, st_base, a0, a1, err_thresh, P.sample_strand != 0, fwd);
-            T.reads[(size_t)r * plane + ev] = (uint8_t)((q_gl << 2) | r_base);
+            if (stage) T.reads[(size_t)r * plane + ev] = (uint8_t)((q_gl << 2) | r_base);
             if (T.reads_out && r < T.reads_out_cap) T.reads_out[(size_t)r * plane + ev] = (uint8_t)((q_i << 2) | r_base);
             const uint64_t one = 1ULL << (16 * r_base);
             ad4 += one;
