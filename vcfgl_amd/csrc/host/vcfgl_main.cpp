@@ -8,7 +8,9 @@
 //     reference's golden VCFs is empty in --rng-mode 1 (serial) runs.
 // Records are batched into tiles and simulated on the GPU by vgl_simulate_tile(); there is no
 //   * the gVCF block builder prepare_gvcf_block()         bcf_utils.cpp:662-942
-// CPU simulation path here.  Not provided: BCF / bgzip output (-O b|u|z), --depth inf, -printTruth.
+//   * --depth inf (simulate_record_true_values, vcfgl.cpp:1089-1262): no sampling at all, the true
+//     genotype gets GL 0 / GP 1 / PL 0 and every other genotype -inf / 0 / 255; written directly
+// CPU simulation path here.  Not provided: BCF / bgzip output (-O b|u|z), -printTruth.
 #include <math.h>
 #include <stdarg.h>
 #include <stdint.h>
@@ -40,7 +42,7 @@ struct Args {
     int add_fmt_ad = 0, add_info_ad = 0, add_fmt_adf = 0, add_info_adf = 0, add_fmt_adr = 0, add_info_adr = 0;
     int rng_mode = VGL_RNG_TILE, beta_sampler = -1, tile_sites = 4096, device = 0, verbose = 0, threads = 1;
     double depth = -1.0, error_rate = -1.0, beta_variance = -1.0, gl1_theta = 0.83, adjust_by = 0.499;
-    bool have_depth = false;
+    bool have_depth = false, depth_inf = false;
     std::string in_fn, out_prefix = "output", output_mode = "v", depths_fn, qs_bins_fn, command;
     std::vector<double> depths;
     std::vector<int32_t> qs_bins;
@@ -65,8 +67,9 @@ static Args parse_args(int argc, char** argv) {
         else if (f == "--output" || f == "-o") a.out_prefix = v;
         else if (f == "--output-mode" || f == "-O") a.output_mode = v;
         else if (f == "--depth" || f == "-d") {
-            if (!strcmp(v, "inf")) die("--depth inf (true-value output, vcfgl.cpp:1089-1262) is outside the simulation hot path");
-            a.depth = D(v); a.have_depth = true;
+            if (!strcmp(v, "inf")) { a.depth_inf = true; a.depth = 0.0; }
+            else a.depth = D(v);
+            a.have_depth = true;
         } else if (f == "--depths-file" || f == "-df") a.depths_fn = v;
         else if (f == "--error-rate" || f == "-e") a.error_rate = D(v);
         else if (f == "--error-qs" || f == "-eq") a.error_qs = I(v);
@@ -114,6 +117,12 @@ static Args parse_args(int argc, char** argv) {
     if (a.in_fn.empty()) die("Input file is not specified. Please use -i/--input option to specify the input file.");
     if (!a.have_depth && a.depths_fn.empty()) die("Average per-site read depth value is required. Please set it using --depth or --depths-file and re-run.");
     if (a.depths_fn.empty()) range(a.depth, 0.0, 500.0, "--depth");
+    if (a.depth_inf) {                                                          // io.cpp:781-850, 1011-1018
+        if (a.rm_invar & 4) die("[--rm-invar-sites %d] Cannot skip invariable sites when --depth inf is set.", a.rm_invar);
+        if (a.do_gvcf) die("[-doGVCF 1] Cannot output gVCF when --depth inf is set.");
+        if (a.add_qs) die("(-addQS 1) QS tag cannot be added when --depth inf is set.");
+        if (a.add_i16) die("(-addI16 1) I16 tag cannot be added when --depth inf is set.");
+    }
     if (a.error_rate < 0) die("Error rate is not specified. Please use --error-rate option to specify the error rate. Allowed range: [0.0, 1.0]");
     if (a.error_rate >= 1.0) die("[Bad argument value: '--error-rate %f'] Allowed range is [0.0,1.0]", a.error_rate);
     range(a.source, 0, 1, "--source"); range(a.error_qs, 0, 2, "--error-qs"); range(a.gl_model, 1, 2, "--gl-model");
@@ -278,6 +287,7 @@ struct Site { const Rec* rec; long pos0; std::string chrom; std::vector<uint8_t>
 
 // check_rec_alleles (vcfgl.cpp:75-163) + the n_allele==1 filter (vcfgl.cpp:335-338); false = skipped
 static bool make_site(const Args& a, const Rec& rec, long pos0, bool blank, int N, Site& out) {
+    // (the n_allele == 1 filter below belongs to simulate_record_values and is not applied with --depth inf)
     const int n_alleles = (int)rec.alleles.size();
     if (n_alleles > 5) die("Multiallelic sites with more than 4 alleles are not supported.");
     int ra[5] = {-1, -1, -1, -1, -1};
@@ -301,7 +311,7 @@ static bool make_site(const Args& a, const Rec& rec, long pos0, bool blank, int 
     }
     if ((a.rm_invar & 1) && allelesum == 0) return false;
     if (a.rm_invar & 2) for (int k = 1; k < n_alleles; k++) if ((long)k * N * 2 == allelesum) return false;
-    if ((a.rm_invar & 3) && n_alleles == 1) return false;
+    if (!a.depth_inf && (a.rm_invar & 3) && n_alleles == 1) return false;
     out.rec = &rec; out.pos0 = pos0; out.chrom = rec.chrom; out.ref_char = (a.source == 0) ? 'A' : rec.ref_char;
     return true;
 }
@@ -429,6 +439,66 @@ int main(int argc, char** argv) {
     if (N <= 0) die("no samples in %s", a.in_fn.c_str());
     if (!a.depths.empty() && (int)a.depths.size() != N) die("--depths-file must hold one depth per sample (%zu given, %d samples)", a.depths.size(), N);
     std::vector<Site> sites = build_sites(a, vcf);
+
+    if (a.depth_inf) {                                   // simulate_record_true_values, vcfgl.cpp:1089-1262
+        const std::string fn = a.out_prefix + ".vcf";
+        FILE* out = fopen(fn.c_str(), "w");
+        if (!out) die("Could not open file: %s", fn.c_str());
+        for (const std::string& h : vcf.header) if (h.find("##FORMAT=<ID=GT,") == std::string::npos) fprintf(out, "%s\n", h.c_str());
+        fprintf(out, "##source=vcfgl_hip\n##source=%s\n", a.command.c_str());
+        if (a.add_gl) fprintf(out, "##FORMAT=<ID=GL,Number=G,Type=Float,Description=\"log10 genotype likelihoods, best = 0\">\n");
+        if (a.add_gp) fprintf(out, "##FORMAT=<ID=GP,Number=G,Type=Float,Description=\"Genotype probabilities\">\n");
+        if (a.add_pl) fprintf(out, "##FORMAT=<ID=PL,Number=G,Type=Integer,Description=\"Phred-scaled genotype likelihoods\">\n");
+        fprintf(out, "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT");
+        for (const std::string& sn : vcf.samples) fprintf(out, "\t%s", sn.c_str());
+        fprintf(out, "\n");
+        const bool explode_acgt = a.do_unobserved >= 3;
+        const bool add_unobs = (a.do_unobserved == 1 || a.do_unobserved == 2 || a.do_unobserved == 4 || a.do_unobserved == 5);
+        const char* nonref = (a.do_unobserved == 1 || a.do_unobserved == 4) ? "<*>" : "<NON_REF>";
+        std::string line;
+        for (const Site& S : sites) {
+            int ac[4] = {0, 0, 0, 0};
+            for (int s = 0; s < N; s++) {
+                const int b0 = S.gt[s] & 0xF, b1 = (S.gt[s] >> 4) & 0xF;
+                if (b0 > 3 || b1 > 3) die("--depth inf needs complete A/C/G/T genotypes (position %ld)", S.pos0 + 1);
+                ac[b0]++; ac[b1]++;
+            }
+            int order[4] = {0, 1, 2, 3}, n_obs = 0;
+            for (int i = 0; i < 4; ++i) {
+                if (ac[i] > 0) n_obs++;
+                for (int j = i; j > 0 && ac[order[j]] > ac[order[j - 1]]; j--) std::swap(order[j], order[j - 1]);
+            }
+            std::vector<std::string> al;
+            int idx_of[5] = {-1, -1, -1, -1, -1};
+            const int n_acgt = explode_acgt ? 4 : n_obs;
+            for (int i = 0; i < n_acgt; i++) { idx_of[order[i]] = (int)al.size(); al.push_back(std::string(1, "ACGT"[order[i]])); }
+            if (add_unobs) al.push_back(nonref);
+            const int nA = (int)al.size(), nG = nA * (nA + 1) / 2;
+            line = S.chrom; char hb[64]; snprintf(hb, sizeof hb, "\t%ld\t", S.pos0 + 1); line += hb;
+            line += S.rec->id; line += '\t'; line += al[0]; line += '\t';
+            if (nA == 1) line += '.'; else for (int k = 1; k < nA; k++) { if (k > 1) line += ','; line += al[k]; }
+            line += '\t'; line += S.rec->qual; line += '\t'; line += S.rec->filt; line += '\t'; line += S.rec->info; line += '\t';
+            std::string fmt;
+            if (a.add_gl) fmt += "GL"; if (a.add_gp) { if (!fmt.empty()) fmt += ':'; fmt += "GP"; } if (a.add_pl) { if (!fmt.empty()) fmt += ':'; fmt += "PL"; }
+            line += fmt.empty() ? "." : fmt;
+            for (int s = 0; s < N; s++) {
+                const int i0 = idx_of[S.gt[s] & 0xF], i1 = idx_of[(S.gt[s] >> 4) & 0xF];
+                const int tg = i0 > i1 ? i0 * (i0 + 1) / 2 + i1 : i1 * (i1 + 1) / 2 + i0;
+                line += '\t';
+                bool first = true;
+                auto sep = [&]() { if (!first) line += ':'; first = false; };
+                if (a.add_gl) { sep(); for (int g = 0; g < nG; g++) { if (g) line += ','; line += (g == tg) ? "0" : "-inf"; } }
+                if (a.add_gp) { sep(); for (int g = 0; g < nG; g++) { if (g) line += ','; line += (g == tg) ? "1" : "0"; } }
+                if (a.add_pl) { sep(); for (int g = 0; g < nG; g++) { if (g) line += ','; line += (g == tg) ? "0" : "255"; } }
+                if (first) line += '.';
+            }
+            line += '\n';
+            fwrite(line.data(), 1, line.size(), out);
+        }
+        fclose(out);
+        fprintf(stderr, "\n\n-> Simulation finished successfully.\n\nSummary:\n\tNumber of samples: %d\n\tTotal number of sites simulated: %zu\n", N, sites.size());
+        return 0;
+    }
 
     vgl_params p; memset(&p, 0, sizeof p);
     p.abi_version = VGL_ABI_VERSION; p.seed = a.seed; p.n_samples = N; p.rng_mode = a.rng_mode; p.beta_sampler = a.beta_sampler;
