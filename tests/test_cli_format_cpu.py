@@ -57,9 +57,12 @@ def test_depth_inf_matches_reference_golden(tmp_path):
     data = os.path.join(gu.REFVCF, "data")
     out = str(tmp_path / "test4")
     argv = ("--seed 42 --output-mode v --depth inf --error-rate 0 --gl-model 1 --precise-gl 0 -explode 1 --rm-empty-sites 1 "
-            "--adjust-qs 1 -doUnobserved 1 -addGP 1 -addPL 1 -addI16 0 -addQS 0 -addFormatDP 0").split()
+            "--adjust-qs 1 -doUnobserved 1 -printTruth 1 -addGP 1 -addPL 1 -addI16 0 -addQS 0 -addFormatDP 0").split()
     r = subprocess.run([BIN, "-i", os.path.join(data, "data3.vcf"), "-o", out] + argv, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-1500:]
     ours = [l for l in open(out + ".vcf") if not l.startswith("##")]
     gold = [l for l in open(os.path.join(gu.REFVCF, "reference", "test4", "test4.vcf")) if not l.startswith("##")]
+    assert ours == gold
+    ours = [l for l in open(out + ".truth.vcf") if not l.startswith("##")]
+    gold = [l for l in open(os.path.join(gu.REFVCF, "reference", "test4", "test4.truth.vcf")) if not l.startswith("##")]
     assert ours == gold

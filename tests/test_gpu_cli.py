@@ -38,8 +38,6 @@ def test_cli_diff_against_reference_golden(name, tmp_path):
         flag, val = toks[i], toks[i + 1]
         if flag in ("--depths-file", "--qs-bins"):
             val = os.path.join(data, os.path.basename(val))
-        if flag == "-printTruth":
-            continue                                   # truth VCF is outside the hot path
         argv += [flag, val]
     out = str(tmp_path / name)
     cmd = [BIN, "-i", os.path.join(data, t["input"]), "-o", out, "--rng-mode", "1"] + argv
@@ -50,6 +48,12 @@ def test_cli_diff_against_reference_golden(name, tmp_path):
     assert len(ours) == len(gold)
     for a, b in zip(ours, gold):
         assert a == b                                   # full text equality, I16 tail-distance fields included
+    truth = os.path.join("/nonexistent")
+    tgold = os.path.join(gu.REFVCF, "reference", name, name + ".truth.vcf")
+    if "-printTruth 1" in t["args"] and os.path.exists(tgold):
+        a = [l for l in open(out + ".truth.vcf") if not l.startswith("##")]
+        b = [l for l in open(tgold) if not l.startswith("##")]
+        assert a == b
     if t.get("pileup"):
         a = gzip.open(out + ".pileup.gz", "rt").read()
         b = gzip.open(os.path.join(gu.REFVCF, "reference", name, name + ".pileup.gz"), "rt").read()

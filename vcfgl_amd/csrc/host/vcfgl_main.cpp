@@ -10,7 +10,8 @@
 //   * the gVCF block builder prepare_gvcf_block()         bcf_utils.cpp:662-942
 //   * --depth inf (simulate_record_true_values, vcfgl.cpp:1089-1262): no sampling at all, the true
 //     genotype gets GL 0 / GP 1 / PL 0 and every other genotype -inf / 0 / 255; written directly
-// CPU simulation path here.  Not provided: BCF / bgzip output (-O b|u|z), -printTruth.
+//   * -printTruth 1: the decoded input records (incl. exploded ones) as <prefix>.truth.vcf
+// CPU simulation path here.  Not provided: BCF / bgzip output (-O b|u|z).
 #include <math.h>
 #include <stdarg.h>
 #include <stdint.h>
@@ -147,7 +148,6 @@ static Args parse_args(int argc, char** argv) {
         parts.push_back(cur);
         for (auto& x : parts) { if (x.empty()) die("Could not parse --gvcf-dps %s", a.gvcf_dps_str.c_str()); const int d = atoi(x.c_str()); if (d < 1) die("Invalid DP range: %d", d); a.gvcf_dps.push_back(d); }
     } else if (!a.gvcf_dps_str.empty()) die("-> [--gvcf-dps] --gvcf-dps requires -doGVCF 1. Please set -doGVCF 1 and rerun.");
-    if (a.print_truth) die("-printTruth 1 is not provided by this front end");
     if (a.output_mode != "v") die("--output-mode %s: only uncompressed VCF text (v) is provided (no htslib on this platform)", a.output_mode.c_str());
     if (a.seed == -1) { a.seed = (int)time(NULL); fprintf(stderr, "\n-> No seed was given. Setting the random seed to the randomly chosen value: %d\n", a.seed); }
     if (a.beta_sampler < 0) a.beta_sampler = (a.rng_mode == VGL_RNG_SERIAL) ? VGL_BETA_STD : VGL_BETA_RAND48;
@@ -210,6 +210,7 @@ struct Rec {
     long pos0;
     std::vector<std::string> alleles;
     std::vector<int8_t> gt;            // 2 per sample, allele index or -1
+    std::vector<std::string> gt_str;   // GT tokens as written in the input (for -printTruth)
     char ref_char;
 };
 
@@ -269,6 +270,7 @@ static Vcf read_vcf(const std::string& fn, int n_expected = -1) {
             std::string x = t.substr(0, sep), y = (sep == std::string::npos) ? x : t.substr(sep + 1);
             r.gt[2 * s] = (x == "." || x.empty()) ? -1 : (int8_t)atoi(x.c_str());
             r.gt[2 * s + 1] = (y == "." || y.empty()) ? -1 : (int8_t)atoi(y.c_str());
+            r.gt_str.push_back(t);
         }
         v.recs.push_back(std::move(r));
     }
@@ -284,6 +286,7 @@ static int allele_to_int(const std::string& a) {
 }
 
 struct Site { const Rec* rec; long pos0; std::string chrom; std::vector<uint8_t> gt; char ref_char; };
+static std::vector<std::string> g_truth_lines;      // -printTruth 1: records as check_rec_alleles() leaves them
 
 // check_rec_alleles (vcfgl.cpp:75-163) + the n_allele==1 filter (vcfgl.cpp:335-338); false = skipped
 static bool make_site(const Args& a, const Rec& rec, long pos0, bool blank, int N, Site& out) {
@@ -311,6 +314,14 @@ static bool make_site(const Args& a, const Rec& rec, long pos0, bool blank, int 
     }
     if ((a.rm_invar & 1) && allelesum == 0) return false;
     if (a.rm_invar & 2) for (int k = 1; k < n_alleles; k++) if ((long)k * N * 2 == allelesum) return false;
+    if (a.print_truth) {                               // bcf_write(out_truth_fp, ...) at vcfgl.cpp:1518,1548,1607
+        std::string l = rec.chrom; char hb[48]; snprintf(hb, sizeof hb, "\t%ld\t", pos0 + 1); l += hb; l += rec.id; l += '\t';
+        if (a.source == 0) l += "A\tC";                // binary source: alleles become A,C (vcfgl.cpp:127)
+        else { l += rec.alleles[0]; l += '\t'; if (n_alleles == 1) l += '.'; else for (int k = 1; k < n_alleles; k++) { if (k > 1) l += ','; l += rec.alleles[k]; } }
+        l += '\t'; l += rec.qual; l += '\t'; l += rec.filt; l += '\t'; l += rec.info; l += "\tGT";
+        for (int s = 0; s < N; s++) { l += '\t'; l += blank ? std::string("0|0") : rec.gt_str[s]; }
+        g_truth_lines.push_back(l);
+    }
     if (!a.depth_inf && (a.rm_invar & 3) && n_alleles == 1) return false;
     out.rec = &rec; out.pos0 = pos0; out.chrom = rec.chrom; out.ref_char = (a.source == 0) ? 'A' : rec.ref_char;
     return true;
@@ -439,6 +450,17 @@ int main(int argc, char** argv) {
     if (N <= 0) die("no samples in %s", a.in_fn.c_str());
     if (!a.depths.empty() && (int)a.depths.size() != N) die("--depths-file must hold one depth per sample (%zu given, %d samples)", a.depths.size(), N);
     std::vector<Site> sites = build_sites(a, vcf);
+    if (a.print_truth) {
+        const std::string fn = a.out_prefix + ".truth.vcf";
+        FILE* tf = fopen(fn.c_str(), "w");
+        if (!tf) die("Could not open file: %s", fn.c_str());
+        for (const std::string& h : vcf.header) fprintf(tf, "%s\n", h.c_str());
+        fprintf(tf, "##source=vcfgl_hip\n##source=%s\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT", a.command.c_str());
+        for (const std::string& sn : vcf.samples) fprintf(tf, "\t%s", sn.c_str());
+        fprintf(tf, "\n");
+        for (const std::string& l : g_truth_lines) fprintf(tf, "%s\n", l.c_str());
+        fclose(tf);
+    }
 
     if (a.depth_inf) {                                   // simulate_record_true_values, vcfgl.cpp:1089-1262
         const std::string fn = a.out_prefix + ".vcf";
