@@ -83,7 +83,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):        # BENCH_FORCE_DIST: exercise the collective path at world 1
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -128,7 +128,7 @@ def main():
                                                         C.c_void_p(stream.cuda_stream)))
         if dist is not None:                                  # record-index gather to the writer rank
             stream.synchronize()
-            gather_site_index(out["site_status"], out["n_alleles"], world, rank, S * world)
+            gather_site_index(out["site_status"], out["n_alleles"], world, rank, S * world, always_collective=True)
 
     def barrier():
         stream.synchronize()

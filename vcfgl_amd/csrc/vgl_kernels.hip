@@ -5,18 +5,27 @@
 // owns 64 consecutive samples of one site, so every per-evaluation global access of a
 // wave is one contiguous segment (structure-of-arrays tiles, sample index fastest).
 //
-//   k_sample   Poisson depth -> per-read haplotype / base-call error / quality score /
-//              strand draws -> per-evaluation ACGT depth; reads staged as 1 byte each in
-//              [read][site][sample] planes; per-site depth sums by DPP wave reduction +
-//              one integer atomic per wave.     (vcfgl.cpp:364-389, 441-640; rng.h)
-//   k_site     per-site allele order / status.  (vcfgl.cpp:396-404, 665-766)
-//   k_gl       genotype likelihoods from the staged reads in the site's allele order,
-//              accumulators in VGPRs, then PL / GP / AD epilogue.
-//                                               (gl_methods.cpp:4-369, vcfgl.cpp:806-970)
-//   k_siteagg  order-dependent per-site float sums (QS, I16).  (vcfgl.cpp:845-898, 982-1074)
+//   k_sample<EQS>    Poisson depth -> per-read haplotype / base-call error / strand draws ->
+//                    per-evaluation ACGT depth; reads staged as 1 byte each in
+//                    [read][site][sample] planes; per-site depth sums by wave reduction + one
+//                    integer atomic per wave and counter.  EQS=2 (a beta deviate per read):
+//                    the quality-score sampling of the wave's reads is an LDS-staged pool dealt
+//                    round-robin to the lanes, each lane a select-only state machine over
+//                    normal-deviate attempts.            (vcfgl.cpp:364-389, 441-640; rng.h)
+//   k_scout, k_sample_serial   VGL_RNG_SERIAL: sequential stream-state scout + parallel
+//                    evaluation from the recorded states (reference draw order, bit for bit).
+//   k_site           per-site allele order / status.     (vcfgl.cpp:396-404, 665-766)
+//   k_gl<A>          genotype likelihoods from the staged reads in the site's allele order
+//                    (lanes re-dealt in depth order inside each workgroup), accumulators in
+//                    VGPRs, then PL / GP / AD epilogue.   (gl_methods.cpp:4-369, vcfgl.cpp:806-970)
+//   k_siteagg        order-dependent per-site float sums (QS, I16).  (vcfgl.cpp:845-898, 982-1074)
 //
 // The float32 accumulation order of the reference is kept exactly (double add rounded to
 // float per genotype per read, float max, float subtract): build with -ffp-contract=off.
+// Decisions that the reference takes on double transcendentals (rejection tests, floor of a
+// scaled tan, (int)(-10 log10 p)) are taken from float32 hardware transcendentals with measured
+// error bounds and fall back to the exact double expression inside the error band, behind
+// wave-uniform branches: results equal the exact evaluation, the common path has no f64 log/tan/exp.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "vgl_device.h"

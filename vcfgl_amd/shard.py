@@ -15,11 +15,11 @@ def site_range(rank: int, world: int, n_sites: int) -> Tuple[int, int]:
 
 
 def gather_site_index(status: torch.Tensor, n_alleles: torch.Tensor, world: int, rank: int,
-                      n_sites_total: int, dst: int = 0) -> Optional[torch.Tensor]:
+                      n_sites_total: int, dst: int = 0, always_collective: bool = False) -> Optional[torch.Tensor]:
     """Gather [status, n_alleles] rows of every rank's sites to `dst` in site order.
     Shards may differ by one site, so rows are padded to the largest shard."""
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not always_collective:
         return torch.stack([status, n_alleles], dim=1)
     longest = -(-n_sites_total // world)
     idx = torch.full((longest, 2), -128, dtype=torch.int32, device=status.device)
