@@ -177,6 +177,38 @@ def test_config_c5_flags(oracle):
     assert (got.numpy("n_alleles") >= 2).all()
 
 
+@pytest.mark.parametrize("seed", [-1, -123456789, 0, 2 ** 31 - 1])
+def test_seed_range(oracle, seed):
+    """io.cpp:1054-1061: the low 32 bits of the (signed) seed seed every stream"""
+    args = VcfglArgs(seed=seed, depth=15, error_rate=0.02, error_qs=2, beta_variance=1e-4, **ALLTAGS)
+    want, got = run_both(oracle, args, synth.acgt_sites(12, 80, seed=2, missing=0.02))
+    assert_parity(want, got)
+
+
+def test_qs_bin_miss_is_an_error(oracle):
+    """apply_qs_bins() exits with "Could not find a range for qs value" (vcfgl.cpp:63): here VGL_E_QSBIN"""
+    from vcfgl_amd import VglError
+    args = VcfglArgs(seed=1, depth=10, error_rate=0.01, error_qs=2, beta_variance=1e-5, qs_bins=[(0, 10, 5)])
+    sim = Simulator(args, 64, max_sites_per_tile=4)
+    with pytest.raises(VglError) as ei:
+        sim.simulate(0, synth.binary_sites(0, 4, 64))
+    assert ei.value.code == _abi.VGL_E_QSBIN
+    sim.close()
+    with pytest.raises(oracle.OracleError) as eo:
+        oracle.Oracle(args, 64).simulate(0, synth.binary_sites(0, 4, 64))
+    assert eo.value.code == _abi.VGL_E_QSBIN
+
+
+def test_bad_parameters_are_rejected_like_the_reference():
+    from vcfgl_amd import VglError
+    for kw, frag in ((dict(depth=5, error_rate=0.1, gl_model=1, precise_gl=1), b"not supported with genotype likelihood model 1"),
+                     (dict(depth=5, error_rate=0.0, error_qs=2, beta_variance=1e-5), b"--error-rate"),
+                     (dict(depth=5, error_rate=0.5, error_qs=1, beta_variance=0.5), b"shape parameters")):
+        with pytest.raises(VglError) as ei:
+            Simulator(VcfglArgs(seed=1, **kw), 4, max_sites_per_tile=2)
+        assert ei.value.code == _abi.VGL_E_ARG and frag in str(ei.value).encode()
+
+
 def test_site_index_invariance(oracle):
     """tiles are addressed by absolute site index: splitting a run into tiles (or shards)
     does not change any value"""

@@ -712,8 +712,8 @@ __global__ __launch_bounds__(64) void k_scout(const VglDevParams P, const VglTil
         for (int s = 0; s < N; ++s) {
             T.sst_depth[e0 + s] = st1;
             int n;
-            if (P.per_sample_depth) { const VglPois pc = P.pois[s]; n = poisson_draw(pc, st1, P.gamma_ln_tab, P.gamma_ln_n); }
-            else n = poisson_draw(P.pois0, st1, P.gamma_ln_tab, P.gamma_ln_n);
+            if (P.per_sample_depth) { const VglPois pc = P.pois[s]; n = poisson_draw_fast(pc, st1, P.gamma_ln_tab, P.gamma_ln_n); }
+            else n = poisson_draw_fast(P.pois0, st1, P.gamma_ln_tab, P.gamma_ln_n);
             const uint32_t g = T.gt[e0 + s];
             if ((g & 0xF) == 0xF || ((g >> 4) & 0xF) == 0xF) n = 0;
             if (n > P.read_cap) n = P.read_cap;                    // flagged by k_sample_serial
