@@ -62,3 +62,33 @@ def test_serial_streams_continue_across_tiles(oracle):
     got_gl = np.concatenate([a.numpy("gl"), b.numpy("gl")]).view(np.uint32)
     assert np.array_equal(got_gl, want.numpy("gl").view(np.uint32))
     assert np.array_equal(np.concatenate([a.numpy("qs"), b.numpy("qs")]).view(np.uint32), want.numpy("qs").view(np.uint32))
+
+
+@pytest.mark.parametrize("kw", [
+    dict(depth=20, error_rate=0.01),                                              # rejection Poisson, no strand
+    dict(depth=30, error_rate=0.05, add_i16=1, add_fmt_adf=1, add_fmt_adr=1),     # strand draws + I16 (libc rand)
+    dict(depth=5, error_rate=0.2),                                                # product-method Poisson, many errors
+    dict(depth=14, error_rate=0.03, error_qs=1, beta_variance=1e-4),              # per-site beta error rate
+    dict(depths=[0.0, 25.0, 3.0, 12.0] * 50, error_rate=0.02, add_i16=1),         # per-sample means incl. zero
+    dict(depth=100, error_rate=0.0, do_unobserved=5),                             # blocks of > 64 reads per sample
+])
+def test_wave_scout_equals_oracle_serial(oracle, kw):
+    """the wave-parallel state scout (no per-read beta) against the CPU oracle's serial mode:
+    every integer field, GL bits, QS bits, I16 incl. tail distances"""
+    import synth
+    from vcfgl_amd import VcfglArgs
+    args = VcfglArgs(seed=42, add_pl=1, add_qs=1, add_fmt_ad=1, add_info_ad=1, add_info_dp=1, **kw)
+    args.rng_mode, args.beta_sampler = _abi.VGL_RNG_SERIAL, _abi.VGL_BETA_STD
+    N, S = 200, 30
+    gt = synth.acgt_sites(S, N, seed=11, missing=0.03)
+    sim = Simulator(args, N, max_sites_per_tile=16)
+    a = sim.simulate(0, gt[:16])
+    b = sim.simulate(16, gt[16:])
+    fields = sim.default_fields()
+    sim.close()
+    want = oracle.Oracle(args, N).simulate(0, gt, fields=fields)
+    for f in ["site_status", "alleles2acgt", "n_alleles", "info_dp", "info_ad", "info_adf", "info_adr", "fmt_dp", "fmt_ad", "fmt_adf", "fmt_adr", "pl"]:
+        assert np.array_equal(np.concatenate([a.numpy(f), b.numpy(f)]), want.numpy(f)), f
+    for f in ["gl", "qs"] + (["i16"] if args.add_i16 else []):
+        got = np.concatenate([a.numpy(f), b.numpy(f)])
+        assert np.array_equal(got.view(np.uint32), want.numpy(f).view(np.uint32)), f

@@ -49,6 +49,7 @@ struct VglDevParams {
     int32_t need_qsum, need_qsumsq, need_adf, i16_mapq;
     int32_t add_i16;
     int32_t serial;          // VGL_RNG_SERIAL
+    int32_t scout_lds_bytes; // dynamic LDS of k_scout_wave (9 bytes per sample when the site fits)
     int32_t beta_std;        // VGL_BETA_STD (serial only)
     double  beta_a, beta_b;  // beta shape parameters (std sampler)
     int32_t dbg_phase;       // diagnostic (VGL_DEBUG_PHASE=n): k_sample returns after phase n; 0 = off
@@ -62,6 +63,7 @@ struct VglDevParams {
     VglAffine site_pow[40];            // J^(block * N * 2^b)
     const VglAffine* samp_tab;         // [N] J^(block * s)
     const VglAffine* qs_read_tab;      // [read_cap] J^(qs_read_stride * r)
+    const VglAffine* step_tab;         // [192] J^k (serial-mode scout)
     // samplers
     VglPois pois0;
     const VglPois* pois;               // [N] when per_sample_depth
@@ -105,9 +107,10 @@ struct VglTilePtrs {
     uint8_t* reads_out; int32_t reads_out_cap;
     unsigned long long* dbg;  // diagnostic cycle stamps (VGL_DEBUG_STAMPS=1), else null
     // VGL_RNG_SERIAL: per-evaluation stream states found by the sequential scout (k_scout)
-    uint64_t* sst_depth; uint64_t* sst_hap; uint64_t* sst_base;   // [n_sites][N]
+    uint64_t* sst_hap; uint64_t* sst_base;   // [n_sites][N]
+    int32_t*  sdp;           // [n_sites][N] depth draws of the scout
     uint64_t* site_thresh;   // [n_sites] per-site base-pick error threshold (error_qs 1)
-    int32_t*  scout_dp;      // [N] scratch of the scout
+    int32_t*  scout_off;     // [N] scratch of the scout: first read index of each sample
     VglSiteTail* site_tail;  // [n_sites] (serial mode with -addI16)
 };
 

@@ -149,7 +149,7 @@ struct vgl_ctx {
     uint32_t* d_errflag = nullptr;
     unsigned long long* d_dbg = nullptr;
     // VGL_RNG_SERIAL
-    VglSerialState* d_serial = nullptr; uint64_t* d_sst = nullptr; uint64_t* d_site_thresh = nullptr; int32_t* d_scout_dp = nullptr; VglSiteTail* d_site_tail = nullptr;
+    VglSerialState* d_serial = nullptr; uint64_t* d_sst = nullptr; uint64_t* d_site_thresh = nullptr; int32_t* d_scout_dp = nullptr; int32_t* d_sdp = nullptr; VglAffine* d_step_tab = nullptr; VglSiteTail* d_site_tail = nullptr;
     int64_t serial_next_site = 0;   // VGL_DEBUG_STAMPS=1 diagnostic counters
     // host-variant mirrors
     uint8_t* d_gt = nullptr; void* d_out[17] = {nullptr}; size_t d_out_bytes[17] = {0};
@@ -233,7 +233,7 @@ extern "C" int vgl_ctx_destroy(vgl_ctx* c) {
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_gl1_fk, c->d_gl1_beta, c->d_gamma_ln, c->d_samp_tab, c->d_qs_read_tab, c->d_pois, c->d_q2gl, c->d_gl1_bsum, c->d_gl1_lhet, c->d_reads, c->d_errp, c->d_ad4,
                     c->d_adf4, c->d_qsum, c->d_qsumsq, c->d_acc, c->d_sinfo, c->d_errflag, c->d_gt, c->d_reads_out, c->d_dbg,
-                    c->d_serial, c->d_sst, c->d_site_thresh, c->d_scout_dp, c->d_site_tail};
+                    c->d_serial, c->d_sst, c->d_site_thresh, c->d_scout_dp, c->d_site_tail, c->d_sdp, c->d_step_tab};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     for (void* q : c->d_out) if (q) (void)hipFree(q);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -299,6 +299,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     D.i16_mapq = p->i16_mapq; D.add_i16 = p->add_i16;
     D.adjust_by = p->adjust_by;
     D.serial = (p->rng_mode == VGL_RNG_SERIAL) ? 1 : 0;
+    D.scout_lds_bytes = ((size_t)p->n_samples * 9 <= 144 * 1024) ? (int32_t)(((size_t)p->n_samples * 9 + 15) & ~(size_t)15) : 0;
     D.beta_std = (p->beta_sampler == VGL_BETA_STD) ? 1 : 0;
     D.dbg_phase = getenv("VGL_DEBUG_PHASE") ? atoi(getenv("VGL_DEBUG_PHASE")) : 0;
     for (int i = 0; i < p->n_qs_bins * 3; i++) D.qs_bins[i] = p->qs_bins[i];
@@ -396,7 +397,15 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     TRY(dmalloc(&c->d_reads, E * D.read_cap));
     if ((p->precise_gl || D.serial) && p->error_qs == 2) TRY(dmalloc(&c->d_errp, E * D.read_cap));
     if (D.serial) {
-        TRY(dmalloc(&c->d_sst, E * 3)); TRY(dmalloc(&c->d_site_thresh, (size_t)max_sites)); TRY(dmalloc(&c->d_scout_dp, (size_t)N));
+        TRY(dmalloc(&c->d_sst, E * 2)); TRY(dmalloc(&c->d_site_thresh, (size_t)max_sites)); TRY(dmalloc(&c->d_scout_dp, (size_t)N)); TRY(dmalloc(&c->d_sdp, E));
+        {
+            std::vector<VglAffine> stp(192);
+            VglAffine cur = {1, 0}; const VglAffine j1 = aff_pow(1);
+            for (int k = 0; k < 192; k++) { stp[k] = cur; cur = aff_compose(j1, cur); }
+            TRY(dmalloc(&c->d_step_tab, (size_t)192));
+            TRYHIP(hipMemcpy(c->d_step_tab, stp.data(), sizeof(VglAffine) * 192, hipMemcpyHostToDevice));
+            D.step_tab = c->d_step_tab;
+        }
         TRY(dmalloc(&c->d_serial, (size_t)1));
         VglSerialState hs; memset(&hs, 0, sizeof hs);
         hs.st0 = hs.st1 = hs.st2 = D.x0;                         // io.cpp:1054-1061: all three streams start equal
@@ -475,8 +484,8 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     T.acc = c->d_acc; T.sinfo = c->d_sinfo; T.errflag = c->d_errflag; T.dbg = c->d_dbg;
     if (D.serial) {
         const size_t E = (size_t)c->max_sites * D.n_samples;
-        T.sst_depth = c->d_sst; T.sst_hap = c->d_sst + E; T.sst_base = c->d_sst + 2 * E;
-        T.site_thresh = c->d_site_thresh; T.scout_dp = c->d_scout_dp; T.site_tail = c->d_site_tail;
+        T.sst_hap = c->d_sst; T.sst_base = c->d_sst + E; T.sdp = c->d_sdp;
+        T.site_thresh = c->d_site_thresh; T.scout_off = c->d_scout_dp; T.site_tail = c->d_site_tail;
         if (site0 != c->serial_next_site)
             return fail(VGL_E_ARG, "VGL_RNG_SERIAL consumes the streams in call order: expected site0 %lld, got %lld", (long long)c->serial_next_site, (long long)site0);
     }

@@ -93,6 +93,42 @@ __device__ int poisson_draw(const VglPois& p, uint64_t& st, const double* __rest
 // expressions are evaluated only inside the error band.  Bounds measured on MI355X
 // (tools/vlogcheck.py): |tanf(x) - tan(x)| <= 1.2 ulp, v_exp_f32 <= 0.71 ulp; 4x margins used.
 // Flat loop: one attempt per iteration for every lane that has not accepted yet.
+// one rejection attempt (rng.h:302-309) from the two generator states it would consume: `neg`: em < 0
+// (only st1 is consumed, no acceptance draw), else `rej` = the acceptance draw u(st2) exceeds t.
+__device__ __forceinline__ void poisson_attempt(const VglPois& p, const uint64_t st1, const uint64_t st2, const bool need,
+                                                const double* __restrict__ glt, const int glt_n, bool& neg, bool& rej, double& em) {
+    const double a = VGL_PI * u01(st1);
+    const float af = (float)a;
+    const float yf = tanf(af);
+    const float y2 = yf * yf;
+    const float dy = fabsf(yf) * 0x1p-21f + (1.0f + y2) * af * 0x1p-23f;      // |yf - tan(a)|
+    const double e0 = p.sq * (double)yf + p.lm;
+    const double derr = p.sq * (double)dy + 1e-9;
+    em = floor(e0);
+    const bool amb_em = (e0 - em < derr) | (em + 1.0 - e0 < derr) | !(fabs(e0) < 1.0e6);
+    neg = e0 < 0.0;
+    const bool in_tab = (em >= 0.0) & (em < (double)(glt_n - 1));
+    const double gl = glt[in_tab ? (int)em + 1 : 1];
+    const double z = em * p.alxm - gl - p.g;
+    const float ex = __builtin_amdgcn_exp2f((float)(z * 1.4426950408889634));
+    const float tt = 0.9f * (1.0f + y2) * ex;
+    const float rel_t = 2.0f * fabsf(yf) * dy / (1.0f + y2) + fabsf((float)z) * 0x1p-22f + 0x1p-19f;
+    const double u2 = u01(st2);
+    rej = u2 > (double)tt;
+    const bool amb_t = fabs(u2 - (double)tt) <= (double)(tt * rel_t) + 1e-30;
+    const bool amb = need & (amb_em | (!neg & (amb_t | !in_tab)));
+    if (__builtin_expect(__ballot(amb) != 0, 0)) {               // exact evaluation (rare, wave-uniform branch)
+        asm volatile("" ::: "memory");
+        const double y = tan(a);
+        double eme = p.sq * y + p.lm;
+        const bool nege = eme < 0.0;
+        eme = floor(eme);
+        const double t = 0.9 * (1.0 + y * y) * exp(eme * p.alxm - ((eme >= 0.0 && eme < (double)(glt_n - 1)) ? glt[(int)eme + 1] : gamma_ln_dev(eme + 1.0)) - p.g);
+        const bool reje = u2 > t;
+        neg = amb ? nege : neg; em = amb ? eme : em; rej = amb ? reje : rej;
+    }
+}
+
 __device__ int poisson_draw_fast(const VglPois& p, uint64_t& st, const double* __restrict__ glt, const int glt_n) {
     if (p.st12) {
         double em = -1.0, t = 1.0;
@@ -104,36 +140,8 @@ __device__ int poisson_draw_fast(const VglPois& p, uint64_t& st, const double* _
     while (__ballot(!done)) {
         const uint64_t st1 = lcg_next(st);
         const uint64_t st2 = lcg_next(st1);
-        const double a = VGL_PI * u01(st1);
-        const float af = (float)a;
-        const float yf = tanf(af);
-        const float y2 = yf * yf;
-        const float dy = fabsf(yf) * 0x1p-21f + (1.0f + y2) * af * 0x1p-23f;      // |yf - tan(a)|
-        const double e0 = p.sq * (double)yf + p.lm;
-        const double derr = p.sq * (double)dy + 1e-9;
-        double em = floor(e0);
-        const bool amb_em = (e0 - em < derr) | (em + 1.0 - e0 < derr) | !(fabs(e0) < 1.0e6);
-        bool neg = e0 < 0.0;
-        const bool in_tab = (em >= 0.0) & (em < (double)(glt_n - 1));
-        const double gl = glt[in_tab ? (int)em + 1 : 1];
-        const double z = em * p.alxm - gl - p.g;
-        const float ex = __builtin_amdgcn_exp2f((float)(z * 1.4426950408889634));
-        const float tt = 0.9f * (1.0f + y2) * ex;
-        const float rel_t = 2.0f * fabsf(yf) * dy / (1.0f + y2) + fabsf((float)z) * 0x1p-22f + 0x1p-19f;
-        const double u2 = u01(st2);
-        bool reject = u2 > (double)tt;
-        const bool amb_t = fabs(u2 - (double)tt) <= (double)(tt * rel_t) + 1e-30;
-        const bool amb = !done & (amb_em | (!neg & (amb_t | !in_tab)));
-        if (__builtin_expect(__ballot(amb) != 0, 0)) {               // exact evaluation (rare, wave-uniform branch)
-            asm volatile("" ::: "memory");
-            const double y = tan(a);
-            double eme = p.sq * y + p.lm;
-            const bool nege = eme < 0.0;
-            eme = floor(eme);
-            const double t = 0.9 * (1.0 + y * y) * exp(eme * p.alxm - ((eme >= 0.0 && eme < (double)(glt_n - 1)) ? glt[(int)eme + 1] : gamma_ln_dev(eme + 1.0)) - p.g);
-            const bool reje = u2 > t;
-            neg = amb ? nege : neg; em = amb ? eme : em; reject = amb ? reje : reject;
-        }
+        bool neg, reject; double em;
+        poisson_attempt(p, st1, st2, !done, glt, glt_n, neg, reject, em);
         const bool acc = !done & !neg & !reject;
         st = done ? st : (neg ? st1 : st2);                          // em < 0 consumes one draw, an attempt two
         em_res = acc ? em : em_res;
@@ -710,14 +718,13 @@ __global__ __launch_bounds__(64) void k_scout(const VglDevParams P, const VglTil
         // depths of all samples first (vcfgl.cpp:364-389)
         long long info_dp = 0;
         for (int s = 0; s < N; ++s) {
-            T.sst_depth[e0 + s] = st1;
             int n;
             if (P.per_sample_depth) { const VglPois pc = P.pois[s]; n = poisson_draw_fast(pc, st1, P.gamma_ln_tab, P.gamma_ln_n); }
             else n = poisson_draw_fast(P.pois0, st1, P.gamma_ln_tab, P.gamma_ln_n);
             const uint32_t g = T.gt[e0 + s];
             if ((g & 0xF) == 0xF || ((g >> 4) & 0xF) == 0xF) n = 0;
-            if (n > P.read_cap) n = P.read_cap;                    // flagged by k_sample_serial
-            T.scout_dp[s] = n;
+            if (n > P.read_cap) { atomicOr(T.errflag, VGL_DEVERR_CAPACITY); n = P.read_cap; }
+            T.sdp[e0 + s] = n;
             info_dp += n;
         }
         uint64_t thresh = P.err_thresh;
@@ -730,7 +737,7 @@ __global__ __launch_bounds__(64) void k_scout(const VglDevParams P, const VglTil
             T.site_thresh[ls] = thresh;
         }
         for (int s = 0; s < N; ++s) {
-            const int dp = T.scout_dp[s];
+            const int dp = T.sdp[e0 + s];
             T.sst_hap[e0 + s] = st1;
             T.sst_base[e0 + s] = st0;
             if (dp == 0) continue;
@@ -755,6 +762,210 @@ __global__ __launch_bounds__(64) void k_scout(const VglDevParams P, const VglTil
     S->st0 = st0; S->st1 = st1;
 }
 
+// Wave-parallel scout for runs without per-read beta deviates (--error-qs 0/1).  The chains stay
+// sequential, but the expensive work on them is done 64 stream positions at a time:
+//   depth stream   every lane evaluates the rejection attempt that would START at its position; the
+//                  chain (1 draw if em<0, else 2; accept ends a sample) is then walked with bit tests
+//   base stream    the error tests of 64 consecutive reads are 64 independent compares on jumped
+//                  states; only a read whose test fires (rate = error rate) is stepped sequentially
+//   haplotype      one draw per read: the state of a sample's first read is a table jump
+// Per-sample start states come from J^k jump tables relative to the current block.
+// ordering between the lanes of the scout's single wavefront: LDS needs only program order,
+// global scratch needs the writes to be visible to the other lanes' loads
+__device__ __forceinline__ void scout_sync(const bool in_lds) {
+    if (in_lds) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+    else __threadfence();
+}
+
+__global__ __launch_bounds__(64) void k_scout_wave(const VglDevParams P, const VglTilePtrs T, VglSerialState* S) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const int lane = threadIdx.x;
+    const int N = P.n_samples;
+    const int stride = P.sample_strand ? 2 : 1;
+    // per-site working set (depths, first-read indices, genotypes) lives in LDS when it fits: every
+    // step of the sequential chains then waits on LDS latency, not on global memory
+    const bool in_lds = (size_t)N * 9 <= (size_t)P.scout_lds_bytes;
+    int32_t* dpv = in_lds ? (int32_t*)lds_raw : nullptr;
+    int32_t* offv = in_lds ? (int32_t*)lds_raw + N : T.scout_off;
+    uint8_t* gtl = in_lds ? (lds_raw + (size_t)8 * N) : nullptr;
+    uint64_t st0 = S->st0, st1 = S->st1;                           // identical in every lane
+    for (int ls = 0; ls < T.n_sites; ++ls) {
+        const size_t e0 = (size_t)ls * N;
+        int32_t* dps = in_lds ? dpv : (T.sdp + e0);
+        const uint8_t* gts = T.gt + e0;
+        if (in_lds) {
+            for (int i = lane; i < N; i += 64) gtl[i] = gts[i];
+            gts = gtl;
+        }
+        scout_sync(in_lds);
+        // ---------------- depths of all samples (vcfgl.cpp:364-389)
+        long long info_dp = 0;
+        if (!P.per_sample_depth && !P.pois0.st12) {
+            int s = 0, sw = -64;
+            uint64_t missm = 0;
+            while (s < N) {
+                const uint64_t x1 = aff(P.step_tab[lane + 1], st1);
+                const uint64_t x2 = lcg_next(x1);
+                bool neg, rej; double em;
+                poisson_attempt(P.pois0, x1, x2, true, P.gamma_ln_tab, P.gamma_ln_n, neg, rej, em);
+                const uint64_t negm = __ballot(neg), rejm = __ballot(rej & !neg);
+                const int emi = (int)em;
+                int pos = 0;
+                while (s < N && pos <= 63) {                       // scalar walk of the attempt chain
+                    if ((negm >> pos) & 1) { pos += 1; continue; }
+                    if ((rejm >> pos) & 1) { pos += 2; continue; }
+                    if (s >= sw + 64) {                            // missing-genotype flags of the next 64 samples
+                        sw = s;
+                        const int sl = s + lane;
+                        const uint32_t g = (sl < N) ? gts[sl] : 0u;
+                        missm = __ballot((g & 0xF) == 0xF || ((g >> 4) & 0xF) == 0xF);
+                    }
+                    int n = __builtin_amdgcn_readlane(emi, __builtin_amdgcn_readfirstlane(pos));
+                    if ((missm >> (s - sw)) & 1) n = 0;
+                    if (n > P.read_cap) { if (lane == 0) atomicOr(T.errflag, VGL_DEVERR_CAPACITY); n = P.read_cap; }
+                    if (lane == 0) { dps[s] = n; if (in_lds) T.sdp[e0 + s] = n; }
+                    info_dp += n; ++s; pos += 2;
+                }
+                st1 = aff(P.step_tab[pos], st1);                   // pos <= 65 draws consumed
+            }
+        } else if (!P.per_sample_depth) {
+            // product method (rng.h:289-297): 64 uniforms per block from jumped states, then the
+            // multiplication chain t *= u walked with scalar lane reads
+            int s = 0, sw = -64;
+            uint64_t missm = 0;
+            double t = 1.0; int em = -1;
+            while (s < N) {
+                const double u = u01(aff(P.step_tab[lane + 1], st1));
+                const int ulo = __double2loint(u), uhi = __double2hiint(u);
+                int pos = 0;
+                while (s < N && pos < 64) {
+                    const int p1 = __builtin_amdgcn_readfirstlane(pos);
+                    const double uk = __hiloint2double(__builtin_amdgcn_readlane(uhi, p1), __builtin_amdgcn_readlane(ulo, p1));
+                    ++em; t *= uk; ++pos;
+                    if (!(t > P.pois0.g)) {
+                        if (s >= sw + 64) {
+                            sw = s;
+                            const int sl = s + lane;
+                            const uint32_t g = (sl < N) ? gts[sl] : 0u;
+                            missm = __ballot((g & 0xF) == 0xF || ((g >> 4) & 0xF) == 0xF);
+                        }
+                        int n = em;
+                        if ((missm >> (s - sw)) & 1) n = 0;
+                        if (n > P.read_cap) { if (lane == 0) atomicOr(T.errflag, VGL_DEVERR_CAPACITY); n = P.read_cap; }
+                        if (lane == 0) { dps[s] = n; if (in_lds) T.sdp[e0 + s] = n; }
+                        info_dp += n; ++s; em = -1; t = 1.0;
+                    }
+                }
+                st1 = aff(P.step_tab[pos], st1);
+            }
+        } else {
+            for (int s = 0; s < N; ++s) {                          // per-sample means: lane-uniform
+                int n;
+                if (P.per_sample_depth) { const VglPois pc = P.pois[s]; n = poisson_draw_fast(pc, st1, P.gamma_ln_tab, P.gamma_ln_n); }
+                else n = poisson_draw_fast(P.pois0, st1, P.gamma_ln_tab, P.gamma_ln_n);
+                const uint32_t g = gts[s];
+                if ((g & 0xF) == 0xF || ((g >> 4) & 0xF) == 0xF) n = 0;
+                if (n > P.read_cap) { if (lane == 0) atomicOr(T.errflag, VGL_DEVERR_CAPACITY); n = P.read_cap; }
+                if (lane == 0) { dps[s] = n; if (in_lds) T.sdp[e0 + s] = n; }
+                info_dp += n;
+            }
+        }
+        uint64_t thresh = P.err_thresh;
+        if (T.site_tail && lane == 0) { VglSiteTail z; z.sum = 0.0f; z.sumsq = 0.0f; z.base = -1; z.pad = 0; T.site_tail[ls] = z; }
+        if (info_dp == 0) { if (P.error_qs == 1 && lane == 0) T.site_thresh[ls] = thresh; continue; }
+        if (P.error_qs == 1) {                                     // one beta deviate per site (vcfgl.cpp:425-437)
+            uint32_t lo = 0, hi = 0;
+            if (lane == 0) {
+                const double pe = serial_beta(P, S);
+                const uint64_t th = (uint64_t)ceil(ldexp(pe, 48));
+                T.site_thresh[ls] = th; lo = (uint32_t)th; hi = (uint32_t)(th >> 32);
+            }
+            lo = __shfl(lo, 0, 64); hi = __shfl(hi, 0, 64);
+            thresh = ((uint64_t)hi << 32) | lo;
+        }
+        scout_sync(in_lds);                                        // depths written by lane 0, read by all lanes below
+        // ---------------- exclusive prefix sums of the depths = first read index of each sample
+        {
+            int run = 0;
+            for (int c0 = 0; c0 < N; c0 += 64) {
+                const int s = c0 + lane;
+                const int d = (s < N) ? dps[s] : 0;
+                int incl = d;
+#pragma unroll
+                for (int k = 1; k < 64; k <<= 1) { const int t = __shfl_up(incl, k, 64); if (lane >= k) incl += t; }
+                if (s < N) offv[s] = run + incl - d;
+                run += __shfl(incl, 63, 64);
+            }
+        }
+        scout_sync(in_lds);
+        // ---------------- reads of the site as one sequence of R = INFO/DP reads (vcfgl.cpp:469-613)
+        const int R = (int)info_dp;
+        int q0 = 0, sn = 0;                                        // reads done / samples whose start state is recorded
+        uint64_t hb = st1, bb = st0;                               // haplotype / base stream states before read q0
+        int last_err_read = -1, last_err_base = -1;
+        while (sn < N || q0 < R) {                                 // every sample recorded and every read consumed
+            const int nb = (R - q0 < 64) ? (R - q0) : 64;
+            bool cand = false;
+            if (lane < nb) cand = aff(P.step_tab[lane * stride + 1], bb) < thresh;      // error test of read q0+lane (u < e)
+            const uint64_t m = __ballot(cand);
+            const int nclean = m ? (__ffsll((unsigned long long)m) - 1) : nb;
+            int cnt;
+            do {                                                   // samples that start inside the clean range
+                const int s = sn + lane;
+                const int o = (s < N) ? offv[s] : 0x7fffffff;
+                const bool ok = (s < N) & (o <= q0 + nclean);
+                if (ok) {
+                    T.sst_hap[e0 + s] = aff(P.step_tab[o - q0], hb);
+                    T.sst_base[e0 + s] = aff(P.step_tab[(o - q0) * stride], bb);
+                }
+                cnt = __popcll(__ballot(ok));
+                sn += cnt;
+            } while (cnt == 64);
+            if (m == 0) {
+                hb = aff(P.step_tab[nb], hb); bb = aff(P.step_tab[nb * stride], bb); q0 += nb;
+            } else {
+                // read q0+nclean is miscalled: its sample is the last recorded one with reads
+                const int qe = q0 + nclean;
+                int se = -1;
+                for (int back = 0; se < 0; back += 64) {
+                    const int s = sn - 1 - back - lane;
+                    const bool has = (s >= 0) && (dps[s] > 0);
+                    const uint64_t hm = __ballot(has);
+                    if (hm) se = sn - 1 - back - (__ffsll((unsigned long long)hm) - 1);
+                    else if (sn - 1 - back - 64 < 0) break;
+                }
+                const uint32_t g = gts[se < 0 ? 0 : se];
+                const uint64_t hx = aff(P.step_tab[nclean + 1], hb);
+                const int true_base = (hx < (1ULL << 47)) ? (int)(g & 0xF) : (int)((g >> 4) & 0xF);
+                uint64_t x = aff(P.step_tab[nclean * stride + 1], bb);
+                int rb;
+                do { x = lcg_next(x); rb = (int)(x >> 46); } while (rb == true_base);      // vcfgl.cpp:487
+                if (P.sample_strand) x = lcg_next(x);
+                bb = x; hb = hx; q0 = qe + 1;
+                last_err_read = qe; last_err_base = rb;
+            }
+        }
+        st1 = hb; st0 = bb;
+        if (P.add_i16 && T.site_tail && lane == 0) {               // vcfgl.cpp:647-663 (stale r_base = base of the last read)
+            int last_base = last_err_base;
+            if (last_err_read != R - 1) {
+                int se = N - 1;
+                while (se > 0 && dps[se] == 0) --se;
+                const uint32_t g = gts[se];
+                last_base = (hb < (1ULL << 47)) ? (int)(g & 0xF) : (int)((g >> 4) & 0xF);
+            }
+            VglSiteTail t; t.sum = 0.0f; t.sumsq = 0.0f; t.base = last_base; t.pad = 0;
+            for (int i = 0; i < R; ++i) {
+                int td = 1 + glibc_rand(S) / (2147483647 / (50 - 1 + 1) + 1);
+                if (td > 25) td = 25;
+                t.sum += td; t.sumsq += (td * td);
+            }
+            T.site_tail[ls] = t;
+        }
+    }
+    if (lane == 0) { S->st0 = st0; S->st1 = st1; }
+}
+
 // parallel evaluation from the recorded states: same per-read code as k_sample
 __global__ __launch_bounds__(256) void k_sample_serial(const VglDevParams P, const VglTilePtrs T) {
     const WavePos wp = wave_pos(P, T);
@@ -770,14 +981,11 @@ __global__ __launch_bounds__(256) void k_sample_serial(const VglDevParams P, con
     uint64_t ad4 = 0, adf4 = 0;
     uint32_t qs[4] = {0, 0, 0, 0}, qq[4] = {0, 0, 0, 0};
     if (active) {
-        uint64_t st_depth = T.sst_depth[ev], st_hap = T.sst_hap[ev], st_base = T.sst_base[ev];
-        int n;
-        if (P.per_sample_depth) { const VglPois pc = P.pois[s]; n = poisson_draw_fast(pc, st_depth, P.gamma_ln_tab, P.gamma_ln_n); }
-        else n = poisson_draw_fast(P.pois0, st_depth, P.gamma_ln_tab, P.gamma_ln_n);
+        uint64_t st_hap = T.sst_hap[ev], st_base = T.sst_base[ev];
         const uint32_t g = T.gt[ev];
         const int a0 = g & 0xF, a1 = (g >> 4) & 0xF;
-        dp = (a0 == 0xF || a1 == 0xF) ? 0 : n;
-        if (dp > P.read_cap) { atomicOr(T.errflag, VGL_DEVERR_CAPACITY); dp = P.read_cap; }
+        dp = T.sdp[ev];                                            // the scout's depth draw (0 for a missing genotype)
+        if (dp >= P.read_cap) atomicOr(T.errflag, (dp > P.read_cap) ? VGL_DEVERR_CAPACITY : 0u);
         const uint64_t err_thresh = (P.error_qs == 1) ? T.site_thresh[ls] : P.err_thresh;
         for (int r = 0; r < dp; ++r) {
             bool fwd;
@@ -1175,7 +1383,8 @@ __global__ __launch_bounds__(64) void k_siteagg(const VglDevParams P, const VglT
 // ------------------------------------------------------------------------------------
 extern "C" int vgl_launch_scout(const VglDevParams* p, const VglTilePtrs* t, VglSerialState* st, void* stream) {
     if (t->n_sites == 0) return 0;
-    hipLaunchKernelGGL(k_scout, dim3(1), dim3(64), 0, (hipStream_t)stream, *p, *t, st);
+    if (p->error_qs != 2) hipLaunchKernelGGL(k_scout_wave, dim3(1), dim3(64), (size_t)p->scout_lds_bytes, (hipStream_t)stream, *p, *t, st);
+    else hipLaunchKernelGGL(k_scout, dim3(1), dim3(64), 0, (hipStream_t)stream, *p, *t, st);
     return (int)hipGetLastError();
 }
 
