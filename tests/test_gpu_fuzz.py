@@ -1,0 +1,104 @@
+"""Randomised differential test: random flag combinations, shapes and inputs; the HIP path (tile mode
+and serial mode) against the CPU oracle on every output field."""
+import numpy as np
+import pytest
+
+import synth
+from vcfgl_amd import Simulator, VcfglArgs, VcfglArgError, _abi
+
+pytestmark = pytest.mark.gpu
+INT_FIELDS = ["site_status", "n_alleles", "n_alleles_obs", "alleles2acgt", "info_dp", "info_ad", "info_adf",
+              "info_adr", "fmt_dp", "pl", "fmt_ad", "fmt_adf", "fmt_adr"]
+
+
+def random_case(rng):
+    eqs = int(rng.choice([0, 0, 1, 2, 2]))
+    gl = int(rng.choice([1, 2, 2]))
+    precise = int(rng.integers(0, 2)) if gl == 2 else 0
+    adj = int(rng.choice([0, 0, 1, 2, 3])) if not precise else int(rng.choice([0, 2]))
+    add_qs = 1 if (adj & 2) else int(rng.integers(0, 2))
+    strand = int(rng.integers(0, 2))
+    kw = dict(
+        seed=int(rng.integers(-2 ** 31, 2 ** 31 - 1)),
+        error_rate=float(rng.choice([0.0, 0.001, 0.01, 0.05, 0.3])) if eqs == 0 else float(rng.choice([0.005, 0.01, 0.05, 0.2])),
+        error_qs=eqs, gl_model=gl, precise_gl=precise, adjust_qs=adj,
+        adjust_by=float(rng.choice([0.499, 0.25, 1.0])),
+        do_unobserved=int(rng.integers(0, 6)), rm_invar_sites=int(rng.choice([0, 0, 4])), rm_empty_sites=int(rng.integers(0, 2)),
+        add_pl=int(rng.integers(0, 2)), add_gp=int(rng.integers(0, 2)), add_qs=add_qs, add_info_dp=1, add_fmt_ad=1, add_info_ad=1,
+        add_i16=strand & int(rng.integers(0, 2)), add_fmt_adf=strand, add_fmt_adr=strand, add_info_adf=strand, add_info_adr=strand,
+        gl1_theta=float(rng.choice([0.83, 0.5])), i16_mapq=20,
+    )
+    if eqs:
+        m = kw["error_rate"]
+        kw["beta_variance"] = float(rng.choice([1e-5, 1e-4, m * (1 - m) * 0.2]))
+    N = int(rng.choice([1, 3, 17, 64, 65, 130, 300]))
+    if rng.random() < 0.25:
+        kw["depths"] = [float(x) for x in rng.choice([0.0, 0.3, 2.0, 8.0, 13.0, 25.0], size=N)]
+    else:
+        kw["depth"] = float(rng.choice([0.0, 0.2, 1.0, 4.0, 11.0, 12.0, 18.0, 33.0]))
+    if eqs == 2 and rng.random() < 0.3:
+        kw["qs_bins"] = [(0, 2, 2), (3, 14, 12), (15, 30, 23), (31, 63, 37)]
+    S = int(rng.integers(1, 40))
+    gt = synth.acgt_sites(S, N, seed=int(rng.integers(0, 1 << 30)), missing=float(rng.choice([0.0, 0.0, 0.05, 0.5])),
+                          n_alleles=int(rng.integers(1, 5)))
+    return kw, N, gt
+
+
+def compare(want, got, tol_gl, tag):
+    for f in INT_FIELDS:
+        assert np.array_equal(want.numpy(f), got.numpy(f)), (tag, f)
+    wb, gb = want.numpy("gl").view(np.uint32), got.numpy("gl").view(np.uint32)
+    if not tol_gl:
+        assert np.array_equal(wb, gb), (tag, "gl", int(np.sum(wb != gb)))
+    else:
+        miss = wb == _abi.FLOAT_MISSING_BITS
+        assert np.array_equal(miss, gb == _abi.FLOAT_MISSING_BITS), (tag, "gl missing")
+        a, b = want.numpy("gl")[~miss].astype(np.float64), got.numpy("gl")[~miss].astype(np.float64)
+        fin = np.isfinite(a)
+        assert np.array_equal(fin, np.isfinite(b)) and np.all(np.abs(a[fin] - b[fin]) <= 1e-6 * np.maximum(1.0, np.abs(a[fin]))), (tag, "gl tol")
+    if "gp" in got.arrays:
+        m = want.numpy("gp").view(np.uint32) == _abi.FLOAT_MISSING_BITS
+        assert np.array_equal(m, got.numpy("gp").view(np.uint32) == _abi.FLOAT_MISSING_BITS), (tag, "gp missing")
+        d = np.abs(want.numpy("gp")[~m].astype(np.float64) - got.numpy("gp")[~m].astype(np.float64))
+        assert np.all(~(d > 1e-6)), (tag, "gp")
+    if "qs" in got.arrays:
+        assert np.array_equal(want.numpy("qs").view(np.uint32), got.numpy("qs").view(np.uint32)), (tag, "qs")
+    if "i16" in got.arrays:
+        assert np.array_equal(want.numpy("i16")[:, :12], got.numpy("i16")[:, :12]), (tag, "i16")
+
+
+@pytest.mark.parametrize("chunk", range(24))
+def test_random_configurations(oracle, chunk):
+    rng = np.random.default_rng(1000 + chunk)
+    done = 0
+    while done < 10:
+        kw, N, gt = random_case(rng)
+        try:
+            base = VcfglArgs(**kw).validate()
+        except VcfglArgError:
+            continue
+        for mode, beta in ((_abi.VGL_RNG_TILE, _abi.VGL_BETA_RAND48), (_abi.VGL_RNG_SERIAL, _abi.VGL_BETA_STD)):
+            args = VcfglArgs(**kw)
+            args.rng_mode, args.beta_sampler = mode, beta
+            tag = (chunk, done, mode, kw, N, gt.shape)
+            try:
+                orc = oracle.Oracle(args, N)
+            except oracle.OracleError:
+                break                                   # e.g. non-positive beta shape parameters: rejected by both
+            sim = Simulator(args, N, max_sites_per_tile=gt.shape[0])
+            fields = sim.default_fields()
+            if not args.add_pl:
+                fields = [f for f in fields if f != "pl"] + ["pl"]
+            try:
+                want = orc.simulate(0, gt, fields=fields)
+            except oracle.OracleError as e:
+                with pytest.raises(Exception):
+                    sim.simulate(0, gt, fields=fields)  # same refusal (qs-bin miss, GL1 depth > 255)
+                sim.close()
+                continue
+            got = sim.simulate(0, gt, fields=fields)
+            sim.close()
+            compare(want, got, tol_gl=bool(args.precise_gl), tag=tag)
+            if mode == _abi.VGL_RNG_SERIAL and args.add_i16:
+                assert np.array_equal(want.numpy("i16"), got.numpy("i16")), (tag, "i16 tail")
+        done += 1
