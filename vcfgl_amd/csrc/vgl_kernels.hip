@@ -778,7 +778,12 @@ __device__ __forceinline__ void scout_sync(const bool in_lds) {
 }
 
 __global__ __launch_bounds__(64) void k_scout_wave(const VglDevParams P, const VglTilePtrs T, VglSerialState* S) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
+    // jump table J^k in LDS: it sits on the critical path of every chain step
+    VglAffine* stp = (VglAffine*)lds_all;
+    { const VglAffine* gtab = P.step_tab; for (int i = threadIdx.x; i < 192; i += 64) stp[i] = gtab[i]; }
+    uint8_t* lds_raw = lds_all + 192 * sizeof(VglAffine);
+    scout_sync(true);
     const int lane = threadIdx.x;
     const int N = P.n_samples;
     const int stride = P.sample_strand ? 2 : 1;
@@ -804,7 +809,7 @@ __global__ __launch_bounds__(64) void k_scout_wave(const VglDevParams P, const V
             int s = 0, sw = -64;
             uint64_t missm = 0;
             while (s < N) {
-                const uint64_t x1 = aff(P.step_tab[lane + 1], st1);
+                const uint64_t x1 = aff(stp[lane + 1], st1);
                 const uint64_t x2 = lcg_next(x1);
                 bool neg, rej; double em;
                 poisson_attempt(P.pois0, x1, x2, true, P.gamma_ln_tab, P.gamma_ln_n, neg, rej, em);
@@ -826,7 +831,7 @@ __global__ __launch_bounds__(64) void k_scout_wave(const VglDevParams P, const V
                     if (lane == 0) { dps[s] = n; if (in_lds) T.sdp[e0 + s] = n; }
                     info_dp += n; ++s; pos += 2;
                 }
-                st1 = aff(P.step_tab[pos], st1);                   // pos <= 65 draws consumed
+                st1 = aff(stp[pos], st1);                   // pos <= 65 draws consumed
             }
         } else if (!P.per_sample_depth) {
             // product method (rng.h:289-297): 64 uniforms per block from jumped states, then the
@@ -835,7 +840,7 @@ __global__ __launch_bounds__(64) void k_scout_wave(const VglDevParams P, const V
             uint64_t missm = 0;
             double t = 1.0; int em = -1;
             while (s < N) {
-                const double u = u01(aff(P.step_tab[lane + 1], st1));
+                const double u = u01(aff(stp[lane + 1], st1));
                 const int ulo = __double2loint(u), uhi = __double2hiint(u);
                 int pos = 0;
                 while (s < N && pos < 64) {
@@ -856,7 +861,7 @@ __global__ __launch_bounds__(64) void k_scout_wave(const VglDevParams P, const V
                         info_dp += n; ++s; em = -1; t = 1.0;
                     }
                 }
-                st1 = aff(P.step_tab[pos], st1);
+                st1 = aff(stp[pos], st1);
             }
         } else {
             for (int s = 0; s < N; ++s) {                          // per-sample means: lane-uniform
@@ -906,7 +911,7 @@ __global__ __launch_bounds__(64) void k_scout_wave(const VglDevParams P, const V
         while (sn < N || q0 < R) {                                 // every sample recorded and every read consumed
             const int nb = (R - q0 < 64) ? (R - q0) : 64;
             bool cand = false;
-            if (lane < nb) cand = aff(P.step_tab[lane * stride + 1], bb) < thresh;      // error test of read q0+lane (u < e)
+            if (lane < nb) cand = aff(stp[lane * stride + 1], bb) < thresh;      // error test of read q0+lane (u < e)
             const uint64_t m = __ballot(cand);
             const int nclean = m ? (__ffsll((unsigned long long)m) - 1) : nb;
             int cnt;
@@ -915,14 +920,14 @@ __global__ __launch_bounds__(64) void k_scout_wave(const VglDevParams P, const V
                 const int o = (s < N) ? offv[s] : 0x7fffffff;
                 const bool ok = (s < N) & (o <= q0 + nclean);
                 if (ok) {
-                    T.sst_hap[e0 + s] = aff(P.step_tab[o - q0], hb);
-                    T.sst_base[e0 + s] = aff(P.step_tab[(o - q0) * stride], bb);
+                    T.sst_hap[e0 + s] = aff(stp[o - q0], hb);
+                    T.sst_base[e0 + s] = aff(stp[(o - q0) * stride], bb);
                 }
                 cnt = __popcll(__ballot(ok));
                 sn += cnt;
             } while (cnt == 64);
             if (m == 0) {
-                hb = aff(P.step_tab[nb], hb); bb = aff(P.step_tab[nb * stride], bb); q0 += nb;
+                hb = aff(stp[nb], hb); bb = aff(stp[nb * stride], bb); q0 += nb;
             } else {
                 // read q0+nclean is miscalled: its sample is the last recorded one with reads
                 const int qe = q0 + nclean;
@@ -935,9 +940,9 @@ __global__ __launch_bounds__(64) void k_scout_wave(const VglDevParams P, const V
                     else if (sn - 1 - back - 64 < 0) break;
                 }
                 const uint32_t g = gts[se < 0 ? 0 : se];
-                const uint64_t hx = aff(P.step_tab[nclean + 1], hb);
+                const uint64_t hx = aff(stp[nclean + 1], hb);
                 const int true_base = (hx < (1ULL << 47)) ? (int)(g & 0xF) : (int)((g >> 4) & 0xF);
-                uint64_t x = aff(P.step_tab[nclean * stride + 1], bb);
+                uint64_t x = aff(stp[nclean * stride + 1], bb);
                 int rb;
                 do { x = lcg_next(x); rb = (int)(x >> 46); } while (rb == true_base);      // vcfgl.cpp:487
                 if (P.sample_strand) x = lcg_next(x);
@@ -1383,7 +1388,7 @@ __global__ __launch_bounds__(64) void k_siteagg(const VglDevParams P, const VglT
 // ------------------------------------------------------------------------------------
 extern "C" int vgl_launch_scout(const VglDevParams* p, const VglTilePtrs* t, VglSerialState* st, void* stream) {
     if (t->n_sites == 0) return 0;
-    if (p->error_qs != 2) hipLaunchKernelGGL(k_scout_wave, dim3(1), dim3(64), (size_t)p->scout_lds_bytes, (hipStream_t)stream, *p, *t, st);
+    if (p->error_qs != 2) hipLaunchKernelGGL(k_scout_wave, dim3(1), dim3(64), (size_t)p->scout_lds_bytes + 192 * sizeof(VglAffine), (hipStream_t)stream, *p, *t, st);
     else hipLaunchKernelGGL(k_scout, dim3(1), dim3(64), 0, (hipStream_t)stream, *p, *t, st);
     return (int)hipGetLastError();
 }
