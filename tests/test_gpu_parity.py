@@ -209,6 +209,27 @@ def test_bad_parameters_are_rejected_like_the_reference():
         assert ei.value.code == _abi.VGL_E_ARG and frag in str(ei.value).encode()
 
 
+@pytest.mark.parametrize("eqs", [0, 2])
+def test_maximum_depth(oracle, eqs):
+    """--depth 500 is the reference's upper bound (shared.h:63, io.cpp:861): ~500 reads per sample,
+    quality-score pools of > 6144 items per wavefront run in several LDS segments"""
+    args = VcfglArgs(seed=42, depth=500, error_rate=0.01, error_qs=eqs, beta_variance=1e-5 if eqs else -1.0, add_pl=1, add_fmt_ad=1, add_qs=1)
+    want, got = run_both(oracle, args, synth.binary_sites(0, 2, 70))
+    assert_parity(want, got, check_gp=False)
+    assert got.numpy("fmt_dp").max() > 500
+
+
+def test_many_samples_and_empty_tile(oracle):
+    """5000 samples (79 wavefronts per site); a zero-site tile is a no-op"""
+    args = VcfglArgs(seed=42, depth=3, error_rate=0.01, add_pl=1)
+    want, got = run_both(oracle, args, synth.binary_sites(7, 3, 5000), site0=7)
+    assert_parity(want, got, check_gp=False, qs=False)
+    sim = Simulator(args, 5000, max_sites_per_tile=4)
+    t = sim.simulate(0, np.zeros((0, 5000), np.uint8))
+    assert t.numpy("fmt_dp").shape == (0, 5000)
+    sim.close()
+
+
 def test_site_index_invariance(oracle):
     """tiles are addressed by absolute site index: splitting a run into tiles (or shards)
     does not change any value"""
