@@ -301,6 +301,8 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     D.serial = (p->rng_mode == VGL_RNG_SERIAL) ? 1 : 0;
     D.scout_lds_bytes = ((size_t)p->n_samples * 9 <= 144 * 1024) ? (int32_t)(((size_t)p->n_samples * 9 + 15) & ~(size_t)15) : 0;
     D.beta_std = (p->beta_sampler == VGL_BETA_STD) ? 1 : 0;
+    D.slow_period = getenv("VGL_SLOW_PERIOD") ? atoi(getenv("VGL_SLOW_PERIOD")) : 2;
+    if (D.slow_period < 1) D.slow_period = 1;
     D.dbg_phase = getenv("VGL_DEBUG_PHASE") ? atoi(getenv("VGL_DEBUG_PHASE")) : 0;
     for (int i = 0; i < p->n_qs_bins * 3; i++) D.qs_bins[i] = p->qs_bins[i];
     D.err_thresh = (uint64_t)ceil(ldexp(p->error_rate, 48));
@@ -432,7 +434,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     TRY(dmalloc(&c->d_sinfo, (size_t)max_sites));
     TRY(dmalloc(&c->d_errflag, (size_t)1));
     TRYHIP(hipMemset(c->d_errflag, 0, sizeof(uint32_t)));
-    if (getenv("VGL_DEBUG_STAMPS")) { TRY(dmalloc(&c->d_dbg, (size_t)16)); TRYHIP(hipMemset(c->d_dbg, 0, 128)); }
+    if (getenv("VGL_DEBUG_STAMPS") || getenv("VGL_DEBUG_PHASE")) { TRY(dmalloc(&c->d_dbg, (size_t)16)); TRYHIP(hipMemset(c->d_dbg, 0, 128)); }
     *out = c;
     return VGL_OK;
 }

@@ -197,6 +197,18 @@ __device__ int apply_bins(const VglDevParams& P, int q, uint32_t* errflag) {
     return 0;
 }
 
+// IEEE-754 quotient n / d for operands far from the exponent limits (here d = u in [2^-48, 1),
+// |n| < 1): v_rcp_f64, two Newton steps and the residual correction -- the compiler's own division
+// sequence without v_div_scale / v_div_fixup, which only act on extreme exponents, NaN and infinity.
+__device__ __forceinline__ double div_inrange(const double n, const double d) {
+    double y = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, y, 1.0); y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-d, y, 1.0); y = __builtin_fma(y, e, y);
+    const double q = n * y;
+    const double r = __builtin_fma(-d, q, n);
+    return __builtin_fma(r, y, q);
+}
+
 // error probability -> qScore / adjusted qScore, vcfgl.cpp:500-523
 __device__ void errprob_to_qs(const VglDevParams& P, double ep, int& q, int& aq, uint32_t* errflag) {
     q = -1; aq = -1;
@@ -261,7 +273,7 @@ __device__ __forceinline__ bool normal_slow_test(const double v, const double u,
     const double m = 4.0 * uu * fast_ln_err(l);
     const bool hi = lhs > rhs + m, lo = lhs < rhs - m;
     bool res = hi;
-    const bool amb = need & !((hi | lo) & (uf > 0.0f));
+    const bool amb = need && !((hi || lo) && (uf > 0.0f));
     if (__builtin_expect(__ballot(amb) != 0, 0)) {          // wave-uniform and rare: a real branch
         asm volatile("" ::: "memory");                      // (keeps the compiler from speculating the double log)
         const bool ex = lhs > -4.0 * log(u) * (u * u);
@@ -289,9 +301,9 @@ __device__ __forceinline__ bool gamma_slow_test(const double u, const double xsq
     const float g = 3.0f * a1f * (s2 * s2) * p;                 // = -(rhs of the reference), >= 0
     const float d = lu + g;                                     // log(u) - rhs
     const float m = fabsf(lu) * 0x1p-20f + 0x1p-21f + g * 4e-6f + 1e-10f;
-    const bool ok = (fabsf(d) > m) & (fabsf(sf) <= 0.3333f) & (uf > 0.0f);
+    const bool ok = (fabsf(d) > m) && (fabsf(sf) <= 0.3333f) && (uf > 0.0f);
     bool res = d > 0.0f;
-    const bool amb = need & !ok;
+    const bool amb = need && !ok;
     if (__builtin_expect(__ballot(amb) != 0, 0)) {          // wave-uniform and rare: a real branch
         asm volatile("" ::: "memory");
         const bool ex = log(u) > 0.5 * xsq + a1 * (1.0 - v + log(v));
@@ -302,20 +314,23 @@ __device__ __forceinline__ bool gamma_slow_test(const double u, const double xsq
 
 // error probability -> qScore / adjusted qScore (vcfgl.cpp:500-523); (int)(-10*log10(p)) is
 // taken from the float32 log2 unless p sits within its error bound of an integer boundary
-__device__ __forceinline__ void errprob_to_qs_fast(const VglDevParams& P, const double ep, int& q, int& aq, uint32_t* errflag, const bool need) {
-    // float32: tf = -10 log10(p) within |tf| 2^-20 + 1e-6 (v_log_f32 bound + argument rounding)
-    const float pf = (float)ep;
+// p = gx / (gx + gy) (rng.h:438) is itself taken in float32 (v_rcp_f32, 1 ulp): relative error of pf
+// <= 2^-24 (gx) + 2^-24 (sum) + 2^-23 (rcp) + 2^-24 (product) < 2^-22, i.e. < 1.1e-6 in tf.
+__device__ __forceinline__ void errprob_to_qs_fast(const VglDevParams& P, const double gx, const double gy, int& q, int& aq, uint32_t* errflag, const bool need) {
+    // float32: tf = -10 log10(p) within |tf| 2^-20 + 2.2e-6 (v_log_f32 bound + argument error)
+    const float pf = (float)gx * __builtin_amdgcn_rcpf((float)(gx + gy));
     const float tf = -3.0103f * __builtin_amdgcn_logf(pf);
-    const float m = tf * 0x1p-19f + 2e-6f;
+    const float m = tf * 0x1p-19f + 4e-6f;
     const float fl = floorf(tf);
     const float t2 = tf + (float)P.adjust_by;
     const float fl2 = floorf(t2);
     bool ok = (pf > 1.0e-37f) && (pf < 1.0f) && (tf - fl > m) && (fl + 1.0f - tf > m);
     if (P.adjust_qs) ok = ok && (t2 > m) && (t2 - fl2 > m) && (fl2 + 1.0f - t2 > m);
     q = (int)fl; aq = P.adjust_qs ? (int)fl2 : -1;
-    ok = ok | !need;
+    ok = ok || !need;
     if (__builtin_expect(__ballot(!ok) != 0, 0)) {     // exact: vcfgl.cpp:500-507 (rare: a real branch)
         asm volatile("" ::: "memory");
+        const double ep = gx / (gx + gy);
         int qe = -1, aqe = -1;
         if (0.0 == ep) qe = CAP_BASEQ;
         else if (1.0 == ep) qe = 0;
@@ -361,7 +376,8 @@ __device__ __forceinline__ int sample_read_base(uint64_t& st_hap, uint64_t& st_b
 // lane's work does not depend on its own evaluation's depth; each lane runs the nested
 // rejection loops of the gamma sampler as one flat state machine (one normal-deviate attempt
 // per iteration) so that lanes at different stages share every iteration.
-template <int EQS>
+// DBG: diagnostic instantiation (VGL_DEBUG_STAMPS / VGL_DEBUG_PHASE), never used in a timed run
+template <int EQS, bool DBG>
 __global__ __launch_bounds__(256) void k_sample(const VglDevParams P, const VglTilePtrs T) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const WavePos wp = wave_pos(P, T);
@@ -379,9 +395,9 @@ __global__ __launch_bounds__(256) void k_sample(const VglDevParams P, const VglT
     uint64_t ad4 = 0, adf4 = 0;
     uint32_t qs0 = 0, qs1 = 0, qs2 = 0, qs3 = 0, qq0 = 0, qq1 = 0, qq2 = 0, qq3 = 0;
     uint64_t st_hap = 0, st_base = 0, st_qs = 0;
-    // diagnostic build only (T.dbg != null): per-phase cycle stamps, never in a timed run
+    // DBG only: per-phase cycle stamps
     unsigned long long c_t0 = 0, c_pois = 0, c_owner = 0, c_pool = 0, c_flush = 0, c_iter = 0, c_items = 0, c_tmp = 0;
-    if (T.dbg) c_t0 = clock64();
+    if (DBG) c_t0 = clock64();
     uint64_t err_thresh = P.err_thresh;
 
     // ---- stream states of this evaluation: J^(off_k) . J^(block*s) . J^(block*N*site) (x0)
@@ -409,8 +425,8 @@ __global__ __launch_bounds__(256) void k_sample(const VglDevParams P, const VglT
         if (dp > P.read_cap) { atomicOr(T.errflag, VGL_DEVERR_CAPACITY); dp = P.read_cap; }
     }
 
-    if (T.dbg) c_pois = clock64() - c_t0;
-    if (P.dbg_phase == 1) return;
+    if (DBG) c_pois = clock64() - c_t0;
+    if (DBG && P.dbg_phase == 1) return;
     if (EQS == 1) {
         // one beta deviate per site: stream 3 of sample 0, read 0 (vcfgl.cpp:425-437); lane 0 draws it
         uint32_t lo = 0, hi = 0;
@@ -465,11 +481,18 @@ __global__ __launch_bounds__(256) void k_sample(const VglDevParams P, const VglT
         const int total = __shfl(incl, 63, 64);
         l_stq[lane] = st_qs;
         int rdone = 0;
+        // Kernel arguments arrive in 16-dword scalar tuples that the register allocator spills and
+        // reloads as a whole (v_readlane, VALU work) inside the loops below; the three values the flush
+        // loop needs are therefore pinned to vector registers.
+        uint8_t* reads_v = T.reads;
+        uint8_t* reads_out_v = T.reads_out;
+        int reads_out_cap_v = T.reads_out ? T.reads_out_cap : 0;
+        asm volatile("" : "+v"(reads_v), "+v"(reads_out_v), "+v"(reads_out_cap_v));
 
         for (int seg0 = 0; seg0 < total; seg0 += cap) {                 // normally one segment
             const int segT = (total - seg0 < cap) ? (total - seg0) : cap;
             // -- owners: bases of their reads that fall into this segment
-            if (T.dbg) c_tmp = clock64();
+            if (DBG) c_tmp = clock64();
             int r_end = seg0 + segT - offs; r_end = r_end > dp ? dp : r_end; r_end = r_end < rdone ? rdone : r_end;
             for (int r = rdone; r < r_end; ++r) {
                 bool fwd;
@@ -490,27 +513,38 @@ __global__ __launch_bounds__(256) void k_sample(const VglDevParams P, const VglT
             //    without branches; lane state (stream, stage, first gamma) advances by selects, so
             //    lanes in different stages of different reads share every instruction.  Real
             //    branches remain only around the rare bounded-log tests and the per-read epilogue.
-            if (T.dbg) { const unsigned long long c = clock64(); c_owner += c - c_tmp; c_tmp = c; c_items += segT; }
-            if (P.dbg_phase == 2) return;
+            if (DBG) { const unsigned long long c = clock64(); c_owner += c - c_tmp; c_tmp = c; c_items += segT; }
+            if (DBG && P.dbg_phase == 2) return;
             {
-                int k = lane;
+                // Items are dealt dynamically: a lane owns its current item k and an item kn claimed one
+                // item ahead (so that kn's operands are in flight while k is worked on); a lane that
+                // finishes an item adopts kn and claims the next unclaimed one.  Each item's stream is
+                // addressed by its read, so the result does not depend on who works on it.
+                int k = lane, kn = lane + 64;
+                int next_free = 128;                         // wave-uniform: first unclaimed item
                 bool have = k < segT;
-                uint64_t st = 0; int stage = 0; double gx = 0.0; int it_o = 0, it_r = 0;
+                bool stage1 = false;                         // false: first gamma deviate (x), true: second (y)
+                uint64_t st = 0; double gx = 0.0; int it_o = 0, it_r = 0;
                 if (have) { const uint32_t m = l_map[k]; it_o = m & 63; it_r = m >> 6; st = aff(P.qs_read_tab[it_r], l_stq[it_o]); }
                 const bool any_changed = (P.gx.changed | P.gy.changed) != 0;
+                // The bounded-log tests are needed by a few lanes per iteration but cost every lane of the
+                // wave; they run only every P.slow_period-th iteration.  In between, a lane that needs one
+                // holds: its state is left untouched, so the later iteration recomputes the same attempt.
+                int slow_cnt = P.slow_period;
                 while (__ballot(have)) {
-                    if (T.dbg) c_iter++;
-                    // operands of this lane's NEXT item, fetched at the top of the iteration and consumed
-                    // at the bottom (unconditional, clamped index: no divergent control flow in the loop)
-                    const int kn = k + 64;
+                    if (DBG) c_iter++;
+                    const bool full = (--slow_cnt == 0);
+                    if (full) slow_cnt = P.slow_period;
+                    // operands of this lane's next item, fetched at the top of the iteration and consumed at
+                    // the bottom (unconditional, clamped index: no divergent control flow in the loop)
                     const bool hn = kn < segT;
-                    const uint32_t m_n = l_map[have ? (hn ? kn : k) : 0];
+                    const uint32_t m_n = l_map[hn ? kn : 0];
                     const int o_n = m_n & 63, r_n = m_n >> 6;
                     const VglAffine tab_n = P.qs_read_tab[r_n];
                     const uint64_t base_n = l_stq[o_n];
 
-                    const double ga1 = stage ? P.gy.a1 : P.gx.a1;
-                    const double ga2 = stage ? P.gy.a2 : P.gx.a2;
+                    const double ga1 = stage1 ? P.gy.a1 : P.gx.a1;
+                    const double ga2 = stage1 ? P.gy.a2 : P.gx.a2;
                     // normal attempt
                     const uint64_t st1 = lcg_next(st);
                     const uint64_t st2 = lcg_next(st1);
@@ -522,47 +556,54 @@ __global__ __launch_bounds__(256) void k_sample(const VglDevParams P, const VglT
                     const double q = (x * x) + y * (0.19600 * y - 0.25472 * x);
                     const bool q_lo = q > 0.27597, q_hi = q > 0.27846;
                     bool slow_n = false;
-                    if (__ballot(have & q_lo & !q_hi)) slow_n = normal_slow_test(v, u, have & q_lo & !q_hi);
-                    const bool acc_n = !(q_lo & (q_hi | slow_n));
+                    const bool n_amb = have && q_lo && !q_hi;
+                    bool hold = n_amb && !full;
+                    if (full && __ballot(n_amb)) slow_n = normal_slow_test(v, u, n_amb);
+                    const bool acc_n = !(q_lo && (q_hi || slow_n));
                     // gamma step on the accepted deviate
-                    const double xn = v / u;
+                    const double xn = div_inrange(v, u);
                     const double w = 1.0 + ga2 * xn;
                     const bool w_pos = w > 0.0;
                     const double vv = w * w * w;
                     const double u2 = u01(st3);
                     const double xsq = xn * xn;
                     const bool sq_fail = u2 > 1.0 - 0.0331 * (xsq * xsq);
-                    const bool g_try = have & acc_n & w_pos;
+                    const bool g_try = have && acc_n && w_pos && !hold;
+                    const bool g_amb = g_try && sq_fail;
+                    hold = hold || (g_amb && !full);
                     bool slow_g = false;
-                    if (__ballot(g_try & sq_fail)) slow_g = gamma_slow_test(u2, xsq, ga1, vv, ga2 * xn, g_try & sq_fail);
-                    const bool acc_g = g_try & !(sq_fail & slow_g);
-                    st = g_try ? st3 : st2;                  // u2 is drawn only when w > 0 (rng.h:140-142)
+                    if (full && __ballot(g_amb)) slow_g = gamma_slow_test(u2, xsq, ga1, vv, ga2 * xn, g_amb);
+                    const bool acc_g = g_try && !(sq_fail && slow_g) && !hold;
+                    st = hold ? st : (g_try ? st3 : st2);    // u2 is drawn only when w > 0 (rng.h:140-142)
                     double val = ga1 * vv;
                     if (any_changed) {                       // alpha < 1 (rng.h:146-148); wave-uniform guard
-                        if (acc_g && (stage ? P.gy.changed : P.gx.changed)) {
+                        if (acc_g && (stage1 ? P.gy.changed : P.gx.changed)) {
                             double u3;
                             do { st = lcg_next(st); u3 = u01(st); } while (u3 == 0.0);
-                            val = pow(u3, 1.0 / (stage ? P.gy.alpha0 : P.gx.alpha0)) * ga1 * vv;
+                            val = pow(u3, 1.0 / (stage1 ? P.gy.alpha0 : P.gx.alpha0)) * ga1 * vv;
                         }
                     }
-                    const bool fin = acc_g & (stage == 1);
+                    const bool fin = acc_g && stage1;
                     // per-read epilogue, computed for every lane, committed where fin (rng.h:438, vcfgl.cpp:500-531)
-                    const double ep = gx / (gx + val);
                     int q_i, aq_i;
-                    errprob_to_qs_fast(P, ep, q_i, aq_i, T.errflag, fin);
+                    errprob_to_qs_fast(P, gx, val, q_i, aq_i, T.errflag, fin);
                     if (fin) {
                         l_pq[k] = (uint8_t)q_i;
                         l_paq[k] = (uint8_t)aq_i;
-                        if (P.precise_gl) T.errp[(size_t)it_r * plane + ev0 + it_o] = ep;
                     }
-                    gx = (acc_g & (stage == 0)) ? val : gx;
-                    stage = acc_g ? (stage ^ 1) : stage;
-                    // advance to the next item by selects
+                    if (P.precise_gl) { if (fin) T.errp[(size_t)it_r * plane + ev0 + it_o] = gx / (gx + val); }
+                    gx = (acc_g && !stage1) ? val : gx;
+                    stage1 = stage1 != acc_g;
+                    // a lane that finished its item adopts kn and claims the next unclaimed item
+                    const uint64_t fin_m = __ballot(fin);
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fin_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fin_m, 0u));
                     const uint64_t st_n = aff(tab_n, base_n);
                     st = fin ? st_n : st;
                     it_o = fin ? o_n : it_o; it_r = fin ? r_n : it_r;
                     k = fin ? kn : k;
-                    have = have & (!fin | hn);
+                    kn = fin ? next_free + rank : kn;
+                    next_free += __popcll(fin_m);
+                    have = have && (!fin || hn);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -570,16 +611,16 @@ __global__ __launch_bounds__(256) void k_sample(const VglDevParams P, const VglT
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
             // -- owners: combine base + quality score, stage the read, quality sums (vcfgl.cpp:525-564)
-            if (T.dbg) { const unsigned long long c = clock64(); c_pool += c - c_tmp; c_tmp = c; }
-            if (P.dbg_phase == 3) return;
+            if (DBG) { const unsigned long long c = clock64(); c_pool += c - c_tmp; c_tmp = c; }
+            if (DBG && P.dbg_phase == 3) return;
             for (int r = rdone; r < r_end; ++r) {
                 const int k = offs + r - seg0;
                 const int r_base = l_pb[k];
                 const int q_i = l_pq[k];
                 const int aq_i = P.adjust_qs ? (int)l_paq[k] : -1;
                 const int q_gl = (P.adjust_qs & 1) ? aq_i : q_i;
-                T.reads[(size_t)r * plane + ev] = (uint8_t)((q_gl << 2) | r_base);
-                if (T.reads_out && r < T.reads_out_cap) T.reads_out[(size_t)r * plane + ev] = (uint8_t)((q_i << 2) | r_base);
+                reads_v[(size_t)r * plane + ev] = (uint8_t)((q_gl << 2) | r_base);
+                if (r < reads_out_cap_v) reads_out_v[(size_t)r * plane + ev] = (uint8_t)((q_i << 2) | r_base);
                 if (P.need_qsum) {
                     const uint32_t qq = (uint32_t)((P.adjust_qs & 2) ? aq_i : q_i);
                     const uint32_t q2 = (uint32_t)qs_to_qssq((int)qq);
@@ -591,8 +632,8 @@ __global__ __launch_bounds__(256) void k_sample(const VglDevParams P, const VglT
             }
             rdone = r_end;
             __builtin_amdgcn_wave_barrier();
-            if (T.dbg) c_flush += clock64() - c_tmp;
-            if (P.dbg_phase == 4) return;
+            if (DBG) c_flush += clock64() - c_tmp;
+            if (DBG && P.dbg_phase == 4) return;
         }
     }
 
@@ -623,7 +664,7 @@ __global__ __launch_bounds__(256) void k_sample(const VglDevParams P, const VglT
         int32_t* acc = T.acc + (size_t)ls * VGL_ACC_STRIDE;
 #pragma unroll
         for (int k = 0; k < 9; ++k) if (v[k]) atomicAdd(&acc[k], v[k]);
-        if (T.dbg) {
+        if (DBG) {
             atomicAdd(&T.dbg[0], 1ULL); atomicAdd(&T.dbg[1], clock64() - c_t0); atomicAdd(&T.dbg[2], c_pois);
             atomicAdd(&T.dbg[3], c_owner); atomicAdd(&T.dbg[4], c_pool); atomicAdd(&T.dbg[5], c_flush);
             atomicAdd(&T.dbg[6], c_iter); atomicAdd(&T.dbg[7], c_items);
@@ -1401,9 +1442,12 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
         hipLaunchKernelGGL(k_sample_serial, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, *t);
         return (int)hipGetLastError();
     }
-    if (p->error_qs == 2) hipLaunchKernelGGL(k_sample<2>, dim3(blocks), dim3(256), (size_t)4 * p->pool_lds_bytes, (hipStream_t)stream, *p, *t);
-    else if (p->error_qs == 1) hipLaunchKernelGGL(k_sample<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, *t);
-    else hipLaunchKernelGGL(k_sample<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, *t);
+    const bool dbg = t->dbg != nullptr;                         // VGL_DEBUG_STAMPS / VGL_DEBUG_PHASE
+    if (p->error_qs == 2) {
+        if (dbg) hipLaunchKernelGGL((k_sample<2, true>), dim3(blocks), dim3(256), (size_t)4 * p->pool_lds_bytes, (hipStream_t)stream, *p, *t);
+        else hipLaunchKernelGGL((k_sample<2, false>), dim3(blocks), dim3(256), (size_t)4 * p->pool_lds_bytes, (hipStream_t)stream, *p, *t);
+    } else if (p->error_qs == 1) hipLaunchKernelGGL((k_sample<1, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, *t);
+    else hipLaunchKernelGGL((k_sample<0, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, *t);
     return (int)hipGetLastError();
 }
 
