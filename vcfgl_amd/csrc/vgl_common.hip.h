@@ -1,0 +1,366 @@
+// vgl_common.hip.h -- device helpers shared by the gfx950 (MI355X, CDNA4) kernels of the vcfgl
+// genotype-likelihood simulation hot path: rand48 arithmetic, the reference's samplers (rng.h) and the
+// bounded float32 decisions that replace double transcendentals.  Wave64 only.
+//
+// Work decomposition (all kernels): one LANE owns one evaluation = one (site, sample); one WAVEFRONT
+// owns 64 consecutive samples of one site, so every per-evaluation global access of a wave is one
+// contiguous segment (structure-of-arrays tiles, sample index fastest).
+//
+//   vgl_sample.hip   k_sample<EQS>: Poisson depth -> per-read haplotype / base-call error / strand /
+//                    quality-score draws -> staged reads + per-evaluation ACGT depth (tile mode)
+//   vgl_serial.hip   k_scout, k_scout_wave, k_sample_serial: VGL_RNG_SERIAL, the reference's own
+//                    draw order (sequential stream-state scout + parallel evaluation from its states)
+//   vgl_gl.hip       k_site (allele order / status), k_gl<A> (likelihoods, PL / GP / AD),
+//                    k_siteagg (order-dependent per-site float sums: QS, I16)
+//
+// The float32 accumulation order of the reference is kept exactly (double add rounded to
+// float per genotype per read, float max, float subtract): build with -ffp-contract=off.
+// Decisions that the reference takes on double transcendentals (rejection tests, floor of a
+// scaled tan, (int)(-10 log10 p)) are taken from float32 hardware transcendentals with measured
+// error bounds and fall back to the exact double expression inside the error band, behind
+// wave-uniform branches: results equal the exact evaluation, the common path has no f64 log/tan/exp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "vgl_device.h"
+
+
+#define VGL_PI 3.141592654            // shared.h:37 (not M_PI)
+#define CAP_BASEQ 63                  // shared.h:241
+#define MAXPL 255                     // shared.h:208
+#define F32_MISSING_BITS 0x7F800001u  // bcf_float_missing
+#define I32_MISSING ((int32_t)0x80000000)
+
+#define SITE_OK 0
+#define SITE_SKIP_INVAR (-3)
+#define SITE_SKIP_EMPTY (-4)
+#define SITE_NO_READS 1
+
+// ------------------------------------------------------------------------------------
+// rand48: X <- (A X + C) mod 2^48, u = X 2^-48   (glibc drand48/erand48; rng.h:8-10)
+__device__ __forceinline__ uint64_t lcg_next(uint64_t x) { return (x * VGL_LCG_A + VGL_LCG_C) & VGL_MASK48; }
+__device__ __forceinline__ uint64_t aff(const VglAffine m, uint64_t x) { return (m.a * x + m.c) & VGL_MASK48; }
+__device__ __forceinline__ double u01(uint64_t x) {
+    // exact for x < 2^48: the 48 bits become the top of the mantissa of 1.xxx (what glibc's erand48 does)
+    return __longlong_as_double((long long)(0x3FF0000000000000ULL | (x << 4))) - 1.0;
+}
+__device__ __forceinline__ double next_u(uint64_t& st) { st = lcg_next(st); return u01(st); }
+
+// gamma_ln, rng.h:38-43,60-64
+static __device__ double gamma_ln_dev(const double xx) {
+    const double cof[6] = {76.18009172947146, -86.50532032941677, 24.01409824083091,
+                           -1.231739572450155, 0.1208650973866179e-2, -0.5395239384953e-5};
+    double x, tmp, y, ser;
+    y = x = xx;
+    tmp = x + 5.5;
+    tmp -= (x + 0.5) * log(tmp);
+    ser = 1.000000000190015;
+#pragma unroll
+    for (int j = 0; j <= 5; j++) ser += cof[j] / ++y;
+    return -tmp + log(2.5066282746310005 * ser / x);
+}
+
+// one depth draw, rng.h:289-312.  gamma_ln(em + 1) of the integer em comes from a table the host
+// fills with the same formula (rng.h:60-64); larger arguments are evaluated here.
+static __device__ int poisson_draw(const VglPois& p, uint64_t& st, const double* __restrict__ glt, const int glt_n) {
+    double em, t;
+    if (p.st12) {
+        em = -1.0; t = 1.0;
+        do { ++em; t *= next_u(st); } while (t > p.g);
+    } else {
+        double y;
+        do {
+            do {
+                y = tan(VGL_PI * next_u(st));
+                em = p.sq * y + p.lm;
+            } while (em < 0.0);
+            em = floor(em);
+            const double gl = (em < (double)(glt_n - 1)) ? glt[(int)em + 1] : gamma_ln_dev(em + 1.0);
+            t = 0.9 * (1.0 + y * y) * exp(em * p.alxm - gl - p.g);
+        } while (next_u(st) > t);
+    }
+    return (int)em;
+}
+
+// The same draw with the transcendental work in float32 (rng.h:300-312 otherwise unchanged).
+// tan() only feeds (1) em = floor(sq*y + lm) and (2) the acceptance bound t, exp() only (2): both are
+// decisions, so float32 values with explicit error bounds decide them and the exact double
+// expressions are evaluated only inside the error band.  Bounds measured on MI355X
+// (tools/vlogcheck.py): |tanf(x) - tan(x)| <= 1.2 ulp, v_exp_f32 <= 0.71 ulp; 4x margins used.
+// Flat loop: one attempt per iteration for every lane that has not accepted yet.
+// one rejection attempt (rng.h:302-309) from the two generator states it would consume: `neg`: em < 0
+// (only st1 is consumed, no acceptance draw), else `rej` = the acceptance draw u(st2) exceeds t.
+__device__ __forceinline__ void poisson_attempt(const VglPois& p, const uint64_t st1, const uint64_t st2, const bool need,
+                                                const double* __restrict__ glt, const int glt_n, bool& neg, bool& rej, double& em) {
+    const double a = VGL_PI * u01(st1);
+    const float af = (float)a;
+    const float yf = tanf(af);
+    const float y2 = yf * yf;
+    const float dy = fabsf(yf) * 0x1p-21f + (1.0f + y2) * af * 0x1p-23f;      // |yf - tan(a)|
+    const double e0 = p.sq * (double)yf + p.lm;
+    const double derr = p.sq * (double)dy + 1e-9;
+    em = floor(e0);
+    const bool amb_em = (e0 - em < derr) | (em + 1.0 - e0 < derr) | !(fabs(e0) < 1.0e6);
+    neg = e0 < 0.0;
+    const bool in_tab = (em >= 0.0) & (em < (double)(glt_n - 1));
+    const double gl = glt[in_tab ? (int)em + 1 : 1];
+    const double z = em * p.alxm - gl - p.g;
+    const float ex = __builtin_amdgcn_exp2f((float)(z * 1.4426950408889634));
+    const float tt = 0.9f * (1.0f + y2) * ex;
+    const float rel_t = 2.0f * fabsf(yf) * dy / (1.0f + y2) + fabsf((float)z) * 0x1p-22f + 0x1p-19f;
+    const double u2 = u01(st2);
+    rej = u2 > (double)tt;
+    const bool amb_t = fabs(u2 - (double)tt) <= (double)(tt * rel_t) + 1e-30;
+    const bool amb = need & (amb_em | (!neg & (amb_t | !in_tab)));
+    if (__builtin_expect(__ballot(amb) != 0, 0)) {               // exact evaluation (rare, wave-uniform branch)
+        asm volatile("" ::: "memory");
+        const double y = tan(a);
+        double eme = p.sq * y + p.lm;
+        const bool nege = eme < 0.0;
+        eme = floor(eme);
+        const double t = 0.9 * (1.0 + y * y) * exp(eme * p.alxm - ((eme >= 0.0 && eme < (double)(glt_n - 1)) ? glt[(int)eme + 1] : gamma_ln_dev(eme + 1.0)) - p.g);
+        const bool reje = u2 > t;
+        neg = amb ? nege : neg; em = amb ? eme : em; rej = amb ? reje : rej;
+    }
+}
+
+static __device__ int poisson_draw_fast(const VglPois& p, uint64_t& st, const double* __restrict__ glt, const int glt_n) {
+    if (p.st12) {
+        double em = -1.0, t = 1.0;
+        do { ++em; t *= next_u(st); } while (t > p.g);
+        return (int)em;
+    }
+    bool done = false;
+    double em_res = 0.0;
+    while (__ballot(!done)) {
+        const uint64_t st1 = lcg_next(st);
+        const uint64_t st2 = lcg_next(st1);
+        bool neg, reject; double em;
+        poisson_attempt(p, st1, st2, !done, glt, glt_n, neg, reject, em);
+        const bool acc = !done & !neg & !reject;
+        st = done ? st : (neg ? st1 : st2);                          // em < 0 consumes one draw, an attempt two
+        em_res = acc ? em : em_res;
+        done = done | acc;
+    }
+    return (int)em_res;
+}
+
+// sample_NormalSampler_0_1_0, rng.h:70-80
+static __device__ double normal_rou(uint64_t& st) {
+    double u, v, x, y, q;
+    do {
+        u = next_u(st);
+        v = 1.7156 * (next_u(st) - 0.5);
+        x = u - 0.449871;
+        y = fabs(v) + 0.386595;
+        q = (x * x) + y * (0.19600 * y - 0.25472 * x);
+    } while ((q > 0.27597) && (q > 0.27846 || (v * v) > -4.0 * log(u) * (u * u)));
+    return v / u;
+}
+
+// Gamma1Sampler::sample, rng.h:133-152
+static __device__ double gamma1_draw(const VglGamma1& g, uint64_t& st) {
+    double u, v, x, xsq;
+    do {
+        do {
+            x = normal_rou(st);
+            v = 1.0 + g.a2 * x;
+        } while (v <= 0.0);
+        v = v * v * v;
+        u = next_u(st);
+        xsq = x * x;
+    } while (u > 1.0 - 0.0331 * (xsq * xsq) && log(u) > 0.5 * xsq + g.a1 * (1.0 - v + log(v)));
+    if (g.changed) {
+        while ((u = next_u(st)) == 0.0);
+        return pow(u, 1.0 / g.alpha0) * g.a1 * v;
+    }
+    return g.a1 * v;
+}
+
+// BetaSampler::sample, rng.h:433-444
+__device__ __forceinline__ double beta_draw(const VglDevParams& P, uint64_t& st) {
+    double x = gamma1_draw(P.gx, st);
+    double y = gamma1_draw(P.gy, st);
+    return x / (x + y);
+}
+
+// apply_qs_bins, vcfgl.cpp:57-64
+static __device__ int apply_bins(const VglDevParams& P, int q, uint32_t* errflag) {
+    for (int i = 0; i < P.n_qs_bins; ++i)
+        if (q >= P.qs_bins[3 * i] && q <= P.qs_bins[3 * i + 1]) return P.qs_bins[3 * i + 2];
+    atomicOr(errflag, VGL_DEVERR_QSBIN);
+    return 0;
+}
+
+// IEEE-754 quotient n / d for operands far from the exponent limits (here d = u in [2^-48, 1),
+// |n| < 1): v_rcp_f64, two Newton steps and the residual correction -- the compiler's own division
+// sequence without v_div_scale / v_div_fixup, which only act on extreme exponents, NaN and infinity.
+__device__ __forceinline__ double div_inrange(const double n, const double d) {
+    double y = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, y, 1.0); y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-d, y, 1.0); y = __builtin_fma(y, e, y);
+    const double q = n * y;
+    const double r = __builtin_fma(-d, q, n);
+    return __builtin_fma(r, y, q);
+}
+
+// error probability -> qScore / adjusted qScore, vcfgl.cpp:500-523
+static __device__ void errprob_to_qs(const VglDevParams& P, double ep, int& q, int& aq, uint32_t* errflag) {
+    q = -1; aq = -1;
+    if (0.0 == ep) q = CAP_BASEQ;
+    else if (1.0 == ep) q = 0;
+    else {
+        double tmp = -10.0 * log10(ep);
+        q = (int)tmp;
+        if (P.adjust_qs) aq = (int)(tmp + P.adjust_by);
+    }
+    if (P.n_qs_bins != 0) {
+        q = apply_bins(P, q, errflag);
+        if (P.adjust_qs) aq = apply_bins(P, aq, errflag);
+    } else {
+        q = (q > CAP_BASEQ) ? CAP_BASEQ : q;
+        if (P.adjust_qs) aq = (aq > CAP_BASEQ) ? CAP_BASEQ : aq;
+    }
+}
+
+__device__ __forceinline__ int qs_to_qssq(int q) { return (0 == q) ? 0 : ((q < CAP_BASEQ) ? q * q : 3969); }  // shared.h:459
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// wave -> (local site, 64-sample chunk); everything here is wave-uniform (SGPRs)
+struct WavePos { int ls; int chunk; int wib; bool valid; };
+__device__ __forceinline__ WavePos wave_pos(const VglDevParams& P, const VglTilePtrs& T) {
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t w = (int64_t)blockIdx.x * (blockDim.x >> 6) + wib;
+    WavePos r;
+    r.wib = wib;
+    r.valid = w < (int64_t)T.n_sites * P.chunks;
+    r.ls = (int)(w / P.chunks);
+    r.chunk = (int)(w - (int64_t)r.ls * P.chunks);
+    return r;
+}
+
+// ---- decisions of the rejection samplers without a float64 logarithm ---------------------
+// The reference compares expressions that contain log() in double.  The hardware float32
+// log2 (v_log_f32) with an explicit error bound decides the comparison unless the two sides
+// are closer than that bound; only then is the exact double expression evaluated, so the
+// decision is always the one the exact expression gives.
+// Bound: for normal float x, |v_log_f32(x) - log2(x)| <= 2^-22.9 |log2 x| (measured on MI355X
+// over 1.2e7 inputs incl. a dense set around 1: tools/vlogcheck.py; relative to |x-1| near 1);
+// with the double->float rounding of the argument and the multiplication by ln 2:
+//     |fast_ln(x) - ln(x)| <= |fast_ln(x)| 2^-21 + 2^-22
+#define VGL_LN2 0.6931471805599453
+__device__ __forceinline__ double fast_ln(const float xf) { return (double)__builtin_amdgcn_logf(xf) * VGL_LN2; }
+__device__ __forceinline__ double fast_ln_err(const double l) { return fabs(l) * 0x1p-21 + 0x1p-22; }
+
+// (v*v) > -4.0*log(u)*(u*u)                                              rng.h:78
+// `need` = lanes whose result is used; only those can force the exact evaluation.
+__device__ __forceinline__ bool normal_slow_test(const double v, const double u, const bool need) {
+    const double lhs = v * v;
+    const float uf = (float)u;
+    const double l = fast_ln(uf);
+    const double uu = u * u;
+    const double rhs = -4.0 * l * uu;
+    const double m = 4.0 * uu * fast_ln_err(l);
+    const bool hi = lhs > rhs + m, lo = lhs < rhs - m;
+    bool res = hi;
+    const bool amb = need && !((hi || lo) && (uf > 0.0f));
+    if (__builtin_expect(__ballot(amb) != 0, 0)) {          // wave-uniform and rare: a real branch
+        asm volatile("" ::: "memory");                      // (keeps the compiler from speculating the double log)
+        const bool ex = lhs > -4.0 * log(u) * (u * u);
+        res = amb ? ex : res;
+    }
+    return res;
+}
+
+// log(u) > 0.5*xsq + a1*(1.0 - v + log(v)),  v = fl(fl(w*w)*w), w = fl(1 + a2 x)    rng.h:139-145
+// With s = a2 x and a2^2 = 1/(9 a1) the quadratic terms cancel analytically:
+//     0.5 x^2 + a1 (1 - (1+s)^3 + 3 ln(1+s)) = -3 a1 s^4 (1/4 - s/5 + s^2/6 - s^3/7 + ...)
+// a well-conditioned series (no cancellation), so float32 is enough for the bounded decision:
+// |s| <= 1/3 => 11 terms leave < 2e-7 relative truncation; float32 evaluation < 1e-6 relative;
+// the reference's own double rounding of its expression is < 1e-12.  Outside the band (or for
+// |s| > 1/3) the exact double expression is evaluated.
+__device__ __forceinline__ bool gamma_slow_test(const double u, const double xsq, const double a1, const double v,
+                                                const double s, const bool need) {
+    const float uf = (float)u, sf = (float)s, a1f = (float)a1;
+    const float lu = __builtin_amdgcn_logf(uf) * 0.69314718f;
+    float p = 1.0f / 14.0f;
+    p = 1.0f / 13.0f - sf * p; p = 1.0f / 12.0f - sf * p; p = 1.0f / 11.0f - sf * p; p = 1.0f / 10.0f - sf * p;
+    p = 1.0f / 9.0f - sf * p; p = 1.0f / 8.0f - sf * p; p = 1.0f / 7.0f - sf * p; p = 1.0f / 6.0f - sf * p;
+    p = 1.0f / 5.0f - sf * p; p = 1.0f / 4.0f - sf * p;
+    const float s2 = sf * sf;
+    const float g = 3.0f * a1f * (s2 * s2) * p;                 // = -(rhs of the reference), >= 0
+    const float d = lu + g;                                     // log(u) - rhs
+    const float m = fabsf(lu) * 0x1p-20f + 0x1p-21f + g * 4e-6f + 1e-10f;
+    const bool ok = (fabsf(d) > m) && (fabsf(sf) <= 0.3333f) && (uf > 0.0f);
+    bool res = d > 0.0f;
+    const bool amb = need && !ok;
+    if (__builtin_expect(__ballot(amb) != 0, 0)) {          // wave-uniform and rare: a real branch
+        asm volatile("" ::: "memory");
+        const bool ex = log(u) > 0.5 * xsq + a1 * (1.0 - v + log(v));
+        res = amb ? ex : res;
+    }
+    return res;
+}
+
+// error probability -> qScore / adjusted qScore (vcfgl.cpp:500-523); (int)(-10*log10(p)) is
+// taken from the float32 log2 unless p sits within its error bound of an integer boundary
+// p = gx / (gx + gy) (rng.h:438) is itself taken in float32 (v_rcp_f32, 1 ulp): relative error of pf
+// <= 2^-24 (gx) + 2^-24 (sum) + 2^-23 (rcp) + 2^-24 (product) < 2^-22, i.e. < 1.1e-6 in tf.
+__device__ __forceinline__ void errprob_to_qs_fast(const VglDevParams& P, const double gx, const double gy, int& q, int& aq, uint32_t* errflag, const bool need) {
+    // float32: tf = -10 log10(p) within |tf| 2^-20 + 2.2e-6 (v_log_f32 bound + argument error)
+    const float pf = (float)gx * __builtin_amdgcn_rcpf((float)(gx + gy));
+    const float tf = -3.0103f * __builtin_amdgcn_logf(pf);
+    const float m = tf * 0x1p-19f + 4e-6f;
+    const float fl = floorf(tf);
+    const float t2 = tf + (float)P.adjust_by;
+    const float fl2 = floorf(t2);
+    bool ok = (pf > 1.0e-37f) && (pf < 1.0f) && (tf - fl > m) && (fl + 1.0f - tf > m);
+    if (P.adjust_qs) ok = ok && (t2 > m) && (t2 - fl2 > m) && (fl2 + 1.0f - t2 > m);
+    q = (int)fl; aq = P.adjust_qs ? (int)fl2 : -1;
+    ok = ok || !need;
+    if (__builtin_expect(__ballot(!ok) != 0, 0)) {     // exact: vcfgl.cpp:500-507 (rare: a real branch)
+        asm volatile("" ::: "memory");
+        const double ep = gx / (gx + gy);
+        int qe = -1, aqe = -1;
+        if (0.0 == ep) qe = CAP_BASEQ;
+        else if (1.0 == ep) qe = 0;
+        else {
+            const double tmp = -10.0 * log10(ep);
+            qe = (int)tmp;
+            if (P.adjust_qs) aqe = (int)(tmp + P.adjust_by);
+        }
+        q = ok ? q : qe; aq = ok ? aq : aqe;
+    }
+    if (P.n_qs_bins != 0) {
+        if (need) {
+            q = apply_bins(P, q, errflag);
+            if (P.adjust_qs) aq = apply_bins(P, aq, errflag);
+        }
+    } else {
+        q = (q > CAP_BASEQ) ? CAP_BASEQ : q;
+        if (P.adjust_qs) aq = (aq > CAP_BASEQ) ? CAP_BASEQ : aq;
+    }
+}
+
+// one read: haplotype pick, base-call error, strand (vcfgl.cpp:473,486-488,581-586); all compares
+// are exact integer restatements on the 48-bit state: u<0.5 <=> X<2^47, u<e <=> X<ceil(e 2^48),
+// floor(4u) = X>>46
+__device__ __forceinline__ int sample_read_base(uint64_t& st_hap, uint64_t& st_base, const int a0, const int a1,
+                                                const uint64_t err_thresh, const bool sample_strand, bool& fwd) {
+    st_hap = lcg_next(st_hap);
+    const int true_base = (st_hap < (1ULL << 47)) ? a0 : a1;
+    int r_base = true_base;
+    st_base = lcg_next(st_base);
+    if (st_base < err_thresh) {
+        do { st_base = lcg_next(st_base); r_base = (int)(st_base >> 46); } while (r_base == true_base);
+    }
+    fwd = true;
+    if (sample_strand) { st_base = lcg_next(st_base); fwd = st_base < (1ULL << 47); }
+    return r_base;
+}
+

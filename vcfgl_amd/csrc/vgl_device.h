@@ -1,5 +1,5 @@
 // vgl_device.h -- structures shared by the host side of the C ABI (vgl_host.cpp) and the
-// gfx950 kernels (vgl_kernels.hip).
+// gfx950 kernels (vgl_sample.hip, vgl_serial.hip, vgl_gl.hip).
 #pragma once
 #include <stdint.h>
 
@@ -129,12 +129,14 @@ struct VglSerialState {
 #ifdef __cplusplus
 extern "C" {
 #endif
-// launch wrappers implemented in vgl_kernels.hip (stream = hipStream_t)
+// launch wrappers implemented beside their kernels in vgl_sample.hip / vgl_serial.hip / vgl_gl.hip
+// (stream = hipStream_t)
 int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, void* stream);
 int vgl_launch_site(const VglDevParams* p, const VglTilePtrs* t, void* stream);
 int vgl_launch_gl(const VglDevParams* p, const VglTilePtrs* t, void* stream);
 int vgl_launch_siteagg(const VglDevParams* p, const VglTilePtrs* t, void* stream);
 int vgl_launch_scout(const VglDevParams* p, const VglTilePtrs* t, struct VglSerialState* st, void* stream);
+int vgl_launch_sample_serial(const VglDevParams* p, const VglTilePtrs* t, void* stream);
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,376 @@
+// vgl_gl.hip -- per-site allele order (k_site), genotype likelihoods and their PL / GP / AD
+// epilogue (k_gl<A>), order-dependent per-site float sums (k_siteagg).
+// (vcfgl.cpp:396-404, 665-970, 982-1074; gl_methods.cpp:4-369)
+#include "vgl_common.hip.h"
+
+// ------------------------------------------------------------------------------------
+// one lane per site: status + allele order (vcfgl.cpp:396-404, 665-766; no-reads :228-315)
+__global__ __launch_bounds__(256) void k_site(const VglDevParams P, const VglTilePtrs T) {
+    const int ls = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ls >= T.n_sites) return;
+    const int32_t* acc = T.acc + (size_t)ls * VGL_ACC_STRIDE;
+    const int A = P.A;
+    const int info_dp = acc[0];
+    int ad[4] = {acc[1], acc[2], acc[3], acc[4]};
+    int a2b[5] = {-1, -1, -1, -1, -1}, b2a[5] = {-1, -1, -1, -1, -1};
+    int status = SITE_OK, nAll = 0, nObs = 0;
+
+    if (0 == info_dp) {
+        if (P.rm_empty_sites) status = SITE_SKIP_EMPTY;
+        else {
+            status = SITE_NO_READS;
+            switch (P.do_unobserved) {
+                case 0: nAll = 1; nObs = 0; break;
+                case 1: case 2: nAll = 1; nObs = 0; a2b[0] = 4; break;
+                case 3: nAll = 4; nObs = 4; for (int a = 0; a < 4; a++) a2b[a] = a; break;
+                default: nAll = 5; nObs = 4; for (int a = 0; a < 4; a++) a2b[a] = a; a2b[4] = 4; break;
+            }
+        }
+    } else {
+        int nObservedBases = 0;
+        for (int b = 0; b < 4; b++) if (ad[b] > 0) nObservedBases++;
+        if ((P.rm_invar_sites & 4) && 1 == nObservedBases) status = SITE_SKIP_INVAR;
+        else {
+            int sorted[4] = {0, 1, 2, 3};
+            for (int i = 1; i < 4; i++)
+                for (int j = i; j > 0 && ad[sorted[j]] > ad[sorted[j - 1]]; j--) { int t = sorted[j]; sorted[j] = sorted[j - 1]; sorted[j - 1] = t; }
+            for (int a = 0; a < 4; a++) { a2b[a] = sorted[a]; b2a[sorted[a]] = a; }
+            const bool explode = P.do_unobserved >= 3, add_unobs = (A == 5);
+            for (int b = 0; b < 4; b++)
+                if (!(ad[b] > 0) && !explode) { a2b[b2a[b]] = -1; b2a[b] = -1; }
+            int unobs = -1, n_all = 0;
+            for (int a = 0; a < 5; a++) { if (-1 == a2b[a]) { if (add_unobs) unobs = a; break; } ++n_all; }
+            if (add_unobs) { a2b[unobs] = 4; b2a[4] = unobs; }
+            nObs = n_all; nAll = n_all + (add_unobs ? 1 : 0);
+        }
+    }
+    VglSiteInfo si;
+    si.status = status; si.n_alleles = nAll;
+    uint32_t pa = 0, pb = 0;
+    for (int k = 0; k < 5; k++) { pa |= (uint32_t)(b2a[k] & 0xF) << (4 * k); pb |= (uint32_t)(a2b[k] & 0xF) << (4 * k); }
+    si.acgt2alleles = pa; si.alleles2acgt = pb;
+    T.sinfo[ls] = si;
+
+    T.site_status[ls] = status;
+    T.n_alleles[ls] = nAll;
+    if (T.n_alleles_obs) T.n_alleles_obs[ls] = nObs;
+    for (int k = 0; k < 5; k++) T.alleles2acgt[(size_t)ls * 5 + k] = (int8_t)a2b[k];
+    if (T.info_dp) T.info_dp[ls] = info_dp;
+    const bool have = (status == SITE_OK);
+    for (int a = 0; a < A; a++) {
+        const int b = (have && a < nAll) ? a2b[a] : -1;
+        const bool real = (b >= 0 && b < 4);
+        const int tot = real ? acc[1 + b] : 0;
+        const int totf = real ? acc[5 + b] : 0;
+        if (T.info_ad) T.info_ad[(size_t)ls * A + a] = tot;
+        if (T.info_adf) T.info_adf[(size_t)ls * A + a] = totf;
+        if (T.info_adr) T.info_adr[(size_t)ls * A + a] = tot - totf;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float f32_missing() { return __uint_as_float(F32_MISSING_BITS); }
+__device__ __forceinline__ int nib(uint32_t v, int k) { return (int)((v >> (4 * k)) & 0xF); }
+__device__ __forceinline__ int cnt_of(uint64_t ad4, int b) { return b < 4 ? (int)((ad4 >> (16 * b)) & 0xFFFF) : 0; }
+
+// Evaluations differ in depth, and the likelihood loop runs once per read: a wavefront is busy for
+// its deepest evaluation.  The 256 evaluations of a workgroup are therefore re-dealt to the lanes in
+// depth order (LDS counting sort of the thread ids), so each wavefront works on evaluations of
+// similar depth; loads and stores stay inside the workgroup's 256-evaluation window of each plane.
+template <int A>
+__global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTilePtrs T) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    __shared__ uint32_t s_hist[1026];
+    __shared__ uint16_t s_perm[256];
+    constexpr int NG = A * (A + 1) / 2;
+    const int N = P.n_samples;
+    const int tid = threadIdx.x;
+    const int64_t nwaves = (int64_t)T.n_sites * P.chunks;
+    // ---- depth of the evaluation this thread would own in natural order
+    int dp0 = -1;                                                      // -1: no evaluation (padding lane)
+    {
+        const int64_t w = (int64_t)blockIdx.x * 4 + (tid >> 6);
+        if (w < nwaves) {
+            const int ls0 = (int)(w / P.chunks);
+            const int s0 = (int)(w - (int64_t)ls0 * P.chunks) * 64 + (tid & 63);
+            if (s0 < N) {
+                const uint64_t a = T.ad4[(size_t)ls0 * N + s0];
+                dp0 = (int)((a & 0xFFFF) + ((a >> 16) & 0xFFFF) + ((a >> 32) & 0xFFFF) + ((a >> 48) & 0xFFFF));
+                if (dp0 > 1023) dp0 = 1023;
+            }
+        }
+    }
+    for (int i = tid; i < 1026; i += 256) s_hist[i] = 0;
+    __syncthreads();
+    const int key = 1024 - dp0;                                        // deepest first; padding (dp0 = -1) last
+    atomicAdd(&s_hist[key], 1u);
+    __syncthreads();
+    if (tid < 64) {                                                    // exclusive scan of 1026 bins by one wavefront
+        uint32_t run = 0;
+        for (int base = 0; base < 1026; base += 64) {
+            const int i = base + tid;
+            const uint32_t v = (i < 1026) ? s_hist[i] : 0u;
+            uint32_t incl = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d, 64); if (tid >= d) incl += t; }
+            if (i < 1026) s_hist[i] = run + incl - v;
+            run += __shfl(incl, 63, 64);
+        }
+    }
+    __syncthreads();
+    s_perm[atomicAdd(&s_hist[key], 1u)] = (uint16_t)tid;
+    __syncthreads();
+    const int otid = s_perm[tid];                                      // thread id whose evaluation this lane processes
+    const int lane = tid & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t w = (int64_t)blockIdx.x * 4 + (otid >> 6);
+    if (w >= nwaves) return;
+    const int ls = (int)(w / P.chunks);
+    const int s = (int)(w - (int64_t)ls * P.chunks) * 64 + (otid & 63);
+    if (s >= N) return;
+    const size_t ev = (size_t)ls * N + s;
+    const size_t plane = (size_t)T.n_sites * N;
+    const VglSiteInfo si = T.sinfo[ls];
+    const int nA = si.n_alleles;
+    const int nG = nA * (nA + 1) / 2;
+    const bool have = (si.status == SITE_OK);
+    const float MISS = f32_missing();
+
+    const uint64_t ad4 = T.ad4[ev];
+    const int dp = have ? (int)((ad4 & 0xFFFF) + ((ad4 >> 16) & 0xFFFF) + ((ad4 >> 32) & 0xFFFF) + ((ad4 >> 48) & 0xFFFF)) : 0;
+
+    float acc[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) acc[i] = -0.0f;                                     // bcf_utils.h:310
+
+    if (dp > 0) {
+        if (P.gl_model == 2) {
+            // gl_methods.cpp:22-59 / :94-139 / :171-220
+            const bool per_read = (P.error_qs == 2);
+            double homT = P.pre_homT, het = P.pre_het, homF = P.pre_homF;
+            for (int r = 0; r < dp; ++r) {
+                const uint32_t rb = T.reads[(size_t)r * plane + ev];
+                const int ao = nib(si.acgt2alleles, (int)(rb & 3));
+                if (per_read) {
+                    if (!P.precise_gl) {
+                        const int q = (int)(rb >> 2);
+                        homT = P.q2gl[q]; het = P.q2gl[257 + q]; homF = P.q2gl[514 + q];
+                    } else {
+                        const double e = T.errp[(size_t)r * plane + ev];
+                        if (0.0 == e) { homT = 0.0; het = -0.30103; homF = -INFINITY; }
+                        else { homT = log10(1.0 - e); het = log10((1.0 - e) / 2.0 + e / 6.0); homF = log10(e / 3.0); }
+                    }
+                }
+                float mx = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < A; ++i) {
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) {
+                        const int idx = i * (i + 1) / 2 + j;                         // bcf_alleles2gt
+                        const double t = (i == j) ? ((ao == i) ? homT : homF) : ((ao == i || ao == j) ? het : homF);
+                        const float v = (float)((double)acc[idx] + t);
+                        acc[idx] = v;
+                        if (i < nA) mx = (v > mx) ? v : mx;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NG; ++i) acc[i] -= mx;
+            }
+        } else {
+            // GL model 1 with one fixed qScore: errmod_cal() reduces to table lookups on the
+            // per-base depths (gl_methods.cpp:304-369; htslib errmod.c restated in vgl_host.cpp)
+            int n = dp;
+            if (n > 255) { atomicOr(T.errflag, VGL_DEVERR_GL1DEPTH); n = 255; }
+            int c[5]; double bs[5];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { c[b] = (int)((ad4 >> (16 * b)) & 0xFFFF); if (c[b] > 255) c[b] = 255; }
+            c[4] = 0; bs[4] = 0.0;
+            if (P.error_qs != 2) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) bs[b] = P.gl1_bsum[n * 256 + c[b]];
+            } else {
+                // per-read qScores (gl_methods.cpp:233-302): errmod_cal() walks the reads in descending
+                // (qual, base) order, so each base accumulates fk[i]*beta[q][n][i] over its own reads in
+                // descending quality: a per-lane (base, qual) histogram in LDS replaces the sort
+                uint8_t* h = lds_raw + (size_t)wib * 16384 + lane;
+                for (int bin = 0; bin < 256; ++bin) h[bin * 64] = 0;
+                for (int r = 0; r < n; ++r) {
+                    const uint32_t rb = T.reads[(size_t)r * plane + ev];
+                    const int bin = (int)(((rb & 3) << 6) | (rb >> 2));
+                    h[bin * 64] = (uint8_t)(h[bin * 64] + 1);
+                }
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    double acc_b = 0.0; int i = 0;
+                    for (int q = 63; q >= 0; --q) {
+                        const int cnt = h[(b * 64 + q) * 64];
+                        const int qq = q < 4 ? 4 : q;                          // errmod_cal clamps qual to [4,63]
+                        for (int j = 0; j < cnt; ++j) { acc_b += P.gl1_fk[i] * P.gl1_beta[((size_t)qq << 16) | ((size_t)n << 8) | (size_t)i]; ++i; }
+                    }
+                    bs[b] = acc_b;
+                }
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < A; ++i) {
+#pragma unroll
+                for (int j = 0; j <= i; ++j) {
+                    const int idx = i * (i + 1) / 2 + j;
+                    const int b1 = nib(si.alleles2acgt, j), b2 = nib(si.alleles2acgt, i);
+                    float tmp1 = 0.0f; int tmp2 = 0;
+#pragma unroll
+                    for (int k = 0; k < 5; ++k)
+                        if (k != b1 && k != b2) { tmp1 = (float)((double)tmp1 + bs[k]); tmp2 += c[k]; }
+                    float q;
+                    if (b1 == b2) q = tmp2 ? tmp1 : 0.0f;
+                    else {
+                        const int lo = b1 < b2 ? b1 : b2, hi = b1 < b2 ? b2 : b1;
+                        const int chi = cnt_of(ad4, hi) > 255 ? 255 : cnt_of(ad4, hi);
+                        int cjk = cnt_of(ad4, lo) + cnt_of(ad4, hi); if (cjk > 255) cjk = 255;
+                        const double lh = P.gl1_lhet[cjk << 8 | chi];
+                        q = tmp2 ? (float)(-4.343 * lh + (double)tmp1) : (float)(-4.343 * lh);
+                    }
+                    if (q < 0.0f) q = 0.0f;
+                    const float v = (float)((-1.0 * (double)q) / 10.0);
+                    acc[idx] = v;
+                    if (i < nA) mx = (v > mx) ? v : mx;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NG; ++i) acc[i] -= mx;
+        }
+    }
+
+    // ---- GL / PL / GP planes (vcfgl.cpp:907-970; no-reads site :297-305)
+    float gp[NG]; float sum_gps = 0.0f;
+    const bool sample_ok = have && dp > 0;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const bool valid = sample_ok && i < nG;
+        const float v = valid ? acc[i] : MISS;
+        const size_t o = ((size_t)ls * NG + i) * N + s;
+        if (T.gl) T.gl[o] = v;
+        if (T.pl) {
+            int32_t x;
+            if (!valid) x = I32_MISSING;
+            else if (v == -INFINITY) x = MAXPL;
+            else { x = (int32_t)lroundf((float)(-10.0 * (double)v)); if (x > MAXPL) x = MAXPL; }
+            T.pl[o] = x;
+        }
+        if (T.gp) { gp[i] = valid ? (float)pow(10.0, (double)v) : 0.0f; if (valid) sum_gps += gp[i]; }
+    }
+    if (T.gp) {
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const bool valid = sample_ok && i < nG;
+            T.gp[((size_t)ls * NG + i) * N + s] = valid ? gp[i] / sum_gps : MISS;
+        }
+    }
+    // ---- FORMAT/AD, ADF, ADR in allele order (vcfgl.cpp:806-843)
+    if (T.fmt_ad || T.fmt_adf || T.fmt_adr) {
+        const uint64_t adf4 = P.need_adf ? T.adf4[ev] : ad4;
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            const int b = (have && a < nA) ? nib(si.alleles2acgt, a) : 0xF;
+            const int v = cnt_of(ad4, b), vf = cnt_of(adf4, b);
+            const size_t o = ((size_t)ls * A + a) * N + s;
+            if (T.fmt_ad) T.fmt_ad[o] = v;
+            if (T.fmt_adf) T.fmt_adf[o] = vf;
+            if (T.fmt_adr) T.fmt_adr[o] = v - vf;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// one lane per site, samples in order: the reference accumulates these in float32 in sample
+// order (vcfgl.cpp:875-897, 997-1066), which a tree reduction would not reproduce bit for bit.
+__global__ __launch_bounds__(64) void k_siteagg(const VglDevParams P, const VglTilePtrs T) {
+    const int ls = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ls >= T.n_sites) return;
+    const int N = P.n_samples, A = P.A;
+    const VglSiteInfo si = T.sinfo[ls];
+    const bool have = (si.status == SITE_OK);
+    const int nA = si.n_alleles;
+    const uint32_t* qsum = T.qsum + (size_t)ls * 4 * N;
+    if (T.qs) {
+        float qsv[5] = {0, 0, 0, 0, 0};
+        if (have && P.need_qsum)
+            for (int s = 0; s < N; ++s) {
+                float sum = 0.0f;
+                uint32_t q[4];
+                for (int b = 0; b < 4; ++b) { q[b] = qsum[(size_t)b * N + s]; sum += (float)(int)q[b]; }
+                if (0.0f != sum)
+                    for (int b = 0; b < 4; ++b) {
+                        const int a = nib(si.acgt2alleles, b);
+                        if (a == 0xF) continue;
+                        const float add = (float)((float)(int)q[b] / sum);
+                        qsv[0] += (a == 0) ? add : 0.0f; qsv[1] += (a == 1) ? add : 0.0f; qsv[2] += (a == 2) ? add : 0.0f;
+                        qsv[3] += (a == 3) ? add : 0.0f; qsv[4] += (a == 4) ? add : 0.0f;
+                    }
+            }
+        for (int a = 0; a < A; ++a) T.qs[(size_t)ls * A + a] = qsv[a];
+    }
+    if (T.i16) {
+        float v[16];
+        for (int k = 0; k < 16; ++k) v[k] = 0.0f;
+        if (have && P.add_i16 && nA > 1) {
+            const int32_t* acc = T.acc + (size_t)ls * VGL_ACC_STRIDE;
+            const uint32_t* qsq = T.qsumsq + (size_t)ls * 4 * N;
+            const int refb = nib(si.alleles2acgt, 0);
+            const int nObs = (A == 5) ? nA - 1 : nA;
+            v[0] = (float)acc[5 + refb]; v[1] = (float)(acc[1 + refb] - acc[5 + refb]);
+            const float mq = (float)P.i16_mapq, mq2 = (float)(P.i16_mapq * P.i16_mapq);
+            for (int s = 0; s < N; ++s) {
+                v[4] += (float)(int)qsum[(size_t)refb * N + s];
+                v[5] += (float)(int)qsq[(size_t)refb * N + s];
+                const uint64_t ad4 = T.ad4[(size_t)ls * N + s];
+                for (int a = 0; a < nA; ++a) {
+                    if (a == nObs) continue;
+                    const int cnt = cnt_of(ad4, nib(si.alleles2acgt, a));
+                    for (int i = 0; i < cnt; ++i) {
+                        if (0 == a) { v[8] += mq; v[9] += mq2; } else { v[10] += mq; v[11] += mq2; }
+                    }
+                }
+            }
+            for (int a = 1; a < nA; ++a) {
+                if (a == nObs) continue;
+                const int b = nib(si.alleles2acgt, a);
+                v[2] += (float)acc[5 + b]; v[3] += (float)(acc[1 + b] - acc[5 + b]);
+                for (int s = 0; s < N; ++s) { v[6] += (float)(int)qsum[(size_t)b * N + s]; v[7] += (float)(int)qsq[(size_t)b * N + s]; }
+            }
+            // tail distance (vcfgl.cpp:1029-1071): drawn from libc rand() by the serial-mode scout; zero in tile mode
+            if (T.site_tail) {
+                const VglSiteTail tl = T.site_tail[ls];
+                if (tl.base == refb) { v[12] = tl.sum; v[13] = tl.sumsq; }
+                for (int a = 1; a < nA; ++a) {
+                    if (a == nObs) continue;
+                    if (nib(si.alleles2acgt, a) == tl.base) { v[14] += tl.sum; v[15] += tl.sumsq; }
+                }
+            }
+        }
+        for (int k = 0; k < 16; ++k) T.i16[(size_t)ls * 16 + k] = v[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------
+extern "C" int vgl_launch_site(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
+    if (t->n_sites == 0) return 0;
+    hipLaunchKernelGGL(k_site, dim3((t->n_sites + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p, *t);
+    return (int)hipGetLastError();
+}
+
+extern "C" int vgl_launch_gl(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
+    const int64_t waves = (int64_t)t->n_sites * p->chunks;
+    if (waves == 0) return 0;
+    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    const size_t lds = (p->gl_model == 1 && p->error_qs == 2) ? (size_t)4 * 16384 : 0;   // (base,qual) histograms
+    if (p->A == 5) hipLaunchKernelGGL(k_gl<5>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, *p, *t);
+    else hipLaunchKernelGGL(k_gl<4>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, *p, *t);
+    return (int)hipGetLastError();
+}
+
+extern "C" int vgl_launch_siteagg(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
+    if (t->n_sites == 0) return 0;
+    hipLaunchKernelGGL(k_siteagg, dim3((t->n_sites + 63) / 64), dim3(64), 0, (hipStream_t)stream, *p, *t);
+    return (int)hipGetLastError();
+}

@@ -1,7 +1,7 @@
 // vgl_host.cpp -- host side of the C ABI declared in include/vcfgl_hip.h.
 // Builds the constant tables a run needs (Poisson constants, beta shape parameters,
 // fixed-qscore terms, qScore LUT, GL-model-1 error-model tables, rand48 jump tables),
-// owns the device workspace, and enqueues the gfx950 kernels of vgl_kernels.hip.
+// owns the device workspace, and enqueues the gfx950 kernels of vgl_sample.hip, vgl_serial.hip and vgl_gl.hip.
 // There is no CPU compute path in this library.
 #include <hip/hip_runtime.h>
 #include <math.h>

@@ -1,0 +1,342 @@
+// vgl_sample.hip -- k_sample<EQS>: the per-read sampling of one tile in VGL_RNG_TILE mode
+// (vcfgl.cpp:364-389, 441-640; rng.h).  See vgl_common.hip.h for the work decomposition.
+//
+// Reads are staged as 1 byte each in [read][site][sample] planes; per-site depth sums by wave
+// reduction + one integer atomic per wave and counter.  EQS=2 (a beta deviate per read): the
+// quality-score sampling of the wave's reads is an LDS-staged pool dealt dynamically to the lanes,
+// each lane a select-only state machine over normal-deviate attempts.
+#include "vgl_common.hip.h"
+
+// ------------------------------------------------------------------------------------
+// EQS = --error-qs.  EQS 2 (a beta deviate per read) runs the quality-score sampling as a
+// wavefront-wide pool: the reads of the wave's 64 evaluations are independent work items
+// (stream 3 is addressed per read), staged in LDS and dealt round-robin to the lanes, so a
+// lane's work does not depend on its own evaluation's depth; each lane runs the nested
+// rejection loops of the gamma sampler as one flat state machine (one normal-deviate attempt
+// per iteration) so that lanes at different stages share every iteration.
+// DBG: diagnostic instantiation (VGL_DEBUG_STAMPS / VGL_DEBUG_PHASE), never used in a timed run
+template <int EQS, bool DBG>
+__global__ __launch_bounds__(256) void k_sample(const VglDevParams P, const VglTilePtrs T) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const WavePos wp = wave_pos(P, T);
+    if (!wp.valid) return;
+    const int lane = threadIdx.x & 63;
+    const int N = P.n_samples;
+    const int ls = wp.ls;
+    const int s = wp.chunk * 64 + lane;
+    const bool active = s < N;
+    const size_t ev0 = (size_t)ls * N + (size_t)wp.chunk * 64;      // evaluation of lane 0
+    const size_t ev = ev0 + (active ? lane : 0);
+    const size_t plane = (size_t)T.n_sites * N;
+
+    int dp = 0, a0 = 0, a1 = 0;
+    uint64_t ad4 = 0, adf4 = 0;
+    uint32_t qs0 = 0, qs1 = 0, qs2 = 0, qs3 = 0, qq0 = 0, qq1 = 0, qq2 = 0, qq3 = 0;
+    uint64_t st_hap = 0, st_base = 0, st_qs = 0;
+    // DBG only: per-phase cycle stamps
+    unsigned long long c_t0 = 0, c_pois = 0, c_owner = 0, c_pool = 0, c_flush = 0, c_iter = 0, c_items = 0, c_tmp = 0;
+    if (DBG) c_t0 = clock64();
+    uint64_t err_thresh = P.err_thresh;
+
+    // ---- stream states of this evaluation: J^(off_k) . J^(block*s) . J^(block*N*site) (x0)
+    const uint64_t site_abs = (uint64_t)(T.site0 + ls);
+    uint64_t xb = P.x0;
+#pragma unroll 1
+    for (int b = 0; b < 40; ++b)
+        if ((site_abs >> b) & 1) xb = aff(P.site_pow[b], xb);
+
+    if (active) {
+        const VglAffine ms = P.samp_tab[s];
+        const uint64_t xe = aff(ms, xb);
+        uint64_t st_depth = aff(P.off[0], xe);
+        st_hap = aff(P.off[1], xe);
+        st_base = aff(P.off[2], xe);
+        st_qs = aff(P.off[3], xe);
+
+        // ---- depth (vcfgl.cpp:364-389): drawn even when the genotype is missing
+        int n;
+        if (P.per_sample_depth) { const VglPois pc = P.pois[s]; n = poisson_draw_fast(pc, st_depth, P.gamma_ln_tab, P.gamma_ln_n); }
+        else n = poisson_draw_fast(P.pois0, st_depth, P.gamma_ln_tab, P.gamma_ln_n);
+        const uint32_t g = T.gt[ev];
+        a0 = g & 0xF; a1 = (g >> 4) & 0xF;
+        dp = (a0 == 0xF || a1 == 0xF) ? 0 : n;
+        if (dp > P.read_cap) { atomicOr(T.errflag, VGL_DEVERR_CAPACITY); dp = P.read_cap; }
+    }
+
+    if (DBG) c_pois = clock64() - c_t0;
+    if (DBG && P.dbg_phase == 1) return;
+    if (EQS == 1) {
+        // one beta deviate per site: stream 3 of sample 0, read 0 (vcfgl.cpp:425-437); lane 0 draws it
+        uint32_t lo = 0, hi = 0;
+        if (lane == 0) {
+            uint64_t st_site = aff(P.off[3], aff(P.samp_tab[0], xb));
+            const double pe = beta_draw(P, st_site);
+            const uint64_t th = (uint64_t)ceil(ldexp(pe, 48));
+            lo = (uint32_t)th; hi = (uint32_t)(th >> 32);
+        }
+        lo = __shfl(lo, 0, 64); hi = __shfl(hi, 0, 64);
+        err_thresh = ((uint64_t)hi << 32) | lo;
+    }
+
+    if (EQS != 2) {
+        // ---- read loop (vcfgl.cpp:469-613), fixed quality score
+        const int q_i = P.pre_q, aq_i = P.pre_adjq;
+        const uint32_t q_gl = (uint32_t)((P.adjust_qs & 1) ? aq_i : q_i);
+        const uint32_t qq = (uint32_t)((P.adjust_qs & 2) ? aq_i : q_i);
+        const uint32_t q2 = (uint32_t)qs_to_qssq((int)qq);
+        const bool stage = (P.gl_model != 1);      // GL model 1 with one fixed qScore needs only the per-base depths
+        for (int r = 0; r < dp; ++r) {
+            bool fwd;
+            const int r_base = sample_read_base(st_hap, st_base, a0, a1, err_thresh, P.sample_strand != 0, fwd);
+            if (stage) T.reads[(size_t)r * plane + ev] = (uint8_t)((q_gl << 2) | r_base);
+            if (T.reads_out && r < T.reads_out_cap) T.reads_out[(size_t)r * plane + ev] = (uint8_t)((q_i << 2) | r_base);
+            const uint64_t one = 1ULL << (16 * r_base);
+            ad4 += one;
+            if (fwd) adf4 += one;
+        }
+        if (P.need_qsum) {
+            qs0 = qq * (uint32_t)(ad4 & 0xFFFF); qs1 = qq * (uint32_t)((ad4 >> 16) & 0xFFFF);
+            qs2 = qq * (uint32_t)((ad4 >> 32) & 0xFFFF); qs3 = qq * (uint32_t)((ad4 >> 48) & 0xFFFF);
+            qq0 = q2 * (uint32_t)(ad4 & 0xFFFF); qq1 = q2 * (uint32_t)((ad4 >> 16) & 0xFFFF);
+            qq2 = q2 * (uint32_t)((ad4 >> 32) & 0xFFFF); qq3 = q2 * (uint32_t)((ad4 >> 48) & 0xFFFF);
+        }
+    } else {
+        // ---- LDS of this wave: [64] u64 qscore-stream bases | [cap] u16 item->(read,owner) |
+        //      [cap] u8 base | [cap] u8 qScore | [cap] u8 adjusted qScore
+        const int cap = P.pool_cap;
+        uint8_t* wl = lds_raw + (size_t)wp.wib * P.pool_lds_bytes;
+        uint64_t* l_stq = (uint64_t*)wl;
+        uint16_t* l_map = (uint16_t*)(wl + 512);
+        uint8_t* l_pb = wl + 512 + 2 * (size_t)cap;
+        uint8_t* l_pq = l_pb + cap;
+        uint8_t* l_paq = l_pq + cap;
+
+        // exclusive prefix sum of the depths = first pool index of each owner
+        int incl = dp;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        const int offs = incl - dp;
+        const int total = __shfl(incl, 63, 64);
+        l_stq[lane] = st_qs;
+        int rdone = 0;
+        // Kernel arguments arrive in 16-dword scalar tuples that the register allocator spills and
+        // reloads as a whole (v_readlane, VALU work) inside the loops below; the three values the flush
+        // loop needs are therefore pinned to vector registers.
+        uint8_t* reads_v = T.reads;
+        uint8_t* reads_out_v = T.reads_out;
+        int reads_out_cap_v = T.reads_out ? T.reads_out_cap : 0;
+        asm volatile("" : "+v"(reads_v), "+v"(reads_out_v), "+v"(reads_out_cap_v));
+
+        for (int seg0 = 0; seg0 < total; seg0 += cap) {                 // normally one segment
+            const int segT = (total - seg0 < cap) ? (total - seg0) : cap;
+            // -- owners: bases of their reads that fall into this segment
+            if (DBG) c_tmp = clock64();
+            int r_end = seg0 + segT - offs; r_end = r_end > dp ? dp : r_end; r_end = r_end < rdone ? rdone : r_end;
+            for (int r = rdone; r < r_end; ++r) {
+                bool fwd;
+                const int r_base = sample_read_base(st_hap, st_base, a0, a1, err_thresh, P.sample_strand != 0, fwd);
+                const uint64_t one = 1ULL << (16 * r_base);
+                ad4 += one;
+                if (fwd) adf4 += one;
+                const int k = offs + r - seg0;
+                l_map[k] = (uint16_t)((r << 6) | lane);
+                l_pb[k] = (uint8_t)r_base;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+            // -- pool: item k -> lane k % 64.  One iteration = one normal-deviate attempt
+            //    (rng.h:72-78) + the gamma step it feeds (rng.h:139-145), computed for every lane
+            //    without branches; lane state (stream, stage, first gamma) advances by selects, so
+            //    lanes in different stages of different reads share every instruction.  Real
+            //    branches remain only around the rare bounded-log tests and the per-read epilogue.
+            if (DBG) { const unsigned long long c = clock64(); c_owner += c - c_tmp; c_tmp = c; c_items += segT; }
+            if (DBG && P.dbg_phase == 2) return;
+            {
+                // Items are dealt dynamically: a lane owns its current item k and an item kn claimed one
+                // item ahead (so that kn's operands are in flight while k is worked on); a lane that
+                // finishes an item adopts kn and claims the next unclaimed one.  Each item's stream is
+                // addressed by its read, so the result does not depend on who works on it.
+                int k = lane, kn = lane + 64;
+                int next_free = 128;                         // wave-uniform: first unclaimed item
+                bool have = k < segT;
+                bool stage1 = false;                         // false: first gamma deviate (x), true: second (y)
+                uint64_t st = 0; double gx = 0.0; int it_o = 0, it_r = 0;
+                if (have) { const uint32_t m = l_map[k]; it_o = m & 63; it_r = m >> 6; st = aff(P.qs_read_tab[it_r], l_stq[it_o]); }
+                const bool any_changed = (P.gx.changed | P.gy.changed) != 0;
+                // The bounded-log tests are needed by a few lanes per iteration but cost every lane of the
+                // wave; they run only every P.slow_period-th iteration.  In between, a lane that needs one
+                // holds: its state is left untouched, so the later iteration recomputes the same attempt.
+                int slow_cnt = P.slow_period;
+                while (__ballot(have)) {
+                    if (DBG) c_iter++;
+                    const bool full = (--slow_cnt == 0);
+                    if (full) slow_cnt = P.slow_period;
+                    // operands of this lane's next item, fetched at the top of the iteration and consumed at
+                    // the bottom (unconditional, clamped index: no divergent control flow in the loop)
+                    const bool hn = kn < segT;
+                    const uint32_t m_n = l_map[hn ? kn : 0];
+                    const int o_n = m_n & 63, r_n = m_n >> 6;
+                    const VglAffine tab_n = P.qs_read_tab[r_n];
+                    const uint64_t base_n = l_stq[o_n];
+
+                    const double ga1 = stage1 ? P.gy.a1 : P.gx.a1;
+                    const double ga2 = stage1 ? P.gy.a2 : P.gx.a2;
+                    // normal attempt
+                    const uint64_t st1 = lcg_next(st);
+                    const uint64_t st2 = lcg_next(st1);
+                    const uint64_t st3 = lcg_next(st2);
+                    const double u = u01(st1);
+                    const double v = 1.7156 * (u01(st2) - 0.5);
+                    const double x = u - 0.449871;
+                    const double y = fabs(v) + 0.386595;
+                    const double q = (x * x) + y * (0.19600 * y - 0.25472 * x);
+                    const bool q_lo = q > 0.27597, q_hi = q > 0.27846;
+                    bool slow_n = false;
+                    const bool n_amb = have && q_lo && !q_hi;
+                    bool hold = n_amb && !full;
+                    if (full && __ballot(n_amb)) slow_n = normal_slow_test(v, u, n_amb);
+                    const bool acc_n = !(q_lo && (q_hi || slow_n));
+                    // gamma step on the accepted deviate
+                    const double xn = div_inrange(v, u);
+                    const double w = 1.0 + ga2 * xn;
+                    const bool w_pos = w > 0.0;
+                    const double vv = w * w * w;
+                    const double u2 = u01(st3);
+                    const double xsq = xn * xn;
+                    const bool sq_fail = u2 > 1.0 - 0.0331 * (xsq * xsq);
+                    const bool g_try = have && acc_n && w_pos && !hold;
+                    const bool g_amb = g_try && sq_fail;
+                    hold = hold || (g_amb && !full);
+                    bool slow_g = false;
+                    if (full && __ballot(g_amb)) slow_g = gamma_slow_test(u2, xsq, ga1, vv, ga2 * xn, g_amb);
+                    const bool acc_g = g_try && !(sq_fail && slow_g) && !hold;
+                    st = hold ? st : (g_try ? st3 : st2);    // u2 is drawn only when w > 0 (rng.h:140-142)
+                    double val = ga1 * vv;
+                    if (any_changed) {                       // alpha < 1 (rng.h:146-148); wave-uniform guard
+                        if (acc_g && (stage1 ? P.gy.changed : P.gx.changed)) {
+                            double u3;
+                            do { st = lcg_next(st); u3 = u01(st); } while (u3 == 0.0);
+                            val = pow(u3, 1.0 / (stage1 ? P.gy.alpha0 : P.gx.alpha0)) * ga1 * vv;
+                        }
+                    }
+                    const bool fin = acc_g && stage1;
+                    // per-read epilogue, computed for every lane, committed where fin (rng.h:438, vcfgl.cpp:500-531)
+                    int q_i, aq_i;
+                    errprob_to_qs_fast(P, gx, val, q_i, aq_i, T.errflag, fin);
+                    if (fin) {
+                        l_pq[k] = (uint8_t)q_i;
+                        l_paq[k] = (uint8_t)aq_i;
+                    }
+                    if (P.precise_gl) { if (fin) T.errp[(size_t)it_r * plane + ev0 + it_o] = gx / (gx + val); }
+                    gx = (acc_g && !stage1) ? val : gx;
+                    stage1 = stage1 != acc_g;
+                    // a lane that finished its item adopts kn and claims the next unclaimed item
+                    const uint64_t fin_m = __ballot(fin);
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fin_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fin_m, 0u));
+                    const uint64_t st_n = aff(tab_n, base_n);
+                    st = fin ? st_n : st;
+                    it_o = fin ? o_n : it_o; it_r = fin ? r_n : it_r;
+                    k = fin ? kn : k;
+                    kn = fin ? next_free + rank : kn;
+                    next_free += __popcll(fin_m);
+                    have = have && (!fin || hn);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+            // -- owners: combine base + quality score, stage the read, quality sums (vcfgl.cpp:525-564)
+            if (DBG) { const unsigned long long c = clock64(); c_pool += c - c_tmp; c_tmp = c; }
+            if (DBG && P.dbg_phase == 3) return;
+            for (int r = rdone; r < r_end; ++r) {
+                const int k = offs + r - seg0;
+                const int r_base = l_pb[k];
+                const int q_i = l_pq[k];
+                const int aq_i = P.adjust_qs ? (int)l_paq[k] : -1;
+                const int q_gl = (P.adjust_qs & 1) ? aq_i : q_i;
+                reads_v[(size_t)r * plane + ev] = (uint8_t)((q_gl << 2) | r_base);
+                if (r < reads_out_cap_v) reads_out_v[(size_t)r * plane + ev] = (uint8_t)((q_i << 2) | r_base);
+                if (P.need_qsum) {
+                    const uint32_t qq = (uint32_t)((P.adjust_qs & 2) ? aq_i : q_i);
+                    const uint32_t q2 = (uint32_t)qs_to_qssq((int)qq);
+                    qs0 += (r_base == 0) ? qq : 0u; qs1 += (r_base == 1) ? qq : 0u;
+                    qs2 += (r_base == 2) ? qq : 0u; qs3 += (r_base == 3) ? qq : 0u;
+                    qq0 += (r_base == 0) ? q2 : 0u; qq1 += (r_base == 1) ? q2 : 0u;
+                    qq2 += (r_base == 2) ? q2 : 0u; qq3 += (r_base == 3) ? q2 : 0u;
+                }
+            }
+            rdone = r_end;
+            __builtin_amdgcn_wave_barrier();
+            if (DBG) c_flush += clock64() - c_tmp;
+            if (DBG && P.dbg_phase == 4) return;
+        }
+    }
+
+    if (active) {
+        if (!P.sample_strand) adf4 = ad4;
+        if (T.fmt_dp) T.fmt_dp[ev] = dp;
+        T.ad4[ev] = ad4;
+        if (P.need_adf) T.adf4[ev] = adf4;
+        if (P.need_qsum) {
+            uint32_t* q = T.qsum + (size_t)ls * 4 * N + s;
+            q[0] = qs0; q[(size_t)N] = qs1; q[(size_t)2 * N] = qs2; q[(size_t)3 * N] = qs3;
+            if (P.need_qsumsq) {
+                uint32_t* qq = T.qsumsq + (size_t)ls * 4 * N + s;
+                qq[0] = qq0; qq[(size_t)N] = qq1; qq[(size_t)2 * N] = qq2; qq[(size_t)3 * N] = qq3;
+            }
+        }
+        if (T.reads_out) for (int r = dp; r < T.reads_out_cap; ++r) T.reads_out[(size_t)r * plane + ev] = 0xFF;
+    }
+
+    // ---- per-site sums: wave reduction, one atomic per wave and counter
+    int v[9];
+    v[0] = dp;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { v[1 + b] = (int)((ad4 >> (16 * b)) & 0xFFFF); v[5 + b] = (int)((adf4 >> (16 * b)) & 0xFFFF); }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) v[k] = wave_sum(v[k]);
+    if (lane == 0) {
+        int32_t* acc = T.acc + (size_t)ls * VGL_ACC_STRIDE;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) if (v[k]) atomicAdd(&acc[k], v[k]);
+        if (DBG) {
+            atomicAdd(&T.dbg[0], 1ULL); atomicAdd(&T.dbg[1], clock64() - c_t0); atomicAdd(&T.dbg[2], c_pois);
+            atomicAdd(&T.dbg[3], c_owner); atomicAdd(&T.dbg[4], c_pool); atomicAdd(&T.dbg[5], c_flush);
+            atomicAdd(&T.dbg[6], c_iter); atomicAdd(&T.dbg[7], c_items);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
+    const int64_t waves = (int64_t)t->n_sites * p->chunks;
+    if (waves == 0) return 0;
+    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    if (p->serial) return vgl_launch_sample_serial(p, t, stream);
+    const bool dbg = t->dbg != nullptr;                         // VGL_DEBUG_STAMPS / VGL_DEBUG_PHASE
+    if (p->error_qs == 2) {
+        if (dbg) hipLaunchKernelGGL((k_sample<2, true>), dim3(blocks), dim3(256), (size_t)4 * p->pool_lds_bytes, (hipStream_t)stream, *p, *t);
+        else hipLaunchKernelGGL((k_sample<2, false>), dim3(blocks), dim3(256), (size_t)4 * p->pool_lds_bytes, (hipStream_t)stream, *p, *t);
+    } else if (p->error_qs == 1) hipLaunchKernelGGL((k_sample<1, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, *t);
+    else hipLaunchKernelGGL((k_sample<0, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, *t);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// debug hook (not part of the C ABI): raw v_log_f32 over a buffer, used by
+// tests/test_gpu_parity.py to check the error bound the fast decision paths assume
+__global__ void k_dbg_vlog(const float* in, float* out, int n, int mode) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (mode == 0) out[i] = __builtin_amdgcn_logf(in[i]);          // v_log_f32
+    else if (mode == 1) out[i] = tanf(in[i]);                      // ocml tanf
+    else out[i] = __builtin_amdgcn_exp2f(in[i]);                   // v_exp_f32
+}
+extern "C" int vgl_dbg_vlog(const float* d_in, float* d_out, int n, int mode) {
+    hipLaunchKernelGGL(k_dbg_vlog, dim3((n + 255) / 256), dim3(256), 0, 0, d_in, d_out, n, mode);
+    return (int)hipDeviceSynchronize();
+}
+
