@@ -49,6 +49,7 @@ WORKLOADS = {
 def workload_args(name="c3"):
     a = VcfglArgs(seed=42, **WORKLOADS[name]["flags"])
     a.rng_mode, a.beta_sampler = _abi.VGL_RNG_TILE, _abi.VGL_BETA_RAND48
+    a._workload = name
     return a
 
 
@@ -67,8 +68,37 @@ def cpu_baseline(args, n_samples, budget_s=15.0):
     n = int(max(n0, min(200000, budget_s / (dt / n0))))
     gt = synth.binary_sites(0, n, n_samples)
     t0 = time.perf_counter(); o.simulate(0, gt, fields=fields); dt = time.perf_counter() - t0
-    return {"value": n * n_samples / dt, "unit": "site-sample GL evals/s", "cores": 1, "kind": "port",
-            "sample": f"first {n} sites x {n_samples} samples of the same workload, oracle/vgl_oracle.c (gcc -O2), {dt:.1f} s"}
+    res = {"value": n * n_samples / dt, "unit": "site-sample GL evals/s", "cores": 1, "kind": "port",
+           "sample": f"first {n} sites x {n_samples} samples of the same workload, oracle/vgl_oracle.c (gcc -O2), {dt:.1f} s"}
+    # All host cores, site-sharded in tile mode (NOT reference behaviour: the reference simulates on one
+    # thread; SURVEY 8d asks for this figure beside the faithful one).  One process per core, each on its
+    # own site range, about 8 s each.
+    try:
+        cores = min(os.cpu_count() or 1, 64)
+        per = int(max(256, min(n, 8.0 * res["value"] / n_samples)))
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", f"{n + k * per},{per}",
+                                   "--workload", args._workload, "--samples", str(n_samples)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for k in range(cores)]
+        dts = [float(json.loads(p.communicate(timeout=300)[0].strip().splitlines()[-1])["dt"]) for p in procs]
+        res["all_cores"] = {"value": cores * per * n_samples / max(dts), "cores": cores,
+                            "note": "site-sharded tile mode, one process per core; not reference behaviour"}
+    except Exception as e:                                     # the single-core figure stands on its own
+        res["all_cores"] = {"error": repr(e)[:200]}
+    return res
+
+
+def cpu_worker(spec, args, n_samples):
+    """One shard of the all-cores CPU leg: the oracle over sites [site0, site0 + n) in chunks."""
+    import oracle_lib
+    site0, n = (int(x) for x in spec.split(","))
+    o = oracle_lib.Oracle(args, n_samples)
+    fields = ["fmt_dp", "gl"]
+    o.simulate(0, synth.binary_sites(0, 4, n_samples), fields=fields)
+    t0 = time.perf_counter()
+    for s0 in range(site0, site0 + n, 256):
+        m = min(256, site0 + n - s0)
+        o.simulate(s0, synth.binary_sites(s0, m, n_samples), fields=fields)
+    print(json.dumps({"dt": time.perf_counter() - t0}))
 
 
 def main():
@@ -81,7 +111,11 @@ def main():
     ap.add_argument("--samples", type=int, default=None)
     ap.add_argument("--tile-sites", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)     # internal: one shard of the all-cores CPU leg
     opt = ap.parse_args()
+    if opt.cpu_worker:                                         # never touches the GPU
+        cpu_worker(opt.cpu_worker, workload_args(opt.workload), opt.samples or WORKLOADS[opt.workload]["samples"])
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -176,6 +210,19 @@ def main():
                 traffic = json.load(open(tpath)).get(names[dom], {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # the box's own device-copy bandwidth (read + write bytes of a 1 GiB device-to-device copy), the
+        # second denominator SURVEY 8d asks for beside the vendor peak
+        src = out["gl"].view(-1)[: min(out["gl"].numel(), 1 << 28)]
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 4 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del dst
         line = {
             "metric": METRIC if opt.workload != "c2" else "site-sample GL evals/s at depth 10", "value": value, "unit": "site-sample GL evals/s",
             "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": dt / opt.steps * 1e3,
@@ -186,6 +233,7 @@ def main():
                        "parallelism": f"site-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "copy_bw_measured": copy_gbs, "frac_of_copy_bw": achieved / copy_gbs,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_eval": b_eval,
                          "kernel_ms_total": dict(zip(names, kms)), "launches": dict(zip(names, klaunch))},
         }

@@ -165,6 +165,9 @@ __global__ __launch_bounds__(256) void k_sample(const VglDevParams P, const VglT
                 uint64_t st = 0; double gx = 0.0; int it_o = 0, it_r = 0;
                 if (have) { const uint32_t m = l_map[k]; it_o = m & 63; it_r = m >> 6; st = aff(P.qs_read_tab[it_r], l_stq[it_o]); }
                 const bool any_changed = (P.gx.changed | P.gy.changed) != 0;
+                // the two gamma samplers' constants, kept in vector registers for the per-iteration selects
+                double gxa1 = P.gx.a1, gxa2 = P.gx.a2, gya1 = P.gy.a1, gya2 = P.gy.a2;
+                asm volatile("" : "+v"(gxa1), "+v"(gxa2), "+v"(gya1), "+v"(gya2));
                 // The bounded-log tests are needed by a few lanes per iteration but cost every lane of the
                 // wave; they run only every P.slow_period-th iteration.  In between, a lane that needs one
                 // holds: its state is left untouched, so the later iteration recomputes the same attempt.
@@ -181,8 +184,8 @@ __global__ __launch_bounds__(256) void k_sample(const VglDevParams P, const VglT
                     const VglAffine tab_n = P.qs_read_tab[r_n];
                     const uint64_t base_n = l_stq[o_n];
 
-                    const double ga1 = stage1 ? P.gy.a1 : P.gx.a1;
-                    const double ga2 = stage1 ? P.gy.a2 : P.gx.a2;
+                    const double ga1 = stage1 ? gya1 : gxa1;
+                    const double ga2 = stage1 ? gya2 : gxa2;
                     // normal attempt
                     const uint64_t st1 = lcg_next(st);
                     const uint64_t st2 = lcg_next(st1);
