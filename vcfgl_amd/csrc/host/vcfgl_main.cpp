@@ -262,10 +262,13 @@ static Vcf read_vcf(const std::string& fn, int n_expected = -1) {
         int gti = -1; for (size_t i = 0; i < fmt.size(); i++) if (fmt[i] == "GT") gti = (int)i;
         if (gti < 0) die("Could not find GT tag at position %ld.", r.pos0 + 1);
         const size_t n = f.size() - 9;
+        if (n != v.samples.size()) die("Record at position %ld has %zu sample columns, the header names %zu samples.", r.pos0 + 1, n, v.samples.size());
+        if (f[3].empty()) die("Empty REF at position %ld.", r.pos0 + 1);
         r.gt.assign(2 * n, -1);
+        static const std::string missing_gt = ".";
         for (size_t s = 0; s < n; s++) {
             split(f[9 + s], ':', g);
-            const std::string& t = g[gti];
+            const std::string& t = ((size_t)gti < g.size()) ? g[gti] : missing_gt;     // trailing FORMAT fields may be dropped
             size_t sep = t.find_first_of("|/");
             std::string x = t.substr(0, sep), y = (sep == std::string::npos) ? x : t.substr(sep + 1);
             r.gt[2 * s] = (x == "." || x.empty()) ? -1 : (int8_t)atoi(x.c_str());
