@@ -1,0 +1,97 @@
+"""--output-mode z / u / b of the host program on the GPU-free --depth inf path: the bgzip'd VCF
+decompresses to the -O v text, and the BCF files, decoded by a reader written from the BCF2 / BGZF
+specifications (tests/bcf_reader.py), give back the same records, truth file included."""
+import gzip
+import os
+import struct
+import subprocess
+
+import pytest
+
+import bcf_reader
+import golden_util as gu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "vcfgl_amd", "bin", "vcfgl_hip")
+DATA = os.path.join(gu.REFVCF, "data")
+pytestmark = pytest.mark.skipif(not os.path.exists(BIN), reason="vcfgl_hip not built")
+
+ARGV = ("--seed 42 --depth inf --error-rate 0 -explode 1 -doUnobserved 1 -printTruth 1 -addGP 1 -addPL 1 "
+        "-addI16 0 -addQS 0 -addFormatDP 0").split()
+
+
+def simple_float(bits):
+    f = struct.unpack("<f", struct.pack("<I", bits))[0]
+    return {0.0: "0", 1.0: "1", float("-inf"): "-inf"}[f]
+
+
+def run(tmp_path, name, mode, vcf="data3.vcf", extra=()):
+    out = str(tmp_path / name)
+    r = subprocess.run([BIN, "-i", os.path.join(DATA, vcf), "-o", out, "-O", mode] + ARGV + list(extra), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1500:]
+    return out
+
+
+def body(lines):
+    return [l.rstrip("\n") for l in lines if not l.startswith("#")]
+
+
+@pytest.mark.parametrize("vcf", ["data3.vcf", "data1.vcf"])
+def test_output_modes_agree(tmp_path, vcf):
+    v = run(tmp_path, "v", "v", vcf)
+    want = body(open(v + ".vcf"))
+    want_truth = body(open(v + ".truth.vcf"))
+    assert len(want) >= 5
+
+    z = run(tmp_path, "z", "z", vcf)
+    raw = open(z + ".vcf.gz", "rb").read()
+    assert body(b"".join(bcf_reader.bgzf_blocks(raw)).decode().splitlines()) == want
+    assert body(gzip.open(z + ".truth.vcf.gz", "rt")) == want_truth
+
+    for mode in ("u", "b"):
+        o = run(tmp_path, mode, mode, vcf)
+        rd = bcf_reader.Reader(o + ".bcf")
+        assert rd.compressed == (mode == "b")
+        assert list(rd.vcf_lines(simple_float)) == want
+        assert rd.header[-1].split("\t")[9:] == open(v + ".vcf").read().split("#CHROM")[1].split("\n")[0].split("\t")[9:]
+        # every dictionary line carries its index; PASS is entry 0
+        assert rd.dict[0] == "PASS"
+        for h in rd.header:
+            if h.startswith(("##FILTER=", "##INFO=", "##FORMAT=", "##contig=")):
+                assert ",IDX=" in h, h
+        rt = bcf_reader.Reader(o + ".truth.bcf")
+        assert list(rt.vcf_lines(simple_float)) == want_truth
+
+
+def test_default_output_mode_is_compressed_bcf(tmp_path):
+    out = str(tmp_path / "dflt")                          # io.cpp:776-777: --output-mode defaults to b
+    r = subprocess.run([BIN, "-i", os.path.join(DATA, "data3.vcf"), "-o", out] + ARGV, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert bcf_reader.Reader(out + ".bcf").compressed
+
+
+def test_record_layout_fields(tmp_path):
+    """Fixed-width fields of the records against the -O v text: 0-based POS, rlen = len(REF), missing QUAL,
+    typed FORMAT arrays; genotypes of the truth file as (allele+1)<<1|phased."""
+    v = run(tmp_path, "v", "v")
+    o = run(tmp_path, "u", "u")
+    rd = bcf_reader.Reader(o + ".bcf")
+    txt = [l.split("\t") for l in body(open(v + ".vcf"))]
+    for rec, src in zip(rd.records(), txt):
+        assert rec["pos0"] == int(src[1]) - 1 and rec["rlen"] == len(src[3]) and rec["qual"] == bcf_reader.F_MISSING
+        assert [k for k, _, _ in rec["fmt"]] == ["GL", "GP", "PL"]
+        assert all(t == 5 for k, t, _ in rec["fmt"] if k in ("GL", "GP"))
+        assert [t for k, t, _ in rec["fmt"] if k == "PL"] == [2]                       # 255 needs int16
+    rt = bcf_reader.Reader(o + ".truth.bcf")
+    for rec, src in zip(rt.records(), [l.split("\t") for l in body(open(v + ".truth.vcf"))]):
+        (k, t, per), = rec["fmt"]
+        assert k == "GT" and t == 1
+        for s, g in enumerate(src[9:]):
+            a, b = g.split("|")
+            assert per[s] == [(int(a) + 1) << 1, ((int(b) + 1) << 1) | 1]
+
+
+def test_multithreading_is_refused_for_text_output(tmp_path):
+    r = subprocess.run([BIN, "-i", os.path.join(DATA, "data3.vcf"), "-o", str(tmp_path / "x"), "-O", "v", "--threads", "4"] + ARGV,
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "Multithreading is not supported for VCF output" in r.stderr       # io.cpp:1206-1210

@@ -29,7 +29,7 @@ def asan_bin(tmp_path_factory):
 
 
 def run(binary, vcf, out, extra=()):
-    r = subprocess.run([binary, "-i", vcf, "-o", out, "--seed", "1", "--depth", "inf", "-e", "0", *extra],
+    r = subprocess.run([binary, "-i", vcf, "-o", out, "--seed", "1", "--depth", "inf", "-e", "0", "-O", "v", *extra],
                        capture_output=True, text=True, timeout=60)
     assert not any(m in r.stderr or m in r.stdout for m in SAN_MARKS), r.stderr[-3000:]
     return r
@@ -45,6 +45,10 @@ def test_reference_case_under_sanitizers(asan_bin, tmp_path):
     ours = [l for l in open(out + ".vcf") if not l.startswith("##")]
     gold = [l for l in open(os.path.join(gu.REFVCF, "reference", "test4", "test4.vcf")) if not l.startswith("##")]
     assert ours == gold
+    for mode in ("z", "u", "b"):                               # the bgzip / BCF writers under the sanitizers
+        r = subprocess.run([asan_bin, "-i", os.path.join(DATA, "data3.vcf"), "-o", out + mode, "--seed", "42", "--depth", "inf",
+                            "--error-rate", "0", "-O", mode] + argv[2:], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and not any(m in r.stderr for m in SAN_MARKS), r.stderr[-3000:]
 
 
 def test_malformed_inputs_fail_cleanly(asan_bin, tmp_path):

@@ -60,6 +60,60 @@ def test_cli_diff_against_reference_golden(name, tmp_path):
         assert a == b
 
 
+class _FloatText:
+    """float32 bit pattern -> VCF text through the host program's own kputd()-style formatter (which
+    tests/test_cli_format_cpu.py pins against every float token of the reference's golden files)."""
+
+    def __init__(self):
+        self.cache = {}
+
+    def prime(self, bits):
+        todo = sorted(set(bits) - set(self.cache))
+        for i in range(0, len(todo), 400):
+            r = subprocess.run([BIN, "--format-floats"] + ["%08x" % b for b in todo[i:i + 400]], capture_output=True, text=True, check=True)
+            self.cache.update(zip(todo[i:i + 400], r.stdout.split("\n")))
+
+    def __call__(self, bits):
+        return self.cache[bits]
+
+
+@pytest.mark.parametrize("mode", ["b", "u"])
+@pytest.mark.parametrize("name", CASES)
+def test_cli_bcf_output_decodes_to_the_reference_golden(name, mode, tmp_path):
+    """--output-mode b / u (the reference's default is b): the BCF file, decoded by the specification-based
+    reader of tests/bcf_reader.py, must give the golden VCF's records (gVCF blocks, truth file included)."""
+    import bcf_reader
+    t = gu.REF_TESTS[name]
+    data = os.path.join(gu.REFVCF, "data")
+    argv, toks = [], t["args"].split()
+    for i in range(0, len(toks), 2):
+        flag, val = toks[i], toks[i + 1]
+        if flag in ("--depths-file", "--qs-bins"):
+            val = os.path.join(data, os.path.basename(val))
+        if flag in ("--output-mode", "-O"):
+            val = mode
+        argv += [flag, val]
+    out = str(tmp_path / name)
+    r = subprocess.run([BIN, "-i", os.path.join(data, t["input"]), "-o", out, "--rng-mode", "1"] + argv, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ft = _FloatText()
+    for suffix in (".bcf", ".truth.bcf"):
+        gold_path = os.path.join(gu.REFVCF, "reference", name, name + suffix.replace("bcf", "vcf"))
+        if suffix == ".truth.bcf" and not ("-printTruth 1" in t["args"] and os.path.exists(gold_path)):
+            continue
+        rd = bcf_reader.Reader(out + suffix)
+        assert rd.compressed == (mode == "b")
+        bits = []
+        for rec in rd.records():
+            bits += [x for _, ty, v in rec["info"] if ty == 5 for x in v]
+            bits += [x for _, ty, per in rec["fmt"] if ty == 5 for v in per for x in v]
+        ft.prime(bits)
+        rd = bcf_reader.Reader(out + suffix)
+        ours = list(rd.vcf_lines(ft))
+        gold = [l.rstrip("\n") for l in open(gold_path) if not l.startswith("#")]
+        assert ours == gold
+
+
 def test_cli_errors_like_the_reference(tmp_path):
     data = os.path.join(gu.REFVCF, "data")
     r = subprocess.run([BIN, "-i", os.path.join(data, "data2.vcf"), "-d", "2"], capture_output=True, text=True)
@@ -75,7 +129,7 @@ def test_cli_tile_mode_independent_of_tile_size(tmp_path):
     for ts in (1, 3, 4096):
         out = str(tmp_path / f"t{ts}")
         r = subprocess.run([BIN, "-i", os.path.join(data, "data3.vcf"), "-o", out, "--seed", "42", "-d", "5", "-e", "0.01", "-explode", "1",
-                            "-addPL", "1", "-addFormatAD", "1", "--tile-sites", str(ts)], capture_output=True, text=True, timeout=300)
+                            "-addPL", "1", "-addFormatAD", "1", "-O", "v", "--tile-sites", str(ts)], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([l for l in open(out + ".vcf") if not l.startswith("##")])
     assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 5

@@ -3,15 +3,15 @@
 //   * the flag parser / defaults / range checks          io.cpp:428-526, 538-752, 757-1000
 //   * the record loop incl. -explode and input filters   vcfgl.cpp:75-163, 1456-1639
 //   * tag formatting of add_tags()                       bcf_utils.cpp:426-507
-//   * VCF text in / out (neither box has htslib): float printing follows htslib's kputd()
-//     (6 significant digits, %g outside [1e-4, 999999]), so `diff -I '^##'` against the
-//     reference's golden VCFs is empty in --rng-mode 1 (serial) runs.
+//   * VCF text in; VCF text / bgzip'd VCF / BCF out (vcf_sink.h; neither box has htslib): float
+//     printing follows htslib's kputd() (6 significant digits, %g outside [1e-4, 999999]), so
+//     `diff -I '^##'` against the reference's golden VCFs is empty in --rng-mode 1 (serial) runs.
 // Records are batched into tiles and simulated on the GPU by vgl_simulate_tile(); there is no
 //   * the gVCF block builder prepare_gvcf_block()         bcf_utils.cpp:662-942
 //   * --depth inf (simulate_record_true_values, vcfgl.cpp:1089-1262): no sampling at all, the true
 //     genotype gets GL 0 / GP 1 / PL 0 and every other genotype -inf / 0 / 255; written directly
 //   * -printTruth 1: the decoded input records (incl. exploded ones) as <prefix>.truth.vcf
-// CPU simulation path here.  Not provided: BCF / bgzip output (-O b|u|z).
+// CPU simulation path here.  Not provided: BCF input.
 #include <math.h>
 #include <stdarg.h>
 #include <stdint.h>
@@ -27,12 +27,19 @@
 #include <vector>
 
 #include "../../../include/vcfgl_hip.h"
+#include "vcf_sink.h"
 
 [[noreturn]] static void die(const char* fmt, ...) {
     va_list ap; va_start(ap, fmt);
     fprintf(stderr, "\n\n*******\n[ERROR] "); vfprintf(stderr, fmt, ap); fprintf(stderr, "\n*******\n");
     va_end(ap);
     exit(1);                                   // shared.h:292-299
+}
+[[noreturn]] void vsink::fail(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt);
+    fprintf(stderr, "\n\n*******\n[ERROR] "); vfprintf(stderr, fmt, ap); fprintf(stderr, "\n*******\n");
+    va_end(ap);
+    exit(1);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -44,7 +51,7 @@ struct Args {
     int rng_mode = VGL_RNG_TILE, beta_sampler = -1, tile_sites = 4096, device = 0, verbose = 0, threads = 1;
     double depth = -1.0, error_rate = -1.0, beta_variance = -1.0, gl1_theta = 0.83, adjust_by = 0.499;
     bool have_depth = false, depth_inf = false;
-    std::string in_fn, out_prefix = "output", output_mode = "v", depths_fn, qs_bins_fn, command;
+    std::string in_fn, out_prefix = "output", output_mode = "b", depths_fn, qs_bins_fn, command;
     std::vector<double> depths;
     std::vector<int32_t> qs_bins;
     std::string gvcf_dps_str;
@@ -148,7 +155,10 @@ static Args parse_args(int argc, char** argv) {
         parts.push_back(cur);
         for (auto& x : parts) { if (x.empty()) die("Could not parse --gvcf-dps %s", a.gvcf_dps_str.c_str()); const int d = atoi(x.c_str()); if (d < 1) die("Invalid DP range: %d", d); a.gvcf_dps.push_back(d); }
     } else if (!a.gvcf_dps_str.empty()) die("-> [--gvcf-dps] --gvcf-dps requires -doGVCF 1. Please set -doGVCF 1 and rerun.");
-    if (a.output_mode != "v") die("--output-mode %s: only uncompressed VCF text (v) is provided (no htslib on this platform)", a.output_mode.c_str());
+    if (a.output_mode != "v" && a.output_mode != "z" && a.output_mode != "u" && a.output_mode != "b")
+        die("[Bad argument value: '--output-mode %s'] Allowed values are b, u, z, v", a.output_mode.c_str());
+    if ((a.output_mode == "v" || a.output_mode == "z") && a.threads > 1)                      // io.cpp:1206-1210
+        die("Multithreading is not supported for VCF output. Please set --threads 1 and rerun.");
     if (a.seed == -1) { a.seed = (int)time(NULL); fprintf(stderr, "\n-> No seed was given. Setting the random seed to the randomly chosen value: %d\n", a.seed); }
     if (a.beta_sampler < 0) a.beta_sampler = (a.rng_mode == VGL_RNG_SERIAL) ? VGL_BETA_STD : VGL_BETA_RAND48;
     if (!a.depths_fn.empty()) {
@@ -417,7 +427,7 @@ struct GvcfBlocker {
         return NO_WRITE;
     }
 
-    void emit(FILE* out, int N) {
+    void emit(vsink::Sink& out, int N) {
         const long end1 = end_pos + 1;                                    // 0-based -> 1-based
         std::string line = chrom;
         char hb[64]; snprintf(hb, sizeof hb, "\t%ld\t.\t", start_pos + 1); line += hb;
@@ -426,7 +436,7 @@ struct GvcfBlocker {
         line += "\t.\t.\t";
         if (end1 - start_pos >= 2) { snprintf(hb, sizeof hb, "END=%ld;", end1); line += hb; }
         snprintf(hb, sizeof hb, "MIN_DP=%d", min_dp); line += hb;
-        if (!qsum.empty()) { line += ";QS="; for (size_t k = 0; k < qsum.size(); k++) { if (k) line += ','; put_float(line, qsum[k]); } }
+        if (!qsum.empty()) { line += ";QS="; for (size_t k = 0; k < qsum.size(); k++) { if (k) line += ','; out.put_float(line, qsum[k]); } }
         line += "\tPL:DP";
         const size_t nG = pl.size() / (size_t)N;
         for (int s = 0; s < N; ++s) {
@@ -434,8 +444,7 @@ struct GvcfBlocker {
             for (size_t g = 0; g < nG; ++g) { if (g) line += ','; put_int(line, pl[(size_t)s * nG + g]); }
             line += ':'; put_int(line, dp[s]);
         }
-        line += '\n';
-        fwrite(line.data(), 1, line.size(), out);
+        out.write_line(line);
         current_dpr = 0; chrom.clear();
     }
 };
@@ -453,30 +462,41 @@ int main(int argc, char** argv) {
     if (N <= 0) die("no samples in %s", a.in_fn.c_str());
     if (!a.depths.empty() && (int)a.depths.size() != N) die("--depths-file must hold one depth per sample (%zu given, %d samples)", a.depths.size(), N);
     std::vector<Site> sites = build_sites(a, vcf);
+    const char mode = a.output_mode[0];
+    const std::string ext = mode == 'v' ? ".vcf" : mode == 'z' ? ".vcf.gz" : ".bcf";
+    // binary output needs every contig / FILTER / INFO key of the records defined in the header
+    auto complete_header = [&](std::vector<std::string>& hdr) {
+        if (mode != 'u' && mode != 'b') return;
+        std::vector<std::string> contigs, filters, keys, tmp;
+        auto add = [](std::vector<std::string>& v, const std::string& x) { if (!x.empty() && std::find(v.begin(), v.end(), x) == v.end()) v.push_back(x); };
+        for (const Site& S : sites) add(contigs, S.chrom);
+        for (const Rec& r : vcf.recs) {
+            add(contigs, r.chrom);
+            split(r.filt, ';', tmp); for (auto& f : tmp) add(filters, f);
+            if (r.info != ".") { split(r.info, ';', tmp); for (auto& kv : tmp) add(keys, kv.substr(0, kv.find('='))); }
+        }
+        vsink::Sink::define_missing(hdr, contigs, filters, keys);
+    };
     if (a.print_truth) {
-        const std::string fn = a.out_prefix + ".truth.vcf";
-        FILE* tf = fopen(fn.c_str(), "w");
-        if (!tf) die("Could not open file: %s", fn.c_str());
-        for (const std::string& h : vcf.header) fprintf(tf, "%s\n", h.c_str());
-        fprintf(tf, "##source=vcfgl_hip\n##source=%s\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT", a.command.c_str());
-        for (const std::string& sn : vcf.samples) fprintf(tf, "\t%s", sn.c_str());
-        fprintf(tf, "\n");
-        for (const std::string& l : g_truth_lines) fprintf(tf, "%s\n", l.c_str());
-        fclose(tf);
+        vsink::Sink ts; ts.text_float = put_float;
+        std::vector<std::string> hdr = vcf.header;
+        hdr.push_back("##source=vcfgl_hip"); hdr.push_back("##source=" + a.command);
+        complete_header(hdr);
+        ts.open(a.out_prefix + ".truth" + ext, mode, hdr, vcf.samples);
+        for (const std::string& l : g_truth_lines) ts.write_line(l);
+        ts.close();
     }
 
     if (a.depth_inf) {                                   // simulate_record_true_values, vcfgl.cpp:1089-1262
-        const std::string fn = a.out_prefix + ".vcf";
-        FILE* out = fopen(fn.c_str(), "w");
-        if (!out) die("Could not open file: %s", fn.c_str());
-        for (const std::string& h : vcf.header) if (h.find("##FORMAT=<ID=GT,") == std::string::npos) fprintf(out, "%s\n", h.c_str());
-        fprintf(out, "##source=vcfgl_hip\n##source=%s\n", a.command.c_str());
-        if (a.add_gl) fprintf(out, "##FORMAT=<ID=GL,Number=G,Type=Float,Description=\"log10 genotype likelihoods, best = 0\">\n");
-        if (a.add_gp) fprintf(out, "##FORMAT=<ID=GP,Number=G,Type=Float,Description=\"Genotype probabilities\">\n");
-        if (a.add_pl) fprintf(out, "##FORMAT=<ID=PL,Number=G,Type=Integer,Description=\"Phred-scaled genotype likelihoods\">\n");
-        fprintf(out, "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT");
-        for (const std::string& sn : vcf.samples) fprintf(out, "\t%s", sn.c_str());
-        fprintf(out, "\n");
+        vsink::Sink out; out.text_float = put_float;
+        std::vector<std::string> hdr;
+        for (const std::string& h : vcf.header) if (h.find("##FORMAT=<ID=GT,") == std::string::npos) hdr.push_back(h);
+        hdr.push_back("##source=vcfgl_hip"); hdr.push_back("##source=" + a.command);
+        if (a.add_gl) hdr.push_back("##FORMAT=<ID=GL,Number=G,Type=Float,Description=\"log10 genotype likelihoods, best = 0\">");
+        if (a.add_gp) hdr.push_back("##FORMAT=<ID=GP,Number=G,Type=Float,Description=\"Genotype probabilities\">");
+        if (a.add_pl) hdr.push_back("##FORMAT=<ID=PL,Number=G,Type=Integer,Description=\"Phred-scaled genotype likelihoods\">");
+        complete_header(hdr);
+        out.open(a.out_prefix + ext, mode, hdr, vcf.samples);
         const bool explode_acgt = a.do_unobserved >= 3;
         const bool add_unobs = (a.do_unobserved == 1 || a.do_unobserved == 2 || a.do_unobserved == 4 || a.do_unobserved == 5);
         const char* nonref = (a.do_unobserved == 1 || a.do_unobserved == 4) ? "<*>" : "<NON_REF>";
@@ -517,10 +537,9 @@ int main(int argc, char** argv) {
                 if (a.add_pl) { sep(); for (int g = 0; g < nG; g++) { if (g) line += ','; line += (g == tg) ? "0" : "255"; } }
                 if (first) line += '.';
             }
-            line += '\n';
-            fwrite(line.data(), 1, line.size(), out);
+            out.write_line(line);
         }
-        fclose(out);
+        out.close();
         fprintf(stderr, "\n\n-> Simulation finished successfully.\n\nSummary:\n\tNumber of samples: %d\n\tTotal number of sites simulated: %zu\n", N, sites.size());
         return 0;
     }
@@ -542,31 +561,33 @@ int main(int argc, char** argv) {
     const int A = vgl_max_alleles(&p), G = vgl_max_genotypes(&p);
 
     // ---- output header (set_hdr, bcf_utils.cpp:511-615): input header minus FORMAT/GT, plus our tags
-    const std::string out_fn = a.out_prefix + ".vcf";
-    FILE* out = fopen(out_fn.c_str(), "w");
-    if (!out) die("Could not open file: %s", out_fn.c_str());
-    for (const std::string& h : vcf.header) if (h.find("##FORMAT=<ID=GT,") == std::string::npos) fprintf(out, "%s\n", h.c_str());
-    fprintf(out, "##source=vcfgl_hip (libvcfgl_hip ABI %d, gfx950)\n##source=%s\n", vgl_abi_version(), a.command.c_str());
-    if (a.do_unobserved == 1 || a.do_unobserved == 4) fprintf(out, "##ALT=<ID=*,Description=\"Any other alternative allele (unobserved)\">\n");
-    if (a.do_unobserved == 2 || a.do_unobserved == 5) fprintf(out, "##ALT=<ID=NON_REF,Description=\"Any other alternative allele (unobserved)\">\n");
-    if (a.do_gvcf) fprintf(out, "##INFO=<ID=END,Number=1,Type=Integer,Description=\"Last position of the non-variant block\">\n"
-                                "##INFO=<ID=MIN_DP,Number=1,Type=Integer,Description=\"Smallest per-sample depth within the block\">\n");
-    if (a.add_fmt_dp) fprintf(out, "##FORMAT=<ID=DP,Number=1,Type=Integer,Description=\"Simulated read depth of the sample\">\n");
-    if (a.add_info_dp) fprintf(out, "##INFO=<ID=DP,Number=1,Type=Integer,Description=\"Read depth summed over samples\">\n");
-    if (a.add_gl) fprintf(out, "##FORMAT=<ID=GL,Number=G,Type=Float,Description=\"log10 genotype likelihoods, best = 0\">\n");
-    if (a.add_pl) fprintf(out, "##FORMAT=<ID=PL,Number=G,Type=Integer,Description=\"Phred-scaled genotype likelihoods\">\n");
-    if (a.add_gp) fprintf(out, "##FORMAT=<ID=GP,Number=G,Type=Float,Description=\"Genotype probabilities\">\n");
-    if (a.add_qs) fprintf(out, "##INFO=<ID=QS,Number=R,Type=Float,Description=\"Normalised per-allele base quality sum\">\n");
-    if (a.add_i16) fprintf(out, "##INFO=<ID=I16,Number=16,Type=Float,Description=\"bcftools call auxiliary tag (fields 13-16 only in --rng-mode 1)\">\n");
-    if (a.add_fmt_ad) fprintf(out, "##FORMAT=<ID=AD,Number=R,Type=Integer,Description=\"Allelic depths\">\n");
-    if (a.add_fmt_adf) fprintf(out, "##FORMAT=<ID=ADF,Number=R,Type=Integer,Description=\"Allelic depths, forward strand\">\n");
-    if (a.add_fmt_adr) fprintf(out, "##FORMAT=<ID=ADR,Number=R,Type=Integer,Description=\"Allelic depths, reverse strand\">\n");
-    if (a.add_info_ad) fprintf(out, "##INFO=<ID=AD,Number=R,Type=Integer,Description=\"Total allelic depths\">\n");
-    if (a.add_info_adf) fprintf(out, "##INFO=<ID=ADF,Number=R,Type=Integer,Description=\"Total allelic depths, forward strand\">\n");
-    if (a.add_info_adr) fprintf(out, "##INFO=<ID=ADR,Number=R,Type=Integer,Description=\"Total allelic depths, reverse strand\">\n");
-    fprintf(out, "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT");
-    for (const std::string& s : vcf.samples) fprintf(out, "\t%s", s.c_str());
-    fprintf(out, "\n");
+    vsink::Sink out; out.text_float = put_float;
+    {
+        std::vector<std::string> hdr;
+        char hb[128];
+        for (const std::string& h : vcf.header) if (h.find("##FORMAT=<ID=GT,") == std::string::npos) hdr.push_back(h);
+        snprintf(hb, sizeof hb, "##source=vcfgl_hip (libvcfgl_hip ABI %d, gfx950)", vgl_abi_version()); hdr.push_back(hb);
+        hdr.push_back("##source=" + a.command);
+        if (a.do_unobserved == 1 || a.do_unobserved == 4) hdr.push_back("##ALT=<ID=*,Description=\"Any other alternative allele (unobserved)\">");
+        if (a.do_unobserved == 2 || a.do_unobserved == 5) hdr.push_back("##ALT=<ID=NON_REF,Description=\"Any other alternative allele (unobserved)\">");
+        if (a.do_gvcf) { hdr.push_back("##INFO=<ID=END,Number=1,Type=Integer,Description=\"Last position of the non-variant block\">");
+                         hdr.push_back("##INFO=<ID=MIN_DP,Number=1,Type=Integer,Description=\"Smallest per-sample depth within the block\">"); }
+        if (a.add_fmt_dp) hdr.push_back("##FORMAT=<ID=DP,Number=1,Type=Integer,Description=\"Simulated read depth of the sample\">");
+        if (a.add_info_dp) hdr.push_back("##INFO=<ID=DP,Number=1,Type=Integer,Description=\"Read depth summed over samples\">");
+        if (a.add_gl) hdr.push_back("##FORMAT=<ID=GL,Number=G,Type=Float,Description=\"log10 genotype likelihoods, best = 0\">");
+        if (a.add_pl) hdr.push_back("##FORMAT=<ID=PL,Number=G,Type=Integer,Description=\"Phred-scaled genotype likelihoods\">");
+        if (a.add_gp) hdr.push_back("##FORMAT=<ID=GP,Number=G,Type=Float,Description=\"Genotype probabilities\">");
+        if (a.add_qs) hdr.push_back("##INFO=<ID=QS,Number=R,Type=Float,Description=\"Normalised per-allele base quality sum\">");
+        if (a.add_i16) hdr.push_back("##INFO=<ID=I16,Number=16,Type=Float,Description=\"bcftools call auxiliary tag (fields 13-16 only in --rng-mode 1)\">");
+        if (a.add_fmt_ad) hdr.push_back("##FORMAT=<ID=AD,Number=R,Type=Integer,Description=\"Allelic depths\">");
+        if (a.add_fmt_adf) hdr.push_back("##FORMAT=<ID=ADF,Number=R,Type=Integer,Description=\"Allelic depths, forward strand\">");
+        if (a.add_fmt_adr) hdr.push_back("##FORMAT=<ID=ADR,Number=R,Type=Integer,Description=\"Allelic depths, reverse strand\">");
+        if (a.add_info_ad) hdr.push_back("##INFO=<ID=AD,Number=R,Type=Integer,Description=\"Total allelic depths\">");
+        if (a.add_info_adf) hdr.push_back("##INFO=<ID=ADF,Number=R,Type=Integer,Description=\"Total allelic depths, forward strand\">");
+        if (a.add_info_adr) hdr.push_back("##INFO=<ID=ADR,Number=R,Type=Integer,Description=\"Total allelic depths, reverse strand\">");
+        complete_header(hdr);
+        out.open(a.out_prefix + ext, mode, hdr, vcf.samples);
+    }
     gzFile pile = nullptr;
     if (a.print_pileup) { pile = gzopen((a.out_prefix + ".pileup.gz").c_str(), "wb"); if (!pile) die("Could not open pileup output"); }
 
@@ -638,32 +659,22 @@ int main(int argc, char** argv) {
             std::string info = (S.rec->info == ".") ? "" : S.rec->info;
             auto add_key = [&](const char* k) { if (!info.empty()) info += ';'; info += k; info += '='; };
             if (a.add_info_dp) { add_key("DP"); put_int(info, idp[i]); }
-            if (a.add_qs) { add_key("QS"); for (int k = 0; k < nA; k++) { if (k) info += ','; put_float(info, qs[(size_t)i * A + k]); } }
-            if (a.add_i16) { add_key("I16"); for (int k = 0; k < 16; k++) { if (k) info += ','; put_float(info, i16[(size_t)i * 16 + k]); } }
+            if (a.add_qs) { add_key("QS"); for (int k = 0; k < nA; k++) { if (k) info += ','; out.put_float(info, qs[(size_t)i * A + k]); } }
+            if (a.add_i16) { add_key("I16"); for (int k = 0; k < 16; k++) { if (k) info += ','; out.put_float(info, i16[(size_t)i * 16 + k]); } }
             if (a.add_info_ad) { add_key("AD"); for (int k = 0; k < nA; k++) { if (k) info += ','; put_int(info, iad[(size_t)i * A + k]); } }
             if (a.add_info_adf) { add_key("ADF"); for (int k = 0; k < nA; k++) { if (k) info += ','; put_int(info, iadf[(size_t)i * A + k]); } }
             if (a.add_info_adr) { add_key("ADR"); for (int k = 0; k < nA; k++) { if (k) info += ','; put_int(info, iadr[(size_t)i * A + k]); } }
             line += info.empty() ? "." : info;
-            // FORMAT keys: DP, GL, PL, GP, AD, ADF, ADR
-            std::string fmt;
-            auto add_fmt = [&](const char* k) { if (!fmt.empty()) fmt += ':'; fmt += k; };
-            if (a.add_fmt_dp) add_fmt("DP"); if (a.add_gl) add_fmt("GL"); if (a.add_pl) add_fmt("PL"); if (a.add_gp) add_fmt("GP");
-            if (a.add_fmt_ad) add_fmt("AD"); if (a.add_fmt_adf) add_fmt("ADF"); if (a.add_fmt_adr) add_fmt("ADR");
-            line += '\t'; line += fmt.empty() ? "." : fmt;
-            for (int s = 0; s < N; s++) {
-                line += '\t';
-                bool first = true;
-                auto sep = [&]() { if (!first) line += ':'; first = false; };
-                if (a.add_fmt_dp) { sep(); put_int(line, dp[(size_t)i * N + s]); }
-                if (a.add_gl) { sep(); for (int g = 0; g < nG; g++) { if (g) line += ','; put_float(line, gl[((size_t)i * G + g) * N + s]); } }
-                if (a.add_pl) { sep(); for (int g = 0; g < nG; g++) { if (g) line += ','; put_int(line, pl[((size_t)i * G + g) * N + s]); } }
-                if (a.add_gp) { sep(); for (int g = 0; g < nG; g++) { if (g) line += ','; put_float(line, gp[((size_t)i * G + g) * N + s]); } }
-                if (a.add_fmt_ad) { sep(); for (int k = 0; k < nA; k++) { if (k) line += ','; put_int(line, ad[((size_t)i * A + k) * N + s]); } }
-                if (a.add_fmt_adf) { sep(); for (int k = 0; k < nA; k++) { if (k) line += ','; put_int(line, adf[((size_t)i * A + k) * N + s]); } }
-                if (a.add_fmt_adr) { sep(); for (int k = 0; k < nA; k++) { if (k) line += ','; put_int(line, adr[((size_t)i * A + k) * N + s]); } }
-                if (first) line += '.';
-            }
-            line += '\n';
+            // FORMAT keys: DP, GL, PL, GP, AD, ADF, ADR; sample s, element k of a tag at plane[k * N + s]
+            std::vector<vsink::FmtDesc> fmt;
+            const size_t sN = (size_t)N;
+            if (a.add_fmt_dp) fmt.push_back({"DP", false, 1, &dp[(size_t)i * N], 1, sN});
+            if (a.add_gl) fmt.push_back({"GL", true, nG, &gl[(size_t)i * G * N], 1, sN});
+            if (a.add_pl) fmt.push_back({"PL", false, nG, &pl[(size_t)i * G * N], 1, sN});
+            if (a.add_gp) fmt.push_back({"GP", true, nG, &gp[(size_t)i * G * N], 1, sN});
+            if (a.add_fmt_ad) fmt.push_back({"AD", false, nA, &ad[(size_t)i * A * N], 1, sN});
+            if (a.add_fmt_adf) fmt.push_back({"ADF", false, nA, &adf[(size_t)i * A * N], 1, sN});
+            if (a.add_fmt_adr) fmt.push_back({"ADR", false, nA, &adr[(size_t)i * A * N], 1, sN});
             if (a.do_gvcf) {                                             // write_record_values, vcfgl.cpp:167-206
                 SiteView sv;
                 sv.chrom = &S.chrom; sv.pos0 = S.pos0; sv.n_obs = nobs[i]; sv.n_alleles = nA; sv.N = N; sv.G = G;
@@ -671,15 +682,15 @@ int main(int argc, char** argv) {
                 sv.alleles = al[0]; for (size_t k = 1; k < al.size(); k++) { sv.alleles += ','; sv.alleles += al[k]; }
                 int ret = gv.prepare(&sv);
                 if (ret == GvcfBlocker::FLUSH_BLOCK) { gv.emit(out, N); n_out++; ret = gv.prepare(&sv); }
-                if (ret == GvcfBlocker::WRITE_SIMREC) { fwrite(line.data(), 1, line.size(), out); n_out++; }
+                if (ret == GvcfBlocker::WRITE_SIMREC) { out.write_rec(line, fmt); n_out++; }
                 continue;
             }
-            fwrite(line.data(), 1, line.size(), out);
+            out.write_rec(line, fmt);
             n_out++;
         }
     }
     if (a.do_gvcf && gv.prepare(nullptr) == GvcfBlocker::FLUSH_BLOCK) { gv.emit(out, N); n_out++; }
-    fclose(out);
+    out.close();
     if (pile) gzclose(pile);
     vgl_ctx_destroy(ctx);
     fprintf(stderr, "\n\n-> Simulation finished successfully.\n\nSummary:\n\tNumber of samples: %d\n\tTotal number of sites simulated: %zu\n"
