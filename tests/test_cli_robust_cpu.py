@@ -24,7 +24,7 @@ def asan_bin(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("asan") / "vcfgl_asan")
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
                            "-I" + os.path.join(ROOT, "include"), "-o", out, os.path.join(CSRC, "host", "vcfgl_main.cpp"),
-                           "-L" + LIB, "-lvcfgl_hip", "-lz", "-Wl,-rpath," + LIB])
+                           "-L" + LIB, "-lvcfgl_hip", "-lz", "-pthread", "-Wl,-rpath," + LIB])
     return out
 
 

@@ -133,3 +133,21 @@ def test_cli_tile_mode_independent_of_tile_size(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([l for l in open(out + ".vcf") if not l.startswith("##")])
     assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 5
+
+
+def test_cli_threads_do_not_change_the_file(tmp_path):
+    """--threads N encodes records and compresses BGZF blocks on N threads; the record bytes are the same
+    (the header differs in its command line)"""
+    import bcf_reader
+    data = os.path.join(gu.REFVCF, "data")
+    blobs = []
+    for th in (1, 7):
+        out = str(tmp_path / f"th{th}")
+        r = subprocess.run([BIN, "-i", os.path.join(data, "data3.vcf"), "-o", out, "--seed", "42", "-d", "5", "-e", "0.01",
+                            "-explode", "1", "-addPL", "1", "-addGP", "1", "-addFormatAD", "1", "-addQS", "1", "-O", "b", "--threads", str(th),
+                            "--tile-sites", "5"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        rd = bcf_reader.Reader(out + ".bcf")
+        assert rd.compressed
+        blobs.append(rd.raw[rd.off:])
+    assert blobs[0] == blobs[1] and len(blobs[0]) > 500

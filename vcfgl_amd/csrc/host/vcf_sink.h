@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace vsink {
@@ -27,37 +28,42 @@ namespace vsink {
 [[noreturn]] void fail(const char* fmt, ...);          // provided by the host program (prints, exits 1)
 
 // ---------------------------------------------------------------------------------------
+// fn(i) for i in [0, n) on up to `threads` threads (contiguous index ranges)
+template <class F>
+static void parallel_for(int n, int threads, F fn) {
+    if (threads <= 1 || n <= 1) { for (int i = 0; i < n; i++) fn(i); return; }
+    const int T = std::min(threads, n);
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++)
+        th.emplace_back([=]() { for (int i = (int)((int64_t)n * t / T), e = (int)((int64_t)n * (t + 1) / T); i < e; i++) fn(i); });
+    for (auto& x : th) x.join();
+}
+
+// ---------------------------------------------------------------------------------------
 // BGZF: a series of gzip members of at most 64 KiB, each carrying its compressed size in a 'BC'
-// extra field, ended by an empty member
+// extra field, ended by an empty member.  Members are independent, so --threads N compresses N
+// at a time (the role of htslib's thread pool, vcfgl.cpp:1790-1803); the file does not depend on N.
 class Bgzf {
   public:
-    void open(FILE* f) { fp = f; buf.reserve(BLOCK); }
+    void open(FILE* f, int threads_) { fp = f; threads = std::max(1, threads_); buf.reserve(BLOCK * (size_t)batch()); }
     void write(const void* p, size_t n) {
         const uint8_t* b = (const uint8_t*)p;
+        const size_t cap = BLOCK * (size_t)batch();
         while (n) {
-            const size_t k = std::min(n, BLOCK - buf.size());
+            const size_t k = std::min(n, cap - buf.size());
             buf.insert(buf.end(), b, b + k); b += k; n -= k;
-            if (buf.size() == BLOCK) flush();
+            if (buf.size() == cap) flush();
         }
     }
     void flush() {
         if (buf.empty()) return;
-        uint8_t out[65536];
-        z_stream zs; memset(&zs, 0, sizeof zs);
-        if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) fail("deflateInit2 failed");
-        zs.next_in = buf.data(); zs.avail_in = (uInt)buf.size();
-        zs.next_out = out + 18; zs.avail_out = sizeof out - 18 - 8;
-        if (deflate(&zs, Z_FINISH) != Z_STREAM_END) fail("BGZF block did not fit");       // 0xff00 input bytes always fit
-        const size_t clen = zs.total_out;
-        deflateEnd(&zs);
-        static const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
-        memcpy(out, hdr, 16);
-        const uint16_t bsize = (uint16_t)(clen + 18 + 8 - 1);
-        out[16] = (uint8_t)(bsize & 0xff); out[17] = (uint8_t)(bsize >> 8);
-        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), buf.data(), (uInt)buf.size()), isz = (uint32_t)buf.size();
-        uint8_t* t = out + 18 + clen;
-        for (int i = 0; i < 4; i++) { t[i] = (uint8_t)(crc >> (8 * i)); t[4 + i] = (uint8_t)(isz >> (8 * i)); }
-        if (fwrite(out, 1, clen + 26, fp) != clen + 26) fail("write error");
+        const int nb = (int)((buf.size() + BLOCK - 1) / BLOCK);
+        std::vector<std::vector<uint8_t>> out(nb);
+        parallel_for(nb, threads, [&](int i) {
+            const size_t off = (size_t)i * BLOCK, len = std::min(BLOCK, buf.size() - off);
+            compress_block(buf.data() + off, len, out[i]);
+        });
+        for (auto& o : out) if (fwrite(o.data(), 1, o.size(), fp) != o.size()) fail("write error");
         buf.clear();
     }
     void close() {
@@ -68,7 +74,28 @@ class Bgzf {
   private:
     static constexpr size_t BLOCK = 0xff00;
     FILE* fp = nullptr;
+    int threads = 1;
     std::vector<uint8_t> buf;
+    int batch() const { return threads == 1 ? 1 : threads * 4; }
+    static void compress_block(const uint8_t* in, size_t len, std::vector<uint8_t>& o) {
+        o.resize(65536);
+        uint8_t* out = o.data();
+        z_stream zs; memset(&zs, 0, sizeof zs);
+        if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) fail("deflateInit2 failed");
+        zs.next_in = const_cast<uint8_t*>(in); zs.avail_in = (uInt)len;
+        zs.next_out = out + 18; zs.avail_out = 65536 - 18 - 8;
+        if (deflate(&zs, Z_FINISH) != Z_STREAM_END) fail("BGZF block did not fit");       // 0xff00 input bytes always fit
+        const size_t clen = zs.total_out;
+        deflateEnd(&zs);
+        static const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+        memcpy(out, hdr, 16);
+        const uint16_t bsize = (uint16_t)(clen + 18 + 8 - 1);
+        out[16] = (uint8_t)(bsize & 0xff); out[17] = (uint8_t)(bsize >> 8);
+        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), in, (uInt)len), isz = (uint32_t)len;
+        uint8_t* t = out + 18 + clen;
+        for (int i = 0; i < 4; i++) { t[i] = (uint8_t)(crc >> (8 * i)); t[4 + i] = (uint8_t)(isz >> (8 * i)); }
+        o.resize(clen + 26);
+    }
 };
 
 // ---------------------------------------------------------------------------------------
@@ -97,11 +124,11 @@ class Sink {
 
     // header = the '##' lines in output order; records may only use contigs / keys these lines define
     // (define_missing() adds the definitions htslib would add with a warning)
-    void open(const std::string& path, char mode_, std::vector<std::string> header, const std::vector<std::string>& samples) {
+    void open(const std::string& path, char mode_, std::vector<std::string> header, const std::vector<std::string>& samples, int threads = 1) {
         mode = mode_; N = (int)samples.size();
         fp = fopen(path.c_str(), "wb");
         if (!fp) fail("Could not open file: %s", path.c_str());
-        if (mode == 'z' || mode == 'b') bg.open(fp);
+        if (mode == 'z' || mode == 'b') bg.open(fp, threads);
         if (binary()) build_dictionaries(header);
         std::string text;
         for (const std::string& h : header) { text += h; text += '\n'; }
@@ -129,22 +156,29 @@ class Sink {
         for (const std::string& k : info_keys) if (!has("##INFO=<", k)) header.push_back("##INFO=<ID=" + k + ",Number=1,Type=String,Description=\"Dummy\">");
     }
 
+    // Records are encoded into byte strings by encode_line() / encode_rec() (const: several threads may
+    // encode different records at once) and appended to the file in order by put().
+    void put(const std::string& bytes) { emit(bytes.data(), bytes.size()); }
+    void write_line(const std::string& line) { std::string b; encode_line(line, b); put(b); }
+    void write_rec(const std::string& shared8, const std::vector<FmtDesc>& fmt) { std::string b; encode_rec(shared8, fmt, b); put(b); }
+
     // a complete VCF record as text (without the newline)
-    void write_line(const std::string& line) {
-        if (!binary()) { emit(line.data(), line.size()); emit("\n", 1); return; }
+    void encode_line(const std::string& line, std::string& out) const {
+        if (!binary()) { out += line; out += '\n'; return; }
         std::vector<std::string> col; split(line, '\t', col);
         if (col.size() < 8) fail("internal: short VCF line");
         std::string shared, indiv;
         uint32_t n_fmt = 0;
         if (col.size() > 9 && col[8] != ".") n_fmt = encode_format_text(col, indiv);
         encode_shared(col, n_fmt, shared);
-        finish(shared, indiv);
+        finish(shared, indiv, out);
     }
 
     // eight fixed columns as text + typed FORMAT arrays
-    void write_rec(const std::string& shared8, const std::vector<FmtDesc>& fmt) {
+    void encode_rec(const std::string& shared8, const std::vector<FmtDesc>& fmt, std::string& out) const {
         if (!binary()) {
-            std::string line = shared8;
+            std::string& line = out;
+            line += shared8;
             line += '\t';
             if (fmt.empty()) line += '.';
             for (size_t i = 0; i < fmt.size(); i++) { if (i) line += ':'; line += fmt[i].key; }
@@ -162,7 +196,6 @@ class Sink {
                 }
             }
             line += '\n';
-            emit(line.data(), line.size());
             return;
         }
         std::vector<std::string> col; split(shared8, '\t', col);
@@ -190,7 +223,7 @@ class Sink {
             }
         }
         encode_shared(col, (uint32_t)fmt.size(), shared);
-        finish(shared, indiv);
+        finish(shared, indiv, out);
     }
 
     void close() {
@@ -212,9 +245,9 @@ class Sink {
         if (mode == 'z' || mode == 'b') bg.write(p, n);
         else if (fwrite(p, 1, n, fp) != n) fail("write error");
     }
-    void finish(const std::string& shared, const std::string& indiv) {
-        std::string h; put_u32(h, (uint32_t)shared.size()); put_u32(h, (uint32_t)indiv.size());
-        emit(h.data(), h.size()); emit(shared.data(), shared.size()); emit(indiv.data(), indiv.size());
+    static void finish(const std::string& shared, const std::string& indiv, std::string& out) {
+        put_u32(out, (uint32_t)shared.size()); put_u32(out, (uint32_t)indiv.size());
+        out += shared; out += indiv;
     }
     static void split(const std::string& s, char c, std::vector<std::string>& out) {
         out.clear(); size_t b = 0;
@@ -301,7 +334,7 @@ class Sink {
     static int32_t int_value(const std::string& t) { return t == "." ? I32_MISSING : (int32_t)strtol(t.c_str(), nullptr, 10); }
 
     // CHROM .. INFO (BCF2 section 6.3.1)
-    void encode_shared(const std::vector<std::string>& col, uint32_t n_fmt, std::string& out) {
+    void encode_shared(const std::vector<std::string>& col, uint32_t n_fmt, std::string& out) const {
         auto c = contig.find(col[0]);
         if (c == contig.end()) fail("contig %s is not defined in the output header", col[0].c_str());
         std::vector<std::string> alleles, alts, infos, filt;
@@ -342,7 +375,7 @@ class Sink {
     }
 
     // FORMAT column + sample columns of a text record (BCF2 section 6.3.3); returns the number of fields
-    uint32_t encode_format_text(const std::vector<std::string>& col, std::string& out) {
+    uint32_t encode_format_text(const std::vector<std::string>& col, std::string& out) const {
         std::vector<std::string> keys; split(col[8], ':', keys);
         if ((int)col.size() - 9 != N) fail("internal: record with %d sample columns, %d samples", (int)col.size() - 9, N);
         std::vector<std::vector<std::string>> smp(N);

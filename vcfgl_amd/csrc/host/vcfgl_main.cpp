@@ -48,7 +48,7 @@ struct Args {
     int explode = 0, rm_invar = 0, rm_empty = 0, do_unobserved = 1, do_gvcf = 0, print_pileup = 0, print_truth = 0;
     int add_gl = 1, add_gp = 0, add_pl = 0, add_i16 = 0, add_qs = 0, add_fmt_dp = 1, add_info_dp = 0;
     int add_fmt_ad = 0, add_info_ad = 0, add_fmt_adf = 0, add_info_adf = 0, add_fmt_adr = 0, add_info_adr = 0;
-    int rng_mode = VGL_RNG_TILE, beta_sampler = -1, tile_sites = 4096, device = 0, verbose = 0, threads = 1;
+    int rng_mode = VGL_RNG_TILE, beta_sampler = -1, tile_sites = 4096, device = 0, verbose = 0, threads = 1, enc_threads = 0;
     double depth = -1.0, error_rate = -1.0, beta_variance = -1.0, gl1_theta = 0.83, adjust_by = 0.499;
     bool have_depth = false, depth_inf = false;
     std::string in_fn, out_prefix = "output", output_mode = "b", depths_fn, qs_bins_fn, command;
@@ -113,6 +113,7 @@ static Args parse_args(int argc, char** argv) {
         else if (f == "-addInfoADR") a.add_info_adr = I(v);
         else if (f == "--verbose" || f == "-V") a.verbose = I(v);
         else if (f == "--threads" || f == "-@") a.threads = I(v);
+        else if (f == "--encode-threads") a.enc_threads = I(v);      // extension: record-encoding threads (any output mode)
         // extensions of this implementation
         else if (f == "--rng-mode") a.rng_mode = I(v);
         else if (f == "--beta-sampler") a.beta_sampler = I(v);
@@ -236,15 +237,17 @@ static void split(const std::string& s, char c, std::vector<std::string>& out) {
     while (true) { size_t e = s.find(c, b); if (e == std::string::npos) { out.push_back(s.substr(b)); break; } out.push_back(s.substr(b, e - b)); b = e + 1; }
 }
 
-static Vcf read_vcf(const std::string& fn, int n_expected = -1) {
+// keep_gt_text: the GT tokens as written are needed only by -printTruth
+static Vcf read_vcf(const std::string& fn, bool keep_gt_text) {
     gzFile fp = gzopen(fn.c_str(), "r");               // plain text or gzip
     if (!fp) die("Could not open file: %s", fn.c_str());
+    gzbuffer(fp, 1 << 20);
     Vcf v;
-    std::string line; char buf[1 << 16];
+    std::string line; std::vector<char> buf(1 << 20);
     std::vector<std::string> f, g, fmt;
     auto getline = [&]() -> bool {
         line.clear();
-        while (gzgets(fp, buf, sizeof buf)) { line += buf; if (!line.empty() && line.back() == '\n') { line.pop_back(); return true; } }
+        while (gzgets(fp, buf.data(), (int)buf.size())) { line += buf.data(); if (!line.empty() && line.back() == '\n') { line.pop_back(); return true; } }
         return !line.empty();
     };
     while (getline()) {
@@ -260,35 +263,50 @@ static Vcf read_vcf(const std::string& fn, int n_expected = -1) {
             }
             continue;
         }
-        split(line, '\t', f);
-        if (line[0] == '#') { for (size_t i = 9; i < f.size(); i++) v.samples.push_back(f[i]); continue; }
-        if (f.size() < 10) die("VCF record with fewer than 10 columns (a FORMAT/GT column is required)");
+        if (line[0] == '#') { split(line, '\t', f); for (size_t i = 9; i < f.size(); i++) v.samples.push_back(f[i]); continue; }
+        // the nine fixed columns, then one pass over the sample columns without copying them
+        size_t col_at[10]; int nc = 0; col_at[0] = 0;
+        for (size_t i = 0; i < line.size() && nc < 9; i++) if (line[i] == '\t') col_at[++nc] = i + 1;
+        if (nc < 9) die("VCF record with fewer than 10 columns (a FORMAT/GT column is required)");
+        auto col = [&](int k) { return line.substr(col_at[k], col_at[k + 1] - 1 - col_at[k]); };
         Rec r;
-        r.chrom = f[0]; r.pos0 = atol(f[1].c_str()) - 1; r.id = f[2]; r.qual = f[5]; r.filt = f[6]; r.info = f[7];
-        r.alleles.push_back(f[3]);
-        if (f[4] != ".") { split(f[4], ',', g); for (auto& x : g) r.alleles.push_back(x); }
-        r.ref_char = f[3][0];
-        split(f[8], ':', fmt);
+        r.chrom = col(0); r.pos0 = atol(line.c_str() + col_at[1]) - 1; r.id = col(2); r.qual = col(5); r.filt = col(6); r.info = col(7);
+        const std::string ref = col(3), alt = col(4);
+        r.alleles.push_back(ref);
+        if (alt != ".") { split(alt, ',', g); for (auto& x : g) r.alleles.push_back(x); }
+        if (ref.empty()) die("Empty REF at position %ld.", r.pos0 + 1);
+        r.ref_char = ref[0];
+        split(col(8), ':', fmt);
         int gti = -1; for (size_t i = 0; i < fmt.size(); i++) if (fmt[i] == "GT") gti = (int)i;
         if (gti < 0) die("Could not find GT tag at position %ld.", r.pos0 + 1);
-        const size_t n = f.size() - 9;
-        if (n != v.samples.size()) die("Record at position %ld has %zu sample columns, the header names %zu samples.", r.pos0 + 1, n, v.samples.size());
-        if (f[3].empty()) die("Empty REF at position %ld.", r.pos0 + 1);
-        r.gt.assign(2 * n, -1);
-        static const std::string missing_gt = ".";
-        for (size_t s = 0; s < n; s++) {
-            split(f[9 + s], ':', g);
-            const std::string& t = ((size_t)gti < g.size()) ? g[gti] : missing_gt;     // trailing FORMAT fields may be dropped
-            size_t sep = t.find_first_of("|/");
-            std::string x = t.substr(0, sep), y = (sep == std::string::npos) ? x : t.substr(sep + 1);
-            r.gt[2 * s] = (x == "." || x.empty()) ? -1 : (int8_t)atoi(x.c_str());
-            r.gt[2 * s + 1] = (y == "." || y.empty()) ? -1 : (int8_t)atoi(y.c_str());
-            r.gt_str.push_back(t);
+        const size_t n_hdr = v.samples.size();
+        r.gt.assign(2 * n_hdr, -1);
+        const char* p = line.c_str() + col_at[9];
+        const char* const end = line.c_str() + line.size();
+        size_t s = 0;
+        while (true) {                                       // p at the start of a sample column
+            const char* ce = (const char*)memchr(p, '\t', (size_t)(end - p)); if (!ce) ce = end;
+            if (s >= n_hdr) { s++; if (ce == end) break; p = ce + 1; continue; }
+            const char* t = p;                               // the gti-th ':'-separated subfield; trailing ones may be dropped
+            for (int k = 0; k < gti && t; k++) { t = (const char*)memchr(t, ':', (size_t)(ce - t)); if (t) t++; }
+            const char* te = t ? (const char*)memchr(t, ':', (size_t)(ce - t)) : nullptr; if (t && !te) te = ce;
+            int8_t a0 = -1, a1 = -1;
+            if (t) {
+                const char* sep = t; while (sep < te && *sep != '|' && *sep != '/') sep++;
+                auto allele = [](const char* b, const char* e) -> int8_t { return (b == e || *b == '.') ? (int8_t)-1 : (int8_t)atoi(std::string(b, e).c_str()); };
+                a0 = allele(t, sep);
+                a1 = (sep == te) ? a0 : allele(sep + 1, te);
+                if (keep_gt_text) r.gt_str.emplace_back(t, te);
+            } else if (keep_gt_text) r.gt_str.emplace_back(".");
+            r.gt[2 * s] = a0; r.gt[2 * s + 1] = a1;
+            s++;
+            if (ce == end) break;
+            p = ce + 1;
         }
+        if (s != n_hdr) die("Record at position %ld has %zu sample columns, the header names %zu samples.", r.pos0 + 1, s, n_hdr);
         v.recs.push_back(std::move(r));
     }
     gzclose(fp);
-    (void)n_expected;
     return v;
 }
 
@@ -457,11 +475,18 @@ int main(int argc, char** argv) {
         return 0;
     }
     Args a = parse_args(argc, argv);
-    Vcf vcf = read_vcf(a.in_fn);
+    // --verbose 1: wall-clock seconds per stage on stderr at the end
+    double t_stage[6] = {0, 0, 0, 0, 0, 0};                   // read, sites, context, simulate, encode, write
+    auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
+    double t_mark = now();
+    auto lap = [&](int k) { const double t = now(); t_stage[k] += t - t_mark; t_mark = t; };
+    Vcf vcf = read_vcf(a.in_fn, a.print_truth != 0);
+    lap(0);
     const int N = (int)vcf.samples.size();
     if (N <= 0) die("no samples in %s", a.in_fn.c_str());
     if (!a.depths.empty() && (int)a.depths.size() != N) die("--depths-file must hold one depth per sample (%zu given, %d samples)", a.depths.size(), N);
     std::vector<Site> sites = build_sites(a, vcf);
+    lap(1);
     const char mode = a.output_mode[0];
     const std::string ext = mode == 'v' ? ".vcf" : mode == 'z' ? ".vcf.gz" : ".bcf";
     // binary output needs every contig / FILTER / INFO key of the records defined in the header
@@ -557,7 +582,9 @@ int main(int argc, char** argv) {
     int TS = a.tile_sites > 0 ? a.tile_sites : 4096;
     if (a.print_pileup) TS = std::max(1, std::min(TS, (int)((64u << 20) / ((size_t)1024 * (size_t)std::max(N, 1)) + 1)));
     vgl_ctx* ctx = nullptr;
+    t_mark = now();
     if (vgl_ctx_create(&p, a.device, TS, &ctx) != VGL_OK) die("%s", vgl_last_error());
+    lap(2);
     const int A = vgl_max_alleles(&p), G = vgl_max_genotypes(&p);
 
     // ---- output header (set_hdr, bcf_utils.cpp:511-615): input header minus FORMAT/GT, plus our tags
@@ -586,7 +613,7 @@ int main(int argc, char** argv) {
         if (a.add_info_adf) hdr.push_back("##INFO=<ID=ADF,Number=R,Type=Integer,Description=\"Total allelic depths, forward strand\">");
         if (a.add_info_adr) hdr.push_back("##INFO=<ID=ADR,Number=R,Type=Integer,Description=\"Total allelic depths, reverse strand\">");
         complete_header(hdr);
-        out.open(a.out_prefix + ext, mode, hdr, vcf.samples);
+        out.open(a.out_prefix + ext, mode, hdr, vcf.samples, a.threads);
     }
     gzFile pile = nullptr;
     if (a.print_pileup) { pile = gzopen((a.out_prefix + ".pileup.gz").c_str(), "wb"); if (!pile) die("Could not open pileup output"); }
@@ -614,7 +641,45 @@ int main(int argc, char** argv) {
     long n_out = 0, n_skipped = 0;
     std::string line;
     GvcfBlocker gv;
+    std::vector<std::string> enc;
     gv.block_dps = a.gvcf_dps;
+    // one simulated record of the current tile: the eight fixed columns as text, the allele strings and the
+    // typed FORMAT arrays (reads the tile buffers only: records of a tile are built on several threads)
+    auto build_record = [&](size_t t0, int i, std::string& line, std::vector<std::string>& al, std::vector<vsink::FmtDesc>& fmt) {
+        const Site& S = sites[t0 + i];
+        const int nA = na[i], nG = nA * (nA + 1) / 2;
+        char hb[64];
+        line += S.chrom; snprintf(hb, sizeof hb, "\t%ld\t", S.pos0 + 1); line += hb;
+        line += S.rec->id; line += '\t';
+        // alleles (vcfgl.cpp:739-762; no-reads site :250-280)
+        al.clear();
+        for (int k = 0; k < nA; k++) { const int b = a2b[(size_t)i * 5 + k]; al.push_back(b == 4 ? nonref : (b >= 0 ? std::string(1, "ACGT"[b]) : ".")); }
+        if (al.empty()) al.push_back(".");
+        line += al[0]; line += '\t';
+        if (al.size() == 1) line += '.';
+        else for (size_t k = 1; k < al.size(); k++) { if (k > 1) line += ','; line += al[k]; }
+        line += '\t'; line += S.rec->qual; line += '\t'; line += S.rec->filt; line += '\t';
+        // INFO in add_tags() order: DP, QS, I16, AD, ADF, ADR (after the input record's own INFO)
+        std::string info = (S.rec->info == ".") ? "" : S.rec->info;
+        auto add_key = [&](const char* k) { if (!info.empty()) info += ';'; info += k; info += '='; };
+        if (a.add_info_dp) { add_key("DP"); put_int(info, idp[i]); }
+        if (a.add_qs) { add_key("QS"); for (int k = 0; k < nA; k++) { if (k) info += ','; out.put_float(info, qs[(size_t)i * A + k]); } }
+        if (a.add_i16) { add_key("I16"); for (int k = 0; k < 16; k++) { if (k) info += ','; out.put_float(info, i16[(size_t)i * 16 + k]); } }
+        if (a.add_info_ad) { add_key("AD"); for (int k = 0; k < nA; k++) { if (k) info += ','; put_int(info, iad[(size_t)i * A + k]); } }
+        if (a.add_info_adf) { add_key("ADF"); for (int k = 0; k < nA; k++) { if (k) info += ','; put_int(info, iadf[(size_t)i * A + k]); } }
+        if (a.add_info_adr) { add_key("ADR"); for (int k = 0; k < nA; k++) { if (k) info += ','; put_int(info, iadr[(size_t)i * A + k]); } }
+        line += info.empty() ? "." : info;
+        // FORMAT keys: DP, GL, PL, GP, AD, ADF, ADR; sample s, element k of a tag at plane[k * N + s]
+        fmt.clear();
+        const size_t sN = (size_t)N;
+        if (a.add_fmt_dp) fmt.push_back({"DP", false, 1, &dp[(size_t)i * N], 1, sN});
+        if (a.add_gl) fmt.push_back({"GL", true, nG, &gl[(size_t)i * G * N], 1, sN});
+        if (a.add_pl) fmt.push_back({"PL", false, nG, &pl[(size_t)i * G * N], 1, sN});
+        if (a.add_gp) fmt.push_back({"GP", true, nG, &gp[(size_t)i * G * N], 1, sN});
+        if (a.add_fmt_ad) fmt.push_back({"AD", false, nA, &ad[(size_t)i * A * N], 1, sN});
+        if (a.add_fmt_adf) fmt.push_back({"ADF", false, nA, &adf[(size_t)i * A * N], 1, sN});
+        if (a.add_fmt_adr) fmt.push_back({"ADR", false, nA, &adr[(size_t)i * A * N], 1, sN});
+    };
     for (size_t t0 = 0; t0 < sites.size(); t0 += TS) {
         const int ns = (int)std::min((size_t)TS, sites.size() - t0);
         for (int i = 0; i < ns; i++) memcpy(&gt_tile[(size_t)i * N], sites[t0 + i].gt.data(), N);
@@ -623,7 +688,9 @@ int main(int argc, char** argv) {
             reads.assign((size_t)pile_cap * ns * N, 0xFF);
             o.reads = reads.data(); o.read_capacity = pile_cap;
         }
+        t_mark = now();
         if (vgl_simulate_tile(ctx, (int64_t)t0, ns, gt_tile.data(), &o) != VGL_OK) die("%s", vgl_last_error());
+        lap(3);
         for (int i = 0; i < ns; i++) {
             const Site& S = sites[t0 + i];
             if (pile && st[i] != VGL_SITE_SKIP_EMPTY) {              // vcfgl.cpp:414-416, 616-634 (printed before skip decisions)
@@ -642,57 +709,42 @@ int main(int argc, char** argv) {
                 gzwrite(pile, line.data(), (unsigned)line.size());
             }
             if (st[i] < 0) { n_skipped++; continue; }
-            const int nA = na[i], nG = nA * (nA + 1) / 2;
+            if (!a.do_gvcf) continue;                                    // plain records: encoded in parallel below
+            // gVCF: write_record_values (vcfgl.cpp:167-206) carries the open block from record to record
+            const int nA = na[i];
+            std::vector<std::string> al; std::vector<vsink::FmtDesc> fmt;
             line.clear();
-            char hb[64];
-            line += S.chrom; snprintf(hb, sizeof hb, "\t%ld\t", S.pos0 + 1); line += hb;
-            line += S.rec->id; line += '\t';
-            // alleles (vcfgl.cpp:739-762; no-reads site :250-280)
-            std::vector<std::string> al;
-            for (int k = 0; k < nA; k++) { const int b = a2b[(size_t)i * 5 + k]; al.push_back(b == 4 ? nonref : (b >= 0 ? std::string(1, "ACGT"[b]) : ".")); }
-            if (al.empty()) al.push_back(".");
-            line += al[0]; line += '\t';
-            if (al.size() == 1) line += '.';
-            else for (size_t k = 1; k < al.size(); k++) { if (k > 1) line += ','; line += al[k]; }
-            line += '\t'; line += S.rec->qual; line += '\t'; line += S.rec->filt; line += '\t';
-            // INFO in add_tags() order: DP, QS, I16, AD, ADF, ADR (after the input record's own INFO)
-            std::string info = (S.rec->info == ".") ? "" : S.rec->info;
-            auto add_key = [&](const char* k) { if (!info.empty()) info += ';'; info += k; info += '='; };
-            if (a.add_info_dp) { add_key("DP"); put_int(info, idp[i]); }
-            if (a.add_qs) { add_key("QS"); for (int k = 0; k < nA; k++) { if (k) info += ','; out.put_float(info, qs[(size_t)i * A + k]); } }
-            if (a.add_i16) { add_key("I16"); for (int k = 0; k < 16; k++) { if (k) info += ','; out.put_float(info, i16[(size_t)i * 16 + k]); } }
-            if (a.add_info_ad) { add_key("AD"); for (int k = 0; k < nA; k++) { if (k) info += ','; put_int(info, iad[(size_t)i * A + k]); } }
-            if (a.add_info_adf) { add_key("ADF"); for (int k = 0; k < nA; k++) { if (k) info += ','; put_int(info, iadf[(size_t)i * A + k]); } }
-            if (a.add_info_adr) { add_key("ADR"); for (int k = 0; k < nA; k++) { if (k) info += ','; put_int(info, iadr[(size_t)i * A + k]); } }
-            line += info.empty() ? "." : info;
-            // FORMAT keys: DP, GL, PL, GP, AD, ADF, ADR; sample s, element k of a tag at plane[k * N + s]
-            std::vector<vsink::FmtDesc> fmt;
-            const size_t sN = (size_t)N;
-            if (a.add_fmt_dp) fmt.push_back({"DP", false, 1, &dp[(size_t)i * N], 1, sN});
-            if (a.add_gl) fmt.push_back({"GL", true, nG, &gl[(size_t)i * G * N], 1, sN});
-            if (a.add_pl) fmt.push_back({"PL", false, nG, &pl[(size_t)i * G * N], 1, sN});
-            if (a.add_gp) fmt.push_back({"GP", true, nG, &gp[(size_t)i * G * N], 1, sN});
-            if (a.add_fmt_ad) fmt.push_back({"AD", false, nA, &ad[(size_t)i * A * N], 1, sN});
-            if (a.add_fmt_adf) fmt.push_back({"ADF", false, nA, &adf[(size_t)i * A * N], 1, sN});
-            if (a.add_fmt_adr) fmt.push_back({"ADR", false, nA, &adr[(size_t)i * A * N], 1, sN});
-            if (a.do_gvcf) {                                             // write_record_values, vcfgl.cpp:167-206
-                SiteView sv;
-                sv.chrom = &S.chrom; sv.pos0 = S.pos0; sv.n_obs = nobs[i]; sv.n_alleles = nA; sv.N = N; sv.G = G;
-                sv.dp = &dp[(size_t)i * N]; sv.pl = &pl[(size_t)i * G * N]; sv.qs = a.add_qs ? &qs[(size_t)i * A] : nullptr;
-                sv.alleles = al[0]; for (size_t k = 1; k < al.size(); k++) { sv.alleles += ','; sv.alleles += al[k]; }
-                int ret = gv.prepare(&sv);
-                if (ret == GvcfBlocker::FLUSH_BLOCK) { gv.emit(out, N); n_out++; ret = gv.prepare(&sv); }
-                if (ret == GvcfBlocker::WRITE_SIMREC) { out.write_rec(line, fmt); n_out++; }
-                continue;
-            }
-            out.write_rec(line, fmt);
-            n_out++;
+            build_record(t0, i, line, al, fmt);
+            SiteView sv;
+            sv.chrom = &S.chrom; sv.pos0 = S.pos0; sv.n_obs = nobs[i]; sv.n_alleles = nA; sv.N = N; sv.G = G;
+            sv.dp = &dp[(size_t)i * N]; sv.pl = &pl[(size_t)i * G * N]; sv.qs = a.add_qs ? &qs[(size_t)i * A] : nullptr;
+            sv.alleles = al[0]; for (size_t k = 1; k < al.size(); k++) { sv.alleles += ','; sv.alleles += al[k]; }
+            int ret = gv.prepare(&sv);
+            if (ret == GvcfBlocker::FLUSH_BLOCK) { gv.emit(out, N); n_out++; ret = gv.prepare(&sv); }
+            if (ret == GvcfBlocker::WRITE_SIMREC) { out.write_rec(line, fmt); n_out++; }
+        }
+        if (!a.do_gvcf) {
+            enc.resize(ns);
+            vsink::parallel_for(ns, a.enc_threads > 0 ? a.enc_threads : a.threads, [&](int i) {
+                enc[i].clear();
+                if (st[i] < 0) return;
+                std::string sh; std::vector<std::string> al; std::vector<vsink::FmtDesc> fmt;
+                build_record(t0, i, sh, al, fmt);
+                out.encode_rec(sh, fmt, enc[i]);
+            });
+            lap(4);
+            for (int i = 0; i < ns; i++) if (st[i] >= 0) { out.put(enc[i]); n_out++; }
+            lap(5);
         }
     }
     if (a.do_gvcf && gv.prepare(nullptr) == GvcfBlocker::FLUSH_BLOCK) { gv.emit(out, N); n_out++; }
+    t_mark = now();
     out.close();
+    lap(5);
     if (pile) gzclose(pile);
     vgl_ctx_destroy(ctx);
+    if (a.verbose) fprintf(stderr, "\n[timing] read input %.3f s, sites %.3f s, device context %.3f s, simulate (incl. PCIe) %.3f s, encode %.3f s, write/compress %.3f s\n",
+                           t_stage[0], t_stage[1], t_stage[2], t_stage[3], t_stage[4], t_stage[5]);
     fprintf(stderr, "\n\n-> Simulation finished successfully.\n\nSummary:\n\tNumber of samples: %d\n\tTotal number of sites simulated: %zu\n"
                     "\tNumber of sites included in simulation output file: %ld\n\tNumber of sites skipped: %ld\n",
             N, sites.size(), n_out, n_skipped);
