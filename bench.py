@@ -40,6 +40,14 @@ WORKLOADS = {
     # BASELINE.json configs[1]
     "c2": dict(sites=10_000, samples=100, flags=dict(depth=10.0, error_rate=0.01, gl_model=1),
                desc="--depth 10 -e 0.01 -GL 1"),
+    # BASELINE.json configs[3], one GPU's share of the 8-GPU job (10M sites / 8)
+    "c4": dict(sites=1_250_000, samples=2000, flags=dict(depth=30.0, error_rate=0.01, error_qs=2, beta_variance=1e-5, gl_model=2,
+                                                         qs_bins=[(0, 2, 2), (3, 14, 12), (15, 30, 23), (31, 40, 37)]),
+               desc="--depth 30 -e 0.01 --error-qs 2 --beta-variance 1e-5 --qs-bins rta3 -GL 2"),
+    # BASELINE.json configs[4]: exploded hom-ref sites, PL for the gVCF blocks.  2M of one GPU's 6.25M sites
+    # (50M / 8): the tile layout keeps G = 15 planes of GL and PL, 120 B per evaluation resident in HBM
+    "c5": dict(sites=2_000_000, samples=500, flags=dict(depth=5.0, error_rate=0.01, gl_model=2, do_unobserved=2, add_pl=1), homref=True,
+               desc="-explode 1 -doUnobserved 2 -addPL 1 --depth 5 -e 0.01 -GL 2 (simulation part of the gVCF job)"),
     # same shape as c3 with one fixed quality score (--error-qs 0, the reference's default)
     "fixedq": dict(sites=1_000_000, samples=1000, flags=dict(depth=20.0, error_rate=0.01, gl_model=2),
                    desc="--depth 20 -e 0.01 --error-qs 0 -GL 2"),
@@ -139,9 +147,12 @@ def main():
 
     # ---- inputs resident in HBM before the timed region
     gt = torch.empty((S, N), dtype=torch.uint8, device=dev)
-    for s0 in range(0, S, 65536):
-        n = min(65536, S - s0)
-        gt[s0:s0 + n] = synth.binary_sites_torch(site_base + s0, n, N, dev)
+    if wl.get("homref"):
+        gt.zero_()
+    else:
+        for s0 in range(0, S, 65536):
+            n = min(65536, S - s0)
+            gt[s0:s0 + n] = synth.binary_sites_torch(site_base + s0, n, N, dev)
     # ---- outputs: the whole job's tag arrays stay in HBM (65 B per evaluation)
     out = {
         "site_status": torch.empty((S,), dtype=torch.int32, device=dev),
@@ -150,6 +161,8 @@ def main():
         "fmt_dp": torch.empty((S, N), dtype=torch.int32, device=dev),
         "gl": torch.empty((S, G, N), dtype=torch.float32, device=dev),
     }
+    if args.add_pl:
+        out["pl"] = torch.empty((S, G, N), dtype=torch.int32, device=dev)
     structs = []
     for s0 in range(0, S, TS):
         n = min(TS, S - s0)
@@ -197,7 +210,7 @@ def main():
     evals_total = float(S) * N * world * opt.steps
     value = evals_total / dt
     if rank == 0:
-        b_eval = 1 + 4 + 4 * G                               # packed GT in + DP out + GL out
+        b_eval = 1 + 4 + 4 * G + (4 * G if args.add_pl else 0)  # packed GT in + DP out + GL (+ PL) out
         names = ["k_sample", "k_site", "k_gl"]
         dom = int(np.argmax(kms))
         avg_ms = kms[dom] / max(klaunch[dom], 1)
@@ -224,12 +237,12 @@ def main():
         copy_gbs = 4 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del dst
         line = {
-            "metric": METRIC if opt.workload != "c2" else "site-sample GL evals/s at depth 10", "value": value, "unit": "site-sample GL evals/s",
+            "metric": METRIC if opt.workload in ("c3", "fixedq") else f"site-sample GL evals/s at depth {args.depth:g}", "value": value, "unit": "site-sample GL evals/s",
             "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": dt / opt.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{opt.workload}: {S} sites x {N} samples per GPU, {wl['desc']}, "
-                                   f"tags GL+DP (G={G}), rng tile mode, rand48 beta sampler", "tile_sites": TS,
+                                   f"tags GL+DP{'+PL' if args.add_pl else ''} (G={G}), rng tile mode, rand48 beta sampler", "tile_sites": TS,
                        "parallelism": f"site-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

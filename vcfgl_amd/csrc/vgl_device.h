@@ -52,6 +52,8 @@ struct VglDevParams {
     int32_t scout_lds_bytes; // dynamic LDS of k_scout_wave (9 bytes per sample when the site fits)
     int32_t beta_std;        // VGL_BETA_STD (serial only)
     double  beta_a, beta_b;  // beta shape parameters (std sampler)
+    int32_t gl_sort;         // k_gl: re-deal the lanes of a workgroup in depth order (pays at depth >= 8; below, natural
+                             // order keeps every store of a wavefront one contiguous segment and the kernel is HBM bound)
     int32_t slow_period;     // k_sample<2>: the bounded-log tests run every slow_period-th pool iteration
     int32_t dbg_phase;       // diagnostic (VGL_DEBUG_PHASE=n): k_sample returns after phase n; 0 = off
     int32_t pre_q, pre_adjq;           // preCalc qScore / adj_qScore (vcfgl.cpp:1697-1702)

@@ -74,9 +74,13 @@ __device__ __forceinline__ int nib(uint32_t v, int k) { return (int)((v >> (4 * 
 __device__ __forceinline__ int cnt_of(uint64_t ad4, int b) { return b < 4 ? (int)((ad4 >> (16 * b)) & 0xFFFF) : 0; }
 
 // Evaluations differ in depth, and the likelihood loop runs once per read: a wavefront is busy for
-// its deepest evaluation.  The 256 evaluations of a workgroup are therefore re-dealt to the lanes in
-// depth order (LDS counting sort of the thread ids), so each wavefront works on evaluations of
-// similar depth; loads and stores stay inside the workgroup's 256-evaluation window of each plane.
+// its deepest evaluation.  At mean depth >= 8 (P.gl_sort) the 256 evaluations of a workgroup are
+// therefore re-dealt to the lanes in depth order (LDS counting sort of the thread ids), so each
+// wavefront works on evaluations of similar depth; loads and stores stay inside the workgroup's
+// 256-evaluation window of each plane, but a store instruction then writes 4-byte pieces of that
+// window (2x the algorithmic write bytes in the PMC) -- harmless while the kernel is VALU bound.
+// At low depth the kernel is HBM bound instead (C5: 125 B per evaluation, 5 reads), the lanes keep
+// their natural order and every store of a wavefront is one contiguous segment.
 template <int A>
 __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTilePtrs T) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
@@ -100,27 +104,30 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
             }
         }
     }
-    for (int i = tid; i < 1026; i += 256) s_hist[i] = 0;
-    __syncthreads();
-    const int key = 1024 - dp0;                                        // deepest first; padding (dp0 = -1) last
-    atomicAdd(&s_hist[key], 1u);
-    __syncthreads();
-    if (tid < 64) {                                                    // exclusive scan of 1026 bins by one wavefront
-        uint32_t run = 0;
-        for (int base = 0; base < 1026; base += 64) {
-            const int i = base + tid;
-            const uint32_t v = (i < 1026) ? s_hist[i] : 0u;
-            uint32_t incl = v;
+    int otid = tid;
+    if (P.gl_sort) {
+        for (int i = tid; i < 1026; i += 256) s_hist[i] = 0;
+        __syncthreads();
+        const int key = 1024 - dp0;                                    // deepest first; padding (dp0 = -1) last
+        atomicAdd(&s_hist[key], 1u);
+        __syncthreads();
+        if (tid < 64) {                                                // exclusive scan of 1026 bins by one wavefront
+            uint32_t run = 0;
+            for (int base = 0; base < 1026; base += 64) {
+                const int i = base + tid;
+                const uint32_t v = (i < 1026) ? s_hist[i] : 0u;
+                uint32_t incl = v;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d, 64); if (tid >= d) incl += t; }
-            if (i < 1026) s_hist[i] = run + incl - v;
-            run += __shfl(incl, 63, 64);
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d, 64); if (tid >= d) incl += t; }
+                if (i < 1026) s_hist[i] = run + incl - v;
+                run += __shfl(incl, 63, 64);
+            }
         }
+        __syncthreads();
+        s_perm[atomicAdd(&s_hist[key], 1u)] = (uint16_t)tid;
+        __syncthreads();
+        otid = s_perm[tid];                                            // thread id whose evaluation this lane processes
     }
-    __syncthreads();
-    s_perm[atomicAdd(&s_hist[key], 1u)] = (uint16_t)tid;
-    __syncthreads();
-    const int otid = s_perm[tid];                                      // thread id whose evaluation this lane processes
     const int lane = tid & 63;
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t w = (int64_t)blockIdx.x * 4 + (otid >> 6);

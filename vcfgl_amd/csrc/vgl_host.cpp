@@ -301,6 +301,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     D.serial = (p->rng_mode == VGL_RNG_SERIAL) ? 1 : 0;
     D.scout_lds_bytes = ((size_t)p->n_samples * 9 <= 144 * 1024) ? (int32_t)(((size_t)p->n_samples * 9 + 15) & ~(size_t)15) : 0;
     D.beta_std = (p->beta_sampler == VGL_BETA_STD) ? 1 : 0;
+    D.gl_sort = getenv("VGL_GL_SORT") ? atoi(getenv("VGL_GL_SORT")) : (dmax >= 8.0 ? 1 : 0);
     D.slow_period = getenv("VGL_SLOW_PERIOD") ? atoi(getenv("VGL_SLOW_PERIOD")) : 2;
     if (D.slow_period < 1) D.slow_period = 1;
     D.dbg_phase = getenv("VGL_DEBUG_PHASE") ? atoi(getenv("VGL_DEBUG_PHASE")) : 0;
