@@ -8,6 +8,7 @@
 #define VGL_LCG_C  0xBULL
 #define VGL_WAVE   64
 #define VGL_MAX_QS_BINS 32
+#define VGL_DEPTH_CHUNK 1024     // evaluations dealt to one wavefront of k_depth
 
 // x -> a*x + c (mod 2^48): a power of the rand48 step
 struct VglAffine { uint64_t a, c; };
@@ -52,6 +53,7 @@ struct VglDevParams {
     int32_t scout_lds_bytes; // dynamic LDS of k_scout_wave (9 bytes per sample when the site fits)
     int32_t beta_std;        // VGL_BETA_STD (serial only)
     double  beta_a, beta_b;  // beta shape parameters (std sampler)
+    int32_t depth_pre;       // depths are drawn by k_depth ahead of k_sample (every sample's mean depth >= 12: rejection method)
     int32_t gl_sort;         // k_gl: re-deal the lanes of a workgroup in depth order (pays at depth >= 8; below, natural
                              // order keeps every store of a wavefront one contiguous segment and the kernel is HBM bound)
     int32_t slow_period;     // k_sample<2>: the bounded-log tests run every slow_period-th pool iteration
@@ -67,6 +69,8 @@ struct VglDevParams {
     const VglAffine* samp_tab;         // [N] J^(block * s)
     const VglAffine* qs_read_tab;      // [read_cap] J^(qs_read_stride * r)
     const VglAffine* step_tab;         // [192] J^k (serial-mode scout)
+    const VglAffine* chunk_tab;        // [VGL_DEPTH_CHUNK] J^(block * i)  (k_depth)
+    const VglAffine* eval_pow_tab;     // [64] J^(block * 2^b)             (k_depth)
     // samplers
     VglPois pois0;
     const VglPois* pois;               // [N] when per_sample_depth
@@ -101,6 +105,7 @@ struct VglTilePtrs {
     int32_t*  acc;           // [n_sites][16]
     VglSiteInfo* sinfo;      // [n_sites]
     uint32_t* errflag;
+    int32_t*  dp_pre;        // [n_sites][N] depth draws of k_depth (tile mode)
     // outputs (caller owned device memory; may be null)
     int32_t* site_status; int32_t* n_alleles; int32_t* n_alleles_obs; int8_t* alleles2acgt;
     int32_t* info_dp; int32_t* info_ad; int32_t* info_adf; int32_t* info_adr;
@@ -133,6 +138,7 @@ extern "C" {
 #endif
 // launch wrappers implemented beside their kernels in vgl_sample.hip / vgl_serial.hip / vgl_gl.hip
 // (stream = hipStream_t)
+int vgl_launch_depth(const VglDevParams* p, const VglTilePtrs* t, void* stream);
 int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, void* stream);
 int vgl_launch_site(const VglDevParams* p, const VglTilePtrs* t, void* stream);
 int vgl_launch_gl(const VglDevParams* p, const VglTilePtrs* t, void* stream);

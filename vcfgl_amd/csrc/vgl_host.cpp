@@ -141,6 +141,7 @@ struct vgl_ctx {
     int max_sites;
     VglDevParams dp;
     // device tables
+    VglAffine* d_chunk_tab = nullptr; VglAffine* d_eval_pow = nullptr; int32_t* d_dp_pre = nullptr;
     VglAffine* d_samp_tab = nullptr; VglAffine* d_qs_read_tab = nullptr; VglPois* d_pois = nullptr;
     double* d_q2gl = nullptr; double* d_gamma_ln = nullptr; double* d_gl1_fk = nullptr; double* d_gl1_beta = nullptr; double* d_gl1_bsum = nullptr; double* d_gl1_lhet = nullptr;
     // workspace
@@ -233,7 +234,8 @@ extern "C" int vgl_ctx_destroy(vgl_ctx* c) {
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_gl1_fk, c->d_gl1_beta, c->d_gamma_ln, c->d_samp_tab, c->d_qs_read_tab, c->d_pois, c->d_q2gl, c->d_gl1_bsum, c->d_gl1_lhet, c->d_reads, c->d_errp, c->d_ad4,
                     c->d_adf4, c->d_qsum, c->d_qsumsq, c->d_acc, c->d_sinfo, c->d_errflag, c->d_gt, c->d_reads_out, c->d_dbg,
-                    c->d_serial, c->d_sst, c->d_site_thresh, c->d_scout_dp, c->d_site_tail, c->d_sdp, c->d_step_tab};
+                    c->d_serial, c->d_sst, c->d_site_thresh, c->d_scout_dp, c->d_site_tail, c->d_sdp, c->d_step_tab,
+                    c->d_chunk_tab, c->d_eval_pow, c->d_dp_pre};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     for (void* q : c->d_out) if (q) (void)hipFree(q);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -301,6 +303,11 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     D.serial = (p->rng_mode == VGL_RNG_SERIAL) ? 1 : 0;
     D.scout_lds_bytes = ((size_t)p->n_samples * 9 <= 144 * 1024) ? (int32_t)(((size_t)p->n_samples * 9 + 15) & ~(size_t)15) : 0;
     D.beta_std = (p->beta_sampler == VGL_BETA_STD) ? 1 : 0;
+    {   // k_depth pays for the rejection sampler (lambda >= 12, rng.h:300); the product method stays inside k_sample
+        double dmin = p->depth;
+        if (p->depths) { dmin = p->depths[0]; for (int i = 1; i < N; i++) if (p->depths[i] < dmin) dmin = p->depths[i]; }
+        D.depth_pre = (!D.serial && dmin >= 12.0) ? 1 : 0;
+    }
     D.gl_sort = getenv("VGL_GL_SORT") ? atoi(getenv("VGL_GL_SORT")) : (dmax >= 8.0 ? 1 : 0);
     D.slow_period = getenv("VGL_SLOW_PERIOD") ? atoi(getenv("VGL_SLOW_PERIOD")) : 2;
     if (D.slow_period < 1) D.slow_period = 1;
@@ -350,6 +357,15 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
 
 #define TRY(x) do { if ((rc = (x))) { vgl_ctx_destroy(c); return rc; } } while (0)
 #define TRYHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { vgl_ctx_destroy(c); return fail(e_ == hipErrorOutOfMemory ? VGL_E_NOMEM : VGL_E_NODEVICE, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
+    if (!D.serial) {                                               // k_depth: J^(block*i) and J^(block*2^b)
+        std::vector<VglAffine> ct(VGL_DEPTH_CHUNK), ep(64);
+        { VglAffine cur = {1, 0}; for (int i = 0; i < VGL_DEPTH_CHUNK; i++) { ct[i] = cur; cur = aff_compose(jb, cur); } }
+        { VglAffine cur = jb; for (int b = 0; b < 64; b++) { ep[b] = cur; cur = aff_compose(cur, cur); } }
+        TRY(dmalloc(&c->d_chunk_tab, (size_t)VGL_DEPTH_CHUNK)); TRY(dmalloc(&c->d_eval_pow, (size_t)64));
+        TRYHIP(hipMemcpy(c->d_chunk_tab, ct.data(), sizeof(VglAffine) * ct.size(), hipMemcpyHostToDevice));
+        TRYHIP(hipMemcpy(c->d_eval_pow, ep.data(), sizeof(VglAffine) * ep.size(), hipMemcpyHostToDevice));
+        D.chunk_tab = c->d_chunk_tab; D.eval_pow_tab = c->d_eval_pow;
+    }
     TRY(dmalloc(&c->d_samp_tab, (size_t)N));
     TRYHIP(hipMemcpy(c->d_samp_tab, samp.data(), sizeof(VglAffine) * N, hipMemcpyHostToDevice));
     D.samp_tab = c->d_samp_tab;
@@ -398,6 +414,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     }
     const size_t E = (size_t)max_sites * N;
     TRY(dmalloc(&c->d_reads, E * D.read_cap));
+    if (!D.serial) TRY(dmalloc(&c->d_dp_pre, E));
     if ((p->precise_gl || D.serial) && p->error_qs == 2) TRY(dmalloc(&c->d_errp, E * D.read_cap));
     if (D.serial) {
         TRY(dmalloc(&c->d_sst, E * 2)); TRY(dmalloc(&c->d_site_thresh, (size_t)max_sites)); TRY(dmalloc(&c->d_scout_dp, (size_t)N)); TRY(dmalloc(&c->d_sdp, E));
@@ -484,7 +501,7 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     memset(&T, 0, sizeof T);
     T.site0 = site0; T.n_sites = n_sites; T.gt = gt;
     T.reads = c->d_reads; T.errp = c->d_errp; T.ad4 = c->d_ad4; T.adf4 = c->d_adf4; T.qsum = c->d_qsum; T.qsumsq = c->d_qsumsq;
-    T.acc = c->d_acc; T.sinfo = c->d_sinfo; T.errflag = c->d_errflag; T.dbg = c->d_dbg;
+    T.acc = c->d_acc; T.sinfo = c->d_sinfo; T.errflag = c->d_errflag; T.dbg = c->d_dbg; T.dp_pre = c->d_dp_pre;
     if (D.serial) {
         const size_t E = (size_t)c->max_sites * D.n_samples;
         T.sst_hap = c->d_sst; T.sst_base = c->d_sst + E; T.sdp = c->d_sdp;
@@ -510,7 +527,7 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     if (D.serial) {
         if (vgl_launch_scout(&D, &T, c->d_serial, st)) return fail(VGL_E_NODEVICE, "k_scout launch failed");
         c->serial_next_site = site0 + n_sites;
-    }
+    } else if (D.depth_pre && vgl_launch_depth(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_depth launch failed");
     if (c->timing) HIPCHK(hipEventRecord(e[0], st));
     if (vgl_launch_sample(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_sample launch failed: %s", hipGetErrorString(hipGetLastError()));
     if (c->timing) HIPCHK(hipEventRecord(e[1], st));

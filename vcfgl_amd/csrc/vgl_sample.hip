@@ -14,8 +14,57 @@
 // lane's work does not depend on its own evaluation's depth; each lane runs the nested
 // rejection loops of the gamma sampler as one flat state machine (one normal-deviate attempt
 // per iteration) so that lanes at different stages share every iteration.
+// Depth draws of a tile (vcfgl.cpp:364-389; rng.h:284-351), ahead of k_sample.  The rejection sampler
+// needs 2 attempts on average but about 7 for the slowest of 64 lanes, so evaluations are not tied to
+// lanes here: a wavefront owns VGL_DEPTH_CHUNK consecutive evaluations and deals them to its lanes as
+// lanes finish; one rejection attempt of every busy lane per iteration, lane state advanced by selects
+// (launched only when every sample's mean depth is >= 12; the short product-method loops stay in k_sample).  Evaluation e = site_abs * N + sample starts its depth stream at
+// J^(off0) J^(block e) (X0): J^(block e_chunk) per wavefront from a power table, one table jump per evaluation.
+__global__ __launch_bounds__(256) void k_depth(const VglDevParams P, const VglTilePtrs T) {
+    const int lane = threadIdx.x & 63;
+    const int N = P.n_samples;
+    const int64_t E = (int64_t)T.n_sites * N;
+    const int64_t c0 = ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * VGL_DEPTH_CHUNK;
+    if (c0 >= E) return;
+    const int cn = (int)((E - c0 < VGL_DEPTH_CHUNK) ? (E - c0) : VGL_DEPTH_CHUNK);
+    const uint64_t e_abs0 = (uint64_t)T.site0 * (uint64_t)N + (uint64_t)c0;
+    uint64_t xc = P.x0;
+#pragma unroll 1
+    for (int b = 0; b < 64; ++b)
+        if ((e_abs0 >> b) & 1) xc = aff(P.eval_pow_tab[b], xc);
+    xc = aff(P.off[0], xc);
+    const uint32_t s_of_c0 = (uint32_t)(e_abs0 % (uint64_t)N);          // sample index of the chunk's first evaluation
+
+    int i = lane, next_free = 64;
+    bool busy = i < cn;
+    uint64_t st = aff(P.chunk_tab[busy ? i : 0], xc);
+    VglPois pp = P.pois0;
+    if (P.per_sample_depth) pp = P.pois[(s_of_c0 + (uint32_t)(busy ? i : 0)) % (uint32_t)N];
+    while (__ballot(busy)) {
+        // one rejection attempt (rng.h:300-312); k_depth runs only when every sample uses this method
+        const uint64_t st1 = lcg_next(st), st2 = lcg_next(st1);
+        bool neg, reject; double e2;
+        poisson_attempt(pp, st1, st2, busy, P.gamma_ln_tab, P.gamma_ln_n, neg, reject, e2);
+        st = neg ? st1 : st2;                                            // em < 0 consumes one draw, an attempt two
+        const bool done = busy && !neg && !reject;
+        const int result = (int)e2;
+        if (done) T.dp_pre[c0 + i] = result;
+        // lanes that finished take the next undealt evaluation of the chunk
+        const uint64_t dm = __ballot(done);
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u));
+        const int i_n = done ? next_free + rank : i;
+        next_free += __popcll(dm);
+        const bool busy_n = done ? (i_n < cn) : busy;
+        const uint64_t st_n = aff(P.chunk_tab[busy_n ? i_n : 0], xc);
+        if (P.per_sample_depth) { const VglPois pn = P.pois[(s_of_c0 + (uint32_t)(busy_n ? i_n : 0)) % (uint32_t)N]; if (done) pp = pn; }
+        st = done ? st_n : st;
+        i = i_n; busy = busy_n;
+    }
+}
+
 // DBG: diagnostic instantiation (VGL_DEBUG_STAMPS / VGL_DEBUG_PHASE), never used in a timed run
-template <int EQS, bool DBG>
+// PRE: depths come from k_depth (the kernel then carries no Poisson code, which costs it registers)
+template <int EQS, bool DBG, bool PRE>
 __global__ __launch_bounds__(256) void k_sample(const VglDevParams P, const VglTilePtrs T) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const WavePos wp = wave_pos(P, T);
@@ -48,15 +97,19 @@ __global__ __launch_bounds__(256) void k_sample(const VglDevParams P, const VglT
     if (active) {
         const VglAffine ms = P.samp_tab[s];
         const uint64_t xe = aff(ms, xb);
-        uint64_t st_depth = aff(P.off[0], xe);
         st_hap = aff(P.off[1], xe);
         st_base = aff(P.off[2], xe);
         st_qs = aff(P.off[3], xe);
 
-        // ---- depth (vcfgl.cpp:364-389): drawn even when the genotype is missing
+        // ---- depth (vcfgl.cpp:364-389): drawn even when the genotype is missing; by k_depth where the
+        //      rejection method applies, here for the short loops of the product method
         int n;
-        if (P.per_sample_depth) { const VglPois pc = P.pois[s]; n = poisson_draw_fast(pc, st_depth, P.gamma_ln_tab, P.gamma_ln_n); }
-        else n = poisson_draw_fast(P.pois0, st_depth, P.gamma_ln_tab, P.gamma_ln_n);
+        if (PRE) n = T.dp_pre[ev];
+        else {
+            uint64_t st_depth = aff(P.off[0], xe);
+            if (P.per_sample_depth) { const VglPois pc = P.pois[s]; n = poisson_draw_fast(pc, st_depth, P.gamma_ln_tab, P.gamma_ln_n); }
+            else n = poisson_draw_fast(P.pois0, st_depth, P.gamma_ln_tab, P.gamma_ln_n);
+        }
         const uint32_t g = T.gt[ev];
         a0 = g & 0xF; a1 = (g >> 4) & 0xF;
         dp = (a0 == 0xF || a1 == 0xF) ? 0 : n;
@@ -314,17 +367,32 @@ __global__ __launch_bounds__(256) void k_sample(const VglDevParams P, const VglT
 }
 
 // ------------------------------------------------------------------------------------
+extern "C" int vgl_launch_depth(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
+    const int64_t E = (int64_t)t->n_sites * p->n_samples;
+    if (E == 0) return 0;
+    const int64_t waves = (E + VGL_DEPTH_CHUNK - 1) / VGL_DEPTH_CHUNK;
+    hipLaunchKernelGGL(k_depth, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *p, *t);
+    return (int)hipGetLastError();
+}
+
 extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
     const int64_t waves = (int64_t)t->n_sites * p->chunks;
     if (waves == 0) return 0;
     const unsigned blocks = (unsigned)((waves + 3) / 4);
     if (p->serial) return vgl_launch_sample_serial(p, t, stream);
     const bool dbg = t->dbg != nullptr;                         // VGL_DEBUG_STAMPS / VGL_DEBUG_PHASE
+    const dim3 g(blocks), b(256);
+    const size_t lds = (size_t)4 * p->pool_lds_bytes;
+    hipStream_t s = (hipStream_t)stream;
     if (p->error_qs == 2) {
-        if (dbg) hipLaunchKernelGGL((k_sample<2, true>), dim3(blocks), dim3(256), (size_t)4 * p->pool_lds_bytes, (hipStream_t)stream, *p, *t);
-        else hipLaunchKernelGGL((k_sample<2, false>), dim3(blocks), dim3(256), (size_t)4 * p->pool_lds_bytes, (hipStream_t)stream, *p, *t);
-    } else if (p->error_qs == 1) hipLaunchKernelGGL((k_sample<1, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, *t);
-    else hipLaunchKernelGGL((k_sample<0, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, *t);
+        if (dbg) { if (p->depth_pre) hipLaunchKernelGGL((k_sample<2, true, true>), g, b, lds, s, *p, *t); else hipLaunchKernelGGL((k_sample<2, true, false>), g, b, lds, s, *p, *t); }
+        else if (p->depth_pre) hipLaunchKernelGGL((k_sample<2, false, true>), g, b, lds, s, *p, *t);
+        else hipLaunchKernelGGL((k_sample<2, false, false>), g, b, lds, s, *p, *t);
+    } else if (p->error_qs == 1) {
+        if (p->depth_pre) hipLaunchKernelGGL((k_sample<1, false, true>), g, b, 0, s, *p, *t); else hipLaunchKernelGGL((k_sample<1, false, false>), g, b, 0, s, *p, *t);
+    } else {
+        if (p->depth_pre) hipLaunchKernelGGL((k_sample<0, false, true>), g, b, 0, s, *p, *t); else hipLaunchKernelGGL((k_sample<0, false, false>), g, b, 0, s, *p, *t);
+    }
     return (int)hipGetLastError();
 }
 
