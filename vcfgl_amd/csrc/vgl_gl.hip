@@ -1,6 +1,8 @@
 // vgl_gl.hip -- per-site allele order (k_site), genotype likelihoods and their PL / GP / AD
 // epilogue (k_gl<A>), order-dependent per-site float sums (k_siteagg).
 // (vcfgl.cpp:396-404, 665-970, 982-1074; gl_methods.cpp:4-369)
+#include <type_traits>
+
 #include "vgl_common.hip.h"
 
 // ------------------------------------------------------------------------------------
@@ -106,20 +108,21 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
     }
     int otid = tid;
     if (P.gl_sort) {
-        for (int i = tid; i < 1026; i += 256) s_hist[i] = 0;
+        const int nb = P.read_cap + 3;                                 // depths 0..read_cap, padding, one spare: <= 1026 bins
+        for (int i = tid; i < nb; i += 256) s_hist[i] = 0;
         __syncthreads();
-        const int key = 1024 - dp0;                                    // deepest first; padding (dp0 = -1) last
+        const int key = P.read_cap + 1 - (dp0 > P.read_cap ? P.read_cap : dp0);   // deepest first; padding (dp0 = -1) last
         atomicAdd(&s_hist[key], 1u);
         __syncthreads();
-        if (tid < 64) {                                                // exclusive scan of 1026 bins by one wavefront
+        if (tid < 64) {                                                // exclusive scan of the bins by one wavefront
             uint32_t run = 0;
-            for (int base = 0; base < 1026; base += 64) {
+            for (int base = 0; base < nb; base += 64) {
                 const int i = base + tid;
-                const uint32_t v = (i < 1026) ? s_hist[i] : 0u;
+                const uint32_t v = (i < nb) ? s_hist[i] : 0u;
                 uint32_t incl = v;
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d, 64); if (tid >= d) incl += t; }
-                if (i < 1026) s_hist[i] = run + incl - v;
+                if (i < nb) s_hist[i] = run + incl - v;
                 run += __shfl(incl, 63, 64);
             }
         }
@@ -154,35 +157,42 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
         if (P.gl_model == 2) {
             // gl_methods.cpp:22-59 / :94-139 / :171-220
             const bool per_read = (P.error_qs == 2);
-            double homT = P.pre_homT, het = P.pre_het, homF = P.pre_homF;
-            for (int r = 0; r < dp; ++r) {
-                const uint32_t rb = T.reads[(size_t)r * plane + ev];
-                const int ao = nib(si.acgt2alleles, (int)(rb & 3));
-                if (per_read) {
-                    if (!P.precise_gl) {
-                        const int q = (int)(rb >> 2);
-                        homT = P.q2gl[q]; het = P.q2gl[257 + q]; homF = P.q2gl[514 + q];
-                    } else {
-                        const double e = T.errp[(size_t)r * plane + ev];
-                        if (0.0 == e) { homT = 0.0; het = -0.30103; homF = -INFINITY; }
-                        else { homT = log10(1.0 - e); het = log10((1.0 - e) / 2.0 + e / 6.0); homF = log10(e / 3.0); }
+            // FULL: every lane of the wavefront is at a site with all A alleles (the usual case with
+            // -doUnobserved 1/2): the running maximum is then a plain v_max_f32 per genotype
+            auto read_loop = [&](auto full_tag) {
+                constexpr bool FULL = decltype(full_tag)::value;
+                double homT = P.pre_homT, het = P.pre_het, homF = P.pre_homF;
+                for (int r = 0; r < dp; ++r) {
+                    const uint32_t rb = T.reads[(size_t)r * plane + ev];
+                    const int ao = nib(si.acgt2alleles, (int)(rb & 3));
+                    if (per_read) {
+                        if (!P.precise_gl) {
+                            const int q = (int)(rb >> 2);
+                            homT = P.q2gl[q]; het = P.q2gl[257 + q]; homF = P.q2gl[514 + q];
+                        } else {
+                            const double e = T.errp[(size_t)r * plane + ev];
+                            if (0.0 == e) { homT = 0.0; het = -0.30103; homF = -INFINITY; }
+                            else { homT = log10(1.0 - e); het = log10((1.0 - e) / 2.0 + e / 6.0); homF = log10(e / 3.0); }
+                        }
                     }
-                }
-                float mx = -INFINITY;
+                    float mx = -INFINITY;
 #pragma unroll
-                for (int i = 0; i < A; ++i) {
+                    for (int i = 0; i < A; ++i) {
 #pragma unroll
-                    for (int j = 0; j <= i; ++j) {
-                        const int idx = i * (i + 1) / 2 + j;                         // bcf_alleles2gt
-                        const double t = (i == j) ? ((ao == i) ? homT : homF) : ((ao == i || ao == j) ? het : homF);
-                        const float v = (float)((double)acc[idx] + t);
-                        acc[idx] = v;
-                        if (i < nA) mx = (v > mx) ? v : mx;
+                        for (int j = 0; j <= i; ++j) {
+                            const int idx = i * (i + 1) / 2 + j;                         // bcf_alleles2gt
+                            const double t = (i == j) ? ((ao == i) ? homT : homF) : ((ao == i || ao == j) ? het : homF);
+                            const float v = (float)((double)acc[idx] + t);
+                            acc[idx] = v;
+                            if (FULL) mx = __builtin_fmaxf(mx, v);                       // = (v > mx) ? v : mx: v is never NaN-greater, mx never NaN
+                            else if (i < nA) mx = (v > mx) ? v : mx;
+                        }
                     }
-                }
 #pragma unroll
-                for (int i = 0; i < NG; ++i) acc[i] -= mx;
-            }
+                    for (int i = 0; i < NG; ++i) acc[i] -= mx;
+                }
+            };
+            if (__ballot(nA != A) == 0) read_loop(std::true_type{}); else read_loop(std::false_type{});
         } else {
             // GL model 1 with one fixed qScore: errmod_cal() reduces to table lookups on the
             // per-base depths (gl_methods.cpp:304-369; htslib errmod.c restated in vgl_host.cpp)
