@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--sites", type=int, default=None)
     ap.add_argument("--samples", type=int, default=None)
-    ap.add_argument("--tile-sites", type=int, default=8192)
+    ap.add_argument("--tile-sites", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)     # internal: one shard of the all-cores CPU leg
     opt = ap.parse_args()
@@ -214,7 +214,7 @@ def main():
         names = ["k_sample", "k_site", "k_gl"]
         dom = int(np.argmax(kms))
         avg_ms = kms[dom] / max(klaunch[dom], 1)
-        evals_per_launch = float(min(TS, S)) * N
+        evals_per_launch = float(S) * N * opt.steps / max(klaunch[dom], 1)     # average over the launches, partial last tile included
         achieved = b_eval * evals_per_launch / (avg_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
