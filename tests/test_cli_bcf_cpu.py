@@ -95,3 +95,24 @@ def test_multithreading_is_refused_for_text_output(tmp_path):
     r = subprocess.run([BIN, "-i", os.path.join(DATA, "data3.vcf"), "-o", str(tmp_path / "x"), "-O", "v", "--threads", "4"] + ARGV,
                        capture_output=True, text=True)
     assert r.returncode != 0 and "Multithreading is not supported for VCF output" in r.stderr       # io.cpp:1206-1210
+
+
+@pytest.mark.parametrize("vals,bt", [
+    ([0, 127, -120], 1), ([128, 0], 2), ([-121, 5], 2), ([32767, -32760], 2), ([32768], 3), ([-32761, 1], 3),
+    ([2147483647, -2147483640], 3), ([".", 7, "."], 1), ([3] * 15, 1), ([1] * 14, 1), (list(range(-100, 100)), 1), ([300] * 130, 2),
+])
+def test_integer_type_choice_at_the_boundaries(tmp_path, vals, bt):
+    """htslib's bcf_enc_vint: int8 holds [-120, 127], int16 [-32760, 32767] (the low values are reserved for
+    missing / end-of-vector); vectors of 15 or more elements carry their length as a typed integer."""
+    for mode in ("u", "b"):
+        out = str(tmp_path / f"st_{mode}.bcf")
+        r = subprocess.run([BIN, "--encode-selftest", mode, out] + [str(v) for v in vals], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        rd = bcf_reader.Reader(out)
+        (rec,) = list(rd.records())
+        want = [None if v == "." else v for v in vals]
+        (k, t, per), = rec["fmt"]
+        assert k == "X" and t == bt and per == [want, want[::-1]]
+        (ik, it, iv), = rec["info"]
+        assert ik == "Y" and iv == want and (it == bt or len(vals) == 1)
+        assert rec["alleles"] == ["A", "C", "<*>"] and rec["filter"] == ["PASS"] and rec["id"] == "rs1" and rec["pos0"] == 4

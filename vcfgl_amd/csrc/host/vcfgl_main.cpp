@@ -474,6 +474,23 @@ int main(int argc, char** argv) {
         for (int i = 2; i < argc; i++) { uint32_t b = (uint32_t)strtoul(argv[i], NULL, 16); float f; memcpy(&f, &b, 4); std::string s; put_float(s, f); printf("%s\n", s.c_str()); }
         return 0;
     }
+    if (argc >= 5 && !strcmp(argv[1], "--encode-selftest")) {
+        // self-test hook of the BCF writer: --encode-selftest <mode> <out path> <int> [<int> ...] writes one record whose
+        // FORMAT/X holds the given integers for sample s1 (and their reverse for s2) and INFO/Y the same list
+        vsink::Sink out; out.text_float = put_float;
+        std::vector<std::string> hdr = {"##fileformat=VCFv4.2", "##contig=<ID=c1,length=10>",
+                                        "##INFO=<ID=Y,Number=.,Type=Integer,Description=\"y\">", "##FORMAT=<ID=X,Number=.,Type=Integer,Description=\"x\">"};
+        out.open(argv[3], argv[2][0], hdr, {"s1", "s2"});
+        std::vector<int32_t> v; for (int i = 4; i < argc; i++) v.push_back(!strcmp(argv[i], ".") ? VGL_INT32_MISSING : (int32_t)strtol(argv[i], NULL, 10));
+        const int n = (int)v.size();
+        std::vector<int32_t> plane(2 * (size_t)n);
+        for (int k = 0; k < n; k++) { plane[(size_t)k * 2] = v[k]; plane[(size_t)k * 2 + 1] = v[n - 1 - k]; }
+        std::string sh = "c1\t5\trs1\tA\tC,<*>\t.\tPASS\tY=";
+        for (int k = 0; k < n; k++) { if (k) sh += ','; put_int(sh, v[k]); }
+        out.write_rec(sh, {{"X", false, n, plane.data(), 1, 2}});
+        out.close();
+        return 0;
+    }
     Args a = parse_args(argc, argv);
     // --verbose 1: wall-clock seconds per stage on stderr at the end
     double t_stage[6] = {0, 0, 0, 0, 0, 0};                   // read, sites, context, simulate, encode, write
