@@ -52,6 +52,7 @@ struct VglDevParams {
     int32_t serial;          // VGL_RNG_SERIAL
     int32_t scout_lds_bytes; // dynamic LDS of k_scout_wave (9 bytes per sample when the site fits)
     int32_t beta_std;        // VGL_BETA_STD (serial only)
+    int32_t beta_chain;      // serial --error-qs 2 with the std sampler: wave scout + vgl_betachain.hip instead of the one-lane scout
     double  beta_a, beta_b;  // beta shape parameters (std sampler)
     int32_t depth_pre;       // depths are drawn by k_depth ahead of k_sample (every sample's mean depth >= 12: rejection method)
     int32_t gl_sort;         // k_gl: re-deal the lanes of a workgroup in depth order (pays at depth >= 8; below, natural
@@ -120,6 +121,20 @@ struct VglTilePtrs {
     uint64_t* site_thresh;   // [n_sites] per-site base-pick error threshold (error_qs 1)
     int32_t*  scout_off;     // [N] scratch of the scout: first read index of each sample
     VglSiteTail* site_tail;  // [n_sites] (serial mode with -addI16)
+    const long long* roff;   // [n_sites][N] index of an evaluation's first read in draw order (serial --error-qs 2, std beta)
+    const double* errp_lin;  // [reads of the tile] beta deviates in draw order (vgl_betachain.hip)
+};
+
+// control block of one chunk of the beta chain (vgl_betachain.hip), device resident, read back by the host
+struct VglChainCtl {
+    long long remaining;     // in: reads still to be served
+    long long n_pos;         // in: chain positions of this chunk whose deviate fits inside the word window
+    long long n_chunk;       // out: reads served by this chunk
+    long long endw;          // out: words consumed (start of the first unserved deviate)
+    int32_t n_seg;           // in
+    int32_t last_seg;        // out: segment that holds the last served read
+    int32_t err;             // out: 1 = a deviate needed more words than the scheme allows
+    int32_t pad;
 };
 
 // persistent serial-mode generator states (device memory, carried from tile to tile)
@@ -145,6 +160,16 @@ int vgl_launch_gl(const VglDevParams* p, const VglTilePtrs* t, void* stream);
 int vgl_launch_siteagg(const VglDevParams* p, const VglTilePtrs* t, void* stream);
 int vgl_launch_scout(const VglDevParams* p, const VglTilePtrs* t, struct VglSerialState* st, void* stream);
 int vgl_launch_sample_serial(const VglDevParams* p, const VglTilePtrs* t, void* stream);
+// vgl_betachain.hip
+int vgl_chain_read_offsets(const int32_t* sdp, long long n, long long* roff, long long* total, void* stream);
+long long vgl_chain_snapshots_needed(long long n_words);
+int vgl_chain_seg(void);
+int vgl_chain_margin_words(void);
+int vgl_chain_chunk(const VglDevParams* p, struct VglSerialState* S, struct VglChainCtl* ctl, uint32_t* W, long long n_words, uint8_t* cons,
+                    uint8_t* seg_exit, int32_t* seg_cnt, uint8_t* seg_entry, long long* seg_base, uint32_t* pos,
+                    uint32_t* snap, long long* snap_words, void* stream);
+int vgl_chain_emit(const VglDevParams* p, struct VglSerialState* S, const struct VglChainCtl* ctl, const uint32_t* W, const uint32_t* pos,
+                   long long n_chunk, double* out, const uint32_t* snap, const long long* snap_words, long long n_snap, void* stream);
 #ifdef __cplusplus
 }
 #endif

@@ -148,6 +148,11 @@ struct vgl_ctx {
     uint8_t* d_reads = nullptr; double* d_errp = nullptr; uint64_t* d_ad4 = nullptr; uint64_t* d_adf4 = nullptr;
     uint32_t* d_qsum = nullptr; uint32_t* d_qsumsq = nullptr; int32_t* d_acc = nullptr; VglSiteInfo* d_sinfo = nullptr;
     uint32_t* d_errflag = nullptr;
+    // beta chain of VGL_RNG_SERIAL with --error-qs 2 and the std beta sampler (vgl_betachain.hip); grow-only buffers
+    long long* d_roff = nullptr; long long* d_rtotal = nullptr; double* d_errp_lin = nullptr; size_t errp_lin_cap = 0;
+    uint32_t* d_cw = nullptr; uint8_t* d_ccons = nullptr; uint8_t* d_cexit = nullptr; int32_t* d_ccnt = nullptr; uint8_t* d_centry = nullptr;
+    long long* d_cbase = nullptr; uint32_t* d_cpos = nullptr; uint32_t* d_csnap = nullptr; long long* d_csnapw = nullptr; VglChainCtl* d_cctl = nullptr;
+    long long chain_words_cap = 0;
     unsigned long long* d_dbg = nullptr;
     // VGL_RNG_SERIAL
     VglSerialState* d_serial = nullptr; uint64_t* d_sst = nullptr; uint64_t* d_site_thresh = nullptr; int32_t* d_scout_dp = nullptr; int32_t* d_sdp = nullptr; VglAffine* d_step_tab = nullptr; VglSiteTail* d_site_tail = nullptr;
@@ -235,7 +240,8 @@ extern "C" int vgl_ctx_destroy(vgl_ctx* c) {
     void* ptrs[] = {c->d_gl1_fk, c->d_gl1_beta, c->d_gamma_ln, c->d_samp_tab, c->d_qs_read_tab, c->d_pois, c->d_q2gl, c->d_gl1_bsum, c->d_gl1_lhet, c->d_reads, c->d_errp, c->d_ad4,
                     c->d_adf4, c->d_qsum, c->d_qsumsq, c->d_acc, c->d_sinfo, c->d_errflag, c->d_gt, c->d_reads_out, c->d_dbg,
                     c->d_serial, c->d_sst, c->d_site_thresh, c->d_scout_dp, c->d_site_tail, c->d_sdp, c->d_step_tab,
-                    c->d_chunk_tab, c->d_eval_pow, c->d_dp_pre};
+                    c->d_chunk_tab, c->d_eval_pow, c->d_dp_pre, c->d_roff, c->d_rtotal, c->d_errp_lin, c->d_cw, c->d_ccons, c->d_cexit,
+                    c->d_ccnt, c->d_centry, c->d_cbase, c->d_cpos, c->d_csnap, c->d_csnapw, c->d_cctl};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     for (void* q : c->d_out) if (q) (void)hipFree(q);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -303,6 +309,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     D.serial = (p->rng_mode == VGL_RNG_SERIAL) ? 1 : 0;
     D.scout_lds_bytes = ((size_t)p->n_samples * 9 <= 144 * 1024) ? (int32_t)(((size_t)p->n_samples * 9 + 15) & ~(size_t)15) : 0;
     D.beta_std = (p->beta_sampler == VGL_BETA_STD) ? 1 : 0;
+    D.beta_chain = (D.serial && D.beta_std && p->error_qs == 2 && !getenv("VGL_NO_BETA_CHAIN")) ? 1 : 0;
     {   // k_depth pays for the rejection sampler (lambda >= 12, rng.h:300); the product method stays inside k_sample
         double dmin = p->depth;
         if (p->depths) { dmin = p->depths[0]; for (int i = 1; i < N; i++) if (p->depths[i] < dmin) dmin = p->depths[i]; }
@@ -415,7 +422,8 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     const size_t E = (size_t)max_sites * N;
     TRY(dmalloc(&c->d_reads, E * D.read_cap));
     if (!D.serial) TRY(dmalloc(&c->d_dp_pre, E));
-    if ((p->precise_gl || D.serial) && p->error_qs == 2) TRY(dmalloc(&c->d_errp, E * D.read_cap));
+    if ((p->precise_gl || (D.serial && !D.beta_chain)) && p->error_qs == 2) TRY(dmalloc(&c->d_errp, E * D.read_cap));
+    if (D.beta_chain) { TRY(dmalloc(&c->d_roff, E)); TRY(dmalloc(&c->d_rtotal, (size_t)1)); TRY(dmalloc(&c->d_cctl, (size_t)1)); }
     if (D.serial) {
         TRY(dmalloc(&c->d_sst, E * 2)); TRY(dmalloc(&c->d_site_thresh, (size_t)max_sites)); TRY(dmalloc(&c->d_scout_dp, (size_t)N)); TRY(dmalloc(&c->d_sdp, E));
         {
@@ -487,6 +495,57 @@ extern "C" int vgl_ctx_kernel_ms(vgl_ctx* c, double ms[3], int64_t launches[3], 
     return VGL_OK;
 }
 
+// VGL_RNG_SERIAL, --error-qs 2, std beta sampler: the beta deviates of the tile's reads in draw order
+// (vgl_betachain.hip).  Synchronises the stream: the number of reads and each chunk's progress come back to the host.
+static int run_beta_chain(vgl_ctx* c, const VglDevParams& D, int n_sites, hipStream_t st) {
+    const long long E = (long long)n_sites * D.n_samples;
+    if (vgl_chain_read_offsets(c->d_sdp, E, c->d_roff, c->d_rtotal, st)) return fail(VGL_E_NODEVICE, "k_read_offsets launch failed");
+    long long R = 0;
+    HIPCHK(hipMemcpyAsync(&R, c->d_rtotal, sizeof R, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (R == 0) return VGL_OK;
+    if ((size_t)R > c->errp_lin_cap) {
+        if (c->d_errp_lin) { HIPCHK(hipFree(c->d_errp_lin)); c->d_errp_lin = nullptr; }
+        c->errp_lin_cap = (size_t)R + (size_t)R / 8 + 1024;
+        if (dmalloc(&c->d_errp_lin, c->errp_lin_cap)) return VGL_E_NOMEM;
+    }
+    const long long margin = vgl_chain_margin_words(), seg = vgl_chain_seg();
+    long long done = 0;
+    while (done < R) {
+        const long long remaining = R - done;
+        // a deviate takes ~15-19 words on average; the chunk is sized for the rest of the tile, at most 2^28 words
+        long long n_words = remaining * 24 + 4096 + margin;
+        long long cap_words = 1LL << 28;
+        if (getenv("VGL_CHAIN_MAX_WORDS")) cap_words = atoll(getenv("VGL_CHAIN_MAX_WORDS"));      // test hook: many small chunks
+        if (n_words > cap_words) n_words = cap_words;
+        n_words &= ~1LL;
+        if (n_words > c->chain_words_cap) {
+            void* old[] = {c->d_cw, c->d_ccons, c->d_cexit, c->d_ccnt, c->d_centry, c->d_cbase, c->d_cpos, c->d_csnap, c->d_csnapw};
+            for (void* q : old) if (q) HIPCHK(hipFree(q));
+            c->d_cw = nullptr; c->d_ccons = nullptr; c->d_cexit = nullptr; c->d_ccnt = nullptr; c->d_centry = nullptr; c->d_cbase = nullptr;
+            c->d_cpos = nullptr; c->d_csnap = nullptr; c->d_csnapw = nullptr;
+            const size_t npos = (size_t)n_words / 2, nseg = npos / (size_t)seg + 2, nsnap = (size_t)vgl_chain_snapshots_needed(n_words);
+            if (dmalloc(&c->d_cw, (size_t)n_words) || dmalloc(&c->d_ccons, npos) || dmalloc(&c->d_cexit, nseg * 64) || dmalloc(&c->d_ccnt, nseg * 64) ||
+                dmalloc(&c->d_centry, nseg) || dmalloc(&c->d_cbase, nseg) || dmalloc(&c->d_cpos, npos / 4 + 1024) ||
+                dmalloc(&c->d_csnap, nsnap * 624) || dmalloc(&c->d_csnapw, nsnap + 1)) return VGL_E_NOMEM;
+            c->chain_words_cap = n_words;
+        }
+        VglChainCtl h; memset(&h, 0, sizeof h);
+        h.remaining = remaining; h.n_pos = (n_words - margin) / 2; h.n_seg = (int)((h.n_pos + seg - 1) / seg);
+        HIPCHK(hipMemcpyAsync(c->d_cctl, &h, sizeof h, hipMemcpyHostToDevice, st));
+        if (vgl_chain_chunk(&D, c->d_serial, c->d_cctl, c->d_cw, n_words, c->d_ccons, c->d_cexit, c->d_ccnt, c->d_centry, c->d_cbase, c->d_cpos,
+                            c->d_csnap, c->d_csnapw, st)) return fail(VGL_E_NODEVICE, "beta chain launch failed: %s", hipGetErrorString(hipGetLastError()));
+        HIPCHK(hipMemcpyAsync(&h, c->d_cctl, sizeof h, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (h.err) return fail(VGL_E_UNSUPPORTED, "a beta deviate consumed more generator words than the chain scheme allows");
+        if (h.n_chunk <= 0 || h.endw <= 0) return fail(VGL_E_NODEVICE, "beta chain made no progress");
+        if (vgl_chain_emit(&D, c->d_serial, c->d_cctl, c->d_cw, c->d_cpos, h.n_chunk, c->d_errp_lin + done, c->d_csnap, c->d_csnapw,
+                           vgl_chain_snapshots_needed(n_words), st)) return fail(VGL_E_NODEVICE, "beta chain launch failed");
+        done += h.n_chunk;
+    }
+    return VGL_OK;
+}
+
 extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sites, const uint8_t* gt,
                                         vgl_tile_out* o, void* stream) {
     if (!c || !o) return fail(VGL_E_ARG, "null argument");
@@ -527,6 +586,11 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     if (D.serial) {
         if (vgl_launch_scout(&D, &T, c->d_serial, st)) return fail(VGL_E_NODEVICE, "k_scout launch failed");
         c->serial_next_site = site0 + n_sites;
+        if (D.beta_chain) {
+            const int rc = run_beta_chain(c, D, n_sites, st);
+            if (rc != VGL_OK) return rc;
+            T.roff = c->d_roff; T.errp_lin = c->d_errp_lin;
+        }
     } else if (D.depth_pre && vgl_launch_depth(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_depth launch failed");
     if (c->timing) HIPCHK(hipEventRecord(e[0], st));
     if (vgl_launch_sample(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_sample launch failed: %s", hipGetErrorString(hipGetLastError()));
@@ -538,6 +602,16 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     if (o->qs || o->i16) if (vgl_launch_siteagg(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_siteagg launch failed");
     if (c->timing) for (int k = 0; k < 4; k++) c->ev.push_back(e[k]);
     return VGL_OK;
+}
+
+// diagnostic (not in the public header): the beta deviates of the last serial tile in draw order
+extern "C" long long vgl_dbg_chain(vgl_ctx* c, double* out, long long n) {
+    if (!c || !c->d_errp_lin) return -1;
+    long long R = 0;
+    if (hipMemcpy(&R, c->d_rtotal, sizeof R, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (n > R) n = R;
+    if (hipMemcpy(out, c->d_errp_lin, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return R;
 }
 
 // diagnostic (not in the public header): read and clear the VGL_DEBUG_STAMPS counters

@@ -368,7 +368,12 @@ __global__ __launch_bounds__(256) void k_sample_serial(const VglDevParams P, con
             bool fwd;
             const int r_base = sample_read_base(st_hap, st_base, a0, a1, err_thresh, P.sample_strand != 0, fwd);
             int q_i = P.pre_q, aq_i = P.pre_adjq;
-            if (P.error_qs == 2) errprob_to_qs(P, T.errp[(size_t)r * plane + ev], q_i, aq_i, T.errflag);
+            if (P.error_qs == 2) {
+                double e;
+                if (T.errp_lin) { e = T.errp_lin[T.roff[ev] + r]; if (P.precise_gl) T.errp[(size_t)r * plane + ev] = e; }   // k_gl reads the planes
+                else e = T.errp[(size_t)r * plane + ev];
+                errprob_to_qs(P, e, q_i, aq_i, T.errflag);
+            }
             const int q_gl = (P.adjust_qs & 1) ? aq_i : q_i;
             T.reads[(size_t)r * plane + ev] = (uint8_t)((q_gl << 2) | r_base);
             if (T.reads_out && r < T.reads_out_cap) T.reads_out[(size_t)r * plane + ev] = (uint8_t)((q_i << 2) | r_base);
@@ -411,7 +416,7 @@ __global__ __launch_bounds__(256) void k_sample_serial(const VglDevParams P, con
 // ------------------------------------------------------------------------------------
 extern "C" int vgl_launch_scout(const VglDevParams* p, const VglTilePtrs* t, VglSerialState* st, void* stream) {
     if (t->n_sites == 0) return 0;
-    if (p->error_qs != 2) hipLaunchKernelGGL(k_scout_wave, dim3(1), dim3(64), (size_t)p->scout_lds_bytes + 192 * sizeof(VglAffine), (hipStream_t)stream, *p, *t, st);
+    if (p->error_qs != 2 || p->beta_chain) hipLaunchKernelGGL(k_scout_wave, dim3(1), dim3(64), (size_t)p->scout_lds_bytes + 192 * sizeof(VglAffine), (hipStream_t)stream, *p, *t, st);
     else hipLaunchKernelGGL(k_scout, dim3(1), dim3(64), 0, (hipStream_t)stream, *p, *t, st);
     return (int)hipGetLastError();
 }
