@@ -116,3 +116,28 @@ def test_integer_type_choice_at_the_boundaries(tmp_path, vals, bt):
         (ik, it, iv), = rec["info"]
         assert ik == "Y" and iv == want and (it == bt or len(vals) == 1)
         assert rec["alleles"] == ["A", "C", "<*>"] and rec["filter"] == ["PASS"] and rec["id"] == "rs1" and rec["pos0"] == 4
+
+
+@pytest.mark.parametrize("vcf,src", [("data3.vcf", 0), ("data2.vcf", 0), ("data5_acgt_multiallelic.vcf", 1), ("data1.vcf", 0)])
+def test_bcf_input_round_trip(tmp_path, vcf, src):
+    """BCF (raw and BGZF) as INPUT: the truth file of a run holds the decoded input records; fed back as
+    BCF (its alleles are already A/C/G/T, hence --source 1) it gives the records of the VCF-text run."""
+    base = ["--seed", "1", "--depth", "inf", "-e", "0", "-printTruth", "1", "-doUnobserved", "1"]
+    ref = str(tmp_path / "ref")
+    r = subprocess.run([BIN, "-i", os.path.join(DATA, vcf), "-o", ref, "-O", "v", "--source", str(src)] + base, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1500:]
+    for mode in ("u", "b"):
+        first = str(tmp_path / ("first_" + mode))
+        r = subprocess.run([BIN, "-i", os.path.join(DATA, vcf), "-o", first, "-O", mode, "--source", str(src)] + base, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-1500:]
+        again = str(tmp_path / ("again_" + mode))
+        r = subprocess.run([BIN, "-i", first + ".truth.bcf", "-o", again, "-O", "v", "--source", "1"] + base, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-1500:]
+        assert body(open(again + ".vcf")) == body(open(ref + ".vcf"))
+        assert body(open(again + ".truth.vcf")) == body(open(ref + ".truth.vcf"))
+
+
+def test_run_log_is_written(tmp_path):
+    out = run(tmp_path, "log", "v")                         # io.cpp:1031: <prefix>.arg
+    txt = open(out + ".arg").read()
+    assert "Command: vcfgl_hip" in txt and "Simulation finished successfully" in txt and out + ".vcf" in txt and "truth" in txt

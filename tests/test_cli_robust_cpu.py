@@ -30,7 +30,7 @@ def asan_bin(tmp_path_factory):
 
 def run(binary, vcf, out, extra=()):
     r = subprocess.run([binary, "-i", vcf, "-o", out, "--seed", "1", "--depth", "inf", "-e", "0", "-O", "v", *extra],
-                       capture_output=True, text=True, timeout=60)
+                       capture_output=True, text=True, errors="replace", timeout=60)
     assert not any(m in r.stderr or m in r.stdout for m in SAN_MARKS), r.stderr[-3000:]
     return r
 
@@ -98,3 +98,25 @@ def test_random_mutations_never_corrupt_memory(asan_bin, tmp_path):
             open(f, "wb").write(bytes(b))
             r = run(asan_bin, f, str(tmp_path / "out_mut"), extra)
             assert r.returncode in (0, 1), (name, k, r.returncode, r.stderr[-500:])
+
+
+def test_random_mutations_of_bcf_input(asan_bin, tmp_path):
+    """the BCF reader under the sanitizers: byte mutations of valid raw BCF files (the host program's own truth output)"""
+    rng = random.Random(7)
+    r = subprocess.run([asan_bin, "-i", os.path.join(DATA, "data5_acgt_multiallelic.vcf"), "-o", str(tmp_path / "seed"), "-O", "u", "--source", "1",
+                        "--seed", "1", "--depth", "inf", "-e", "0", "-printTruth", "1"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr[-2000:]
+    src = bytearray(open(str(tmp_path / "seed") + ".truth.bcf", "rb").read())
+    hdr_end = 9 + int.from_bytes(src[5:9], "little")
+    for k in range(200):
+        b = bytearray(src)
+        for _ in range(rng.randint(1, 4)):
+            i = rng.randrange(5, len(b)) if rng.random() < 0.3 else rng.randrange(hdr_end, len(b))   # mostly inside the records
+            if rng.random() < 0.7:
+                b[i] = rng.randrange(256)
+            else:
+                del b[i:i + rng.randint(1, 9)]
+        f = str(tmp_path / "mut.bcf")
+        open(f, "wb").write(bytes(b))
+        r = run(asan_bin, f, str(tmp_path / "out_mutb"), ("--source", "1"))
+        assert r.returncode in (0, 1), (k, r.returncode, r.stderr[-500:])

@@ -11,7 +11,7 @@
 //   * --depth inf (simulate_record_true_values, vcfgl.cpp:1089-1262): no sampling at all, the true
 //     genotype gets GL 0 / GP 1 / PL 0 and every other genotype -inf / 0 / 255; written directly
 //   * -printTruth 1: the decoded input records (incl. exploded ones) as <prefix>.truth.vcf
-// CPU simulation path here.  Not provided: BCF input.
+// CPU simulation path here.  Input: VCF text, gzip / bgzip'd VCF, BCF (raw or BGZF).
 #include <math.h>
 #include <stdarg.h>
 #include <stdint.h>
@@ -237,11 +237,153 @@ static void split(const std::string& s, char c, std::vector<std::string>& out) {
     while (true) { size_t e = s.find(c, b); if (e == std::string::npos) { out.push_back(s.substr(b)); break; } out.push_back(s.substr(b, e - b)); b = e + 1; }
 }
 
+// ---------------------------------------------------------------------------------------
+// BCF 2.x input (raw or BGZF; zlib reads the gzip members): header text, then records decoded back
+// into the same Rec the text reader fills -- QUAL / FILTER / INFO as VCF text, GT as allele indices.
+struct BcfIn {
+    std::vector<uint8_t> buf; size_t off = 0;
+    std::map<int, std::string> dict, contig; std::map<std::string, int> info_is_flag;
+    uint32_t u32() { if (off + 4 > buf.size()) die("truncated BCF record"); uint32_t v; memcpy(&v, &buf[off], 4); off += 4; return v; }
+    void typed(int& type, int& n) {
+        if (off >= buf.size()) die("truncated BCF record");
+        const uint8_t b = buf[off++]; type = b & 15; n = b >> 4;
+        if (n == 15) { int t2, n2; typed(t2, n2); std::vector<int32_t> v; ints(t2, n2, v); if (v.empty() || v[0] < 0) die("bad BCF vector length"); n = v[0]; }
+    }
+    void ints(int type, int n, std::vector<int32_t>& out) {          // missing -> INT32_MIN, end-of-vector -> INT32_MIN + 1
+        const int w = type == 1 ? 1 : type == 2 ? 2 : type == 3 ? 4 : 0;
+        if (!w) die("BCF: integer vector expected (type %d)", type);
+        if (off + (size_t)w * n > buf.size()) die("truncated BCF record");
+        out.clear();
+        for (int i = 0; i < n; i++, off += w) {
+            int32_t v;
+            if (w == 1) { const int8_t x = (int8_t)buf[off]; v = x == -128 ? INT32_MIN : x == -127 ? INT32_MIN + 1 : x; }
+            else if (w == 2) { int16_t x; memcpy(&x, &buf[off], 2); v = x == -32768 ? INT32_MIN : x == -32767 ? INT32_MIN + 1 : x; }
+            else memcpy(&v, &buf[off], 4);
+            out.push_back(v);
+        }
+    }
+    std::string str(int n) { if (off + n > buf.size()) die("truncated BCF record"); std::string r((const char*)&buf[off], n); off += n; return r; }
+    static std::string attr(const std::string& h, const char* key) {
+        const std::string k = std::string(key) + "=";
+        size_t a = h.find("<" + k); if (a == std::string::npos) a = h.find("," + k); if (a == std::string::npos) return "";
+        a += k.size() + 1;
+        return h.substr(a, h.find_first_of(",>", a) - a);
+    }
+};
+
+static Vcf read_bcf(std::vector<uint8_t>&& raw, bool keep_gt_text) {
+    BcfIn in; in.buf = std::move(raw);
+    if (in.buf.size() < 9 || memcmp(in.buf.data(), "BCF\2", 4) != 0) die("not a BCF2 file");
+    in.off = 5;
+    const uint32_t l_text = in.u32();
+    if (in.off + l_text > in.buf.size()) die("truncated BCF header");
+    std::string text((const char*)&in.buf[in.off], l_text); in.off += l_text;
+    while (!text.empty() && (text.back() == '\0' || text.back() == '\n')) text.pop_back();
+    Vcf v; std::vector<std::string> lines, f; split(text, '\n', lines);
+    int nd = 0, nc = 0; bool have_pass = false;
+    for (const std::string& h : lines) if (h.compare(0, 10, "##FILTER=<") == 0 && BcfIn::attr(h, "ID") == "PASS") have_pass = true;
+    if (!have_pass) { in.dict[0] = "PASS"; nd = 1; }
+    for (const std::string& h : lines) {
+        if (h.compare(0, 2, "##") != 0) { if (!h.empty() && h[0] == '#') { split(h, '\t', f); for (size_t i = 9; i < f.size(); i++) v.samples.push_back(f[i]); } continue; }
+        v.header.push_back(h);
+        const bool fil = h.compare(0, 10, "##FILTER=<") == 0, inf = h.compare(0, 8, "##INFO=<") == 0, fmt = h.compare(0, 10, "##FORMAT=<") == 0;
+        const bool ctg = h.compare(0, 10, "##contig=<") == 0;
+        if (!(fil || inf || fmt || ctg)) continue;
+        const std::string id = BcfIn::attr(h, "ID"), idx_s = BcfIn::attr(h, "IDX");
+        if (ctg) {
+            const int idx = idx_s.empty() ? nc : atoi(idx_s.c_str());
+            in.contig[idx] = id; nc = std::max(nc, idx + 1);
+            const std::string len = BcfIn::attr(h, "length"); v.contig_len[id] = len.empty() ? -1 : atol(len.c_str());
+            continue;
+        }
+        int idx = -1;
+        for (auto& kv : in.dict) if (kv.second == id) idx = kv.first;
+        if (idx < 0) idx = idx_s.empty() ? nd : atoi(idx_s.c_str());
+        in.dict[idx] = id; nd = std::max(nd, idx + 1);
+        if (inf) in.info_is_flag[id] = BcfIn::attr(h, "Type") == "Flag";
+    }
+    const size_t N = v.samples.size();
+    std::vector<int32_t> iv; int type, n;
+    while (in.off < in.buf.size()) {
+        const uint32_t l_shared = in.u32(), l_indiv = in.u32();
+        const size_t rec_end = in.off + (size_t)l_shared + l_indiv, shared_end = in.off + l_shared;
+        if (rec_end > in.buf.size()) die("truncated BCF record");
+        Rec r;
+        const int32_t chrom = (int32_t)in.u32(); r.pos0 = (int32_t)in.u32(); (void)in.u32();
+        const uint32_t qual = in.u32(), nai = in.u32(), nfs = in.u32();
+        const int n_allele = nai >> 16, n_info = nai & 0xFFFF, n_fmt = nfs >> 24; const size_t n_sample = nfs & 0xFFFFFF;
+        if (!in.contig.count(chrom)) die("BCF record with an undefined contig index %d", chrom);
+        if (n_sample != N) die("Record at position %ld has %zu samples, the header names %zu samples.", r.pos0 + 1, n_sample, N);
+        r.chrom = in.contig[chrom];
+        if (qual == VGL_FLOAT_MISSING_BITS) r.qual = "."; else { float q; memcpy(&q, &qual, 4); put_float(r.qual, q); }
+        in.typed(type, n); r.id = (type == 7) ? in.str(n) : "."; if (r.id.empty()) r.id = ".";
+        for (int i = 0; i < n_allele; i++) { in.typed(type, n); if (type != 7) die("BCF: allele string expected"); r.alleles.push_back(in.str(n)); }
+        if (r.alleles.empty() || r.alleles[0].empty()) die("Empty REF at position %ld.", r.pos0 + 1);
+        r.ref_char = r.alleles[0][0];
+        in.typed(type, n);
+        if (type == 0 || n == 0) r.filt = "."; else { in.ints(type, n, iv); for (size_t i = 0; i < iv.size(); i++) { if (i) r.filt += ';'; if (!in.dict.count(iv[i])) die("BCF: undefined FILTER index"); r.filt += in.dict[iv[i]]; } }
+        for (int i = 0; i < n_info; i++) {
+            in.typed(type, n); in.ints(type, n, iv);
+            if (iv.empty() || !in.dict.count(iv[0])) die("BCF: undefined INFO key");
+            const std::string key = in.dict[iv[0]];
+            if (!r.info.empty()) r.info += ';';
+            r.info += key;
+            in.typed(type, n);
+            if (type == 0 || n == 0) continue;                              // flag
+            r.info += '=';
+            if (type == 7) r.info += in.str(n);
+            else if (type == 5) { for (int k = 0; k < n; k++) { const uint32_t b = in.u32(); if (b == 0x7F800002u) continue; if (k) r.info += ','; float x; memcpy(&x, &b, 4); put_float(r.info, x); } }
+            else { in.ints(type, n, iv); bool first = true; for (int32_t x : iv) { if (x == INT32_MIN + 1) continue; if (!first) r.info += ','; first = false; put_int(r.info, x); } }
+        }
+        if (r.info.empty()) r.info = ".";
+        if (in.off != shared_end) die("BCF record: shared block length mismatch at position %ld", r.pos0 + 1);
+        bool have_gt = false;
+        r.gt.assign(2 * N, -1);
+        for (int k = 0; k < n_fmt; k++) {
+            in.typed(type, n); in.ints(type, n, iv);
+            if (iv.empty() || !in.dict.count(iv[0])) die("BCF: undefined FORMAT key");
+            const bool is_gt = in.dict[iv[0]] == "GT";
+            in.typed(type, n);
+            const size_t w = type == 1 ? 1 : type == 2 ? 2 : (type == 3 || type == 5) ? 4 : type == 7 ? 1 : 0;
+            if (!is_gt) { if (in.off + w * n * N > in.buf.size()) die("truncated BCF record"); in.off += w * n * N; continue; }
+            have_gt = true;
+            for (size_t s = 0; s < N; s++) {
+                in.ints(type, n, iv);
+                int8_t a[2] = {-1, -1}; std::string txt;
+                for (int j = 0; j < n && iv[j] != INT32_MIN + 1; j++) {
+                    const int al = (iv[j] >> 1) - 1;
+                    if (j < 2) a[j] = (int8_t)al;
+                    if (keep_gt_text) { if (j) txt += (iv[j] & 1) ? '|' : '/'; if (al < 0) txt += '.'; else { char t[16]; snprintf(t, sizeof t, "%d", al); txt += t; } }
+                }
+                if (n == 1 || (n >= 2 && iv[1] == INT32_MIN + 1)) a[1] = a[0];     // haploid call: both alleles, as the text reader does
+                r.gt[2 * s] = a[0]; r.gt[2 * s + 1] = a[1];
+                if (keep_gt_text) r.gt_str.push_back(txt.empty() ? "." : txt);
+            }
+        }
+        if (!have_gt) die("Could not find GT tag at position %ld.", r.pos0 + 1);
+        in.off = rec_end;
+        v.recs.push_back(std::move(r));
+    }
+    return v;
+}
+
 // keep_gt_text: the GT tokens as written are needed only by -printTruth
 static Vcf read_vcf(const std::string& fn, bool keep_gt_text) {
-    gzFile fp = gzopen(fn.c_str(), "r");               // plain text or gzip
+    gzFile fp = gzopen(fn.c_str(), "r");               // plain text or gzip / BGZF
     if (!fp) die("Could not open file: %s", fn.c_str());
     gzbuffer(fp, 1 << 20);
+    {
+        char magic[4] = {0, 0, 0, 0};
+        const int got = gzread(fp, magic, 3);
+        if (got == 3 && !memcmp(magic, "BCF", 3)) {     // BCF: the whole (decompressed) file, then the binary decoder
+            std::vector<uint8_t> raw(magic, magic + 3), chunk(1 << 22);
+            int k;
+            while ((k = gzread(fp, chunk.data(), (unsigned)chunk.size())) > 0) raw.insert(raw.end(), chunk.begin(), chunk.begin() + k);
+            gzclose(fp);
+            return read_bcf(std::move(raw), keep_gt_text);
+        }
+        gzrewind(fp);
+    }
     Vcf v;
     std::string line; std::vector<char> buf(1 << 20);
     std::vector<std::string> f, g, fmt;
@@ -467,6 +609,26 @@ struct GvcfBlocker {
     }
 };
 
+// <prefix>.arg: the run log the reference writes beside its outputs (io.cpp:1031,1109; vcfgl.cpp:1657-1871)
+struct RunLog {
+    FILE* fp = nullptr; std::string prefix; time_t t0 = 0; clock_t c0 = 0;
+    void open(const Args& a) {
+        prefix = a.out_prefix; t0 = time(NULL); c0 = clock();
+        fp = fopen((prefix + ".arg").c_str(), "w");
+        if (!fp) die("Could not open file: %s.arg", prefix.c_str());
+        char when[64]; struct tm tmv; localtime_r(&t0, &tmv); strftime(when, sizeof when, "%a %b %d %H:%M:%S %Y", &tmv);
+        fprintf(fp, "vcfgl_hip (libvcfgl_hip ABI %d, gfx950)\n\n%s\n\n\n[Program start] %s\n", vgl_abi_version(), a.command.c_str(), when);
+    }
+    void finish(const std::string& summary, const std::vector<std::string>& files) {
+        if (!fp) return;
+        fputs(summary.c_str(), fp);
+        fprintf(fp, "\n\tElapsed time (CPU): %f seconds\n\tElapsed time (Real): %f seconds\n", (double)(clock() - c0) / CLOCKS_PER_SEC, difftime(time(NULL), t0));
+        fprintf(fp, "\n-> Log file: %s.arg\n", prefix.c_str());
+        for (const std::string& f : files) fprintf(fp, "%s\n", f.c_str());
+        fclose(fp); fp = nullptr;
+    }
+};
+
 // ---------------------------------------------------------------------------------------
 int main(int argc, char** argv) {
     if (argc >= 2 && !strcmp(argv[1], "--format-floats")) {
@@ -492,6 +654,7 @@ int main(int argc, char** argv) {
         return 0;
     }
     Args a = parse_args(argc, argv);
+    RunLog runlog; runlog.open(a);
     // --verbose 1: wall-clock seconds per stage on stderr at the end
     double t_stage[6] = {0, 0, 0, 0, 0, 0};                   // read, sites, context, simulate, encode, write
     auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
@@ -582,7 +745,11 @@ int main(int argc, char** argv) {
             out.write_line(line);
         }
         out.close();
-        fprintf(stderr, "\n\n-> Simulation finished successfully.\n\nSummary:\n\tNumber of samples: %d\n\tTotal number of sites simulated: %zu\n", N, sites.size());
+        char sb[512]; snprintf(sb, sizeof sb, "\n\n-> Simulation finished successfully.\n\nSummary:\n\tNumber of samples: %d\n\tTotal number of sites simulated: %zu\n", N, sites.size());
+        fputs(sb, stderr);
+        std::vector<std::string> files = {"-> Simulation output file: " + a.out_prefix + ext};
+        if (a.print_truth) files.push_back("-> True genotypes output file: " + a.out_prefix + ".truth" + ext);
+        runlog.finish(sb, files);
         return 0;
     }
 
@@ -762,8 +929,13 @@ int main(int argc, char** argv) {
     vgl_ctx_destroy(ctx);
     if (a.verbose) fprintf(stderr, "\n[timing] read input %.3f s, sites %.3f s, device context %.3f s, simulate (incl. PCIe) %.3f s, encode %.3f s, write/compress %.3f s\n",
                            t_stage[0], t_stage[1], t_stage[2], t_stage[3], t_stage[4], t_stage[5]);
-    fprintf(stderr, "\n\n-> Simulation finished successfully.\n\nSummary:\n\tNumber of samples: %d\n\tTotal number of sites simulated: %zu\n"
-                    "\tNumber of sites included in simulation output file: %ld\n\tNumber of sites skipped: %ld\n",
-            N, sites.size(), n_out, n_skipped);
+    char sb[512];
+    snprintf(sb, sizeof sb, "\n\n-> Simulation finished successfully.\n\nSummary:\n\tNumber of samples: %d\n\tTotal number of sites simulated: %zu\n"
+                            "\tNumber of sites included in simulation output file: %ld\n\tNumber of sites skipped: %ld\n", N, sites.size(), n_out, n_skipped);
+    fputs(sb, stderr);
+    std::vector<std::string> files = {"-> Simulation output file: " + a.out_prefix + ext};
+    if (a.print_pileup) files.push_back("-> Pileup output file: " + a.out_prefix + ".pileup.gz");
+    if (a.print_truth) files.push_back("-> True genotypes output file: " + a.out_prefix + ".truth" + ext);
+    runlog.finish(sb, files);
     return 0;
 }
