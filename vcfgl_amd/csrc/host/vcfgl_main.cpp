@@ -49,6 +49,7 @@ struct Args {
     int add_gl = 1, add_gp = 0, add_pl = 0, add_i16 = 0, add_qs = 0, add_fmt_dp = 1, add_info_dp = 0;
     int add_fmt_ad = 0, add_info_ad = 0, add_fmt_adf = 0, add_info_adf = 0, add_fmt_adr = 0, add_info_adr = 0;
     int rng_mode = VGL_RNG_TILE, beta_sampler = -1, tile_sites = 4096, device = 0, verbose = 0, threads = 1, enc_threads = 0;
+    bool threads_given = false;
     double depth = -1.0, error_rate = -1.0, beta_variance = -1.0, gl1_theta = 0.83, adjust_by = 0.499;
     bool have_depth = false, depth_inf = false;
     std::string in_fn, out_prefix = "output", output_mode = "b", depths_fn, qs_bins_fn, command;
@@ -112,7 +113,7 @@ static Args parse_args(int argc, char** argv) {
         else if (f == "-addFormatADR") a.add_fmt_adr = I(v);
         else if (f == "-addInfoADR") a.add_info_adr = I(v);
         else if (f == "--verbose" || f == "-V") a.verbose = I(v);
-        else if (f == "--threads" || f == "-@") a.threads = I(v);
+        else if (f == "--threads" || f == "-@") { a.threads = I(v); a.threads_given = true; }
         else if (f == "--encode-threads") a.enc_threads = I(v);      // extension: record-encoding threads (any output mode)
         // extensions of this implementation
         else if (f == "--rng-mode") a.rng_mode = I(v);
@@ -797,7 +798,8 @@ int main(int argc, char** argv) {
         if (a.add_info_adf) hdr.push_back("##INFO=<ID=ADF,Number=R,Type=Integer,Description=\"Total allelic depths, forward strand\">");
         if (a.add_info_adr) hdr.push_back("##INFO=<ID=ADR,Number=R,Type=Integer,Description=\"Total allelic depths, reverse strand\">");
         complete_header(hdr);
-        out.open(a.out_prefix + ext, mode, hdr, vcf.samples, a.threads);
+        // BGZF compression threads: --threads as in the reference; when it is not given, up to 8 (same bytes either way)
+        out.open(a.out_prefix + ext, mode, hdr, vcf.samples, a.threads_given ? a.threads : (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
     }
     gzFile pile = nullptr;
     if (a.print_pileup) { pile = gzopen((a.out_prefix + ".pileup.gz").c_str(), "wb"); if (!pile) die("Could not open pileup output"); }
@@ -826,6 +828,10 @@ int main(int argc, char** argv) {
     std::string line;
     GvcfBlocker gv;
     std::vector<std::string> enc;
+    // record encoding threads: --encode-threads, else --threads when given, else up to 8 of the machine's threads --
+    // the bytes written do not depend on it
+    int enc_threads = a.enc_threads > 0 ? a.enc_threads : a.threads;
+    if (a.enc_threads <= 0 && !a.threads_given) { const unsigned hc = std::thread::hardware_concurrency(); enc_threads = (int)std::max(1u, std::min(8u, hc)); }
     gv.block_dps = a.gvcf_dps;
     // one simulated record of the current tile: the eight fixed columns as text, the allele strings and the
     // typed FORMAT arrays (reads the tile buffers only: records of a tile are built on several threads)
@@ -909,7 +915,7 @@ int main(int argc, char** argv) {
         }
         if (!a.do_gvcf) {
             enc.resize(ns);
-            vsink::parallel_for(ns, a.enc_threads > 0 ? a.enc_threads : a.threads, [&](int i) {
+            vsink::parallel_for(ns, enc_threads, [&](int i) {
                 enc[i].clear();
                 if (st[i] < 0) return;
                 std::string sh; std::vector<std::string> al; std::vector<vsink::FmtDesc> fmt;
