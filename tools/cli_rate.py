@@ -24,10 +24,11 @@ with open(vcf, "w") as f:
         f.write("chr1\t%d\t.\t0\t1\t.\tPASS\t.\tGT\t" % (i + 1) + "\t".join(tok[idx]) + "\n")
 print(f"input: {S} sites x {N} samples, {os.path.getsize(vcf) / 1e6:.1f} MB of VCF text")
 flags = "--seed 42 --depth 20 -e 0.01 --error-qs 2 --beta-variance 1e-5 -GL 2".split()
-for mode, threads in (("v", 1), ("u", 1), ("u", 16), ("b", 1), ("b", 16), ("b", 64)):
+for mode, threads in (("v", 0), ("v", 1), ("u", 0), ("u", 1), ("u", 16), ("b", 0), ("b", 1), ("b", 64)):
     out = os.path.join(d, f"o_{mode}{threads}")
     t0 = time.perf_counter()
-    r = subprocess.run([BIN, "-i", vcf, "-o", out, "-O", mode, "--threads", str(threads), "--verbose", "1"] + flags, capture_output=True, text=True)
+    th = ["--threads", str(threads)] if threads else []          # 0: not given (the program's default: up to 8 internal threads)
+    r = subprocess.run([BIN, "-i", vcf, "-o", out, "-O", mode, "--verbose", "1"] + th + flags, capture_output=True, text=True)
     dt = time.perf_counter() - t0
     assert r.returncode == 0, r.stderr[-800:]
     fn = out + {"v": ".vcf", "z": ".vcf.gz", "u": ".bcf", "b": ".bcf"}[mode]
