@@ -216,11 +216,12 @@ def main():
         avg_ms = kms[dom] / max(klaunch[dom], 1)
         evals_per_launch = float(S) * N * opt.steps / max(klaunch[dom], 1)     # average over the launches, partial last tile included
         achieved = b_eval * evals_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = valu_busy = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(names[dom], {}).get("hbm_bytes_per_launch")
+                prof = json.load(open(tpath)).get(names[dom], {})
+                traffic, valu_busy = prof.get("hbm_bytes_per_launch"), prof.get("valu_busy_frac")
             except Exception:
                 traffic = None
         # the box's own device-copy bandwidth (read + write bytes of a 1 GiB device-to-device copy), the
@@ -247,6 +248,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "copy_bw_measured": copy_gbs, "frac_of_copy_bw": achieved / copy_gbs,
+                         "valu_busy_frac": valu_busy,     # from the committed PMC profile: what actually bounds this kernel
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_eval": b_eval,
                          "kernel_ms_total": dict(zip(names, kms)), "launches": dict(zip(names, klaunch))},
         }
