@@ -64,9 +64,11 @@ extern "C" {
  * (io.cpp:1054-1061, shared.h:17-22).  They differ in WHICH draw index a consumer uses. */
 #define VGL_RNG_TILE    0  /* counter addressed: each (site,sample) owns a private window      */
 #define VGL_RNG_SERIAL  1  /* the reference's serial consumption order: reproduces the reference
-                              program bit for bit.  On the device a sequential scout records the
-                              stream states per (site,sample), everything else runs in parallel;
-                              tiles must be submitted in site order (site0 = sites done so far). */
+                              program bit for bit.  On the device scout kernels resolve the serial
+                              stream chains (64 stream positions at a time; the std::mt19937 beta
+                              stream as a parallel chain over the generator output) and record the
+                              stream states per (site,sample); everything else runs in parallel.
+                              Tiles must be submitted in site order (site0 = sites done so far). */
 
 /* quality-score error sampler (rng.h:353-500) */
 #define VGL_BETA_RAND48 0  /* rng.h:426-446, reference built with -D__USE_STD_BETA__=0, rng2   */
@@ -189,7 +191,9 @@ int vgl_simulate_tile(vgl_ctx* ctx, int64_t site0, int32_t n_sites,
  * (hipMalloc / a torch tensor's data_ptr); work is enqueued on `hip_stream` (a hipStream_t
  * cast to void*, NULL = default stream) and the call returns without synchronising.  A context owns
  * one staging workspace: tiles of one context must be enqueued on one stream (or otherwise ordered);
- * use one context per stream / per GPU for concurrent tiles. */
+ * use one context per stream / per GPU for concurrent tiles.
+ * (VGL_RNG_SERIAL with error_qs 2 and VGL_BETA_STD synchronises the stream inside the call: the number of
+ * reads of the tile and the progress of the beta chain come back to the host.) */
 int vgl_simulate_tile_device(vgl_ctx* ctx, int64_t site0, int32_t n_sites,
                              const uint8_t* gt, vgl_tile_out* out, void* hip_stream);
 
