@@ -36,9 +36,10 @@ for k, v in out.items():
         traffic[k.split("<")[0]] = {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"],
                                     "raw_fetch_variant": v["hbm_bytes_per_launch_raw_fetch"], "source": tag}
     if "SQ_ACTIVE_INST_VALU" in v and v.get("GRBM_GUI_ACTIVE"):
-        # VALU pipes busy: SQ_ACTIVE_INST_VALU counts 4-cycle quads summed over the chip's 1024 SIMDs (256 CUs x 4),
-        # GRBM_GUI_ACTIVE the cycles the kernel was resident -- independent of the clock the part ran at
-        v["valu_busy_frac"] = 4.0 * v["SQ_ACTIVE_INST_VALU"] / (1024.0 * v["GRBM_GUI_ACTIVE"])
+        # VALU pipes busy: SQ_ACTIVE_INST_VALU counts 4-cycle quads summed over the chip's 1024 SIMDs (256 CUs x 4);
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs (value / 8 / duration = 2.39 GHz, the part's clock), so one XCD's
+        # busy cycles are value / 8 and each XCD holds 128 SIMDs
+        v["valu_busy_frac"] = 4.0 * v["SQ_ACTIVE_INST_VALU"] / (128.0 * v["GRBM_GUI_ACTIVE"])
         traffic.setdefault(k.split("<")[0], {})["valu_busy_frac"] = v["valu_busy_frac"]
     if "SQ_INSTS_VALU" in v and "SQ_WAVES" in v:
         v["valu_insts_per_wave"] = v["SQ_INSTS_VALU"] / v["SQ_WAVES"]

@@ -294,8 +294,8 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
         }
         int pc = (int)ceil(lmax + 8.0 * sqrt(lmax) + 64.0);
         pc = (pc + 63) & ~63;
-        if (pc > 2496) pc = 2496;                      // 4 waves x (512 + 5 x 2496) B = 52 KB: three workgroups per CU (160 KB LDS),
-                                                       // what the kernel's registers allow; larger pools run in several segments
+        if (pc > 1920) pc = 1920;                      // 512 + 5 x 1920 B per wavefront: 16 wavefronts (the 4 per SIMD the kernel is
+                                                       // built for) fit a CU's 160 KB LDS; larger pools run in several segments
         D.pool_cap = pc;
         D.pool_lds_bytes = 512 + 5 * pc;
     }

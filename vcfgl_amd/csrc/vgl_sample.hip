@@ -5,6 +5,8 @@
 // reduction + one integer atomic per wave and counter.  EQS=2 (a beta deviate per read): the
 // quality-score sampling of the wave's reads is an LDS-staged pool dealt dynamically to the lanes,
 // each lane a select-only state machine over normal-deviate attempts.
+#include <stdlib.h>
+
 #include "vgl_common.hip.h"
 
 // ------------------------------------------------------------------------------------
@@ -64,8 +66,10 @@ __global__ __launch_bounds__(256) void k_depth(const VglDevParams P, const VglTi
 
 // DBG: diagnostic instantiation (VGL_DEBUG_STAMPS / VGL_DEBUG_PHASE), never used in a timed run
 // PRE: depths come from k_depth (the kernel then carries no Poisson code, which costs it registers)
+// EQS 2 is built for 4 wavefronts per SIMD (128 VGPRs, 32 spilled into rarely executed fallback code): with 3 the VALU
+// pipes were 86 % busy; the fourth wave hides the dependent f64 chains of the pool loop (+8 % on C3)
 template <int EQS, bool DBG, bool PRE>
-__global__ __launch_bounds__(256) void k_sample(const VglDevParams P, const VglTilePtrs T) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 4 : 1, EQS == 2 ? 4 : 8))) void k_sample(const VglDevParams P, const VglTilePtrs T) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const WavePos wp = wave_pos(P, T);
     if (!wp.valid) return;
@@ -378,11 +382,13 @@ extern "C" int vgl_launch_depth(const VglDevParams* p, const VglTilePtrs* t, voi
 extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
     const int64_t waves = (int64_t)t->n_sites * p->chunks;
     if (waves == 0) return 0;
-    const unsigned blocks = (unsigned)((waves + 3) / 4);
     if (p->serial) return vgl_launch_sample_serial(p, t, stream);
     const bool dbg = t->dbg != nullptr;                         // VGL_DEBUG_STAMPS / VGL_DEBUG_PHASE
-    const dim3 g(blocks), b(256);
-    const size_t lds = (size_t)4 * p->pool_lds_bytes;
+    // wavefronts never cooperate here, and a workgroup's wave slots and LDS are only handed on when its last
+    // wavefront retires: one wavefront per workgroup keeps every SIMD at its full complement of waves
+    const int wpb = getenv("VGL_SAMPLE_WPB") ? atoi(getenv("VGL_SAMPLE_WPB")) : 1;
+    const dim3 g((unsigned)((waves + wpb - 1) / wpb)), b(64 * wpb);
+    const size_t lds = (size_t)wpb * p->pool_lds_bytes;
     hipStream_t s = (hipStream_t)stream;
     if (p->error_qs == 2) {
         if (dbg) { if (p->depth_pre) hipLaunchKernelGGL((k_sample<2, true, true>), g, b, lds, s, *p, *t); else hipLaunchKernelGGL((k_sample<2, true, false>), g, b, lds, s, *p, *t); }
