@@ -224,7 +224,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 const bool any_changed = (P.gx.changed | P.gy.changed) != 0;
                 // the two gamma samplers' constants, kept in vector registers for the per-iteration selects
                 double gxa1 = P.gx.a1, gxa2 = P.gx.a2, gya1 = P.gy.a1, gya2 = P.gy.a2;
-                asm volatile("" : "+v"(gxa1), "+v"(gxa2), "+v"(gya1), "+v"(gya2));
                 // The bounded-log tests are needed by a few lanes per iteration but cost every lane of the
                 // wave; they run only every P.slow_period-th iteration.  In between, a lane that needs one
                 // holds: its state is left untouched, so the later iteration recomputes the same attempt.
