@@ -83,7 +83,9 @@ __device__ __forceinline__ int cnt_of(uint64_t ad4, int b) { return b < 4 ? (int
 // window (2x the algorithmic write bytes in the PMC) -- harmless while the kernel is VALU bound.
 // At low depth the kernel is HBM bound instead (C5: 125 B per evaluation, 5 reads), the lanes keep
 // their natural order and every store of a wavefront is one contiguous segment.
-template <int A>
+// GLM, PREC: the GL model (1 / 2) and --precise-gl as template parameters -- the paths share no code, and the
+// model-1 tables and the double log10 of --precise-gl 1 would cost the plain model-2 loop registers (occupancy)
+template <int A, int GLM, bool PREC>
 __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTilePtrs T) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     __shared__ uint32_t s_hist[1026];
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
     for (int i = 0; i < NG; ++i) acc[i] = -0.0f;                                     // bcf_utils.h:310
 
     if (dp > 0) {
-        if (P.gl_model == 2) {
+        if (GLM == 2) {
             // gl_methods.cpp:22-59 / :94-139 / :171-220
             const bool per_read = (P.error_qs == 2);
             // FULL: every lane of the wavefront is at a site with all A alleles (the usual case with
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
                     const uint32_t rb = T.reads[(size_t)r * plane + ev];
                     const int ao = nib(si.acgt2alleles, (int)(rb & 3));
                     if (per_read) {
-                        if (!P.precise_gl) {
+                        if (!PREC) {
                             const int q = (int)(rb >> 2);
                             homT = P.q2gl[q]; het = P.q2gl[257 + q]; homF = P.q2gl[514 + q];
                         } else {
@@ -259,7 +261,6 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
     }
 
     // ---- GL / PL / GP planes (vcfgl.cpp:907-970; no-reads site :297-305)
-    float gp[NG]; float sum_gps = 0.0f;
     const bool sample_ok = have && dp > 0;
 #pragma unroll
     for (int i = 0; i < NG; ++i) {
@@ -274,13 +275,19 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
             else { x = (int32_t)lroundf((float)(-10.0 * (double)v)); if (x > MAXPL) x = MAXPL; }
             T.pl[o] = x;
         }
-        if (T.gp) { gp[i] = valid ? (float)pow(10.0, (double)v) : 0.0f; if (valid) sum_gps += gp[i]; }
     }
-    if (T.gp) {
+    if (T.gp) {                                                          // GP = 10^GL normalised by its float32 sum in genotype order
+        float sum_gps = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {                                   // (the likelihoods are not needed any more: reuse their registers)
+            const bool valid = sample_ok && i < nG;
+            acc[i] = valid ? (float)pow(10.0, (double)acc[i]) : 0.0f;
+            if (valid) sum_gps += acc[i];
+        }
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
             const bool valid = sample_ok && i < nG;
-            T.gp[((size_t)ls * NG + i) * N + s] = valid ? gp[i] / sum_gps : MISS;
+            T.gp[((size_t)ls * NG + i) * N + s] = valid ? acc[i] / sum_gps : MISS;
         }
     }
     // ---- FORMAT/AD, ADF, ADR in allele order (vcfgl.cpp:806-843)
@@ -381,8 +388,15 @@ extern "C" int vgl_launch_gl(const VglDevParams* p, const VglTilePtrs* t, void* 
     if (waves == 0) return 0;
     const unsigned blocks = (unsigned)((waves + 3) / 4);
     const size_t lds = (p->gl_model == 1 && p->error_qs == 2) ? (size_t)4 * 16384 : 0;   // (base,qual) histograms
-    if (p->A == 5) hipLaunchKernelGGL(k_gl<5>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, *p, *t);
-    else hipLaunchKernelGGL(k_gl<4>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, *p, *t);
+    const dim3 g(blocks), b(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (p->gl_model == 2 && p->precise_gl) {
+        if (p->A == 5) hipLaunchKernelGGL((k_gl<5, 2, true>), g, b, lds, s, *p, *t); else hipLaunchKernelGGL((k_gl<4, 2, true>), g, b, lds, s, *p, *t);
+    } else if (p->gl_model == 2) {
+        if (p->A == 5) hipLaunchKernelGGL((k_gl<5, 2, false>), g, b, lds, s, *p, *t); else hipLaunchKernelGGL((k_gl<4, 2, false>), g, b, lds, s, *p, *t);
+    } else {
+        if (p->A == 5) hipLaunchKernelGGL((k_gl<5, 1, false>), g, b, lds, s, *p, *t); else hipLaunchKernelGGL((k_gl<4, 1, false>), g, b, lds, s, *p, *t);
+    }
     return (int)hipGetLastError();
 }
 
