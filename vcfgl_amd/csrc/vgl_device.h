@@ -54,7 +54,8 @@ struct VglDevParams {
     int32_t beta_std;        // VGL_BETA_STD (serial only)
     int32_t beta_chain;      // serial --error-qs 2 with the std sampler: wave scout + vgl_betachain.hip instead of the one-lane scout
     double  beta_a, beta_b;  // beta shape parameters (std sampler)
-    int32_t depth_pre;       // depths are drawn by k_depth ahead of k_sample (every sample's mean depth >= 12: rejection method)
+    int32_t depth_pre;       // depth mode of k_sample: 1 = drawn by k_depth ahead of it (every mean depth >= 12: rejection method),
+                             // 2 = product method in place (every mean depth < 12), 0 = mixed means, general sampler in place
     int32_t gl_sort;         // k_gl: re-deal the lanes of a workgroup in depth order (pays at depth >= 8; below, natural
                              // order keeps every store of a wavefront one contiguous segment and the kernel is HBM bound)
     int32_t slow_period;     // k_sample<2>: the bounded-log tests run every slow_period-th pool iteration

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "../../include/vcfgl_hip.h"
@@ -311,10 +312,11 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     D.scout_lds_bytes = ((size_t)p->n_samples * 9 <= 144 * 1024) ? (int32_t)(((size_t)p->n_samples * 9 + 15) & ~(size_t)15) : 0;
     D.beta_std = (p->beta_sampler == VGL_BETA_STD) ? 1 : 0;
     D.beta_chain = (D.serial && D.beta_std && p->error_qs == 2 && !getenv("VGL_NO_BETA_CHAIN")) ? 1 : 0;
-    {   // k_depth pays for the rejection sampler (lambda >= 12, rng.h:300); the product method stays inside k_sample
-        double dmin = p->depth;
-        if (p->depths) { dmin = p->depths[0]; for (int i = 1; i < N; i++) if (p->depths[i] < dmin) dmin = p->depths[i]; }
-        D.depth_pre = (!D.serial && dmin >= 12.0) ? 1 : 0;
+    {   // depth mode: k_depth pays for the rejection sampler (lambda >= 12, rng.h:300); the product method's short loop
+        // stays inside k_sample, which is specialised for "all product" (2) and "mixed" (0)
+        double dmin = p->depth, dmx = p->depth;
+        if (p->depths) { dmin = dmx = p->depths[0]; for (int i = 1; i < N; i++) { dmin = std::min(dmin, p->depths[i]); dmx = std::max(dmx, p->depths[i]); } }
+        D.depth_pre = D.serial ? 0 : (dmin >= 12.0 ? 1 : (dmx < 12.0 ? 2 : 0));
     }
     D.gl_sort = getenv("VGL_GL_SORT") ? atoi(getenv("VGL_GL_SORT")) : (dmax >= 8.0 ? 1 : 0);
     D.slow_period = getenv("VGL_SLOW_PERIOD") ? atoi(getenv("VGL_SLOW_PERIOD")) : 2;
@@ -592,7 +594,7 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
             if (rc != VGL_OK) return rc;
             T.roff = c->d_roff; T.errp_lin = c->d_errp_lin;
         }
-    } else if (D.depth_pre && vgl_launch_depth(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_depth launch failed");
+    } else if (D.depth_pre == 1 && vgl_launch_depth(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_depth launch failed");
     if (c->timing) HIPCHK(hipEventRecord(e[0], st));
     if (vgl_launch_sample(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_sample launch failed: %s", hipGetErrorString(hipGetLastError()));
     if (c->timing) HIPCHK(hipEventRecord(e[1], st));

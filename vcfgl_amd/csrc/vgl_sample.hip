@@ -65,10 +65,12 @@ __global__ __launch_bounds__(256) void k_depth(const VglDevParams P, const VglTi
 }
 
 // DBG: diagnostic instantiation (VGL_DEBUG_STAMPS / VGL_DEBUG_PHASE), never used in a timed run
-// PRE: depths come from k_depth (the kernel then carries no Poisson code, which costs it registers)
+// DM (depth mode): 1 = depths come from k_depth, 2 = every sample uses the product method (mean depth < 12), drawn
+// in place by its short loop, 0 = mixed means, the general sampler in place (its float32-bounded rejection path costs
+// the kernel registers, hence the specialisations)
 // EQS 2 is built for 4 wavefronts per SIMD (128 VGPRs, 32 spilled into rarely executed fallback code): with 3 the VALU
 // pipes were 86 % busy; the fourth wave hides the dependent f64 chains of the pool loop (+8 % on C3)
-template <int EQS, bool DBG, bool PRE>
+template <int EQS, bool DBG, int DM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 4 : 1, EQS == 2 ? 4 : 8))) void k_sample(const VglDevParams P, const VglTilePtrs T) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const WavePos wp = wave_pos(P, T);
@@ -108,11 +110,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
         // ---- depth (vcfgl.cpp:364-389): drawn even when the genotype is missing; by k_depth where the
         //      rejection method applies, here for the short loops of the product method
         int n;
-        if (PRE) n = T.dp_pre[ev];
+        if (DM == 1) n = T.dp_pre[ev];
         else {
             uint64_t st_depth = aff(P.off[0], xe);
-            if (P.per_sample_depth) { const VglPois pc = P.pois[s]; n = poisson_draw_fast(pc, st_depth, P.gamma_ln_tab, P.gamma_ln_n); }
-            else n = poisson_draw_fast(P.pois0, st_depth, P.gamma_ln_tab, P.gamma_ln_n);
+            VglPois pc = P.pois0;
+            if (P.per_sample_depth) pc = P.pois[s];
+            if (DM == 2) {                                               // rng.h:289-299
+                double em = -1.0, t = 1.0;
+                do { ++em; t *= next_u(st_depth); } while (t > pc.g);
+                n = (int)em;
+            } else n = poisson_draw_fast(pc, st_depth, P.gamma_ln_tab, P.gamma_ln_n);
         }
         const uint32_t g = T.gt[ev];
         a0 = g & 0xF; a1 = (g >> 4) & 0xF;
@@ -389,15 +396,15 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
     const dim3 g((unsigned)((waves + wpb - 1) / wpb)), b(64 * wpb);
     const size_t lds = (size_t)wpb * p->pool_lds_bytes;
     hipStream_t s = (hipStream_t)stream;
-    if (p->error_qs == 2) {
-        if (dbg) { if (p->depth_pre) hipLaunchKernelGGL((k_sample<2, true, true>), g, b, lds, s, *p, *t); else hipLaunchKernelGGL((k_sample<2, true, false>), g, b, lds, s, *p, *t); }
-        else if (p->depth_pre) hipLaunchKernelGGL((k_sample<2, false, true>), g, b, lds, s, *p, *t);
-        else hipLaunchKernelGGL((k_sample<2, false, false>), g, b, lds, s, *p, *t);
-    } else if (p->error_qs == 1) {
-        if (p->depth_pre) hipLaunchKernelGGL((k_sample<1, false, true>), g, b, 0, s, *p, *t); else hipLaunchKernelGGL((k_sample<1, false, false>), g, b, 0, s, *p, *t);
-    } else {
-        if (p->depth_pre) hipLaunchKernelGGL((k_sample<0, false, true>), g, b, 0, s, *p, *t); else hipLaunchKernelGGL((k_sample<0, false, false>), g, b, 0, s, *p, *t);
-    }
+    const int dm = p->depth_pre;                                  // 0 mixed / 1 k_depth / 2 product method only
+#define VGL_LAUNCH_SAMPLE(EQS, DBG, LDS) \
+    do { if (dm == 1) hipLaunchKernelGGL((k_sample<EQS, DBG, 1>), g, b, LDS, s, *p, *t); \
+         else if (dm == 2) hipLaunchKernelGGL((k_sample<EQS, DBG, 2>), g, b, LDS, s, *p, *t); \
+         else hipLaunchKernelGGL((k_sample<EQS, DBG, 0>), g, b, LDS, s, *p, *t); } while (0)
+    if (p->error_qs == 2) { if (dbg) VGL_LAUNCH_SAMPLE(2, true, lds); else VGL_LAUNCH_SAMPLE(2, false, lds); }
+    else if (p->error_qs == 1) VGL_LAUNCH_SAMPLE(1, false, 0);
+    else VGL_LAUNCH_SAMPLE(0, false, 0);
+#undef VGL_LAUNCH_SAMPLE
     return (int)hipGetLastError();
 }
 
