@@ -369,87 +369,85 @@ static Vcf read_bcf(std::vector<uint8_t>&& raw, bool keep_gt_text) {
 }
 
 // keep_gt_text: the GT tokens as written are needed only by -printTruth
-static Vcf read_vcf(const std::string& fn, bool keep_gt_text) {
-    gzFile fp = gzopen(fn.c_str(), "r");               // plain text or gzip / BGZF
+// one record line [lb, le) -> Rec (thread safe: records are parsed in parallel)
+static void parse_record(const char* lb, const char* le, const size_t n_hdr, const bool keep_gt_text, Rec& r) {
+    const char* col_at[10]; int nc = 0; col_at[0] = lb;
+    for (const char* q = lb; q < le && nc < 9; q++) if (*q == '\t') col_at[++nc] = q + 1;
+    if (nc < 9) die("VCF record with fewer than 10 columns (a FORMAT/GT column is required)");
+    auto col = [&](int k) { return std::string(col_at[k], (size_t)(col_at[k + 1] - 1 - col_at[k])); };
+    std::vector<std::string> g, fmt;
+    r.chrom = col(0); r.pos0 = atol(col(1).c_str()) - 1; r.id = col(2); r.qual = col(5); r.filt = col(6); r.info = col(7);
+    const std::string ref = col(3), alt = col(4);
+    r.alleles.push_back(ref);
+    if (alt != ".") { split(alt, ',', g); for (auto& x : g) r.alleles.push_back(x); }
+    if (ref.empty()) die("Empty REF at position %ld.", r.pos0 + 1);
+    r.ref_char = ref[0];
+    split(col(8), ':', fmt);
+    int gti = -1; for (size_t i = 0; i < fmt.size(); i++) if (fmt[i] == "GT") gti = (int)i;
+    if (gti < 0) die("Could not find GT tag at position %ld.", r.pos0 + 1);
+    r.gt.assign(2 * n_hdr, -1);
+    const char* p = col_at[9];
+    const char* const end = le;
+    size_t s = 0;
+    while (true) {                                       // p at the start of a sample column
+        const char* ce = (const char*)memchr(p, '\t', (size_t)(end - p)); if (!ce) ce = end;
+        if (s >= n_hdr) { s++; if (ce == end) break; p = ce + 1; continue; }
+        const char* t = p;                               // the gti-th ':'-separated subfield; trailing ones may be dropped
+        for (int k = 0; k < gti && t; k++) { t = (const char*)memchr(t, ':', (size_t)(ce - t)); if (t) t++; }
+        const char* te = t ? (const char*)memchr(t, ':', (size_t)(ce - t)) : nullptr; if (t && !te) te = ce;
+        int8_t a0 = -1, a1 = -1;
+        if (t) {
+            const char* sep = t; while (sep < te && *sep != '|' && *sep != '/') sep++;
+            auto allele = [](const char* b, const char* e) -> int8_t { return (b == e || *b == '.') ? (int8_t)-1 : (int8_t)atoi(std::string(b, e).c_str()); };
+            a0 = allele(t, sep);
+            a1 = (sep == te) ? a0 : allele(sep + 1, te);
+            if (keep_gt_text) r.gt_str.emplace_back(t, te);
+        } else if (keep_gt_text) r.gt_str.emplace_back(".");
+        r.gt[2 * s] = a0; r.gt[2 * s + 1] = a1;
+        s++;
+        if (ce == end) break;
+        p = ce + 1;
+    }
+    if (s != n_hdr) die("Record at position %ld has %zu sample columns, the header names %zu samples.", r.pos0 + 1, s, n_hdr);
+}
+
+// keep_gt_text: the GT tokens as written are needed only by -printTruth.  The (decompressed) file is read whole,
+// the header lines are taken in order and the record lines are parsed on `threads` threads.
+static Vcf read_vcf(const std::string& fn, bool keep_gt_text, int threads) {
+    gzFile fp = gzopen(fn.c_str(), "r");               // plain text, gzip / BGZF, or BCF inside either
     if (!fp) die("Could not open file: %s", fn.c_str());
     gzbuffer(fp, 1 << 20);
-    {
-        char magic[4] = {0, 0, 0, 0};
-        const int got = gzread(fp, magic, 3);
-        if (got == 3 && !memcmp(magic, "BCF", 3)) {     // BCF: the whole (decompressed) file, then the binary decoder
-            std::vector<uint8_t> raw(magic, magic + 3), chunk(1 << 22);
-            int k;
-            while ((k = gzread(fp, chunk.data(), (unsigned)chunk.size())) > 0) raw.insert(raw.end(), chunk.begin(), chunk.begin() + k);
-            gzclose(fp);
-            return read_bcf(std::move(raw), keep_gt_text);
-        }
-        gzrewind(fp);
-    }
-    Vcf v;
-    std::string line; std::vector<char> buf(1 << 20);
-    std::vector<std::string> f, g, fmt;
-    auto getline = [&]() -> bool {
-        line.clear();
-        while (gzgets(fp, buf.data(), (int)buf.size())) { line += buf.data(); if (!line.empty() && line.back() == '\n') { line.pop_back(); return true; } }
-        return !line.empty();
-    };
-    while (getline()) {
-        if (line.empty()) continue;
-        if (line.compare(0, 2, "##") == 0) {
-            v.header.push_back(line);
-            if (line.compare(0, 10, "##contig=<") == 0) {
-                size_t a = line.find("ID="), l = line.find("length=");
-                if (a != std::string::npos) {
-                    std::string id = line.substr(a + 3, line.find_first_of(",>", a) - a - 3);
-                    v.contig_len[id] = (l != std::string::npos) ? atol(line.c_str() + l + 7) : -1;
-                }
-            }
-            continue;
-        }
-        if (line[0] == '#') { split(line, '\t', f); for (size_t i = 9; i < f.size(); i++) v.samples.push_back(f[i]); continue; }
-        // the nine fixed columns, then one pass over the sample columns without copying them
-        size_t col_at[10]; int nc = 0; col_at[0] = 0;
-        for (size_t i = 0; i < line.size() && nc < 9; i++) if (line[i] == '\t') col_at[++nc] = i + 1;
-        if (nc < 9) die("VCF record with fewer than 10 columns (a FORMAT/GT column is required)");
-        auto col = [&](int k) { return line.substr(col_at[k], col_at[k + 1] - 1 - col_at[k]); };
-        Rec r;
-        r.chrom = col(0); r.pos0 = atol(line.c_str() + col_at[1]) - 1; r.id = col(2); r.qual = col(5); r.filt = col(6); r.info = col(7);
-        const std::string ref = col(3), alt = col(4);
-        r.alleles.push_back(ref);
-        if (alt != ".") { split(alt, ',', g); for (auto& x : g) r.alleles.push_back(x); }
-        if (ref.empty()) die("Empty REF at position %ld.", r.pos0 + 1);
-        r.ref_char = ref[0];
-        split(col(8), ':', fmt);
-        int gti = -1; for (size_t i = 0; i < fmt.size(); i++) if (fmt[i] == "GT") gti = (int)i;
-        if (gti < 0) die("Could not find GT tag at position %ld.", r.pos0 + 1);
-        const size_t n_hdr = v.samples.size();
-        r.gt.assign(2 * n_hdr, -1);
-        const char* p = line.c_str() + col_at[9];
-        const char* const end = line.c_str() + line.size();
-        size_t s = 0;
-        while (true) {                                       // p at the start of a sample column
-            const char* ce = (const char*)memchr(p, '\t', (size_t)(end - p)); if (!ce) ce = end;
-            if (s >= n_hdr) { s++; if (ce == end) break; p = ce + 1; continue; }
-            const char* t = p;                               // the gti-th ':'-separated subfield; trailing ones may be dropped
-            for (int k = 0; k < gti && t; k++) { t = (const char*)memchr(t, ':', (size_t)(ce - t)); if (t) t++; }
-            const char* te = t ? (const char*)memchr(t, ':', (size_t)(ce - t)) : nullptr; if (t && !te) te = ce;
-            int8_t a0 = -1, a1 = -1;
-            if (t) {
-                const char* sep = t; while (sep < te && *sep != '|' && *sep != '/') sep++;
-                auto allele = [](const char* b, const char* e) -> int8_t { return (b == e || *b == '.') ? (int8_t)-1 : (int8_t)atoi(std::string(b, e).c_str()); };
-                a0 = allele(t, sep);
-                a1 = (sep == te) ? a0 : allele(sep + 1, te);
-                if (keep_gt_text) r.gt_str.emplace_back(t, te);
-            } else if (keep_gt_text) r.gt_str.emplace_back(".");
-            r.gt[2 * s] = a0; r.gt[2 * s + 1] = a1;
-            s++;
-            if (ce == end) break;
-            p = ce + 1;
-        }
-        if (s != n_hdr) die("Record at position %ld has %zu sample columns, the header names %zu samples.", r.pos0 + 1, s, n_hdr);
-        v.recs.push_back(std::move(r));
-    }
+    std::vector<uint8_t> raw, chunk(1 << 22);
+    int k;
+    while ((k = gzread(fp, chunk.data(), (unsigned)chunk.size())) > 0) raw.insert(raw.end(), chunk.begin(), chunk.begin() + k);
     gzclose(fp);
+    if (raw.size() >= 3 && !memcmp(raw.data(), "BCF", 3)) return read_bcf(std::move(raw), keep_gt_text);
+    Vcf v;
+    std::vector<std::string> f;
+    std::vector<std::pair<const char*, const char*>> rec_lines;
+    const char* p = (const char*)raw.data(); const char* const end = p + raw.size();
+    while (p < end) {
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+        const char* le = nl ? nl : end;
+        if (le > p) {
+            if (le - p >= 2 && p[0] == '#' && p[1] == '#') {
+                const std::string line(p, le);
+                v.header.push_back(line);
+                if (line.compare(0, 10, "##contig=<") == 0) {
+                    size_t a = line.find("ID="), l = line.find("length=");
+                    if (a != std::string::npos) {
+                        std::string id = line.substr(a + 3, line.find_first_of(",>", a) - a - 3);
+                        v.contig_len[id] = (l != std::string::npos) ? atol(line.c_str() + l + 7) : -1;
+                    }
+                }
+            } else if (p[0] == '#') { split(std::string(p, le), '\t', f); for (size_t i = 9; i < f.size(); i++) v.samples.push_back(f[i]); }
+            else rec_lines.emplace_back(p, le);
+        }
+        p = nl ? nl + 1 : end;
+    }
+    v.recs.resize(rec_lines.size());
+    const size_t n_hdr = v.samples.size();
+    vsink::parallel_for((int)rec_lines.size(), threads, [&](int i) { parse_record(rec_lines[i].first, rec_lines[i].second, n_hdr, keep_gt_text, v.recs[i]); });
     return v;
 }
 
@@ -661,7 +659,11 @@ int main(int argc, char** argv) {
     auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
     double t_mark = now();
     auto lap = [&](int k) { const double t = now(); t_stage[k] += t - t_mark; t_mark = t; };
-    Vcf vcf = read_vcf(a.in_fn, a.print_truth != 0);
+    // host threads for parsing and record encoding: --encode-threads, else --threads when given, else up to 8 of the
+    // machine's threads -- the bytes written do not depend on it
+    int enc_threads = a.enc_threads > 0 ? a.enc_threads : a.threads;
+    if (a.enc_threads <= 0 && !a.threads_given) { const unsigned hc = std::thread::hardware_concurrency(); enc_threads = (int)std::max(1u, std::min(8u, hc)); }
+    Vcf vcf = read_vcf(a.in_fn, a.print_truth != 0, enc_threads);
     lap(0);
     const int N = (int)vcf.samples.size();
     if (N <= 0) die("no samples in %s", a.in_fn.c_str());
@@ -828,10 +830,6 @@ int main(int argc, char** argv) {
     std::string line;
     GvcfBlocker gv;
     std::vector<std::string> enc;
-    // record encoding threads: --encode-threads, else --threads when given, else up to 8 of the machine's threads --
-    // the bytes written do not depend on it
-    int enc_threads = a.enc_threads > 0 ? a.enc_threads : a.threads;
-    if (a.enc_threads <= 0 && !a.threads_given) { const unsigned hc = std::thread::hardware_concurrency(); enc_threads = (int)std::max(1u, std::min(8u, hc)); }
     gv.block_dps = a.gvcf_dps;
     // one simulated record of the current tile: the eight fixed columns as text, the allele strings and the
     // typed FORMAT arrays (reads the tile buffers only: records of a tile are built on several threads)
