@@ -307,13 +307,19 @@ __device__ __forceinline__ bool gamma_slow_test(const double u, const double xsq
     return res;
 }
 
-// error probability -> qScore / adjusted qScore (vcfgl.cpp:500-523); (int)(-10*log10(p)) is
-// taken from the float32 log2 unless p sits within its error bound of an integer boundary
-// p = gx / (gx + gy) (rng.h:438) is itself taken in float32 (v_rcp_f32, 1 ulp): relative error of pf
-// <= 2^-24 (gx) + 2^-24 (sum) + 2^-23 (rcp) + 2^-24 (product) < 2^-22, i.e. < 1.1e-6 in tf.
-__device__ __forceinline__ void errprob_to_qs_fast(const VglDevParams& P, const double gx, const double gy, int& q, int& aq, uint32_t* errflag, const bool need) {
-    // float32: tf = -10 log10(p) within |tf| 2^-20 + 2.2e-6 (v_log_f32 bound + argument error)
-    const float pf = (float)gx * __builtin_amdgcn_rcpf((float)(gx + gy));
+// error probability -> qScore / adjusted qScore (vcfgl.cpp:500-523) in two steps.  k_sample<2> leaves
+// p = gx / (gx + gy) (rng.h:438) of every finished read in LDS as a float32 (qs_stage_pf), and a dense pass over
+// the wave's reads -- 64 useful lanes per instruction, where the pool loop would spend the same instructions
+// on every iteration for the few lanes that finish a read in it -- takes (int)(-10*log10(p)) from the float32
+// log2 unless p sits within its error bound of an integer boundary (qs_decide_pf); those reads (about 1 in
+// 10^4) are drawn again in double by the lane that owns them (beta_draw + errprob_raw).
+// pf: v_rcp_f32 is 1 ulp, so its relative error is <= 2^-24 (gx) + 2^-24 (sum) + 2^-23 (rcp) + 2^-24 (product)
+// < 2^-22, i.e. < 1.1e-6 in tf; tf = -10 log10(p) within |tf| 2^-20 + 2.2e-6 (v_log_f32 bound + argument error).
+__device__ __forceinline__ float qs_stage_pf(const double gx, const double gy) {
+    return (float)gx * __builtin_amdgcn_rcpf((float)(gx + gy));
+}
+// returns false where the float32 value cannot decide (the caller then needs the exact evaluation)
+__device__ __forceinline__ bool qs_decide_pf(const VglDevParams& P, const float pf, int& q, int& aq) {
     const float tf = -3.0103f * __builtin_amdgcn_logf(pf);
     const float m = tf * 0x1p-19f + 4e-6f;
     const float fl = floorf(tf);
@@ -322,20 +328,21 @@ __device__ __forceinline__ void errprob_to_qs_fast(const VglDevParams& P, const 
     bool ok = (pf > 1.0e-37f) && (pf < 1.0f) && (tf - fl > m) && (fl + 1.0f - tf > m);
     if (P.adjust_qs) ok = ok && (t2 > m) && (t2 - fl2 > m) && (fl2 + 1.0f - t2 > m);
     q = (int)fl; aq = P.adjust_qs ? (int)fl2 : -1;
-    ok = ok || !need;
-    if (__builtin_expect(__ballot(!ok) != 0, 0)) {     // exact: vcfgl.cpp:500-507 (rare: a real branch)
-        asm volatile("" ::: "memory");
-        const double ep = gx / (gx + gy);
-        int qe = -1, aqe = -1;
-        if (0.0 == ep) qe = CAP_BASEQ;
-        else if (1.0 == ep) qe = 0;
-        else {
-            const double tmp = -10.0 * log10(ep);
-            qe = (int)tmp;
-            if (P.adjust_qs) aqe = (int)(tmp + P.adjust_by);
-        }
-        q = ok ? q : qe; aq = ok ? aq : aqe;
+    return ok;
+}
+// vcfgl.cpp:500-507, exact
+static __device__ void errprob_raw(const VglDevParams& P, const double ep, int& q, int& aq) {
+    q = -1; aq = -1;
+    if (0.0 == ep) q = CAP_BASEQ;
+    else if (1.0 == ep) q = 0;
+    else {
+        const double tmp = -10.0 * log10(ep);
+        q = (int)tmp;
+        if (P.adjust_qs) aq = (int)(tmp + P.adjust_by);
     }
+}
+// vcfgl.cpp:509-523: bins or the cap
+__device__ __forceinline__ void qs_finish(const VglDevParams& P, int& q, int& aq, uint32_t* errflag, const bool need) {
     if (P.n_qs_bins != 0) {
         if (need) {
             q = apply_bins(P, q, errflag);

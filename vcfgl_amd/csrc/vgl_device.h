@@ -43,7 +43,7 @@ struct VglDevParams {
     int32_t A, G;            // max alleles / genotypes of the tile layout
     int32_t read_cap;        // staged reads per (site,sample)
     int32_t pool_cap;        // quality-score work items per wavefront and LDS segment
-    int32_t pool_lds_bytes;  // LDS bytes per wavefront of k_sample<2>: 512 + 5 * pool_cap
+    int32_t pool_lds_bytes;  // LDS bytes per wavefront of k_sample<2>: 512 + 4 * (pool_cap + 2) + pool_cap
     // flags
     int32_t error_qs, gl_model, precise_gl, adjust_qs, n_qs_bins, do_unobserved;
     int32_t rm_invar_sites, rm_empty_sites, sample_strand, per_sample_depth;

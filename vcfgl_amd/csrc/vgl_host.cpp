@@ -295,10 +295,10 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
         }
         int pc = (int)ceil(lmax + 8.0 * sqrt(lmax) + 64.0);
         pc = (pc + 63) & ~63;
-        if (pc > 1920) pc = 1920;                      // 512 + 5 x 1920 B per wavefront: 16 wavefronts (the 4 per SIMD the kernel is
+        if (pc > 1920) pc = 1920;                      // 520 + 5 x 1920 B per wavefront: 16 wavefronts (the 4 per SIMD the kernel is
                                                        // built for) fit a CU's 160 KB LDS; larger pools run in several segments
         D.pool_cap = pc;
-        D.pool_lds_bytes = 512 + 5 * pc;
+        D.pool_lds_bytes = 512 + 4 * (pc + 2) + pc;    // stream bases | item slots (+ the zero slot) | bases
     }
     D.error_qs = p->error_qs; D.gl_model = p->gl_model; D.precise_gl = p->precise_gl; D.adjust_qs = p->adjust_qs;
     D.n_qs_bins = p->n_qs_bins; D.do_unobserved = p->do_unobserved; D.rm_invar_sites = p->rm_invar_sites;

@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256) void k_depth(const VglDevParams P, const VglTi
 // the kernel registers, hence the specialisations)
 // EQS 2 is built for 4 wavefronts per SIMD (128 VGPRs, 32 spilled into rarely executed fallback code): with 3 the VALU
 // pipes were 86 % busy; the fourth wave hides the dependent f64 chains of the pool loop (+8 % on C3)
-template <int EQS, bool DBG, int DM>
+// PREC: --precise-gl 1 with EQS 2 (the exact error probability of every read is staged for k_gl)
+template <int EQS, bool DBG, int DM, bool PREC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 4 : 1, EQS == 2 ? 4 : 8))) void k_sample(const VglDevParams P, const VglTilePtrs T) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const WavePos wp = wave_pos(P, T);
@@ -165,15 +166,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
             qq2 = q2 * (uint32_t)((ad4 >> 32) & 0xFFFF); qq3 = q2 * (uint32_t)((ad4 >> 48) & 0xFFFF);
         }
     } else {
-        // ---- LDS of this wave: [64] u64 qscore-stream bases | [cap] u16 item->(read,owner) |
-        //      [cap] u8 base | [cap] u8 qScore | [cap] u8 adjusted qScore
+        // ---- LDS of this wave: [64] u64 qscore-stream bases | [cap + 2] u32 item slot | [cap] u8 base.
+        //      An item's slot holds (read << 6) | owner until the item is finished, then the float32 error
+        //      probability of its read, then (dense pass) qScore | adjusted qScore << 8.  Slot [cap] stays 0: the
+        //      prefetch of a lane that has no next item reads it.
         const int cap = P.pool_cap;
         uint8_t* wl = lds_raw + (size_t)wp.wib * P.pool_lds_bytes;
         uint64_t* l_stq = (uint64_t*)wl;
-        uint16_t* l_map = (uint16_t*)(wl + 512);
-        uint8_t* l_pb = wl + 512 + 2 * (size_t)cap;
-        uint8_t* l_pq = l_pb + cap;
-        uint8_t* l_paq = l_pq + cap;
+        uint32_t* l_it = (uint32_t*)(wl + 512);
+        uint8_t* l_pb = wl + 512 + 4 * ((size_t)cap + 2);
 
         // exclusive prefix sum of the depths = first pool index of each owner
         int incl = dp;
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
         const int offs = incl - dp;
         const int total = __shfl(incl, 63, 64);
         l_stq[lane] = st_qs;
+        if (lane == 0) l_it[cap] = 0u;
         int rdone = 0;
         // Kernel arguments arrive in 16-dword scalar tuples that the register allocator spills and
         // reloads as a whole (v_readlane, VALU work) inside the loops below; the three values the flush
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 ad4 += one;
                 if (fwd) adf4 += one;
                 const int k = offs + r - seg0;
-                l_map[k] = (uint16_t)((r << 6) | lane);
+                l_it[k] = (uint32_t)((r << 6) | lane);
                 l_pb[k] = (uint8_t)r_base;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -227,10 +229,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 bool have = k < segT;
                 bool stage1 = false;                         // false: first gamma deviate (x), true: second (y)
                 uint64_t st = 0; double gx = 0.0; int it_o = 0, it_r = 0;
-                if (have) { const uint32_t m = l_map[k]; it_o = m & 63; it_r = m >> 6; st = aff(P.qs_read_tab[it_r], l_stq[it_o]); }
+                if (have) { const uint32_t m = l_it[k]; it_o = m & 63; it_r = m >> 6; st = aff(P.qs_read_tab[it_r], l_stq[it_o]); }
                 const bool any_changed = (P.gx.changed | P.gy.changed) != 0;
                 // the two gamma samplers' constants, kept in vector registers for the per-iteration selects
                 double gxa1 = P.gx.a1, gxa2 = P.gx.a2, gya1 = P.gy.a1, gya2 = P.gy.a2;
+                asm volatile("" : "+v"(gxa1), "+v"(gxa2), "+v"(gya1), "+v"(gya2));
                 // The bounded-log tests are needed by a few lanes per iteration but cost every lane of the
                 // wave; they run only every P.slow_period-th iteration.  In between, a lane that needs one
                 // holds: its state is left untouched, so the later iteration recomputes the same attempt.
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     // operands of this lane's next item, fetched at the top of the iteration and consumed at
                     // the bottom (unconditional, clamped index: no divergent control flow in the loop)
                     const bool hn = kn < segT;
-                    const uint32_t m_n = l_map[hn ? kn : 0];
+                    const uint32_t m_n = l_it[hn ? kn : cap];
                     const int o_n = m_n & 63, r_n = m_n >> 6;
                     const VglAffine tab_n = P.qs_read_tab[r_n];
                     const uint64_t base_n = l_stq[o_n];
@@ -288,14 +291,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                         }
                     }
                     const bool fin = acc_g && stage1;
-                    // per-read epilogue, computed for every lane, committed where fin (rng.h:438, vcfgl.cpp:500-531)
-                    int q_i, aq_i;
-                    errprob_to_qs_fast(P, gx, val, q_i, aq_i, T.errflag, fin);
-                    if (fin) {
-                        l_pq[k] = (uint8_t)q_i;
-                        l_paq[k] = (uint8_t)aq_i;
-                    }
-                    if (P.precise_gl) { if (fin) T.errp[(size_t)it_r * plane + ev0 + it_o] = gx / (gx + val); }
+                    // a finished read leaves its error probability (rng.h:438) as a float32 in the item's slot; the
+                    // quality scores are taken from it by the dense pass after the loop
+                    const float pf = qs_stage_pf(gx, val);
+                    if (fin) l_it[k] = __float_as_uint(pf);
+                    if (PREC) { if (fin) T.errp[(size_t)it_r * plane + ev0 + it_o] = gx / (gx + val); }
                     gx = (acc_g && !stage1) ? val : gx;
                     stage1 = stage1 != acc_g;
                     // a lane that finished its item adopts kn and claims the next unclaimed item
@@ -314,14 +314,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-            // -- owners: combine base + quality score, stage the read, quality sums (vcfgl.cpp:525-564)
             if (DBG) { const unsigned long long c = clock64(); c_pool += c - c_tmp; c_tmp = c; }
             if (DBG && P.dbg_phase == 3) return;
+            // -- quality scores of the segment's reads (vcfgl.cpp:500-523), item kb + lane per lane
+            for (int kb = 0; kb < segT; kb += 64) {
+                const int kk = kb + lane;
+                const bool inb = kk < segT;
+                const float pf = __uint_as_float(l_it[inb ? kk : cap]);
+                int q_i, aq_i;
+                const bool ok = qs_decide_pf(P, pf, q_i, aq_i);
+                uint64_t amb = __ballot(inb && !ok);
+                if (__builtin_expect(amb != 0, 0)) {
+                    // undecided in float32: the owner of the read draws its deviate again in double (rng.h:433-444)
+                    while (amb) {
+                        const int b = __builtin_ctzll(amb);
+                        amb &= amb - 1;
+                        const int Kb = seg0 + kb + b;                   // index of the read in the wave's pool
+                        if (active && Kb >= offs && Kb < offs + dp) {
+                            uint64_t st_x = aff(P.qs_read_tab[Kb - offs], l_stq[lane]);
+                            const double ep = beta_draw(P, st_x);
+                            int qe, aqe;
+                            errprob_raw(P, ep, qe, aqe);
+                            l_it[kb + b] = (uint32_t)(uint16_t)qe | ((uint32_t)(uint16_t)aqe << 16);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (inb && !ok) { const uint32_t e = l_it[kk]; q_i = (int)(int16_t)(e & 0xFFFF); aq_i = (int)(int16_t)(e >> 16); }
+                }
+                qs_finish(P, q_i, aq_i, T.errflag, inb);
+                if (inb) l_it[kk] = (uint32_t)(q_i & 0xFF) | ((uint32_t)(aq_i & 0xFF) << 8);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+            // -- owners: combine base + quality score, stage the read, quality sums (vcfgl.cpp:525-564)
             for (int r = rdone; r < r_end; ++r) {
                 const int k = offs + r - seg0;
                 const int r_base = l_pb[k];
-                const int q_i = l_pq[k];
-                const int aq_i = P.adjust_qs ? (int)l_paq[k] : -1;
+                const uint32_t qe = l_it[k];
+                const int q_i = (int)(qe & 0xFF);
+                const int aq_i = P.adjust_qs ? (int)((qe >> 8) & 0xFF) : -1;
                 const int q_gl = (P.adjust_qs & 1) ? aq_i : q_i;
                 reads_v[(size_t)r * plane + ev] = (uint8_t)((q_gl << 2) | r_base);
                 if (r < reads_out_cap_v) reads_out_v[(size_t)r * plane + ev] = (uint8_t)((q_i << 2) | r_base);
@@ -397,13 +432,17 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
     const size_t lds = (size_t)wpb * p->pool_lds_bytes;
     hipStream_t s = (hipStream_t)stream;
     const int dm = p->depth_pre;                                  // 0 mixed / 1 k_depth / 2 product method only
-#define VGL_LAUNCH_SAMPLE(EQS, DBG, LDS) \
-    do { if (dm == 1) hipLaunchKernelGGL((k_sample<EQS, DBG, 1>), g, b, LDS, s, *p, *t); \
-         else if (dm == 2) hipLaunchKernelGGL((k_sample<EQS, DBG, 2>), g, b, LDS, s, *p, *t); \
-         else hipLaunchKernelGGL((k_sample<EQS, DBG, 0>), g, b, LDS, s, *p, *t); } while (0)
-    if (p->error_qs == 2) { if (dbg) VGL_LAUNCH_SAMPLE(2, true, lds); else VGL_LAUNCH_SAMPLE(2, false, lds); }
-    else if (p->error_qs == 1) VGL_LAUNCH_SAMPLE(1, false, 0);
-    else VGL_LAUNCH_SAMPLE(0, false, 0);
+#define VGL_LAUNCH_SAMPLE(EQS, DBG, PREC, LDS) \
+    do { if (dm == 1) hipLaunchKernelGGL((k_sample<EQS, DBG, 1, PREC>), g, b, LDS, s, *p, *t); \
+         else if (dm == 2) hipLaunchKernelGGL((k_sample<EQS, DBG, 2, PREC>), g, b, LDS, s, *p, *t); \
+         else hipLaunchKernelGGL((k_sample<EQS, DBG, 0, PREC>), g, b, LDS, s, *p, *t); } while (0)
+    if (p->error_qs == 2) {
+        if (dbg && !p->precise_gl) VGL_LAUNCH_SAMPLE(2, true, false, lds);   // diagnostic build: --precise-gl 0 only
+        else if (p->precise_gl) VGL_LAUNCH_SAMPLE(2, false, true, lds);
+        else VGL_LAUNCH_SAMPLE(2, false, false, lds);
+    }
+    else if (p->error_qs == 1) VGL_LAUNCH_SAMPLE(1, false, false, 0);
+    else VGL_LAUNCH_SAMPLE(0, false, false, 0);
 #undef VGL_LAUNCH_SAMPLE
     return (int)hipGetLastError();
 }
