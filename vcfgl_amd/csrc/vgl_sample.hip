@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 // addressed by its read, so the result does not depend on who works on it.
                 int k = lane, kn = lane + 64;
                 int next_free = 128;                         // wave-uniform: first unclaimed item
-                bool have = k < segT;
+                bool have = k < segT;                        // == (k < segT) throughout: the loop tests that compare
                 bool stage1 = false;                         // false: first gamma deviate (x), true: second (y)
                 uint64_t st = 0; double gx = 0.0; int it_o = 0, it_r = 0;
                 if (have) { const uint32_t m = l_it[k]; it_o = m & 63; it_r = m >> 6; st = aff(P.qs_read_tab[it_r], l_stq[it_o]); }
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 // wave; they run only every P.slow_period-th iteration.  In between, a lane that needs one
                 // holds: its state is left untouched, so the later iteration recomputes the same attempt.
                 int slow_cnt = P.slow_period;
-                while (__ballot(have)) {
+                while (__ballot(k < segT)) {
                     if (DBG) c_iter++;
                     const bool full = (--slow_cnt == 0);
                     if (full) slow_cnt = P.slow_period;
@@ -283,7 +283,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     const bool acc_g = g_try && !(sq_fail && slow_g) && !hold;
                     st = hold ? st : (g_try ? st3 : st2);    // u2 is drawn only when w > 0 (rng.h:140-142)
                     double val = ga1 * vv;
-                    if (any_changed) {                       // alpha < 1 (rng.h:146-148); wave-uniform guard
+                    if (__builtin_expect(any_changed, 0)) {  // alpha < 1 (rng.h:146-148); wave-uniform guard
+                        asm volatile("" ::: "memory");       // (keeps the per-lane part of the test out of the common path)
                         if (acc_g && (stage1 ? P.gy.changed : P.gx.changed)) {
                             double u3;
                             do { st = lcg_next(st); u3 = u01(st); } while (u3 == 0.0);
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     k = fin ? kn : k;
                     kn = fin ? next_free + rank : kn;
                     next_free += __popcll(fin_m);
-                    have = have && (!fin || hn);
+                    have = k < segT;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
