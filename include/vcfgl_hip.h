@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VGL_ABI_VERSION 1
+#define VGL_ABI_VERSION 2
 
 /* ---- error codes (returned by every entry point; 0 = success) ----------------------- */
 #define VGL_OK              0
@@ -158,7 +158,14 @@ typedef struct vgl_tile_out {
     int32_t* fmt_adr;        /* [n_sites][A][n_samples]                                        */
     /* optional per-read staging dump (reference: -printPileup, vcfgl.cpp:616-634)            */
     uint8_t* reads;          /* [read_capacity][n_sites][n_samples]  (qs << 2) | base           */
-    int32_t  read_capacity;  /* rows available in `reads` (0 = not requested)                  */
+    int32_t  read_capacity;  /* rows available in `reads` / `read_errp` (0 = not requested)    */
+    /* optional dumps behind -printQsError / -printGlError / -printQScores / -printBasePickError and
+     * --adjust-qs 4|8|16 (vcfgl.cpp:430-435, 533-554): the deviates themselves, from which the caller derives
+     * qScore and adjusted qScore exactly as vcfgl.cpp:500-523 does.  (ABI version 2.)                    */
+    double*  read_errp;      /* [read_capacity][n_sites][n_samples]  error_prob_forQs_i of every read
+                                (error_qs 2 only; rows >= the library's staging capacity hold NaN)         */
+    double*  site_pick_err;  /* [n_sites]  base_pick_error_prob of the site (error_qs 1 only; written for
+                                sites that reach the read loop, i.e. INFO/DP > 0)                          */
 } vgl_tile_out;
 
 typedef struct vgl_ctx vgl_ctx;

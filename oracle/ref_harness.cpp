@@ -78,6 +78,7 @@ void ref_beta(double mean, double var, int seed, int n, double* out) {
 /* shared.cpp tables */
 double ref_q2log10gl(int row, int q) { return qScore_to_log10_gl[row][q]; }
 int ref_qs2(int q) { return QS_TO_QSSQ(q); }
+double ref_qs_to_errprob(int q) { return QS_TO_ERRPROB(q); }      /* shared.h:493 over shared.cpp:31 */
 int ref_ngt(int n) { return NALLELES_TO_NGTS(n); }
 
 }

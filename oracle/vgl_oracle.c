@@ -690,6 +690,7 @@ static int simulate_site(vgl_oracle* o, int64_t site_abs, int32_t ls, int32_t n_
     /* ---- per-site base-pick error (error_qs 1: one beta deviate, vcfgl.cpp:425-437) */
     double base_pick_error_prob = p->error_rate;
     if (1 == p->error_qs) base_pick_error_prob = beta_draw(o, tile ? &st_qs[0] : &o->st2);
+    if (1 == p->error_qs && out->site_pick_err) out->site_pick_err[ls] = base_pick_error_prob;   /* -printBasePickError, :430-435 */
 
     /* ---- read loop (vcfgl.cpp:441-640) */
     for (int s = 0; s < N; s++) {
@@ -866,6 +867,13 @@ write_site:
             }
         }
         for (int i = 0; i < 16; i++) out->i16[(size_t)ls * 16 + i] = v[i];
+    }
+    /* per-read deviates (-printQsError, vcfgl.cpp:533-536) */
+    if (out->read_errp && out->read_capacity > 0 && 2 == p->error_qs) {
+        for (int s = 0; s < N; s++)
+            for (int r = 0; r < out->read_capacity; r++)
+                if (status != VGL_SITE_SKIP_EMPTY && status != VGL_SITE_NO_READS && r < dp[s])
+                    out->read_errp[((size_t)r * n_sites + ls) * N + s] = o->errp[(size_t)s * o->cap + r];
     }
     /* per-read dump (pileup, vcfgl.cpp:616-634) */
     if (out->reads && out->read_capacity > 0) {

@@ -52,10 +52,10 @@ class Oracle:
             raise OracleError(rc, lib().vgl_oracle_last_error().decode())
         self.A, self.G = args.max_alleles, args.max_genotypes
 
-    def simulate(self, site0, gt, fields=None, read_capacity=0):
+    def simulate(self, site0, gt, fields=None, read_capacity=0, deviates=False):
         gt = np.ascontiguousarray(gt, dtype=np.uint8)
         n_sites = gt.shape[0]
-        tile = Tile(n_sites, self.n_samples, self.A, self.G, fields=fields, read_capacity=read_capacity)
+        tile = Tile(n_sites, self.n_samples, self.A, self.G, fields=fields, read_capacity=read_capacity, deviates=deviates)
         rc = lib().vgl_oracle_simulate(self.h, site0, n_sites, gt.ctypes.data, tile.byref())
         if rc != 0:
             raise OracleError(rc, lib().vgl_oracle_last_error().decode())

@@ -151,3 +151,57 @@ def test_cli_threads_do_not_change_the_file(tmp_path):
         assert rd.compressed
         blobs.append(rd.raw[rd.off:])
     assert blobs[0] == blobs[1] and len(blobs[0]) > 500
+
+
+DOC = os.path.join(ROOT, "tests", "golden", "doc_error_qs")
+
+
+@pytest.mark.parametrize("eq", [0, 1, 2])
+def test_cli_tsv_dumps_against_documented_outputs(eq, tmp_path):
+    """-printBasePickError / -printQsError / -printGlError / -printQScores (vcfgl.cpp:430-435, 533-554, 1745-1755;
+    io.cpp:1089-1100): the three runs the reference documents in doc/error_qs.MD, their TSV listings (sorted
+    there), pileups and VCF records reproduced as text through the GPU in serial RNG mode."""
+    out = str(tmp_path / f"error_qs{eq}")
+    cmd = [BIN, "-i", os.path.join(gu.REFVCF, "data", "data2.vcf"), "-o", out, "--rng-mode", "1", "--depth", "2",
+           "--error-rate", "0.4", "--error-qs", str(eq), "-addFormatAD", "1", "-printPileup", "1", "-s", "42", "-O", "v",
+           "-printBasePickError", "1", "-printQsError", "1", "-printGlError", "1", "-printQScores", "1"]
+    if eq:
+        cmd += ["--beta-variance", "1e-1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = sorted(open(os.path.join(DOC, f"details_qs{eq}.tsv")).read().splitlines())
+    assert sorted(r.stdout.splitlines()) == want
+    assert gzip.open(out + ".pileup.gz", "rt").read() == open(os.path.join(DOC, f"error_qs{eq}.pileup")).read()
+    ours = [l.rstrip("\n") for l in open(out + ".vcf") if not l.startswith("##")]
+    gold = [l.rstrip("\n") for l in open(os.path.join(DOC, f"error_qs{eq}.vcf")) if not l.startswith("##")]
+    assert ours == gold
+
+
+def test_cli_tsv_line_order_and_adjusted_scores(tmp_path):
+    """Unsorted stdout: per site and sample, the lines of a read follow each other in the order qs_error_prob, qs,
+    gl_error_prob (vcfgl.cpp:533-554); --adjust-qs 8 / 16 / 4 switch the printed score, the GL error probability
+    and the pileup to the adjusted quality score."""
+    base = [BIN, "-i", os.path.join(gu.REFVCF, "data", "data2.vcf"), "--rng-mode", "1", "--depth", "3", "--error-rate", "0.1",
+            "--error-qs", "2", "--beta-variance", "1e-3", "-s", "7", "-O", "v", "-printPileup", "1",
+            "-printQsError", "1", "-printGlError", "1", "-printQScores", "1"]
+    r0 = subprocess.run(base + ["-o", str(tmp_path / "a")], capture_output=True, text=True, timeout=300)
+    r1 = subprocess.run(base + ["-o", str(tmp_path / "b"), "--adjust-qs", "28", "--adjust-by", "0.499"], capture_output=True, text=True, timeout=300)
+    assert r0.returncode == 0 and r1.returncode == 0, r0.stderr[-1000:] + r1.stderr[-1000:]
+    l0, l1 = r0.stdout.splitlines(), r1.stdout.splitlines()
+    assert len(l0) == len(l1) and len(l0) % 3 == 0 and len(l0) > 0
+    import math
+    n_adj = 0
+    for k in range(0, len(l0), 3):
+        a, b, c = (x.split("\t") for x in l0[k:k + 3])
+        assert (a[0], b[0], c[0]) == ("qs_error_prob", "qs", "gl_error_prob") and a[1:5] == b[1:5] == c[1:5]
+        a1, b1, c1 = (x.split("\t") for x in l1[k:k + 3])
+        assert a1 == a                                          # same deviates
+        ep = float(a[5])
+        if 1e-5 < ep < 0.99 and abs((-10 * math.log10(ep)) % 1 - 0.5) > 0.01:   # away from the %f rounding of the printed deviate
+            q, aq = int(-10 * math.log10(ep)), int(-10 * math.log10(ep) + 0.499)
+            assert int(b[5]) == min(q, 63) and int(b1[5]) == min(aq, 63)
+            n_adj += aq != q
+    assert n_adj > 0
+    pa = gzip.open(str(tmp_path / "a") + ".pileup.gz", "rt").read()
+    pb = gzip.open(str(tmp_path / "b") + ".pileup.gz", "rt").read()
+    assert pa != pb and len(pa) == len(pb)

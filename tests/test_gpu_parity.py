@@ -304,3 +304,42 @@ def test_capacity_overflow_is_reported(oracle, eqs, monkeypatch):
         sim.simulate(0, synth.binary_sites(0, 8, 100))
     assert ei.value.code == _abi.VGL_E_CAPACITY
     sim.close()
+
+
+@pytest.mark.parametrize("serial", [0, 1])
+def test_deviate_dumps_match_oracle(oracle, serial):
+    """ABI 2: read_errp (error_qs 2) and site_pick_err (error_qs 1) are the doubles the reference prints with
+    -printQsError / -printBasePickError; bit-equal to the oracle's in both RNG modes, with and without the
+    --precise-gl staging planes."""
+    gt = synth.binary_sites(0, 24, 70)
+    for precise in (0, 1):
+        args = VcfglArgs(seed=11, depth=5, error_rate=0.02, error_qs=2, beta_variance=1e-4, precise_gl=precise)
+        args.rng_mode = _abi.VGL_RNG_SERIAL if serial else _abi.VGL_RNG_TILE
+        args.beta_sampler = _abi.VGL_BETA_STD if serial else _abi.VGL_BETA_RAND48
+        sim = Simulator(args, 70, device=0, max_sites_per_tile=24)
+        want = oracle.Oracle(args, 70).simulate(0, gt, fields=sim.default_fields(), read_capacity=32, deviates=True)
+        got = sim.simulate(0, gt, read_capacity=32, deviates=True)
+        plain = sim.simulate(24, gt) if not serial else None          # a later tile without the dump still runs
+        sim.close()
+        dp = want.numpy("fmt_dp")
+        assert np.array_equal(dp, got.numpy("fmt_dp")) and dp.max() <= 32
+        live = np.arange(32)[:, None, None] < dp[None, :, :]
+        w, g = want.numpy("read_errp"), got.numpy("read_errp")
+        assert live.sum() > 1000
+        if serial:      # libstdc++'s gamma_distribution: log / sqrt / pow of the device's libm, within 1e-12 of glibc's (as tests/test_gpu_betachain.py)
+            assert np.all(np.abs(w[live] - g[live]) <= 1e-12 * np.abs(w[live]))
+        else:
+            assert np.array_equal(w[live].view(np.uint64), g[live].view(np.uint64))
+        assert np.array_equal(want.numpy("reads"), got.numpy("reads"))
+        assert plain is None or plain.numpy("fmt_dp").shape == dp.shape
+    args = VcfglArgs(seed=11, depth=5, error_rate=0.05, error_qs=1, beta_variance=1e-3)
+    args.rng_mode = _abi.VGL_RNG_SERIAL if serial else _abi.VGL_RNG_TILE
+    args.beta_sampler = _abi.VGL_BETA_STD if serial else _abi.VGL_BETA_RAND48
+    sim = Simulator(args, 70, device=0, max_sites_per_tile=24)
+    want = oracle.Oracle(args, 70).simulate(0, gt, fields=sim.default_fields(), deviates=True)
+    got = sim.simulate(0, gt, deviates=True)
+    sim.close()
+    reach = want.numpy("info_dp") > 0
+    assert reach.sum() > 10
+    w, g = want.numpy("site_pick_err")[reach], got.numpy("site_pick_err")[reach]
+    assert np.all(np.abs(w - g) <= 1e-12 * np.abs(w)) if serial else np.array_equal(w.view(np.uint64), g.view(np.uint64))

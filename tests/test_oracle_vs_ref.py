@@ -103,3 +103,17 @@ def test_doc_known_answers(oracle):
     b = np.zeros(4)
     o.vgl_oracle_beta_std_draws(0.4, 0.1, 42, 4, b.ctypes.data)
     assert [f"{x:.6f}" for x in b] == ["0.621323", "0.960007", "0.525474", "0.002457"]
+
+
+def test_host_program_qs_to_errprob_table():
+    """QS_TO_ERRPROB (shared.h:493 over the literals of shared.cpp:31), as the host program restates it for the
+    gl_error_prob lines of -printGlError: equal to the reference's table for every quality score."""
+    import subprocess
+    binp = os.path.join(ROOT, "vcfgl_amd", "bin", "vcfgl_hip")
+    if not os.path.exists(binp):
+        pytest.skip("vcfgl_hip not built")
+    r = _ref(STD)
+    r.ref_qs_to_errprob.restype = C.c_double
+    qs = list(range(0, 80))
+    out = subprocess.run([binp, "--qs-to-errprob"] + [str(q) for q in qs], capture_output=True, text=True, check=True).stdout.split()
+    assert [float(x) for x in out] == [r.ref_qs_to_errprob(q) for q in qs]

@@ -6,7 +6,7 @@ not been built -- the product path never falls back to a CPU implementation.
 import ctypes as C
 import os
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 VGL_OK = 0
 VGL_E_ARG, VGL_E_NODEVICE, VGL_E_NOMEM, VGL_E_CAPACITY, VGL_E_UNSUPPORTED, VGL_E_QSBIN = -1, -2, -3, -4, -5, -6
@@ -50,6 +50,7 @@ class TileOut(C.Structure):
         ("fmt_dp", C.c_void_p), ("gl", C.c_void_p), ("pl", C.c_void_p), ("gp", C.c_void_p),
         ("fmt_ad", C.c_void_p), ("fmt_adf", C.c_void_p), ("fmt_adr", C.c_void_p),
         ("reads", C.c_void_p), ("read_capacity", C.c_int32),
+        ("read_errp", C.c_void_p), ("site_pick_err", C.c_void_p),
     ]
 
 

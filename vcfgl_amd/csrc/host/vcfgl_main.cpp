@@ -46,6 +46,7 @@
 struct Args {
     int seed = -1, source = 0, error_qs = 0, gl_model = 2, precise_gl = 0, i16_mapq = 20, adjust_qs = 0;
     int explode = 0, rm_invar = 0, rm_empty = 0, do_unobserved = 1, do_gvcf = 0, print_pileup = 0, print_truth = 0;
+    int print_bpe = 0, print_qs_err = 0, print_gl_err = 0, print_qscores = 0;     // per-read / per-site TSV lines on stdout
     int add_gl = 1, add_gp = 0, add_pl = 0, add_i16 = 0, add_qs = 0, add_fmt_dp = 1, add_info_dp = 0;
     int add_fmt_ad = 0, add_info_ad = 0, add_fmt_adf = 0, add_info_adf = 0, add_fmt_adr = 0, add_info_adr = 0;
     int rng_mode = VGL_RNG_TILE, beta_sampler = -1, tile_sites = 4096, device = 0, verbose = 0, threads = 1, enc_threads = 0;
@@ -98,7 +99,10 @@ static Args parse_args(int argc, char** argv) {
         else if (f == "-doGVCF") a.do_gvcf = I(v);
         else if (f == "-printPileup") a.print_pileup = I(v);
         else if (f == "-printTruth") a.print_truth = I(v);
-        else if (f == "-printBasePickError" || f == "-printQsError" || f == "-printGlError" || f == "-printQScores") { if (I(v)) die("%s is not provided", f.c_str()); }
+        else if (f == "-printBasePickError") a.print_bpe = I(v);
+        else if (f == "-printQsError") a.print_qs_err = I(v);
+        else if (f == "-printGlError") a.print_gl_err = I(v);
+        else if (f == "-printQScores") a.print_qscores = I(v);
         else if (f == "-addGL" || f == "-addFormatGL") a.add_gl = I(v);
         else if (f == "-addGP" || f == "-addFormatGP") a.add_gp = I(v);
         else if (f == "-addPL" || f == "-addFormatPL") a.add_pl = I(v);
@@ -141,6 +145,13 @@ static Args parse_args(int argc, char** argv) {
     if (a.adjust_qs && a.adjust_by == 0.0) die("--adjust-qs %d requires a non-zero value for --adjust-by. Please set --adjust-by and rerun.", a.adjust_qs);
     if ((a.adjust_qs & 1) && a.precise_gl) die("--adjust-qs 1 requires --precise-gl 0. Please set --precise-gl 0 and rerun.");
     if ((a.adjust_qs & 2) && !a.add_qs) die("--adjust-qs 2 requires -addQS 1. Please set -addQS 1 and rerun.");
+    if ((a.adjust_qs & 4) && !a.print_pileup) die("--adjust-qs 4 requires --printPileup 1. Please set --printPileup 1 and rerun.");   // io.cpp:891-898
+    if ((a.adjust_qs & 8) && !a.print_qscores) die("--adjust-qs 8 requires --printQScores 1. Please set --printQScores and rerun.");
+    if ((a.adjust_qs & 16) && !a.print_gl_err) die("--adjust-qs 16 requires --printGlError 1. Please set --printGlError 1 and rerun.");
+    range(a.print_pileup, 0, 1, "-printPileup"); range(a.print_truth, 0, 1, "-printTruth"); range(a.print_bpe, 0, 1, "-printBasePickError");
+    range(a.print_qs_err, 0, 1, "-printQsError"); range(a.print_gl_err, 0, 1, "-printGlError"); range(a.print_qscores, 0, 1, "-printQScores");
+    if (a.print_gl_err && a.gl_model == 1)                                                                                              // io.cpp:993
+        die("-> [-printGlError 1] Printing the error probability used in genotype likelihood calculations (-printGlError 1) is not supported with genotype likelihood model 1 (--gl-model 1).");
     if (a.gl_model == 1 && a.precise_gl) die("Precise genotype likelihood error (--precise-gl 1) is not supported with genotype likelihood model 1 (--gl-model 1).");
     if (a.error_qs == 0 && a.beta_variance >= 0) die("--beta-variance %e requires --error-qs 1 or 2.", a.beta_variance);
     if (a.error_qs != 0 && !(a.error_rate > 0)) die("--error-qs 1 or 2 requires --error-rate > 0 (found %f).", a.error_rate);
@@ -457,6 +468,35 @@ static int allele_to_int(const std::string& a) {
     switch (a[0]) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return -1; }
 }
 
+// ---------------------------------------------------------------------------------------
+// qScores on the host, for the TSV lines of -printQsError / -printGlError / -printQScores and the adjusted
+// pileup (--adjust-qs 4): the library hands over the deviates, this is vcfgl.cpp:494-523 / :1664-1693 on them.
+static void host_errprob_to_qs(const Args& a, double ep, int& q, int& aq) {
+    q = -1; aq = -1;
+    if (0.0 == ep) { q = 63; if (a.error_qs != 2) aq = 63; }                   // CAP_BASEQ; the preCalc block also sets adjqs (:1668-1673)
+    else if (1.0 == ep) { q = 0; if (a.error_qs != 2) aq = 0; }
+    else if (0.0 < ep && ep < 1.0) {
+        const double tmp = -10.0 * log10(ep);
+        q = (int)tmp;
+        if (a.adjust_qs) aq = (int)(tmp + a.adjust_by);
+    } else die("Bad error probability value: %f", ep);
+    auto bins = [&](int v) {                                                    // apply_qs_bins, vcfgl.cpp:57-64
+        for (size_t i = 0; i + 2 < a.qs_bins.size(); i += 3) if (v >= a.qs_bins[i] && v <= a.qs_bins[i + 1]) return (int)a.qs_bins[i + 2];
+        die("Could not find a range for the simulated qs value: %d", v);
+        return 0;
+    };
+    if (!a.qs_bins.empty()) { q = bins(q); if (a.adjust_qs) aq = bins(aq); }
+    else { q = q > 63 ? 63 : q; if (a.adjust_qs) aq = aq > 63 ? 63 : aq; }
+}
+// QS_TO_ERRPROB (shared.h:493): the table shared.cpp:31 holds 10^(-q/10) at 7 significant digits (checked for
+// every entry by tests/test_cli_format_cpu.py against the reference's own table)
+static double host_qs_to_errprob(int q) {
+    if (q == 0) return 1.0;
+    if (q >= 63) return 0.0000005011872;
+    char b[40]; snprintf(b, sizeof b, "%.7g", pow(10.0, -(double)q / 10.0));
+    return strtod(b, nullptr);
+}
+
 struct Site { const Rec* rec; long pos0; std::string chrom; std::vector<uint8_t> gt; char ref_char; };
 static std::vector<std::string> g_truth_lines;      // -printTruth 1: records as check_rec_alleles() leaves them
 
@@ -635,6 +675,10 @@ int main(int argc, char** argv) {
         for (int i = 2; i < argc; i++) { uint32_t b = (uint32_t)strtoul(argv[i], NULL, 16); float f; memcpy(&f, &b, 4); std::string s; put_float(s, f); printf("%s\n", s.c_str()); }
         return 0;
     }
+    if (argc >= 2 && !strcmp(argv[1], "--qs-to-errprob")) {        // test hook: QS_TO_ERRPROB of every argument, 17 digits
+        for (int i = 2; i < argc; i++) printf("%.17g\n", host_qs_to_errprob(atoi(argv[i])));
+        return 0;
+    }
     if (argc >= 5 && !strcmp(argv[1], "--encode-selftest")) {
         // self-test hook of the BCF writer: --encode-selftest <mode> <out path> <int> [<int> ...] writes one record whose
         // FORMAT/X holds the given integers for sample s1 (and their reverse for s2) and INFO/Y the same list
@@ -767,7 +811,8 @@ int main(int argc, char** argv) {
     p.add_fmt_dp = a.add_fmt_dp; p.add_info_dp = a.add_info_dp; p.add_fmt_ad = a.add_fmt_ad; p.add_info_ad = a.add_info_ad;
     p.add_fmt_adf = a.add_fmt_adf; p.add_info_adf = a.add_info_adf; p.add_fmt_adr = a.add_fmt_adr; p.add_info_adr = a.add_info_adr;
     int TS = a.tile_sites > 0 ? a.tile_sites : 4096;
-    if (a.print_pileup) TS = std::max(1, std::min(TS, (int)((64u << 20) / ((size_t)1024 * (size_t)std::max(N, 1)) + 1)));
+    if (a.print_pileup || a.print_qs_err || a.print_gl_err || a.print_qscores)      // per-read dumps: bounded host / device staging
+        TS = std::max(1, std::min(TS, (int)((64u << 20) / ((size_t)1024 * (size_t)std::max(N, 1)) + 1)));
     vgl_ctx* ctx = nullptr;
     t_mark = now();
     if (vgl_ctx_create(&p, a.device, TS, &ctx) != VGL_OK) die("%s", vgl_last_error());
@@ -805,6 +850,18 @@ int main(int argc, char** argv) {
     }
     gzFile pile = nullptr;
     if (a.print_pileup) { pile = gzopen((a.out_prefix + ".pileup.gz").c_str(), "wb"); if (!pile) die("Could not open pileup output"); }
+    // ---- TSV lines on stdout (vcfgl.cpp:430-435, 533-554, 1745-1755)
+    int pre_q = -1, pre_adjq = -1;                                              // preCalc->qScore / adj_qScore
+    if (a.print_bpe && a.error_qs != 1) printf("base_pick_error_prob\tNA\tNA\tNA\tNA\t%f\n", a.error_rate);   // io.cpp:1089-1100
+    if (a.error_qs != 2) {
+        host_errprob_to_qs(a, a.error_rate, pre_q, pre_adjq);
+        if (a.print_gl_err) printf("gl_error_prob\tNA\tNA\tNA\tNA\t%f\n", a.precise_gl ? a.error_rate : host_qs_to_errprob((a.adjust_qs & 1) ? pre_adjq : pre_q));
+        if (a.print_qs_err) printf("qs_error_prob\tNA\tNA\tNA\tNA\t%f\n", a.error_rate);
+        if (a.print_qscores) printf("qs\tNA\tNA\tNA\tNA\t%d\n", a.adjust_qs ? pre_adjq : pre_q);
+    }
+    const bool dump_reads = a.error_qs == 2 && (a.print_qs_err || a.print_gl_err || a.print_qscores);
+    const bool want_errp = dump_reads || (a.error_qs == 2 && pile && (a.adjust_qs & 4));
+    const bool dump_pick = a.error_qs == 1 && a.print_bpe;
 
     // ---- tile buffers (host side of vgl_tile_out)
     const size_t E = (size_t)TS * N;
@@ -817,6 +874,8 @@ int main(int argc, char** argv) {
     double dmax = a.depth; for (double d : a.depths) dmax = std::max(dmax, d); if (!(dmax >= 0)) dmax = 0;
     const int pile_cap = (((int)ceil(dmax + 8.0 * sqrt(dmax) + 16.0)) + 3) & ~3;
     std::vector<uint8_t> reads, gt_tile(E);
+    std::vector<double> errp, pick;
+    std::string tsv;
     vgl_tile_out o; memset(&o, 0, sizeof o);
     o.site_status = st.data(); o.n_alleles = na.data(); o.n_alleles_obs = nobs.data(); o.alleles2acgt = a2b.data();
     o.info_dp = idp.data(); o.info_ad = iad.data(); o.info_adf = iadf.data(); o.info_adr = iadr.data();
@@ -876,11 +935,33 @@ int main(int argc, char** argv) {
             reads.assign((size_t)pile_cap * ns * N, 0xFF);
             o.reads = reads.data(); o.read_capacity = pile_cap;
         }
+        if (want_errp) { errp.resize((size_t)pile_cap * ns * N); o.read_errp = errp.data(); o.read_capacity = pile_cap; }
+        if (dump_pick) { pick.resize(ns); o.site_pick_err = pick.data(); }
         t_mark = now();
         if (vgl_simulate_tile(ctx, (int64_t)t0, ns, gt_tile.data(), &o) != VGL_OK) die("%s", vgl_last_error());
         lap(3);
         for (int i = 0; i < ns; i++) {
             const Site& S = sites[t0 + i];
+            if ((dump_pick || dump_reads) && st[i] != VGL_SITE_SKIP_EMPTY && idp[i] > 0) {      // sites that reach the read loop (vcfgl.cpp:396-404)
+                tsv.clear();
+                char hb[96];
+                if (dump_pick) for (int s = 0; s < N; s++) {                                   // vcfgl.cpp:430-435
+                    tsv += "base_pick_error_prob\t"; tsv += vcf.samples[s]; tsv += '\t'; tsv += S.chrom;
+                    snprintf(hb, sizeof hb, "\t%ld\tNA\t%f\n", S.pos0 + 1, pick[i]); tsv += hb;
+                }
+                if (dump_reads) for (int s = 0; s < N; s++) {                                  // vcfgl.cpp:533-554
+                    const int n = dp[(size_t)i * N + s];
+                    for (int r = 0; r < n; r++) {
+                        const double ep = errp[((size_t)r * ns + i) * N + s];
+                        int q, aq; host_errprob_to_qs(a, ep, q, aq);
+                        auto head = [&](const char* type) { tsv += type; tsv += '\t'; tsv += vcf.samples[s]; tsv += '\t'; tsv += S.chrom; snprintf(hb, sizeof hb, "\t%ld\t%d\t", S.pos0 + 1, r); tsv += hb; };
+                        if (a.print_qs_err) { head("qs_error_prob"); snprintf(hb, sizeof hb, "%f\n", ep); tsv += hb; }
+                        if (a.print_qscores) { head("qs"); snprintf(hb, sizeof hb, "%d\n", (a.adjust_qs & 8) ? aq : q); tsv += hb; }
+                        if (a.print_gl_err) { head("gl_error_prob"); snprintf(hb, sizeof hb, "%f\n", a.precise_gl ? ep : host_qs_to_errprob((a.adjust_qs & 16) ? aq : q)); tsv += hb; }
+                    }
+                }
+                fwrite(tsv.data(), 1, tsv.size(), stdout);
+            }
             if (pile && st[i] != VGL_SITE_SKIP_EMPTY) {              // vcfgl.cpp:414-416, 616-634 (printed before skip decisions)
                 line.clear();
                 char hb[64]; snprintf(hb, sizeof hb, "\t%ld\t%c", S.pos0 + 1, S.ref_char);
@@ -891,7 +972,9 @@ int main(int argc, char** argv) {
                     snprintf(hb, sizeof hb, "\t%d\t", n); line += hb;
                     for (int r = 0; r < n; r++) line += "ACGT"[reads[((size_t)r * ns + i) * N + s] & 3];
                     line += '\t';
-                    for (int r = 0; r < n; r++) line += (char)((reads[((size_t)r * ns + i) * N + s] >> 2) + 33);
+                    if (!(a.adjust_qs & 4)) for (int r = 0; r < n; r++) line += (char)((reads[((size_t)r * ns + i) * N + s] >> 2) + 33);
+                    else if (a.error_qs != 2) line.append((size_t)n, (char)(pre_adjq + 33));                  // PROGRAM_WILL_ADJUST_QS_FOR_PILEUP
+                    else for (int r = 0; r < n; r++) { int q, aq; host_errprob_to_qs(a, errp[((size_t)r * ns + i) * N + s], q, aq); line += (char)(aq + 33); }
                 }
                 line += '\n';
                 gzwrite(pile, line.data(), (unsigned)line.size());
@@ -940,6 +1023,11 @@ int main(int argc, char** argv) {
     std::vector<std::string> files = {"-> Simulation output file: " + a.out_prefix + ext};
     if (a.print_pileup) files.push_back("-> Pileup output file: " + a.out_prefix + ".pileup.gz");
     if (a.print_truth) files.push_back("-> True genotypes output file: " + a.out_prefix + ".truth" + ext);
+    if (a.print_bpe) files.push_back("-> Base pick error output: stdout");
+    if (a.print_qs_err) files.push_back("-> QS error output: stdout");
+    if (a.print_gl_err) files.push_back("-> GL error output: stdout");
+    if (a.print_qscores) files.push_back("-> Qscores output: stdout");
+    fflush(stdout);
     runlog.finish(sb, files);
     return 0;
 }

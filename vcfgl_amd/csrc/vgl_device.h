@@ -115,6 +115,7 @@ struct VglTilePtrs {
     int32_t* fmt_dp; float* gl; int32_t* pl; float* gp;
     int32_t* fmt_ad; int32_t* fmt_adf; int32_t* fmt_adr;
     uint8_t* reads_out; int32_t reads_out_cap;
+    double* site_pick_err;    // [n_sites] per-site beta deviate of --error-qs 1 (dump; may be null)
     unsigned long long* dbg;  // diagnostic cycle stamps (VGL_DEBUG_STAMPS=1), else null
     // VGL_RNG_SERIAL: per-evaluation stream states found by the sequential scout (k_scout)
     uint64_t* sst_hap; uint64_t* sst_base;   // [n_sites][N]

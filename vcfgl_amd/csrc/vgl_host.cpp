@@ -161,6 +161,8 @@ struct vgl_ctx {
     // host-variant mirrors
     uint8_t* d_gt = nullptr; void* d_out[17] = {nullptr}; size_t d_out_bytes[17] = {0};
     uint8_t* d_reads_out = nullptr; size_t d_reads_out_bytes = 0;
+    double* d_errp_out = nullptr; size_t d_errp_out_bytes = 0;     // host-variant staging of read_errp / site_pick_err
+    double* d_pick_out = nullptr;
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;     // groups of 4
@@ -239,7 +241,7 @@ extern "C" int vgl_ctx_destroy(vgl_ctx* c) {
     if (!c) return VGL_OK;
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_gl1_fk, c->d_gl1_beta, c->d_gamma_ln, c->d_samp_tab, c->d_qs_read_tab, c->d_pois, c->d_q2gl, c->d_gl1_bsum, c->d_gl1_lhet, c->d_reads, c->d_errp, c->d_ad4,
-                    c->d_adf4, c->d_qsum, c->d_qsumsq, c->d_acc, c->d_sinfo, c->d_errflag, c->d_gt, c->d_reads_out, c->d_dbg,
+                    c->d_adf4, c->d_qsum, c->d_qsumsq, c->d_acc, c->d_sinfo, c->d_errflag, c->d_gt, c->d_reads_out, c->d_errp_out, c->d_pick_out, c->d_dbg,
                     c->d_serial, c->d_sst, c->d_site_thresh, c->d_scout_dp, c->d_site_tail, c->d_sdp, c->d_step_tab,
                     c->d_chunk_tab, c->d_eval_pow, c->d_dp_pre, c->d_roff, c->d_rtotal, c->d_errp_lin, c->d_cw, c->d_ccons, c->d_cexit,
                     c->d_ccnt, c->d_centry, c->d_cbase, c->d_cpos, c->d_csnap, c->d_csnapw, c->d_cctl};
@@ -582,6 +584,13 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
                               (size_t)(o->read_capacity - D.read_cap) * n_sites * D.n_samples, st));
     if ((o->qs && !D.need_qsum) || (o->i16 && !D.need_qsumsq))
         return fail(VGL_E_ARG, "qs / i16 outputs need -addQS / -addI16 in the context parameters");
+    // dumps of the deviates (ABI 2): the per-read error probabilities go through the --precise-gl staging planes
+    const bool dump_errp = o->read_errp && o->read_capacity > 0 && D.error_qs == 2;
+    if (dump_errp && !c->d_errp && dmalloc(&c->d_errp, (size_t)c->max_sites * D.n_samples * D.read_cap))
+        return fail(VGL_E_NOMEM, "out of device memory (read_errp staging)");
+    const bool errp_always = (c->p.precise_gl || (D.serial && !D.beta_chain)) && D.error_qs == 2;    // as sized by vgl_ctx_create
+    T.errp = (errp_always || dump_errp) ? c->d_errp : nullptr;
+    T.site_pick_err = (D.error_qs == 1) ? o->site_pick_err : nullptr;
 
     hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
     if (c->timing) for (int k = 0; k < 4; k++) HIPCHK(hipEventCreate(&e[k]));
@@ -603,6 +612,13 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     if (vgl_launch_gl(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_gl launch failed");
     if (c->timing) HIPCHK(hipEventRecord(e[3], st));
     if (o->qs || o->i16) if (vgl_launch_siteagg(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_siteagg launch failed");
+    if (dump_errp) {
+        const size_t row = (size_t)n_sites * D.n_samples;
+        const size_t rows = (size_t)(o->read_capacity < D.read_cap ? o->read_capacity : D.read_cap);
+        HIPCHK(hipMemcpyAsync(o->read_errp, c->d_errp, rows * row * sizeof(double), hipMemcpyDeviceToDevice, st));
+        if ((size_t)o->read_capacity > rows)
+            HIPCHK(hipMemsetAsync(o->read_errp + rows * row, 0xFF, ((size_t)o->read_capacity - rows) * row * sizeof(double), st));
+    }
     if (c->timing) for (int k = 0; k < 4; k++) c->ev.push_back(e[k]);
     return VGL_OK;
 }
@@ -695,6 +711,21 @@ extern "C" int vgl_simulate_tile(vgl_ctx* c, int64_t site0, int32_t n_sites, con
         }
         d.reads = c->d_reads_out; d.read_capacity = o->read_capacity;
     }
+    if (o->read_errp && o->read_capacity > 0) {
+        const size_t need = (size_t)o->read_capacity * c->max_sites * N * sizeof(double);
+        if (c->d_errp_out_bytes < need) {
+            if (c->d_errp_out) (void)hipFree(c->d_errp_out);
+            c->d_errp_out = nullptr; c->d_errp_out_bytes = 0;
+            HIPCHK(hipMalloc((void**)&c->d_errp_out, need));
+            c->d_errp_out_bytes = need;
+        }
+        d.read_errp = c->d_errp_out; d.read_capacity = o->read_capacity;
+    }
+    if (o->site_pick_err) {
+        if (!c->d_pick_out) HIPCHK(hipMalloc((void**)&c->d_pick_out, (size_t)c->max_sites * sizeof(double)));
+        HIPCHK(hipMemset(c->d_pick_out, 0xFF, (size_t)n_sites * sizeof(double)));
+        d.site_pick_err = c->d_pick_out;
+    }
     int rc = vgl_simulate_tile_device(c, site0, n_sites, c->d_gt, &d, nullptr);
     if (rc) return rc;
     if ((rc = vgl_ctx_check(c, nullptr))) return rc;
@@ -704,5 +735,7 @@ extern "C" int vgl_simulate_tile(vgl_ctx* c, int64_t site0, int32_t n_sites, con
         HIPCHK(hipMemcpy(host, c->d_out[f], field_count(c, FIELDS[f].kind, (size_t)n_sites) * FIELDS[f].esz, hipMemcpyDeviceToHost));
     }
     if (d.reads) HIPCHK(hipMemcpy(o->reads, d.reads, (size_t)o->read_capacity * n_sites * N, hipMemcpyDeviceToHost));
+    if (d.read_errp && c->dp.error_qs == 2) HIPCHK(hipMemcpy(o->read_errp, d.read_errp, (size_t)o->read_capacity * n_sites * N * sizeof(double), hipMemcpyDeviceToHost));
+    if (d.site_pick_err) HIPCHK(hipMemcpy(o->site_pick_err, d.site_pick_err, (size_t)n_sites * sizeof(double), hipMemcpyDeviceToHost));
     return VGL_OK;
 }

@@ -136,6 +136,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
         if (lane == 0) {
             uint64_t st_site = aff(P.off[3], aff(P.samp_tab[0], xb));
             const double pe = beta_draw(P, st_site);
+            if (T.site_pick_err && wp.chunk == 0) T.site_pick_err[ls] = pe;
             const uint64_t th = (uint64_t)ceil(ldexp(pe, 48));
             lo = (uint32_t)th; hi = (uint32_t)(th >> 32);
         }
@@ -438,8 +439,8 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
          else if (dm == 2) hipLaunchKernelGGL((k_sample<EQS, DBG, 2, PREC>), g, b, LDS, s, *p, *t); \
          else hipLaunchKernelGGL((k_sample<EQS, DBG, 0, PREC>), g, b, LDS, s, *p, *t); } while (0)
     if (p->error_qs == 2) {
-        if (dbg && !p->precise_gl) VGL_LAUNCH_SAMPLE(2, true, false, lds);   // diagnostic build: --precise-gl 0 only
-        else if (p->precise_gl) VGL_LAUNCH_SAMPLE(2, false, true, lds);
+        if (dbg && !t->errp) VGL_LAUNCH_SAMPLE(2, true, false, lds);   // diagnostic build: --precise-gl 0 only
+        else if (t->errp) VGL_LAUNCH_SAMPLE(2, false, true, lds);     // --precise-gl 1, or the deviates were asked for
         else VGL_LAUNCH_SAMPLE(2, false, false, lds);
     }
     else if (p->error_qs == 1) VGL_LAUNCH_SAMPLE(1, false, false, 0);

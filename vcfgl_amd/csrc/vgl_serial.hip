@@ -105,6 +105,7 @@ __global__ __launch_bounds__(64) void k_scout(const VglDevParams P, const VglTil
         if (info_dp == 0) { if (P.error_qs == 1) T.site_thresh[ls] = thresh; continue; }   // nothing else is drawn (vcfgl.cpp:396-404)
         if (P.error_qs == 1) {                                     // vcfgl.cpp:425-437
             const double pe = serial_beta(P, S);
+            if (T.site_pick_err) T.site_pick_err[ls] = pe;
             thresh = (uint64_t)ceil(ldexp(pe, 48));
             T.site_thresh[ls] = thresh;
         }
@@ -254,6 +255,7 @@ __global__ __launch_bounds__(64) void k_scout_wave(const VglDevParams P, const V
             uint32_t lo = 0, hi = 0;
             if (lane == 0) {
                 const double pe = serial_beta(P, S);
+                if (T.site_pick_err) T.site_pick_err[ls] = pe;
                 const uint64_t th = (uint64_t)ceil(ldexp(pe, 48));
                 T.site_thresh[ls] = th; lo = (uint32_t)th; hi = (uint32_t)(th >> 32);
             }
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(256) void k_sample_serial(const VglDevParams P, con
             int q_i = P.pre_q, aq_i = P.pre_adjq;
             if (P.error_qs == 2) {
                 double e;
-                if (T.errp_lin) { e = T.errp_lin[T.roff[ev] + r]; if (P.precise_gl) T.errp[(size_t)r * plane + ev] = e; }   // k_gl reads the planes
+                if (T.errp_lin) { e = T.errp_lin[T.roff[ev] + r]; if (T.errp) T.errp[(size_t)r * plane + ev] = e; }   // k_gl reads the planes
                 else e = T.errp[(size_t)r * plane + ev];
                 errprob_to_qs(P, e, q_i, aq_i, T.errflag);
             }

@@ -40,6 +40,8 @@ _FLAGS = {
     "-doUnobserved": ("do_unobserved", int),
     "-doGVCF": ("do_gvcf", int),
     "-printPileup": ("print_pileup", int), "-printTruth": ("print_truth", int),
+    "-printBasePickError": ("print_base_pick_error", int), "-printQsError": ("print_qs_error", int),
+    "-printGlError": ("print_gl_error", int), "-printQScores": ("print_qscores", int),
     "-addGL": ("add_gl", int), "-addFormatGL": ("add_gl", int),
     "-addGP": ("add_gp", int), "-addFormatGP": ("add_gp", int),
     "-addPL": ("add_pl", int), "-addFormatPL": ("add_pl", int),
@@ -81,6 +83,10 @@ class VcfglArgs:
     do_gvcf: int = 0
     print_pileup: int = 0
     print_truth: int = 0
+    print_base_pick_error: int = 0       # TSV lines on stdout (vcfgl.cpp:430-435, 533-554)
+    print_qs_error: int = 0
+    print_gl_error: int = 0
+    print_qscores: int = 0
     add_gl: int = 1
     add_gp: int = 0
     add_pl: int = 0
@@ -155,6 +161,14 @@ class VcfglArgs:
             raise VcfglArgError("--adjust-qs 1 requires --precise-gl 0.")
         if (self.adjust_qs & 2) and not self.add_qs:
             raise VcfglArgError("--adjust-qs 2 requires -addQS 1.")
+        if (self.adjust_qs & 4) and not self.print_pileup:                     # io.cpp:891-898
+            raise VcfglArgError("--adjust-qs 4 requires --printPileup 1.")
+        if (self.adjust_qs & 8) and not self.print_qscores:
+            raise VcfglArgError("--adjust-qs 8 requires --printQScores 1.")
+        if (self.adjust_qs & 16) and not self.print_gl_error:
+            raise VcfglArgError("--adjust-qs 16 requires --printGlError 1.")
+        if self.print_gl_error and self.gl_model == 1:                         # io.cpp:993
+            raise VcfglArgError("-printGlError 1 is not supported with genotype likelihood model 1 (--gl-model 1).")
         if self.gl_model == 1 and self.precise_gl:
             raise VcfglArgError("Precise genotype likelihood error (--precise-gl 1) is not supported with genotype likelihood model 1 (--gl-model 1).")
         if self.error_qs == 0 and self.beta_variance >= 0:

@@ -57,16 +57,16 @@ class Simulator:
             skip.add("i16")
         return [f for f, _, _ in _abi.TILE_FIELDS if f not in skip]
 
-    def new_tile(self, n_sites, fields=None, device=None, read_capacity=0):
+    def new_tile(self, n_sites, fields=None, device=None, read_capacity=0, deviates=False):
         if fields is None:
             fields = self.default_fields()
-        return Tile(n_sites, self.n_samples, self.A, self.G, fields=fields, device=device, read_capacity=read_capacity)
+        return Tile(n_sites, self.n_samples, self.A, self.G, fields=fields, device=device, read_capacity=read_capacity, deviates=deviates)
 
-    def simulate(self, site0, gt, fields=None, read_capacity=0):
+    def simulate(self, site0, gt, fields=None, read_capacity=0, deviates=False):
         gt = np.ascontiguousarray(gt, dtype=np.uint8)
         n_sites = gt.shape[0]
         assert gt.shape == (n_sites, self.n_samples)
-        tile = self.new_tile(n_sites, fields=fields, read_capacity=read_capacity)
+        tile = self.new_tile(n_sites, fields=fields, read_capacity=read_capacity, deviates=deviates)
         self._check(self.lib.vgl_simulate_tile(self.ctx, site0, n_sites, gt.ctypes.data, tile.byref()))
         return tile
 

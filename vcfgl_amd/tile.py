@@ -19,7 +19,7 @@ class Tile:
 
     ALWAYS = ("site_status", "n_alleles", "n_alleles_obs", "alleles2acgt")
 
-    def __init__(self, n_sites, n_samples, max_alleles, max_genotypes, fields=None, device=None, read_capacity=0):
+    def __init__(self, n_sites, n_samples, max_alleles, max_genotypes, fields=None, device=None, read_capacity=0, deviates=False):
         self.n_sites, self.n_samples, self.A, self.G = n_sites, n_samples, max_alleles, max_genotypes
         self.device = device
         want = set(self.ALWAYS) | set(fields if fields is not None else [f for f, _, _ in _abi.TILE_FIELDS])
@@ -37,6 +37,14 @@ class Tile:
             self.arrays["reads"] = arr
             self.struct.reads = self._ptr(arr)
             self.struct.read_capacity = read_capacity
+            if deviates:                                  # ABI 2: error_prob_forQs_i of every read (error_qs 2)
+                arr = self._alloc((read_capacity, n_sites, n_samples), "float64")
+                self.arrays["read_errp"] = arr
+                self.struct.read_errp = self._ptr(arr)
+        if deviates:                                      # ABI 2: base_pick_error_prob of every site (error_qs 1)
+            arr = self._alloc((n_sites,), "float64")
+            self.arrays["site_pick_err"] = arr
+            self.struct.site_pick_err = self._ptr(arr)
 
     def _alloc(self, shape, dtype):
         if self.device is None:
