@@ -288,10 +288,14 @@ __device__ __forceinline__ bool gamma_slow_test(const double u, const double xsq
                                                 const double s, const bool need) {
     const float uf = (float)u, sf = (float)s, a1f = (float)a1;
     const float lu = __builtin_amdgcn_logf(uf) * 0.69314718f;
+    // Horner steps as explicit fused multiply-adds: this is the bounded estimate, not the reference's arithmetic
+    // (the translation unit is built with -ffp-contract=off), and a fused step only tightens the bound below
+    const float ns = -sf;
     float p = 1.0f / 14.0f;
-    p = 1.0f / 13.0f - sf * p; p = 1.0f / 12.0f - sf * p; p = 1.0f / 11.0f - sf * p; p = 1.0f / 10.0f - sf * p;
-    p = 1.0f / 9.0f - sf * p; p = 1.0f / 8.0f - sf * p; p = 1.0f / 7.0f - sf * p; p = 1.0f / 6.0f - sf * p;
-    p = 1.0f / 5.0f - sf * p; p = 1.0f / 4.0f - sf * p;
+    p = __builtin_fmaf(ns, p, 1.0f / 13.0f); p = __builtin_fmaf(ns, p, 1.0f / 12.0f); p = __builtin_fmaf(ns, p, 1.0f / 11.0f);
+    p = __builtin_fmaf(ns, p, 1.0f / 10.0f); p = __builtin_fmaf(ns, p, 1.0f / 9.0f); p = __builtin_fmaf(ns, p, 1.0f / 8.0f);
+    p = __builtin_fmaf(ns, p, 1.0f / 7.0f); p = __builtin_fmaf(ns, p, 1.0f / 6.0f); p = __builtin_fmaf(ns, p, 1.0f / 5.0f);
+    p = __builtin_fmaf(ns, p, 1.0f / 4.0f);
     const float s2 = sf * sf;
     const float g = 3.0f * a1f * (s2 * s2) * p;                 // = -(rhs of the reference), >= 0
     const float d = lu + g;                                     // log(u) - rhs
