@@ -111,3 +111,62 @@ def test_sampled_sites_equal_oracle(oracle):
         assert np.array_equal(o["fmt_ad"][site].cpu().numpy(), want.numpy("fmt_ad")[0]), site
         assert np.array_equal(o["gl"][site].cpu().numpy().view(np.uint32), want.numpy("gl")[0].view(np.uint32)), site
         assert np.array_equal(o["alleles2acgt"][site].cpu().numpy(), want.numpy("alleles2acgt")[0]), site
+
+
+def test_full_c3_job_tiling_invariance_and_spot_parity(oracle):
+    """BASELINE.json configs[2] at its full size -- 1,000,000 sites x 1000 samples, depth 20, --error-qs 2, GL 2 (1e9
+    evaluations, 2e10 reads), the job bench.py times -- through size-independent properties: a checksum of per-tile
+    checksums that two different tilings must agree on, the accounting identity DP == sum(AD) on every tile, the Poisson
+    mean over all 1e9 depth draws, and oracle equality on sites scattered up to the last one."""
+    S_FULL = 1_000_000
+    dev = torch.device("cuda", 0)
+    a = _args()
+    keep = (0, 16383, 16384, 500_000, 777_777, S_FULL - 1)
+
+    def job(tile_sites):
+        sim = Simulator(a, N, max_sites_per_tile=tile_sites)
+        buf = {"site_status": torch.empty((tile_sites,), dtype=torch.int32, device=dev),
+               "n_alleles": torch.empty((tile_sites,), dtype=torch.int32, device=dev),
+               "alleles2acgt": torch.empty((tile_sites, 5), dtype=torch.int8, device=dev),
+               "fmt_dp": torch.empty((tile_sites, N), dtype=torch.int32, device=dev),
+               "fmt_ad": torch.empty((tile_sites, sim.A, N), dtype=torch.int32, device=dev),
+               "gl": torch.empty((tile_sites, sim.G, N), dtype=torch.float32, device=dev)}
+        sums = {k: torch.zeros((), dtype=torch.int64, device=dev) for k in buf}
+        dp_total = torch.zeros((), dtype=torch.int64, device=dev)
+        bad = torch.zeros((), dtype=torch.int64, device=dev)
+        kept = {}
+        for s0 in range(0, S_FULL, tile_sites):
+            n = min(tile_sites, S_FULL - s0)
+            gt = synth.binary_sites_torch(s0, n, N, dev)
+            t = _abi.TileOut()
+            for k, v in buf.items():
+                setattr(t, k, v.data_ptr())
+            sim._check(sim.lib.vgl_simulate_tile_device(sim.ctx, s0, n, gt.data_ptr(), C.byref(t), None))
+            for k, v in buf.items():                               # wrap-around int64 sums of the raw bits
+                x = v[:n]
+                sums[k] += (x.view(torch.int32) if x.dtype == torch.float32 else x).sum(dtype=torch.int64)
+            dp_total += buf["fmt_dp"][:n].sum(dtype=torch.int64)
+            bad += (buf["fmt_ad"][:n].sum(dim=1) != buf["fmt_dp"][:n]).sum()
+            for site in keep:
+                if s0 <= site < s0 + n:
+                    kept[site] = {k: buf[k][site - s0].cpu().numpy().copy() for k in ("fmt_dp", "fmt_ad", "gl", "alleles2acgt")}
+        sim.check()
+        sim.close()
+        tot = 0
+        for k in sorted(sums):
+            tot = (tot * 1000003 + int(sums[k].item())) % (1 << 61)
+        return tot, int(dp_total.item()), int(bad.item()), kept
+
+    c1, dp1, bad1, kept1 = job(16384)
+    c2, dp2, bad2, kept2 = job(10000)
+    assert c1 == c2 and dp1 == dp2
+    assert bad1 == 0 and bad2 == 0
+    assert abs(dp1 / (S_FULL * N) - 20.0) < 2e-3                   # sd of the mean of 1e9 Poisson(20) draws: 1.4e-4
+    orc = oracle.Oracle(a, N)
+    for site in keep:
+        want = orc.simulate(site, synth.binary_sites(site, 1, N), fields=["fmt_dp", "gl", "fmt_ad"])
+        for got in (kept1[site], kept2[site]):
+            assert np.array_equal(got["fmt_dp"], want.numpy("fmt_dp")[0]), site
+            assert np.array_equal(got["fmt_ad"], want.numpy("fmt_ad")[0]), site
+            assert np.array_equal(got["gl"].view(np.uint32), want.numpy("gl")[0].view(np.uint32)), site
+            assert np.array_equal(got["alleles2acgt"], want.numpy("alleles2acgt")[0]), site
