@@ -343,3 +343,16 @@ def test_deviate_dumps_match_oracle(oracle, serial):
     assert reach.sum() > 10
     w, g = want.numpy("site_pick_err")[reach], got.numpy("site_pick_err")[reach]
     assert np.all(np.abs(w - g) <= 1e-12 * np.abs(w)) if serial else np.array_equal(w.view(np.uint64), g.view(np.uint64))
+
+
+@pytest.mark.parametrize("depth,N", [(8, 100), (70, 64)])
+def test_undecided_quality_scores_are_redrawn_exactly(oracle, monkeypatch, depth, N):
+    """k_sample<2> takes a read's quality score from the float32 error probability unless that sits within the
+    float32 bound of an integer boundary (about 1 read in 10^4); such a read is drawn again in double by the lane
+    that owns it.  VGL_DEBUG_QS_EXACT=1 sends EVERY read down that path (second case: several LDS segments per
+    wavefront): results must not change."""
+    monkeypatch.setenv("VGL_DEBUG_QS_EXACT", "1")
+    args = VcfglArgs(seed=5, depth=depth, error_rate=0.01, error_qs=2, beta_variance=1e-5, adjust_qs=3, **ALLTAGS)
+    want, got = run_both(oracle, args, synth.binary_sites(0, 12, N), read_capacity=128)
+    assert np.array_equal(want.numpy("reads"), got.numpy("reads"))
+    assert_parity(want, got)

@@ -60,6 +60,7 @@ struct VglDevParams {
                              // order keeps every store of a wavefront one contiguous segment and the kernel is HBM bound)
     int32_t slow_period;     // k_sample<2>: the bounded-log tests run every slow_period-th pool iteration
     int32_t dbg_phase;       // diagnostic (VGL_DEBUG_PHASE=n): k_sample returns after phase n; 0 = off
+    int32_t dbg_qs_exact;    // test hook (VGL_DEBUG_QS_EXACT=1): k_sample<2> treats every read as undecided in float32
     int32_t pre_q, pre_adjq;           // preCalc qScore / adj_qScore (vcfgl.cpp:1697-1702)
     double  adjust_by;
     double  pre_homT, pre_het, pre_homF;

@@ -324,6 +324,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     D.slow_period = getenv("VGL_SLOW_PERIOD") ? atoi(getenv("VGL_SLOW_PERIOD")) : 2;
     if (D.slow_period < 1) D.slow_period = 1;
     D.dbg_phase = getenv("VGL_DEBUG_PHASE") ? atoi(getenv("VGL_DEBUG_PHASE")) : 0;
+    D.dbg_qs_exact = getenv("VGL_DEBUG_QS_EXACT") ? atoi(getenv("VGL_DEBUG_QS_EXACT")) : 0;
     for (int i = 0; i < p->n_qs_bins * 3; i++) D.qs_bins[i] = p->qs_bins[i];
     D.err_thresh = (uint64_t)ceil(ldexp(p->error_rate, 48));
 

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 const bool inb = kk < segT;
                 const float pf = __uint_as_float(l_it[inb ? kk : cap]);
                 int q_i, aq_i;
-                const bool ok = qs_decide_pf(P, pf, q_i, aq_i);
+                const bool ok = qs_decide_pf(P, pf, q_i, aq_i) && !P.dbg_qs_exact;
                 uint64_t amb = __ballot(inb && !ok);
                 if (__builtin_expect(amb != 0, 0)) {
                     // undecided in float32: the owner of the read draws its deviate again in double (rng.h:433-444)
