@@ -205,3 +205,15 @@ def test_cli_tsv_line_order_and_adjusted_scores(tmp_path):
     pa = gzip.open(str(tmp_path / "a") + ".pileup.gz", "rt").read()
     pb = gzip.open(str(tmp_path / "b") + ".pileup.gz", "rt").read()
     assert pa != pb and len(pa) == len(pb)
+
+
+def test_cli_documented_msprime_run(tmp_path):
+    """doc/with_msprime.MD: 3 samples, --depth 10 --error-rate 0 --source 0 --seed 42; the listed records as text"""
+    d = os.path.join(ROOT, "tests", "golden", "doc_msprime")
+    out = str(tmp_path / "sim_source0")
+    r = subprocess.run([BIN, "-i", os.path.join(d, "msprime_output.vcf"), "-O", "v", "-o", out, "--rng-mode", "1", "--depth", "10",
+                        "--error-rate", "0", "--source", "0", "--seed", "42"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ours = [l.rstrip("\n") for l in open(out + ".vcf") if not l.startswith("##")]
+    gold = [l.rstrip("\n") for l in open(os.path.join(d, "sim_source0.vcf")) if not l.startswith("##")]
+    assert ours == gold

@@ -43,3 +43,30 @@ def test_reference_golden_pileup(oracle):
             ours_b = "".join("ACGT"[reads[r, i, s] & 3] for r in range(n))
             ours_q = "".join(chr((reads[r, i, s] >> 2) + 33) for r in range(n))
             assert (ours_b, ours_q) == (bases, quals), (chrom, pos, s)
+
+
+DOC_RUNS = {
+    # documented runs of the reference (doc/with_msprime.MD, doc/error_qs.MD): flags, input, expected VCF listing
+    "msprime": ("--depth 10 --error-rate 0 --source 0 --seed 42", "doc_msprime/msprime_output.vcf", "doc_msprime/sim_source0.vcf"),
+    "error_qs0": ("--depth 2 --error-rate 0.4 --error-qs 0 -addFormatAD 1 --seed 42", "ref_vcf/data/data2.vcf", "doc_error_qs/error_qs0.vcf"),
+    "error_qs1": ("--depth 2 --error-rate 0.4 --error-qs 1 --beta-variance 1e-1 -addFormatAD 1 --seed 42", "ref_vcf/data/data2.vcf", "doc_error_qs/error_qs1.vcf"),
+    "error_qs2": ("--depth 2 --error-rate 0.4 --error-qs 2 --beta-variance 1e-1 -addFormatAD 1 --seed 42", "ref_vcf/data/data2.vcf", "doc_error_qs/error_qs2.vcf"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(DOC_RUNS))
+def test_documented_runs_of_the_reference(oracle, name):
+    """The output listings in the reference's documentation pin the oracle beyond its test-suite: depth 10 (eleven
+    to sixteen reads per sample, quality score capped at 63) and the three --error-qs modes at error rate 0.4."""
+    from vcfgl_amd.params import VcfglArgs
+    from vcfgl_amd.recordloop import iter_sites
+    from vcfgl_amd.vcfio import read_vcf
+    flags, inp, exp = DOC_RUNS[name]
+    args = VcfglArgs.from_argv(flags.split()).validate()
+    args.rng_mode, args.beta_sampler = _abi.VGL_RNG_SERIAL, _abi.VGL_BETA_STD
+    vcf = read_vcf(os.path.join(gu.GOLD, inp))
+    sites = list(iter_sites(vcf, args))
+    gold = read_vcf(os.path.join(gu.GOLD, exp))
+    tile = oracle.Oracle(args, len(vcf.samples)).simulate(0, np.stack([s.gt for s in sites]))
+    errs = gu.compare_with_golden(args, sites, tile, gold)
+    assert not errs, "\n".join(errs[:40])
