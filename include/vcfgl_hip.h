@@ -46,6 +46,9 @@ extern "C" {
 #define VGL_E_CAPACITY     (-4)  /* a per-sample read depth exceeded the staging capacity        */
 #define VGL_E_UNSUPPORTED  (-5)  /* flag combination not implemented on the device path          */
 #define VGL_E_QSBIN        (-6)  /* "Could not find a range for qs value" (vcfgl.cpp:63)         */
+#define VGL_E_ADJQ         (-7)  /* --adjust-qs 1|2 met a read without a valid adjusted quality score: error probability
+                                    exactly 0 or 1, or a negative adjusted score (the reference exits on
+                                    ASSERT(adjqScore_i != -1), vcfgl.cpp:558, and ASSERT(qs >= 0 ...), gl_methods.cpp:101) */
 
 /* ---- per-site status (reference: return value of simulate_record_values) ------------- */
 #define VGL_SITE_OK            0

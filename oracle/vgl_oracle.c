@@ -512,6 +512,7 @@ int vgl_oracle_create(const vgl_params* p, vgl_oracle** out) {
         int r = errprob_to_qs(o, p->error_rate, 1, &o->pre_q, &o->pre_adjq);
         if (r) { vgl_oracle_destroy(o); return r; }
         if (!p->adjust_qs) o->pre_adjq = -1;
+        if ((p->adjust_qs & 3) && o->pre_adjq < 0) { vgl_oracle_destroy(o); OFAIL(VGL_E_ADJQ, "--adjust-qs %d: the adjusted quality score is negative", p->adjust_qs); }
         if (p->gl_model == 2) {
             if (!p->precise_gl) {
                 int q = (p->adjust_qs & 1) ? o->pre_adjq : o->pre_q;
@@ -711,6 +712,10 @@ static int simulate_site(vgl_oracle* o, int64_t site_abs, int32_t ls, int32_t n_
                 if (tile) { st_read = vgl_oracle_rand48_jump(st_qs[s], (uint64_t)r * o->lay.qs_read_stride); sq = &st_read; }
                 double ep = beta_draw(o, sq);
                 if ((rc = errprob_to_qs(o, ep, 0, &q_i, &aq_i))) goto done;
+                if (aq_i < 0 && (p->adjust_qs & 3)) {       /* the reference exits: ASSERT(adjqScore_i != -1) :558, ASSERT(qs >= 0 ...) gl_methods.cpp:101 */
+                    snprintf(g_err, sizeof g_err, "--adjust-qs %d: a read has no valid adjusted quality score (error probability %g)", p->adjust_qs, ep);
+                    rc = VGL_E_ADJQ; goto done;
+                }
                 o->qsc[(size_t)s * o->cap + r] = q_i;
                 o->adjq[(size_t)s * o->cap + r] = aq_i;
                 o->errp[(size_t)s * o->cap + r] = ep;

@@ -1,5 +1,7 @@
 """Randomised differential test: random flag combinations, shapes and inputs; the HIP path (tile mode
 and serial mode) against the CPU oracle on every output field."""
+import os
+
 import numpy as np
 import pytest
 
@@ -67,9 +69,10 @@ def compare(want, got, tol_gl, tag):
         assert np.array_equal(want.numpy("i16")[:, :12], got.numpy("i16")[:, :12]), (tag, "i16")
 
 
-@pytest.mark.parametrize("chunk", range(24))
+# VGL_FUZZ_CHUNKS / VGL_FUZZ_SEED: longer one-off runs (10 configurations x 2 RNG modes per chunk)
+@pytest.mark.parametrize("chunk", range(int(os.environ.get("VGL_FUZZ_CHUNKS", "24"))))
 def test_random_configurations(oracle, chunk):
-    rng = np.random.default_rng(1000 + chunk)
+    rng = np.random.default_rng(int(os.environ.get("VGL_FUZZ_SEED", "1000")) + chunk)
     done = 0
     while done < 10:
         kw, N, gt = random_case(rng)
@@ -102,3 +105,37 @@ def test_random_configurations(oracle, chunk):
             if mode == _abi.VGL_RNG_SERIAL and args.add_i16:
                 assert np.array_equal(want.numpy("i16"), got.numpy("i16")), (tag, "i16 tail")
         done += 1
+
+
+def test_error_probability_zero_with_adjusted_scores_is_refused(oracle):
+    """Found by a longer run of the test above (VGL_FUZZ_SEED=50000, chunk 74, configuration 7): beta(0.02, 3.98) quality-score
+    noise gives a read an error probability of exactly 0, for which the reference leaves the adjusted quality score
+    at -1 and then exits on ASSERT(adjqScore_i != -1) (vcfgl.cpp:558; gl_methods.cpp:101 for --adjust-qs 1).  Serial
+    mode reaches that read: oracle and HIP path both refuse with VGL_E_ADJQ; without --adjust-qs the run is fine."""
+    rng = np.random.default_rng(50000 + 74)
+    done = 0
+    while True:
+        kw, N, gt = random_case(rng)
+        try:
+            VcfglArgs(**kw).validate()
+        except VcfglArgError:
+            continue
+        if done == 7:
+            break
+        done += 1
+    assert kw["error_qs"] == 2 and kw["adjust_qs"] == 3 and N == 300
+    for adj, fails in ((3, True), (0, False)):
+        args = VcfglArgs(**dict(kw, adjust_qs=adj))
+        args.rng_mode, args.beta_sampler = _abi.VGL_RNG_SERIAL, _abi.VGL_BETA_STD
+        sim = Simulator(args, N, max_sites_per_tile=gt.shape[0])
+        orc = oracle.Oracle(args, N)
+        if fails:
+            with pytest.raises(oracle.OracleError) as eo:
+                orc.simulate(0, gt, fields=sim.default_fields())
+            assert eo.value.code == _abi.VGL_E_ADJQ
+            with pytest.raises(Exception) as ei:
+                sim.simulate(0, gt)
+            assert getattr(ei.value, "code", None) == _abi.VGL_E_ADJQ
+        else:
+            compare(orc.simulate(0, gt, fields=sim.default_fields()), sim.simulate(0, gt), tol_gl=False, tag="adj0")
+        sim.close()

@@ -9,7 +9,7 @@ import os
 ABI_VERSION = 2
 
 VGL_OK = 0
-VGL_E_ARG, VGL_E_NODEVICE, VGL_E_NOMEM, VGL_E_CAPACITY, VGL_E_UNSUPPORTED, VGL_E_QSBIN = -1, -2, -3, -4, -5, -6
+VGL_E_ARG, VGL_E_NODEVICE, VGL_E_NOMEM, VGL_E_CAPACITY, VGL_E_UNSUPPORTED, VGL_E_QSBIN, VGL_E_ADJQ = -1, -2, -3, -4, -5, -6, -7
 VGL_SITE_OK, VGL_SITE_SKIP_INVAR, VGL_SITE_SKIP_EMPTY, VGL_SITE_NO_READS = 0, -3, -4, 1
 VGL_RNG_TILE, VGL_RNG_SERIAL = 0, 1
 VGL_BETA_RAND48, VGL_BETA_STD = 0, 1

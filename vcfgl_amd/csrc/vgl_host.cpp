@@ -334,6 +334,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     D.pre_q = D.pre_adjq = -1;
     if (p->error_qs == 0 || p->error_qs == 1) {                  // preCalc, vcfgl.cpp:1661-1743
         if ((rc = errprob_to_qs_fixed(p, p->error_rate, &D.pre_q, &D.pre_adjq))) { vgl_ctx_destroy(c); return rc; }
+        if ((p->adjust_qs & 3) && D.pre_adjq < 0) { vgl_ctx_destroy(c); return fail(VGL_E_ADJQ, "--adjust-qs %d --adjust-by %g: the adjusted quality score is negative", p->adjust_qs, p->adjust_by); }
         if (p->gl_model == 2) {
             if (!p->precise_gl) {
                 const int q = (p->adjust_qs & 1) ? D.pre_adjq : D.pre_q;
@@ -653,6 +654,7 @@ extern "C" int vgl_ctx_check(vgl_ctx* c, void* stream) {
     if (flag & VGL_DEVERR_CAPACITY) return fail(VGL_E_CAPACITY, "a simulated read depth exceeded the staging capacity of %d reads per sample", c->dp.read_cap);
     if (flag & VGL_DEVERR_QSBIN) return fail(VGL_E_QSBIN, "Could not find a range for a simulated qs value in --qs-bins");
     if (flag & VGL_DEVERR_GL1DEPTH) return fail(VGL_E_UNSUPPORTED, "GL model 1 with depth > 255 (htslib subsamples with drand48) is not supported");
+    if (flag & VGL_DEVERR_ADJQ) return fail(VGL_E_ADJQ, "--adjust-qs %d: a read has no valid adjusted quality score (error probability exactly 0 or 1, or a negative adjusted score)", c->dp.adjust_qs);
     return VGL_OK;
 }
 

@@ -337,6 +337,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                             const double ep = beta_draw(P, st_x);
                             int qe, aqe;
                             errprob_raw(P, ep, qe, aqe);
+                            if (aqe < 0 && (P.adjust_qs & 3)) atomicOr(T.errflag, VGL_DEVERR_ADJQ);   // vcfgl.cpp:558, gl_methods.cpp:101
                             l_it[kb + b] = (uint32_t)(uint16_t)qe | ((uint32_t)(uint16_t)aqe << 16);
                         }
                     }

@@ -375,6 +375,7 @@ __global__ __launch_bounds__(256) void k_sample_serial(const VglDevParams P, con
                 if (T.errp_lin) { e = T.errp_lin[T.roff[ev] + r]; if (T.errp) T.errp[(size_t)r * plane + ev] = e; }   // k_gl reads the planes
                 else e = T.errp[(size_t)r * plane + ev];
                 errprob_to_qs(P, e, q_i, aq_i, T.errflag);
+                if (aq_i < 0 && (P.adjust_qs & 3)) atomicOr(T.errflag, VGL_DEVERR_ADJQ);               // vcfgl.cpp:558, gl_methods.cpp:101
             }
             const int q_gl = (P.adjust_qs & 1) ? aq_i : q_i;
             T.reads[(size_t)r * plane + ev] = (uint8_t)((q_gl << 2) | r_base);
