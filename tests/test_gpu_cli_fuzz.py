@@ -1,0 +1,142 @@
+"""Randomised differential test of the C++ front end (vcfgl_amd/bin/vcfgl_hip): random input VCFs (ACGT or binary
+alleles, multi-allelic records, missing genotypes, gaps for -explode) and random flag combinations, the VCF text it
+writes against the CPU oracle driven through the Python mirror of the record loop -- record selection, allele columns,
+INFO / FORMAT key sets and order, every value (floats at the 6 significant digits the text carries)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+from vcfgl_amd import VcfglArgs, VcfglArgError, _abi
+from vcfgl_amd.recordloop import iter_sites
+from vcfgl_amd.vcfio import read_vcf
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "vcfgl_amd", "bin", "vcfgl_hip")
+
+
+def random_vcf(rng, path, binary):
+    N = int(rng.choice([1, 2, 5, 70]))
+    S = int(rng.integers(1, 25))
+    length = S * 3 + 5
+    pos = np.sort(rng.choice(np.arange(1, length), size=S, replace=False))
+    miss = float(rng.choice([0.0, 0.0, 0.1]))
+    with open(path, "w") as fh:
+        fh.write("##fileformat=VCFv4.2\n##FILTER=<ID=PASS,Description=\"All filters passed\">\n")
+        fh.write(f"##contig=<ID=chr7,length={length}>\n##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n")
+        fh.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(f"smp{i}" for i in range(N)) + "\n")
+        for p in pos:
+            if binary:
+                alleles = ["0", "1"]
+            else:
+                alleles = list(rng.permutation(list("ACGT"))[: int(rng.integers(2, 5))])
+            gts = []
+            for _ in range(N):
+                if rng.random() < miss:
+                    gts.append(".|." if rng.random() < 0.5 else "./.")
+                else:
+                    a, b = rng.integers(0, len(alleles), size=2)
+                    gts.append(f"{a}{'|' if rng.random() < 0.7 else '/'}{b}")
+            fh.write(f"chr7\t{p}\t.\t{alleles[0]}\t{','.join(alleles[1:])}\t.\tPASS\t.\tGT\t" + "\t".join(gts) + "\n")
+    return N
+
+
+def random_flags(rng, tmp, N, binary):
+    eqs = int(rng.choice([0, 0, 1, 2, 2]))
+    gl = int(rng.choice([1, 2, 2]))
+    precise = int(rng.integers(0, 2)) if gl == 2 else 0
+    adj = int(rng.choice([0, 0, 1, 2, 3])) if not precise else int(rng.choice([0, 2]))
+    strand = int(rng.integers(0, 2))
+    f = ["--source", "0" if binary else "1", "--seed", str(int(rng.integers(0, 2 ** 31 - 1))),
+         "--error-rate", str(float(rng.choice([0.0, 0.002, 0.01, 0.2])) if eqs == 0 else float(rng.choice([0.005, 0.01, 0.2]))),
+         "--error-qs", str(eqs), "--gl-model", str(gl), "--precise-gl", str(precise), "--adjust-qs", str(adj),
+         "--adjust-by", str(float(rng.choice([0.499, 0.25]))), "-explode", str(int(rng.integers(0, 2))),
+         "-doUnobserved", str(int(rng.integers(0, 6))), "--rm-invar-sites", str(int(rng.choice([0, 0, 1, 2, 4, 7]))),
+         "--rm-empty-sites", str(int(rng.integers(0, 2))),
+         "-addGL", str(int(rng.choice([1, 1, 0]))), "-addGP", str(int(rng.integers(0, 2))), "-addPL", str(int(rng.integers(0, 2))),
+         "-addQS", str(1 if (adj & 2) else int(rng.integers(0, 2))), "-addI16", str(strand & int(rng.integers(0, 2))),
+         "-addFormatDP", str(int(rng.choice([1, 1, 0]))), "-addInfoDP", str(int(rng.integers(0, 2))),
+         "-addFormatAD", str(int(rng.integers(0, 2))), "-addInfoAD", str(int(rng.integers(0, 2))),
+         "-addFormatADF", str(strand), "-addInfoADF", str(strand & int(rng.integers(0, 2))),
+         "-addFormatADR", str(strand & int(rng.integers(0, 2))), "-addInfoADR", str(strand)]
+    if f[f.index("-addGL") + 1] == "0" and f[f.index("-addFormatDP") + 1] == "0":
+        f[f.index("-addFormatDP") + 1] = "1"                      # at least one FORMAT tag
+    if eqs:
+        f += ["--beta-variance", str(float(rng.choice([1e-5, 1e-4])))]
+    if rng.random() < 0.25:
+        dfile = os.path.join(tmp, "depths.txt")
+        with open(dfile, "w") as fh:
+            fh.write("\n".join(str(float(x)) for x in rng.choice([0.0, 0.5, 3.0, 14.0], size=N)) + "\n")
+        f += ["--depths-file", dfile]
+    else:
+        f += ["--depth", str(float(rng.choice([0.0, 0.3, 2.0, 6.0, 13.0])))]
+    if eqs == 2 and rng.random() < 0.3:
+        bfile = os.path.join(tmp, "bins.csv")
+        with open(bfile, "w") as fh:
+            fh.write("0,2,2\n3,14,12\n15,30,23\n31,63,37\n")
+        f += ["--qs-bins", bfile]
+    return f
+
+
+def expected_keys(a):
+    fmt = [k for k, on in (("DP", a.add_fmt_dp), ("GL", a.add_gl), ("PL", a.add_pl), ("GP", a.add_gp), ("AD", a.add_fmt_ad),
+                           ("ADF", a.add_fmt_adf), ("ADR", a.add_fmt_adr)) if on]
+    info = [k for k, on in (("DP", a.add_info_dp), ("QS", a.add_qs), ("I16", a.add_i16), ("AD", a.add_info_ad),
+                            ("ADF", a.add_info_adf), ("ADR", a.add_info_adr)) if on]
+    return fmt, info
+
+
+@pytest.mark.parametrize("chunk", range(int(os.environ.get("VGL_CLI_FUZZ_CHUNKS", "8"))))
+def test_random_cli_runs_against_the_oracle(oracle, chunk, tmp_path):
+    rng = np.random.default_rng(int(os.environ.get("VGL_CLI_FUZZ_SEED", "7000")) + chunk)
+    done = 0
+    while done < 6:
+        binary = bool(rng.integers(0, 2))
+        inp = str(tmp_path / f"in{done}.vcf")
+        N = random_vcf(rng, inp, binary)
+        flags = random_flags(rng, str(tmp_path), N, binary)
+        try:
+            VcfglArgs.from_argv(flags).validate()
+        except VcfglArgError:
+            continue
+        for mode, beta in ((_abi.VGL_RNG_TILE, _abi.VGL_BETA_RAND48), (_abi.VGL_RNG_SERIAL, _abi.VGL_BETA_STD)):
+            tag = (chunk, done, mode, " ".join(flags))
+            args = VcfglArgs.from_argv(flags).validate()
+            args.rng_mode, args.beta_sampler = mode, beta
+            vcf = read_vcf(inp)
+            sites = list(iter_sites(vcf, args))
+            out = str(tmp_path / f"out{done}_{mode}")
+            r = subprocess.run([BIN, "-i", inp, "-o", out, "-O", "v", "--rng-mode", str(mode), "--tile-sites", str(int(rng.choice([1, 4, 4096])))] + flags,
+                               capture_output=True, text=True, timeout=300)
+            try:
+                orc = oracle.Oracle(args, N)
+                fields = [f for f, _, _ in _abi.TILE_FIELDS if not (f == "qs" and not (args.add_qs or args.add_i16)) and not (f == "i16" and not args.add_i16)]
+                tile = orc.simulate(0, np.stack([s.gt for s in sites]), fields=fields) if sites else None
+            except oracle.OracleError as e:
+                assert r.returncode != 0, (tag, "oracle refuses, program does not", str(e))     # qs-bin miss, VGL_E_ADJQ, bad beta shape ...
+                continue
+            assert r.returncode == 0, (tag, r.stderr[-1500:])
+            got = read_vcf(out + ".vcf")
+            if tile is None:
+                assert not got.records, tag
+                continue
+            strict = gu.close6
+            if args.precise_gl or args.add_gp or (mode == _abi.VGL_RNG_SERIAL and args.error_qs):
+                # a device log10 / pow feeds these floats (1e-6): one unit of the sixth printed digit
+                gu.close6 = lambda x, y: strict(x, y) or (np.isfinite(x) and np.isfinite(y) and abs(x - y) <= 2e-5 * max(abs(x), abs(y), 1e-30))
+            try:
+                errs = gu.compare_with_golden(args, sites, tile, got, check_i16_tail=(mode == _abi.VGL_RNG_SERIAL))
+            finally:
+                gu.close6 = strict
+            assert not errs, (tag, errs[:10])
+            fmt, info = expected_keys(args)
+            for line in open(out + ".vcf"):
+                if line.startswith("#"):
+                    continue
+                c = line.rstrip("\n").split("\t")
+                assert c[8] == (":".join(fmt) if fmt else "."), (tag, c[8])
+                assert [kv.split("=")[0] for kv in c[7].split(";") if kv != "."] == info, (tag, c[7])
+        done += 1
