@@ -59,7 +59,8 @@ struct VglDevParams {
                              // 2 = product method in place (every mean depth < 12), 0 = mixed means, general sampler in place
     int32_t gl_sort;         // k_gl: re-deal the lanes of a workgroup in depth order (pays at depth >= 8; below, natural
                              // order keeps every store of a wavefront one contiguous segment and the kernel is HBM bound)
-    int32_t slow_period;     // k_sample<2>: the bounded-log tests run every slow_period-th pool iteration
+    int32_t slow_period;     // k_sample<2>: the bounded-log test of the gamma sampler runs every slow_period-th pool iteration,
+    int32_t slow_period_n;   //              that of the normal sampler every slow_period_n-th
     int32_t dbg_phase;       // diagnostic (VGL_DEBUG_PHASE=n): k_sample returns after phase n; 0 = off
     int32_t dbg_qs_exact;    // test hook (VGL_DEBUG_QS_EXACT=1): k_sample<2> treats every read as undecided in float32
     int32_t pre_q, pre_adjq;           // preCalc qScore / adj_qScore (vcfgl.cpp:1697-1702)
