@@ -356,3 +356,14 @@ def test_undecided_quality_scores_are_redrawn_exactly(oracle, monkeypatch, depth
     want, got = run_both(oracle, args, synth.binary_sites(0, 12, N), read_capacity=128)
     assert np.array_equal(want.numpy("reads"), got.numpy("reads"))
     assert_parity(want, got)
+
+
+@pytest.mark.parametrize("var", [1e-9, 1e-12])
+def test_error_qs2_very_large_shape_parameters(oracle, var):
+    """beta shape parameters of 1e4 .. 1e10 (--beta-variance 1e-9 / 1e-12): the gamma sampler's second test compares
+    quantities of order x^4 / a1 against the rounding of a1 (1 - v + log v); the sure-accept bound of k_sample<2>
+    carries a slack that grows with a1 (vgl_host.cpp: sure_margin)"""
+    args = VcfglArgs(seed=9, depth=8, error_rate=0.01, error_qs=2, beta_variance=var, **ALLTAGS)
+    want, got = run_both(oracle, args, synth.binary_sites(0, 40, 100), read_capacity=40)
+    assert np.array_equal(want.numpy("reads"), got.numpy("reads"))
+    assert_parity(want, got)

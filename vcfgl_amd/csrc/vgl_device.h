@@ -80,6 +80,7 @@ struct VglDevParams {
     VglPois pois0;
     const VglPois* pois;               // [N] when per_sample_depth
     VglGamma1 gx, gy;
+    double sure_margin;                // absolute slack of k_sample<2>'s sure-accept bound (host: 1e-9 + 1e-14 max a1)
     int32_t qs_bins[VGL_MAX_QS_BINS * 3];
     // tables
     const double* q2gl;                // [3][257]

@@ -355,6 +355,9 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
         const double a = (((1.0 - mean) / var) - oom) * pow(mean, 2), b = a * (oom - 1);
         if (a <= 0.0 || b <= 0.0) { vgl_ctx_destroy(c); return fail(VGL_E_ARG, "Beta shape parameters must be positive (alpha=%f beta=%f); use different --error-rate / --beta-variance", a, b); }
         gamma1_init(&D.gx, a); gamma1_init(&D.gy, b);
+        // k_sample<2>'s sure-accept bound: far above the rounding of the reference's own right-hand side
+        // 0.5 x^2 + a1 (1 - v + log v), which is about 4e-16 a1 + 1e-16 x^2
+        D.sure_margin = 1e-9 + 1e-14 * std::max(D.gx.a1, D.gy.a1);
         D.beta_a = a; D.beta_b = b;
     }
     pois_init(&D.pois0, p->depths ? 0.0 : p->depth);

@@ -282,10 +282,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     // Where the squeeze fails the reference accepts iff log(u) <= 0.5 x^2 + a1 (1 - v + log v) = -x^2 s^2 P(s) / 3,
                     // s = a2 x, P(s) = 1/4 - s/5 + s^2/6 - ... (gamma_slow_test).  -log(1 - t) >= t, and P < 0.45 for s >= -1/2
                     // (P <= 1/4 for s >= 0; 1/4 + |s|/5 + s^2 / (6 (1 - |s|)) <= 0.434 for -1/2 <= s < 0), so
-                    // 1 - u >= 0.15 a2^2 x^4 (+ 1e-9, far above the rounding of either side) is a sure accept: it settles 97 %
+                    // 1 - u >= 0.15 a2^2 x^4 (+ P.sure_margin, far above the rounding of either side) is a sure accept: it settles 97 %
                     // of these cases (the sampler's rejection rate is 0.3 % for alpha ~ 10 and 0.003 % for alpha ~ 1000), and the
                     // bounded test below is left with ~0.2 % of the lanes of an iteration.
-                    const bool sure = (1.0 - u2 >= (ga2 * ga2) * 0.15 * x4 + 1e-9) && (w >= 0.5);
+                    const bool sure = (1.0 - u2 >= (ga2 * ga2) * 0.15 * x4 + P.sure_margin) && (w >= 0.5);
                     const bool g_try = have && acc_n && w_pos && !hold;
                     const bool g_amb = g_try && sq_fail && !sure;
                     hold = hold || (g_amb && !full);
