@@ -231,6 +231,15 @@ __device__ __forceinline__ int wave_sum(int v) {
     return v;
 }
 
+// Workgroups are handed to the 8 XCDs of the part round-robin by index, and each XCD has its own L2.  xcd_block() maps
+// the hardware index to a logical one so that every XCD walks ONE contiguous range of the tile (sites in order): the
+// pieces of a plane that neighbouring workgroups write then meet in one L2 and leave it as long runs (a bijection of
+// [0, n) for any n; only an affinity -- nothing depends on where a workgroup really runs).
+__device__ __forceinline__ uint32_t xcd_block(const uint32_t b, const uint32_t n) {
+    const uint32_t q = n >> 3, r = n & 7u, x = b & 7u, i = b >> 3;
+    return x * q + (x < r ? x : r) + i;
+}
+
 // wave -> (local site, 64-sample chunk); everything here is wave-uniform (SGPRs)
 struct WavePos { int ls; int chunk; int wib; bool valid; };
 __device__ __forceinline__ WavePos wave_pos(const VglDevParams& P, const VglTilePtrs& T) {

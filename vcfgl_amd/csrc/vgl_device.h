@@ -61,6 +61,8 @@ struct VglDevParams {
                              // order keeps every store of a wavefront one contiguous segment and the kernel is HBM bound)
     int32_t slow_period;     // k_sample<2>: the bounded-log test of the gamma sampler runs every slow_period-th pool iteration,
     int32_t slow_period_n;   //              that of the normal sampler every slow_period_n-th
+    int32_t xcd_map;         // k_gl: workgroup index -> XCD-contiguous logical index (VGL_XCD_MAP=0 turns it off; k_sample, which is
+                             // bound by its arithmetic, measured 1-3 % slower with it and keeps the hardware order)
     int32_t dbg_phase;       // diagnostic (VGL_DEBUG_PHASE=n): k_sample returns after phase n; 0 = off
     int32_t dbg_qs_exact;    // test hook (VGL_DEBUG_QS_EXACT=1): k_sample<2> treats every read as undecided in float32
     int32_t pre_q, pre_adjq;           // preCalc qScore / adj_qScore (vcfgl.cpp:1697-1702)

@@ -73,6 +73,15 @@ __global__ __launch_bounds__(256) void k_site(const VglDevParams P, const VglTil
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ float f32_missing() { return __uint_as_float(F32_MISSING_BITS); }
 __device__ __forceinline__ int nib(uint32_t v, int k) { return (int)((v >> (4 * k)) & 0xF); }
+// PL of one likelihood (vcfgl.cpp:907-939)
+__device__ __forceinline__ uint32_t pl_of(const float v, const bool valid) {
+    int32_t x;
+    if (!valid) x = I32_MISSING;
+    else if (v == -INFINITY) x = MAXPL;
+    // lroundf(-10.0 * gl): the double product of a float and -10 is exact, so its conversion to float is the float product
+    else { x = (int32_t)lroundf(v * -10.0f); if (x > MAXPL) x = MAXPL; }
+    return (uint32_t)x;
+}
 __device__ __forceinline__ int cnt_of(uint64_t ad4, int b) { return b < 4 ? (int)((ad4 >> (16 * b)) & 0xFFFF) : 0; }
 
 // Evaluations differ in depth, and the likelihood loop runs once per read: a wavefront is busy for
@@ -91,13 +100,15 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
     __shared__ uint32_t s_hist[1026];
     __shared__ uint16_t s_perm[256];
     constexpr int NG = A * (A + 1) / 2;
+    __shared__ uint32_t s_x[NG * 256];                                  // gl_sort 2: one tag's planes of the workgroup, in natural order
     const int N = P.n_samples;
     const int tid = threadIdx.x;
     const int64_t nwaves = (int64_t)T.n_sites * P.chunks;
+    const uint32_t bx = P.xcd_map ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x;     // logical workgroup (XCD-contiguous)
     // ---- depth of the evaluation this thread would own in natural order
     int dp0 = -1;                                                      // -1: no evaluation (padding lane)
     {
-        const int64_t w = (int64_t)blockIdx.x * 4 + (tid >> 6);
+        const int64_t w = (int64_t)bx * 4 + (tid >> 6);
         if (w < nwaves) {
             const int ls0 = (int)(w / P.chunks);
             const int s0 = (int)(w - (int64_t)ls0 * P.chunks) * 64 + (tid & 63);
@@ -131,15 +142,20 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
         __syncthreads();
         s_perm[atomicAdd(&s_hist[key], 1u)] = (uint16_t)tid;
         __syncthreads();
-        otid = s_perm[tid];                                            // thread id whose evaluation this lane processes
+        // thread id whose evaluation this lane processes.  Which wavefront of the workgroup takes the deepest 64 evaluations
+        // rotates with the workgroup index: wavefront k of every workgroup tends to land on the same SIMD of its CU, and
+        // the deep groups must not all queue on one of them
+        otid = s_perm[(tid + 64 * (int)(bx & 3)) & 255];
     }
     const int lane = tid & 63;
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t w = (int64_t)blockIdx.x * 4 + (otid >> 6);
-    if (w >= nwaves) return;
-    const int ls = (int)(w / P.chunks);
-    const int s = (int)(w - (int64_t)ls * P.chunks) * 64 + (otid & 63);
-    if (s >= N) return;
+    const int64_t w = (int64_t)bx * 4 + (otid >> 6);
+    const bool xpose = (P.gl_sort == 2);                               // sorted lanes, natural-order stores through LDS
+    int ls = 0, s = N;
+    if (w < nwaves) { ls = (int)(w / P.chunks); s = (int)(w - (int64_t)ls * P.chunks) * 64 + (otid & 63); }
+    const bool live = s < N;
+    if (!xpose && !live) return;                                       // with gl_sort 2 every thread reaches the barriers below
+    if (!live) { ls = 0; s = 0; }                                      // padding lane: reads stay in range, nothing is stored
     const size_t ev = (size_t)ls * N + s;
     const size_t plane = (size_t)T.n_sites * N;
     const VglSiteInfo si = T.sinfo[ls];
@@ -149,7 +165,7 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
     const float MISS = f32_missing();
 
     const uint64_t ad4 = T.ad4[ev];
-    const int dp = have ? (int)((ad4 & 0xFFFF) + ((ad4 >> 16) & 0xFFFF) + ((ad4 >> 32) & 0xFFFF) + ((ad4 >> 48) & 0xFFFF)) : 0;
+    const int dp = (have && live) ? (int)((ad4 & 0xFFFF) + ((ad4 >> 16) & 0xFFFF) + ((ad4 >> 32) & 0xFFFF) + ((ad4 >> 48) & 0xFFFF)) : 0;
 
     float acc[NG];
 #pragma unroll
@@ -260,22 +276,35 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
         }
     }
 
-    // ---- GL / PL / GP planes (vcfgl.cpp:907-970; no-reads site :297-305)
+    // ---- GL / PL / GP planes (vcfgl.cpp:907-970; no-reads site :297-305), FORMAT/AD, ADF, ADR (vcfgl.cpp:806-843).
+    // put(): element i of this lane's evaluation -> plane i of a tag.  With gl_sort 2 the lanes have worked in depth order,
+    // but a plane's 256-evaluation window of the workgroup is written in natural order: the values pass through LDS
+    // (s_x[plane][natural thread id]) so that every store of a wavefront is one contiguous segment.
     const bool sample_ok = have && dp > 0;
-#pragma unroll
-    for (int i = 0; i < NG; ++i) {
-        const bool valid = sample_ok && i < nG;
-        const float v = valid ? acc[i] : MISS;
-        const size_t o = ((size_t)ls * NG + i) * N + s;
-        if (T.gl) T.gl[o] = v;
-        if (T.pl) {
-            int32_t x;
-            if (!valid) x = I32_MISSING;
-            else if (v == -INFINITY) x = MAXPL;
-            else { x = (int32_t)lroundf((float)(-10.0 * (double)v)); if (x > MAXPL) x = MAXPL; }
-            T.pl[o] = x;
-        }
-    }
+    // this thread's own (natural-order) evaluation, for the stores of gl_sort 2
+    const int64_t w0 = (int64_t)bx * 4 + (tid >> 6);
+    const int ls0 = (int)(w0 / P.chunks);
+    const int s0 = (int)(w0 - (int64_t)ls0 * P.chunks) * 64 + (tid & 63);
+    const bool live0 = (w0 < nwaves) && (s0 < N);
+    // VGL_PUT(base, NP, expr of i): the loops are spelled out here (not in a lambda) so that acc[] stays in registers
+#define VGL_PUT(BASE, NP, EXPR)                                                                          \
+    do {                                                                                                 \
+        uint32_t* const base_ = (uint32_t*)(BASE);                                                       \
+        if (base_) {                                                                                     \
+            if (!xpose) {                                                                                \
+                _Pragma("unroll") for (int i = 0; i < (NP); ++i) base_[((size_t)ls * (NP) + i) * N + s] = (EXPR); \
+            } else {                                                                                     \
+                _Pragma("unroll") for (int i = 0; i < (NP); ++i) s_x[i * 256 + otid] = (EXPR);           \
+                __syncthreads();                                                                         \
+                if (live0) {                                                                             \
+                    _Pragma("unroll") for (int i = 0; i < (NP); ++i) base_[((size_t)ls0 * (NP) + i) * N + s0] = s_x[i * 256 + tid]; \
+                }                                                                                        \
+                __syncthreads();                                                                         \
+            }                                                                                            \
+        }                                                                                                \
+    } while (0)
+    VGL_PUT(T.gl, NG, __float_as_uint((sample_ok && i < nG) ? acc[i] : MISS));
+    VGL_PUT(T.pl, NG, pl_of(acc[i], sample_ok && i < nG));
     if (T.gp) {                                                          // GP = 10^GL normalised by its float32 sum in genotype order
         float sum_gps = 0.0f;
 #pragma unroll
@@ -284,25 +313,15 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
             acc[i] = valid ? (float)pow(10.0, (double)acc[i]) : 0.0f;
             if (valid) sum_gps += acc[i];
         }
-#pragma unroll
-        for (int i = 0; i < NG; ++i) {
-            const bool valid = sample_ok && i < nG;
-            T.gp[((size_t)ls * NG + i) * N + s] = valid ? acc[i] / sum_gps : MISS;
-        }
+        VGL_PUT(T.gp, NG, __float_as_uint((sample_ok && i < nG) ? acc[i] / sum_gps : MISS));
     }
-    // ---- FORMAT/AD, ADF, ADR in allele order (vcfgl.cpp:806-843)
     if (T.fmt_ad || T.fmt_adf || T.fmt_adr) {
         const uint64_t adf4 = P.need_adf ? T.adf4[ev] : ad4;
-#pragma unroll
-        for (int a = 0; a < A; ++a) {
-            const int b = (have && a < nA) ? nib(si.alleles2acgt, a) : 0xF;
-            const int v = cnt_of(ad4, b), vf = cnt_of(adf4, b);
-            const size_t o = ((size_t)ls * A + a) * N + s;
-            if (T.fmt_ad) T.fmt_ad[o] = v;
-            if (T.fmt_adf) T.fmt_adf[o] = vf;
-            if (T.fmt_adr) T.fmt_adr[o] = v - vf;
-        }
+        VGL_PUT(T.fmt_ad, A, (uint32_t)cnt_of(ad4, (have && i < nA) ? nib(si.alleles2acgt, i) : 0xF));
+        VGL_PUT(T.fmt_adf, A, (uint32_t)cnt_of(adf4, (have && i < nA) ? nib(si.alleles2acgt, i) : 0xF));
+        VGL_PUT(T.fmt_adr, A, (uint32_t)(cnt_of(ad4, (have && i < nA) ? nib(si.alleles2acgt, i) : 0xF) - cnt_of(adf4, (have && i < nA) ? nib(si.alleles2acgt, i) : 0xF)));
     }
+#undef VGL_PUT
 }
 
 // ------------------------------------------------------------------------------------

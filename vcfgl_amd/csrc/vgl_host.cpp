@@ -320,11 +320,14 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
         if (p->depths) { dmin = dmx = p->depths[0]; for (int i = 1; i < N; i++) { dmin = std::min(dmin, p->depths[i]); dmx = std::max(dmx, p->depths[i]); } }
         D.depth_pre = D.serial ? 0 : (dmin >= 12.0 ? 1 : (dmx < 12.0 ? 2 : 0));
     }
-    D.gl_sort = getenv("VGL_GL_SORT") ? atoi(getenv("VGL_GL_SORT")) : (dmax >= 8.0 ? 1 : 0);
+    // k_gl lane order: 0 natural, 1 depth-sorted lanes storing their own evaluations (4-byte pieces), 2 depth-sorted lanes and
+    // natural-order stores through LDS -- the last is at least as fast as the others from depth 5 (config C5) to depth 30
+    D.gl_sort = getenv("VGL_GL_SORT") ? atoi(getenv("VGL_GL_SORT")) : (dmax >= 1.0 ? 2 : 0);
     D.slow_period = getenv("VGL_SLOW_PERIOD") ? atoi(getenv("VGL_SLOW_PERIOD")) : 4;
     if (D.slow_period < 1) D.slow_period = 1;
     D.slow_period_n = getenv("VGL_SLOW_PERIOD_N") ? atoi(getenv("VGL_SLOW_PERIOD_N")) : 4;
     if (D.slow_period_n < 1) D.slow_period_n = 1;
+    D.xcd_map = getenv("VGL_XCD_MAP") ? atoi(getenv("VGL_XCD_MAP")) : 1;
     D.dbg_phase = getenv("VGL_DEBUG_PHASE") ? atoi(getenv("VGL_DEBUG_PHASE")) : 0;
     D.dbg_qs_exact = getenv("VGL_DEBUG_QS_EXACT") ? atoi(getenv("VGL_DEBUG_QS_EXACT")) : 0;
     for (int i = 0; i < p->n_qs_bins * 3; i++) D.qs_bins[i] = p->qs_bins[i];
