@@ -468,7 +468,9 @@ __global__ void k_dbg_vlog(const float* in, float* out, int n, int mode) {
     if (i >= n) return;
     if (mode == 0) out[i] = __builtin_amdgcn_logf(in[i]);          // v_log_f32
     else if (mode == 1) out[i] = tanf(in[i]);                      // ocml tanf
-    else out[i] = __builtin_amdgcn_exp2f(in[i]);                   // v_exp_f32
+    else if (mode == 2) out[i] = __builtin_amdgcn_exp2f(in[i]);    // v_exp_f32
+    else if (mode == 3) out[i] = __builtin_amdgcn_sinf(in[i]);     // v_sin_f32: sin(2 pi x)
+    else out[i] = __builtin_amdgcn_cosf(in[i]);                    // v_cos_f32: cos(2 pi x)
 }
 extern "C" int vgl_dbg_vlog(const float* d_in, float* d_out, int n, int mode) {
     hipLaunchKernelGGL(k_dbg_vlog, dim3((n + 255) / 256), dim3(256), 0, 0, d_in, d_out, n, mode);
