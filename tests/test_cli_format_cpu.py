@@ -66,3 +66,17 @@ def test_depth_inf_matches_reference_golden(tmp_path):
     ours = [l for l in open(out + ".truth.vcf") if not l.startswith("##")]
     gold = [l for l in open(os.path.join(gu.REFVCF, "reference", "test4", "test4.truth.vcf")) if not l.startswith("##")]
     assert ours == gold
+
+
+@pytest.mark.skipif(not os.path.exists(BIN), reason="vcfgl_hip not built")
+def test_flag_matching_follows_the_reference():
+    """io.cpp:538-752: the long simulation flags are compared with strcasecmp, the short / common ones with strcmp; -v / --version
+    and -vv print and exit 0 (no GPU needed for any of this)"""
+    data = os.path.join(gu.REFVCF, "data", "data2.vcf")
+    r = subprocess.run([BIN, "-i", data, "-d", "2", "-e", "0.1", "--GL-Model", "1", "--PRECISE-GL", "1"], capture_output=True, text=True)
+    assert r.returncode == 1 and "not supported with genotype likelihood model 1" in r.stderr
+    r = subprocess.run([BIN, "-I", data, "-d", "2", "-e", "0.1"], capture_output=True, text=True)        # -i is case-sensitive
+    assert r.returncode == 1 and "Unknown argument" in r.stderr
+    for flag in ("-v", "--version", "-vv"):
+        r = subprocess.run([BIN, flag], capture_output=True, text=True)
+        assert r.returncode == 0 and "ABI" in r.stderr

@@ -66,9 +66,19 @@ static Args parse_args(int argc, char** argv) {
     for (int i = 1; i < argc; i++) { a.command += " "; a.command += argv[i]; }
     auto I = [&](const char* v) { return atoi(v); };
     auto D = [&](const char* v) { return atof(v); };
+    // io.cpp:538-752 compares the long simulation flags with strcasecmp (--error-qs, -addGL, -printPileup, -GL, -bv, -eq ...) and the
+    // short / common ones (-s, -i, -o, -O, -d, -e, -V, -@ and their long forms) with strcmp: the former are matched in any case here too
+    static const char* const nocase[] = {"--adjust-by", "--adjust-qs", "--beta-variance", "--error-qs", "--gl-model", "--gl1-theta", "--gvcf-dps",
+        "--i16-mapq", "--precise-gl", "--qs-bins", "--rm-empty-sites", "--rm-invar-sites", "-GL", "-addFormatAD", "-addFormatADF", "-addFormatADR",
+        "-addFormatDP", "-addFormatGL", "-addFormatGP", "-addFormatI16", "-addFormatPL", "-addFormatQS", "-addGL", "-addGP", "-addI16", "-addInfoAD",
+        "-addInfoADF", "-addInfoADR", "-addInfoDP", "-addPL", "-addQS", "-bv", "-doGVCF", "-doUnobserved", "-eq", "-explode", "-printBasePickError",
+        "-printGlError", "-printPileup", "-printQScores", "-printQsError", "-printTruth"};
     for (int i = 1; i < argc; i += 2) {
-        const std::string f = argv[i];
+        std::string f = argv[i];
+        for (const char* c : nocase) if (strcasecmp(c, f.c_str()) == 0) { f = c; break; }
         if (f == "-h" || f == "--help") { printf("vcfgl_hip: vcfgl flag surface over libvcfgl_hip.so; see README of vcfgl for the flags.\n"); exit(0); }
+        if (f == "--version" || f == "-v") { fprintf(stderr, "vcfgl_hip [libvcfgl_hip ABI %d] [gfx950] [flag surface of vcfgl v1.3.0]\n\n", vgl_abi_version()); exit(0); }
+        if (f == "-vv") { fprintf(stderr, "libvcfgl_hip ABI %d\n", vgl_abi_version()); exit(0); }
         if (i + 1 >= argc) die("Argument %s requires a value", argv[i]);
         const char* v = argv[i + 1];
         if (f == "--seed" || f == "-s") a.seed = I(v);
