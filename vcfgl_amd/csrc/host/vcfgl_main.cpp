@@ -60,6 +60,27 @@ struct Args {
     std::vector<int> gvcf_dps;
 };
 
+static const char USAGE[] =
+    "\nvcfgl_hip: genotype-likelihood simulation on an MI355X (vcfgl's flags; every flag takes one value)\n\n"
+    "Usage: vcfgl_hip -i <in.vcf|vcf.gz|bcf> -e <error rate> -d <depth>|inf | -df <depths file> [options]\n\n"
+    "  input / output   -i --input FILE    -o --output PREFIX [output]    -O --output-mode b|u|z|v [b]    --source 0|1 [0: binary alleles, 1: ACGT]\n"
+    "                   -@ --threads INT [1]    -V --verbose INT [0]    -s --seed INT [time]\n"
+    "  depth            -d --depth FLOAT|inf    -df --depths-file FILE (one mean depth per sample)\n"
+    "  errors           -e --error-rate FLOAT    -eq --error-qs 0|1|2 [0]    -bv --beta-variance FLOAT    --qs-bins FILE (lo,hi,value per line)\n"
+    "                   --adjust-qs 0..31 [0: bit 1 GL, 2 QS tag, 4 pileup, 8 -printQScores, 16 -printGlError]    --adjust-by FLOAT [0.499]\n"
+    "  likelihoods      -GL --gl-model 1|2 [2]    --gl1-theta FLOAT [0.83]    --precise-gl 0|1 [0]    --i16-mapq INT [20]\n"
+    "  sites            -explode 0|1 [0]    --rm-invar-sites 0..7 [0]    --rm-empty-sites 0|1 [0]    -doUnobserved 0..5 [1]\n"
+    "                   -doGVCF 0|1 [0]    --gvcf-dps INT,INT,... (with -doGVCF 1)\n"
+    "  tags             -addGL [1] -addGP [0] -addPL [0] -addI16 [0] -addQS [0] -addFormatDP [1] -addInfoDP [0]\n"
+    "                   -addFormatAD -addInfoAD -addFormatADF -addInfoADF -addFormatADR -addInfoADR [0]\n"
+    "  extra files      -printPileup 0|1 (<prefix>.pileup.gz)    -printTruth 0|1 (<prefix>.truth.*)\n"
+    "  lines on stdout  -printBasePickError -printQsError -printGlError -printQScores 0|1\n"
+    "  this program     --rng-mode 0|1 [0: counter-addressed windows of the rand48 sequence (fast, shards over GPUs);\n"
+    "                                   1: the reference program's own draw order (reproduces its output)]\n"
+    "                   --beta-sampler 0|1 [0: the rand48 sampler, 1: std::mt19937 (default with --rng-mode 1)]\n"
+    "                   --tile-sites INT [4096]    --device INT [0]    --encode-threads INT\n"
+    "                   -v --version    -vv    -h --help\n\n";
+
 static Args parse_args(int argc, char** argv) {
     Args a;
     a.command = "Command: vcfgl_hip";
@@ -76,7 +97,7 @@ static Args parse_args(int argc, char** argv) {
     for (int i = 1; i < argc; i += 2) {
         std::string f = argv[i];
         for (const char* c : nocase) if (strcasecmp(c, f.c_str()) == 0) { f = c; break; }
-        if (f == "-h" || f == "--help") { printf("vcfgl_hip: vcfgl flag surface over libvcfgl_hip.so; see README of vcfgl for the flags.\n"); exit(0); }
+        if (f == "-h" || f == "--help") { fputs(USAGE, stderr); exit(0); }
         if (f == "--version" || f == "-v") { fprintf(stderr, "vcfgl_hip [libvcfgl_hip ABI %d] [gfx950] [flag surface of vcfgl v1.3.0]\n\n", vgl_abi_version()); exit(0); }
         if (f == "-vv") { fprintf(stderr, "libvcfgl_hip ABI %d\n", vgl_abi_version()); exit(0); }
         if (i + 1 >= argc) die("Argument %s requires a value", argv[i]);
