@@ -44,7 +44,7 @@ struct VglDevParams {
     int32_t A, G;            // max alleles / genotypes of the tile layout
     int32_t read_cap;        // staged reads per (site,sample)
     int32_t pool_cap;        // quality-score work items per wavefront and LDS segment
-    int32_t pool_lds_bytes;  // LDS bytes per wavefront of k_sample<2>: 512 + 4 * (pool_cap + 2) + pool_cap (+ 2 * (pool_cap + 1), not --precise-gl)
+    int32_t pool_lds_bytes;  // LDS bytes per wavefront of k_sample<2>: 512 + 4 * (pool_cap + 2) + pool_cap
     // flags
     int32_t error_qs, gl_model, precise_gl, adjust_qs, n_qs_bins, do_unobserved;
     int32_t rm_invar_sites, rm_empty_sites, sample_strand, per_sample_depth;
@@ -75,7 +75,6 @@ struct VglDevParams {
     VglAffine site_pow[40];            // J^(block * N * 2^b)
     const VglAffine* samp_tab;         // [N] J^(block * s)
     const VglAffine* qs_read_tab;      // [read_cap] J^(qs_read_stride * r)
-    VglAffine qs_stride1;              // J^(qs_read_stride): from one read's quality-score stream to the next
     const VglAffine* step_tab;         // [192] J^k (serial-mode scout)
     const VglAffine* chunk_tab;        // [VGL_DEPTH_CHUNK] J^(block * i)  (k_depth)
     const VglAffine* eval_pow_tab;     // [64] J^(block * 2^b)             (k_depth)

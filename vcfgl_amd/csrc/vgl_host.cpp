@@ -297,13 +297,10 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
         }
         int pc = (int)ceil(lmax + 8.0 * sqrt(lmax) + 64.0);
         pc = (pc + 63) & ~63;
-        // 16 wavefronts (the 4 per SIMD the kernel is built for) share a CU's 160 KB LDS; larger pools run in several segments.
-        // An item takes 5 bytes with --precise-gl 1 ((read, owner) slot + base) and 7 without (start state of its stream + base)
-        const int pc_max = p->precise_gl ? 1920 : 1384;
-        if (pc > pc_max) pc = pc_max;
+        if (pc > 1920) pc = 1920;                      // 520 + 5 x 1920 B per wavefront: 16 wavefronts (the 4 per SIMD the kernel is
+                                                       // built for) fit a CU's 160 KB LDS; larger pools run in several segments
         D.pool_cap = pc;
-        D.pool_lds_bytes = 512 + 4 * (pc + 2) + pc + (p->precise_gl ? 0 : 2 * (pc + 1));    // stream bases | item slots (+ the zero slot) | bases | high words
-        D.pool_lds_bytes = (D.pool_lds_bytes + 7) & ~7;
+        D.pool_lds_bytes = 512 + 4 * (pc + 2) + pc;    // stream bases | item slots (+ the zero slot) | bases
     }
     D.error_qs = p->error_qs; D.gl_model = p->gl_model; D.precise_gl = p->precise_gl; D.adjust_qs = p->adjust_qs;
     D.n_qs_bins = p->n_qs_bins; D.do_unobserved = p->do_unobserved; D.rm_invar_sites = p->rm_invar_sites;
@@ -403,7 +400,6 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
         TRY(dmalloc(&c->d_qs_read_tab, (size_t)D.read_cap));
         TRYHIP(hipMemcpy(c->d_qs_read_tab, rt.data(), sizeof(VglAffine) * D.read_cap, hipMemcpyHostToDevice));
         D.qs_read_tab = c->d_qs_read_tab;
-        D.qs_stride1 = rt[1];
     }
     if (p->depths) {
         std::vector<VglPois> pv(N);

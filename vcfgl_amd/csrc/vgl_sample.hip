@@ -176,12 +176,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
         uint64_t* l_stq = (uint64_t*)wl;
         uint32_t* l_it = (uint32_t*)(wl + 512);
         uint8_t* l_pb = wl + 512 + 4 * ((size_t)cap + 2);
-        // Without the --precise-gl staging an item's slot holds the low 32 bits of the START STATE of its read's quality-score
-        // stream instead (the high 16 bits in l_hi), written by its owner, who walks from read to read with one uniform jump:
-        // the lane that is dealt the item then needs two LDS reads, where the (read, owner) form costs a table load and a 64-bit
-        // affine map per pool iteration.
-        uint16_t* l_hi = (uint16_t*)(l_pb + cap);               // [cap + 1] (!PREC)
-        uint64_t st_item = st_qs;                               // start state of the owner's next read (!PREC)
 
         // exclusive prefix sum of the depths = first pool index of each owner
         int incl = dp;
@@ -190,7 +184,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
         const int offs = incl - dp;
         const int total = __shfl(incl, 63, 64);
         l_stq[lane] = st_qs;
-        if (lane == 0) { l_it[cap] = 0u; if (!PREC) l_hi[cap] = 0; }
+        if (lane == 0) l_it[cap] = 0u;
         int rdone = 0;
         // Kernel arguments arrive in 16-dword scalar tuples that the register allocator spills and
         // reloads as a whole (v_readlane, VALU work) inside the loops below; the three values the flush
@@ -212,8 +206,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 ad4 += one;
                 if (fwd) adf4 += one;
                 const int k = offs + r - seg0;
-                if (PREC) l_it[k] = (uint32_t)((r << 6) | lane);
-                else { l_it[k] = (uint32_t)st_item; l_hi[k] = (uint16_t)(st_item >> 32); st_item = aff(P.qs_stride1, st_item); }
+                l_it[k] = (uint32_t)((r << 6) | lane);
                 l_pb[k] = (uint8_t)r_base;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -237,10 +230,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 bool have = k < segT;                        // == (k < segT) throughout: the loop tests that compare
                 bool stage1 = false;                         // false: first gamma deviate (x), true: second (y)
                 uint64_t st = 0; double gx = 0.0; int it_o = 0, it_r = 0;
-                if (have) {
-                    if (PREC) { const uint32_t m = l_it[k]; it_o = m & 63; it_r = m >> 6; st = aff(P.qs_read_tab[it_r], l_stq[it_o]); }
-                    else st = ((uint64_t)l_hi[k] << 32) | l_it[k];
-                }
+                if (have) { const uint32_t m = l_it[k]; it_o = m & 63; it_r = m >> 6; st = aff(P.qs_read_tab[it_r], l_stq[it_o]); }
                 const bool any_changed = (P.gx.changed | P.gy.changed) != 0;
                 // the two gamma samplers' constants, kept in vector registers for the per-iteration selects
                 double gxa1 = P.gx.a1, gxa2 = P.gx.a2, gya1 = P.gy.a1, gya2 = P.gy.a2;
@@ -258,14 +248,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     // operands of this lane's next item, fetched at the top of the iteration and consumed at
                     // the bottom (unconditional, clamped index: no divergent control flow in the loop)
                     const bool hn = kn < segT;
-                    const int kn_c = hn ? kn : cap;
-                    const uint32_t m_n = l_it[kn_c];
-                    int o_n = 0, r_n = 0;
-                    VglAffine tab_n; tab_n.a = 0; tab_n.c = 0;
-                    uint64_t base_n = 0;
-                    uint32_t hi_n = 0;
-                    if (PREC) { o_n = m_n & 63; r_n = m_n >> 6; tab_n = P.qs_read_tab[r_n]; base_n = l_stq[o_n]; }
-                    else hi_n = l_hi[kn_c];
+                    const uint32_t m_n = l_it[hn ? kn : cap];
+                    const int o_n = m_n & 63, r_n = m_n >> 6;
+                    const VglAffine tab_n = P.qs_read_tab[r_n];
+                    const uint64_t base_n = l_stq[o_n];
 
                     const double ga1 = stage1 ? gya1 : gxa1;
                     const double ga2 = stage1 ? gya2 : gxa2;
@@ -327,7 +313,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     // a lane that finished its item adopts kn and claims the next unclaimed item
                     const uint64_t fin_m = __ballot(fin);
                     const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fin_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fin_m, 0u));
-                    const uint64_t st_n = PREC ? aff(tab_n, base_n) : (((uint64_t)hi_n << 32) | m_n);
+                    const uint64_t st_n = aff(tab_n, base_n);
                     st = fin ? st_n : st;
                     it_o = fin ? o_n : it_o; it_r = fin ? r_n : it_r;
                     k = fin ? kn : k;
