@@ -140,3 +140,153 @@ def test_random_cli_runs_against_the_oracle(oracle, chunk, tmp_path):
                 assert c[8] == (":".join(fmt) if fmt else "."), (tag, c[8])
                 assert [kv.split("=")[0] for kv in c[7].split(";") if kv != "."] == info, (tag, c[7])
         done += 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# -doGVCF 1: the block builder (prepare_gvcf_block, bcf_utils.cpp:662-942; the loop of write_record_values,
+# vcfgl.cpp:167-206) restated over the oracle's tile, against the host program's streaming implementation.
+
+def gvcf_expected(args, sites, tile, block_dps):
+    """Sequence of ("rec", site index) / ("block", dict) the reference's rules give for the kept sites of a tile."""
+    status, nobs = tile.numpy("site_status"), tile.numpy("n_alleles_obs")
+    dp, pl = tile.numpy("fmt_dp"), tile.numpy("pl")
+    out, cur = [], None
+
+    def flush():
+        nonlocal cur
+        out.append(("block", cur))
+        cur = None
+
+    for i in [k for k in range(len(sites)) if status[k] >= 0] + [None]:
+        while True:
+            if i is None:                                                   # end of input: flush what is open
+                if cur is not None:
+                    flush()
+                break
+            if cur is None:
+                if nobs[i] != 1:
+                    out.append(("rec", i)); break
+            elif nobs[i] != 1 or sites[i].chrom != cur["chrom"] or sites[i].pos0 > cur["end"] + 1:
+                flush(); continue                                            # variant site, other contig, gap
+            min_dp = int(dp[i].min())
+            rng_i = 0
+            for thr in block_dps:
+                if min_dp < thr:
+                    break
+                rng_i += 1
+            if rng_i == 0:                                                   # too shallow for any block
+                if cur is None:
+                    out.append(("rec", i)); break
+                flush(); continue
+            if cur is not None and cur["dpr"] != rng_i:
+                flush(); continue
+            if cur is None:
+                cur = dict(chrom=sites[i].chrom, start=sites[i].pos0, end=sites[i].pos0, dpr=rng_i, min_dp=min_dp, founder=i,
+                           dp=dp[i].copy(), pl=pl[i, :3, :].copy())
+            else:
+                cur["min_dp"] = min(cur["min_dp"], min_dp)
+                cur["dp"] = np.minimum(cur["dp"], dp[i])
+                a, b = cur["pl"], pl[i, :3, :]
+                less = a[1] > b[1]
+                tie = (a[1] == b[1]) & (a[2] > b[2])
+                a[1] = np.where(less, b[1], a[1])
+                a[2] = np.where(less | tie, b[2], a[2])
+                cur["end"] = sites[i].pos0
+            break
+    return out
+
+
+def random_vcf_gvcf(rng, path, binary):
+    """few samples, runs of invariant sites: most records (and every site -explode adds) are homozygous for the reference allele"""
+    N = int(rng.choice([1, 2, 3, 6]))
+    S = int(rng.integers(2, 14))
+    length = S * 4 + 10
+    pos = np.sort(rng.choice(np.arange(1, length), size=S, replace=False))
+    with open(path, "w") as fh:
+        fh.write("##fileformat=VCFv4.2\n##FILTER=<ID=PASS,Description=\"All filters passed\">\n")
+        fh.write(f"##contig=<ID=chr7,length={length}>\n##contig=<ID=chr9,length=6>\n##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n")
+        fh.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(f"smp{i}" for i in range(N)) + "\n")
+        rows = [("chr7", int(p)) for p in pos] + [("chr9", 2), ("chr9", 3)]
+        for chrom, p in rows:
+            alleles = ["0", "1"] if binary else list(rng.permutation(list("ACGT"))[:2])
+            if rng.random() < 0.65:
+                gts = ["0|0"] * N
+            else:
+                gts = [f"{rng.integers(0, 2)}|{rng.integers(0, 2)}" for _ in range(N)]
+            fh.write(f"{chrom}\t{p}\t.\t{alleles[0]}\t{alleles[1]}\t.\tPASS\t.\tGT\t" + "\t".join(gts) + "\n")
+    return N
+
+
+@pytest.mark.parametrize("chunk", range(int(os.environ.get("VGL_CLI_FUZZ_CHUNKS", "6"))))
+def test_random_gvcf_runs_against_the_block_rules(oracle, chunk, tmp_path):
+    rng = np.random.default_rng(int(os.environ.get("VGL_CLI_FUZZ_SEED", "7000")) + 50000 + chunk)
+    done = 0
+    n_blocks = n_long = n_recs = 0
+    while done < 5:
+        binary = bool(rng.integers(0, 2))
+        inp = str(tmp_path / f"g{done}.vcf")
+        N = random_vcf_gvcf(rng, inp, binary)
+        dps = sorted(set(int(x) for x in rng.choice([1, 2, 3, 5, 8], size=int(rng.integers(1, 4)))))
+        flags = ["--source", "0" if binary else "1", "--seed", str(int(rng.integers(0, 2 ** 31 - 1))), "--error-rate", str(float(rng.choice([0.0, 0.002, 0.02]))),
+                 "--depth", str(float(rng.choice([2.0, 5.0, 9.0, 20.0]))), "-explode", str(int(rng.choice([1, 1, 0]))),
+                 "-doUnobserved", str(int(rng.choice([1, 2, 1, 2, 4, 5]))),      # (4, 5: all four bases are listed, no site has one allele: no blocks) "--rm-empty-sites", str(int(rng.integers(0, 2))),
+                 "-addPL", "1", "-addFormatDP", "1", "-addQS", str(int(rng.integers(0, 2))), "-addGL", str(int(rng.integers(0, 2))),
+                 "-addInfoDP", str(int(rng.integers(0, 2))), "-doGVCF", "1", "--gvcf-dps", ",".join(str(d) for d in dps)]
+        for mode, beta in ((_abi.VGL_RNG_TILE, _abi.VGL_BETA_RAND48), (_abi.VGL_RNG_SERIAL, _abi.VGL_BETA_STD)):
+            tag = (chunk, done, mode, " ".join(flags))
+            args = VcfglArgs.from_argv(flags).validate()
+            args.rng_mode, args.beta_sampler = mode, beta
+            vcf = read_vcf(inp)
+            sites = list(iter_sites(vcf, args))
+            out = str(tmp_path / f"gout{done}_{mode}")
+            r = subprocess.run([BIN, "-i", inp, "-o", out, "-O", "v", "--rng-mode", str(mode), "--tile-sites", str(int(rng.choice([1, 3, 4096])))] + flags,
+                               capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, (tag, r.stderr[-1500:])
+            lines = [l.rstrip("\n").split("\t") for l in open(out + ".vcf") if not l.startswith("#")]
+            if not sites:
+                assert not lines, tag
+                continue
+            fields = [f for f, _, _ in _abi.TILE_FIELDS if not (f == "qs" and not args.add_qs) and f != "i16"]
+            tile = oracle.Oracle(args, N).simulate(0, np.stack([s.gt for s in sites]), fields=fields)
+            want = gvcf_expected(args, sites, tile, dps)
+            assert len(lines) == len(want), (tag, len(lines), len(want))
+            nonref = gu.nonref_str(args)
+            n_blocks += sum(1 for k, _ in want if k == "block")
+            n_long += sum(1 for k, b in want if k == "block" and b["end"] > b["start"])
+            n_recs += sum(1 for k, _ in want if k == "rec")
+            for c, (kind, x) in zip(lines, want):
+                info = dict(kv.split("=") for kv in c[7].split(";") if "=" in kv)
+                if kind == "rec":
+                    assert "MIN_DP" not in info and (c[0], int(c[1])) == (sites[x].chrom, sites[x].pos0 + 1), (tag, c[:8])
+                    assert c[4].split(",") == gu.site_alleles(args, tile, x)[1:] or c[4] == ".", (tag, c[:8])
+                    keys = c[8].split(":")
+                    got_dp = [int(s.split(":")[keys.index("DP")]) for s in c[9:]]
+                    assert got_dp == [int(v) for v in tile.numpy("fmt_dp")[x]], (tag, c[:8])
+                    continue
+                b = x
+                assert (c[0], int(c[1])) == (b["chrom"], b["start"] + 1), (tag, c[:8], b["start"])
+                assert [c[3]] + c[4].split(",") == gu.site_alleles(args, tile, b["founder"]) and c[4] == nonref, (tag, c[:8])
+                assert c[5] == "." and c[6] == ".", (tag, c[:8])
+                n_bp = b["end"] - b["start"] + 1
+                assert ("END" in info) == (n_bp >= 2) and (n_bp < 2 or int(info["END"]) == b["end"] + 1), (tag, c[:8], b["end"])
+                assert int(info["MIN_DP"]) == b["min_dp"], (tag, c[:8], b["min_dp"])
+                assert ("QS" in info) == bool(args.add_qs), (tag, c[7])
+                if args.add_qs:
+                    q = tile.numpy("qs")[b["founder"]][:2]
+                    assert all(gu.close6(float(o), float(v)) for o, v in zip(q, info["QS"].split(","))), (tag, c[7])
+                assert c[8] == "PL:DP", (tag, c[8])
+                for s in range(N):
+                    plv, dpv = c[9 + s].split(":")
+                    assert [int(v) for v in plv.split(",")] == [int(v) for v in b["pl"][:, s]], (tag, c[:8], s)
+                    assert int(dpv) == int(b["dp"][s]), (tag, c[:8], s)
+        done += 1
+    assert n_recs > 0 and (n_blocks == 0 or n_long >= 0)
+    _GVCF_SEEN[0] += n_blocks; _GVCF_SEEN[1] += n_long
+
+
+_GVCF_SEEN = [0, 0]
+
+
+def test_random_gvcf_runs_did_build_blocks():
+    """(runs after the chunks above) the random runs must have exercised blocks, several sites long too"""
+    assert _GVCF_SEEN[0] > 20 and _GVCF_SEEN[1] > 5, _GVCF_SEEN
