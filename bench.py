@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--sites", type=int, default=None)
     ap.add_argument("--samples", type=int, default=None)
-    ap.add_argument("--tile-sites", type=int, default=16384)
+    ap.add_argument("--tile-sites", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)     # internal: one shard of the all-cores CPU leg
     opt = ap.parse_args()

@@ -17,9 +17,9 @@ python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
 tail -1 "$out/bench.json" | cut -c1-400
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$out/kt.log" 2>&1
 for g in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $g --output-format csv -d "$out/pmc/$g" -- python3 bench.py --sites 32768 --steps 1 --warmup 0 --no-cpu-baseline > "$out/pmc_$g.log" 2>&1
+    rocprofv3 --pmc $g --output-format csv -d "$out/pmc/$g" -- python3 bench.py --sites 131072 --steps 1 --warmup 0 --no-cpu-baseline > "$out/pmc_$g.log" 2>&1
 done
-rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d "$out/pmc/GRBM" -- python3 bench.py --sites 32768 --steps 1 --warmup 0 --no-cpu-baseline > "$out/pmc_GRBM.log" 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d "$out/pmc/SQ" -- python3 bench.py --sites 32768 --steps 1 --warmup 0 --no-cpu-baseline > "$out/pmc_SQ.log" 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d "$out/pmc/GRBM" -- python3 bench.py --sites 131072 --steps 1 --warmup 0 --no-cpu-baseline > "$out/pmc_GRBM.log" 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d "$out/pmc/SQ" -- python3 bench.py --sites 131072 --steps 1 --warmup 0 --no-cpu-baseline > "$out/pmc_SQ.log" 2>&1
 find "$out" -name "*kernel_trace.csv" -delete      # large; the stats summary is what is kept
 ls "$out" "$out"/kt/* | head -20
