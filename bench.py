@@ -24,7 +24,7 @@ import torch  # noqa: E402
 
 import synth  # noqa: E402
 from vcfgl_amd import Simulator, VcfglArgs, _abi  # noqa: E402
-from vcfgl_amd.shard import gather_site_index  # noqa: E402
+from vcfgl_amd.shard import gather_site_index, reduce_site_counters  # noqa: E402
 
 try:
     METRIC = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]     # the reference's headline metric, verbatim
@@ -180,6 +180,7 @@ def main():
         if dist is not None:                                  # record-index gather to the writer rank
             stream.synchronize()
             gather_site_index(out["site_status"], out["n_alleles"], world, rank, S * world, always_collective=True)
+            reduce_site_counters(out["site_status"], world, always_collective=True)             # the run summary's totals
 
     def barrier():
         stream.synchronize()

@@ -22,7 +22,7 @@ def _worker(rank, world, port, n_sites, N, q):
     import oracle_lib
     import synth
     from vcfgl_amd import VcfglArgs, _abi
-    from vcfgl_amd.shard import gather_site_index, site_range
+    from vcfgl_amd.shard import gather_site_index, reduce_site_counters, site_range
     args = VcfglArgs(seed=42, depth=3, error_rate=0.05, rm_invar_sites=4, rm_empty_sites=1)
     args.rng_mode = _abi.VGL_RNG_TILE
     b, e = site_range(rank, world, n_sites)
@@ -31,8 +31,9 @@ def _worker(rank, world, port, n_sites, N, q):
                             world, rank, n_sites)
     dpsum = torch.tensor([int(t.numpy("fmt_dp").sum())])
     dist.all_reduce(dpsum)
+    cnt = reduce_site_counters(torch.from_numpy(t.numpy("site_status")), world)
     if rank == 0:
-        q.put((idx.numpy(), int(dpsum.item())))
+        q.put((idx.numpy(), int(dpsum.item()), cnt.tolist()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -59,7 +60,7 @@ def test_two_rank_shard_equals_single_process(oracle):
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_sites, N, q)) for r in range(world)]
     for p in procs:
         p.start()
-    idx, dpsum = q.get(timeout=240)
+    idx, dpsum, cnt = q.get(timeout=240)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -69,4 +70,6 @@ def test_two_rank_shard_equals_single_process(oracle):
     assert np.array_equal(idx[:, 0], whole.numpy("site_status"))
     assert np.array_equal(idx[:, 1], whole.numpy("n_alleles"))
     assert dpsum == int(whole.numpy("fmt_dp").sum())
+    st = whole.numpy("site_status")
+    assert cnt == [n_sites, int((st >= 0).sum()), int((st < 0).sum())]
     assert (idx[:, 0] < 0).any() and (idx[:, 0] == 0).any()      # both skipped and kept sites occur

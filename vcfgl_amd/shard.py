@@ -14,6 +14,16 @@ def site_range(rank: int, world: int, n_sites: int) -> Tuple[int, int]:
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+def reduce_site_counters(status: torch.Tensor, world: int, always_collective: bool = False) -> torch.Tensor:
+    """[sites simulated, sites written, sites skipped] summed over the ranks: the run summary the reference prints at the
+    end (vcfgl.cpp:1633) -- one small all-reduce, every rank gets the totals."""
+    import torch.distributed as dist
+    c = torch.stack([torch.tensor(status.numel(), device=status.device), (status >= 0).sum(), (status < 0).sum()]).to(torch.int64)
+    if world > 1 or always_collective:
+        dist.all_reduce(c)
+    return c
+
+
 def gather_site_index(status: torch.Tensor, n_alleles: torch.Tensor, world: int, rank: int,
                       n_sites_total: int, dst: int = 0, always_collective: bool = False) -> Optional[torch.Tensor]:
     """Gather [status, n_alleles] rows of every rank's sites to `dst` in site order.
