@@ -177,6 +177,10 @@ typedef struct vgl_ctx vgl_ctx;
 int32_t vgl_max_alleles(const vgl_params* p);      /* 4 or 5:  shared.h:148-152              */
 int32_t vgl_max_genotypes(const vgl_params* p);    /* 10 or 15: lut_nAlleles_to_nGenotypes    */
 int     vgl_default_rng_layout(const vgl_params* p, vgl_rng_layout* out);
+/* VGL_RNG_TILE addresses one rand48 sequence of period 2^48: a job may use sites [0, *max_sites) before its windows
+ * would repeat (BASELINE config C4, 1e7 sites x 2000 samples at depth 30, uses 48 % of it).  vgl_simulate_tile* return
+ * VGL_E_ARG beyond that.  The reference's serial streams have no such limit (rng.h:8-10) -- VGL_RNG_SERIAL neither. */
+int     vgl_rng_tile_max_sites(const vgl_params* p, int64_t* max_sites);
 int     vgl_abi_version(void);
 const char* vgl_last_error(void);
 

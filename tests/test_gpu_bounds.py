@@ -1,0 +1,88 @@
+"""The error bounds behind every float32 decision of the HIP kernels, asserted on the device.
+
+The kernels decide the reference's double-precision comparisons (rejection tests, floor of a scaled tan,
+(int)(-10 log10 p)) from float32 hardware transcendentals and fall back to the exact double expression inside an
+explicit error band (vgl_common.hip.h).  Every result is exact only if those bands really contain the error of
+v_log_f32 / v_exp_f32 / v_rcp_f32 / ocml tanf on this toolchain and part.  vgl_bounds.hip sweeps EVERY float32 argument
+of each function's range of use through the same inline helpers the kernels call and counts the arguments whose
+error exceeds the bound the kernels use (less the share reserved for rounding the double argument to float).
+Zero violations are required; the worst ratio error / bound is printed so that the margin is on record."""
+import ctypes as C
+import struct
+
+import pytest
+
+from vcfgl_amd import _abi
+
+pytestmark = pytest.mark.gpu
+
+FAST_LN, GAMMA_LU, GAMMA_SERIES, GAMMA_REFEXPR, QS_TF, RCP, TANF, EXP2, DIV = range(9)
+
+
+def f2b(x):
+    return struct.unpack("<I", struct.pack("<f", x))[0]
+
+
+def sweep(mode, lo_bits, hi_bits, param=0.0, count=None):
+    lib = _abi.load_library()
+    lib.vgl_dbg_bound_sweep.argtypes = [C.c_int, C.c_uint32, C.c_ulonglong, C.c_double, C.POINTER(C.c_double)]
+    out = (C.c_double * 4)()
+    n = count if count is not None else hi_bits - lo_bits + 1
+    assert lib.vgl_dbg_bound_sweep(mode, lo_bits, n, param, out) == 0
+    return {"n": int(out[0]), "violations": int(out[1]), "max_ratio": out[2], "arg_bits": int(out[3])}
+
+
+def check(name, r, n_min):
+    print(f"{name}: {r['n']} arguments, worst error/bound {r['max_ratio']:.4f} at bits 0x{r['arg_bits']:08x}, violations {r['violations']}")
+    assert r["n"] >= n_min, (name, r)
+    assert r["violations"] == 0, (name, r)
+    assert r["max_ratio"] <= 1.0, (name, r)
+
+
+def test_fast_ln_bound_every_float_in_unit_interval():
+    """normal_slow_test: |fast_ln(uf) - ln(u)| <= |l| 2^-21 + 2^-22 for every float in [2^-49, 1] (u = X 2^-48 >= 2^-48)"""
+    check("fast_ln", sweep(FAST_LN, f2b(2.0 ** -49), f2b(1.0)), 4e8)
+
+
+def test_gamma_test_log_bound_every_float_in_unit_interval():
+    """gamma_slow_test: |lu - ln(u)| <= |lu| 2^-20 + 2^-21"""
+    check("gamma_test_lu", sweep(GAMMA_LU, f2b(2.0 ** -49), f2b(1.0)), 4e8)
+
+
+@pytest.mark.parametrize("a1", [0.7, 1.2266666, 9.5676, 979.3, 31000.0])
+def test_gamma_series_bound_every_float_s(a1):
+    """gamma_slow_test: the float32 series 3 a1 s^4 P(s) against the analytic series and against the reference's own double
+    expression -(0.5 x^2 + a1 (1 - v + log v)) for every float |s| <= 0.3333, within 4e-6 g (+ 1e-10 for the reference's
+    cancellation); a1 spans --error-qs shapes from alpha' in (1, 2) to beta ~ 3e4"""
+    hi = f2b(0.3333)
+    for mode, name in ((GAMMA_SERIES, "series"), (GAMMA_REFEXPR, "refexpr")):
+        check(f"gamma {name} a1={a1} s>0", sweep(mode, 1, hi, a1), 1e9)
+        check(f"gamma {name} a1={a1} s<0", sweep(mode, 0x80000001, 0x80000000 | hi, a1), 1e9)
+
+
+def test_qs_tf_bound_every_float_probability():
+    """qs_decide_pf: |tf - (-10 log10 p)| <= tf 2^-19 + 4e-6 for every float pf in (1e-37, 1)"""
+    check("qs_tf", sweep(QS_TF, f2b(1.0e-37) + 1, f2b(1.0) - 1), 9e8)
+
+
+def test_v_rcp_f32_one_ulp_every_normal_float():
+    """qs_stage_pf: v_rcp_f32 within 1 ulp wherever 1/x is a normal float"""
+    check("v_rcp_f32", sweep(RCP, f2b(2.0 ** -126), f2b(2.0 ** 126)), 2e9)
+
+
+def test_tanf_bound_every_float_up_to_pi():
+    """poisson_attempt: |tanf(af) - tan(af)| <= |y| 2^-21 + (1 + y^2) af 2^-24 on (2^-50, (float)3.141592654]"""
+    check("tanf", sweep(TANF, f2b(2.0 ** -50), f2b(3.141592654)), 4e8)
+
+
+def test_v_exp_f32_bound():
+    """poisson_attempt: v_exp_f32 relative error <= 2^-19 - 2^-22 on [-126, 8]"""
+    check("v_exp_f32 x>0", sweep(EXP2, 0, f2b(8.0)), 1e9)
+    check("v_exp_f32 x<0", sweep(EXP2, 0x80000000, f2b(-126.0)), 1e9)
+
+
+def test_div_inrange_equals_ieee_division():
+    """k_sample<2>: the division sequence without v_div_scale / v_div_fixup gives the IEEE quotient of v / u for the
+    operands of the ratio-of-uniforms normal sampler (u = X 2^-48 incl. the smallest, v = 1.7156 (u' - 0.5))"""
+    r = sweep(DIV, 0, 0, count=4_000_000_000)
+    check("div_inrange", r, 4e9)

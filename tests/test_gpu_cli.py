@@ -217,3 +217,31 @@ def test_cli_documented_msprime_run(tmp_path):
     ours = [l.rstrip("\n") for l in open(out + ".vcf") if not l.startswith("##")]
     gold = [l.rstrip("\n") for l in open(os.path.join(d, "sim_source0.vcf")) if not l.startswith("##")]
     assert ours == gold
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_baseline_config_c1_cli_equals_oracle(oracle, mode, tmp_path):
+    """BASELINE.json configs[0]: `test/data/data2.vcf --depth 4 --error-rate 0.01 -GL 1 --seed 42` -- the reference's own
+    CPU-runnable case.  No golden file of the reference holds this run, so the host program's VCF text is compared with
+    the oracle driven through the Python mirror of the record loop, in both RNG modes (in serial mode the oracle replays
+    the reference's stream order, which the 14 golden VCFs pin)."""
+    import numpy as np
+    from vcfgl_amd import VcfglArgs, _abi
+    from vcfgl_amd.recordloop import iter_sites
+    from vcfgl_amd.vcfio import read_vcf
+    inp = os.path.join(gu.REFVCF, "data", "data2.vcf")
+    flags = ["--depth", "4", "--error-rate", "0.01", "-GL", "1", "--seed", "42"]
+    args = VcfglArgs.from_argv(flags).validate()
+    args.rng_mode, args.beta_sampler = mode, (_abi.VGL_BETA_STD if mode == 1 else _abi.VGL_BETA_RAND48)
+    out = str(tmp_path / f"c1_{mode}")
+    r = subprocess.run([BIN, "-i", inp, "-o", out, "-O", "v", "--rng-mode", str(mode)] + flags, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    vcf = read_vcf(inp)
+    sites = list(iter_sites(vcf, args))
+    tile = oracle.Oracle(args, len(vcf.samples)).simulate(0, np.stack([s.gt for s in sites]),
+                                                          fields=[f for f, _, _ in _abi.TILE_FIELDS if f not in ("qs", "i16")])
+    got = read_vcf(out + ".vcf")
+    assert len(got.records) == int((tile.numpy("site_status") >= 0).sum()) > 0
+    errs = gu.compare_with_golden(args, sites, tile, got)
+    assert not errs, errs[:10]
+    assert int(tile.numpy("fmt_dp").max()) >= 4            # depth-4 reads really reach GL model 1 (n up to ~10)

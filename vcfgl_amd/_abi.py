@@ -68,7 +68,7 @@ TILE_FIELDS = [
 EXPORTS = [
     "vgl_max_alleles", "vgl_max_genotypes", "vgl_default_rng_layout", "vgl_abi_version",
     "vgl_last_error", "vgl_ctx_create", "vgl_ctx_destroy", "vgl_simulate_tile",
-    "vgl_simulate_tile_device", "vgl_ctx_check", "vgl_ctx_timing", "vgl_ctx_kernel_ms",
+    "vgl_simulate_tile_device", "vgl_ctx_check", "vgl_ctx_timing", "vgl_ctx_kernel_ms", "vgl_rng_tile_max_sites",
 ]
 
 _LIB = None
@@ -100,6 +100,7 @@ def load_library():
     lib.vgl_max_genotypes.argtypes = [C.POINTER(Params)]
     lib.vgl_default_rng_layout.argtypes = [C.POINTER(Params), C.POINTER(RngLayout)]
     lib.vgl_last_error.restype = C.c_char_p
+    lib.vgl_rng_tile_max_sites.argtypes = [C.POINTER(Params), C.POINTER(C.c_int64)]
     lib.vgl_ctx_create.argtypes = [C.POINTER(Params), C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
     lib.vgl_ctx_destroy.argtypes = [C.c_void_p]
     lib.vgl_simulate_tile.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.POINTER(TileOut)]

@@ -1,0 +1,162 @@
+// vgl_bounds.hip -- the error bounds that the float32 decision paths of vgl_common.hip.h assume, measured on the
+// device over EVERY float32 argument of the range each one is used on (a sweep of 10^9 bit patterns takes a fraction of
+// a second here).  Diagnostic entry point, not part of the public C ABI: tests/test_gpu_bounds.py asserts
+// `violations == 0` for every mode, so an ocml / compiler / hardware change that moves a bound fails the -m gpu suite
+// instead of silently changing an integer somewhere in 10^9 evaluations.
+//
+// Every mode evaluates the SAME inline helper the kernels use (fast_ln, gamma_test_lu, gamma_rhs_series, qs_tf,
+// tanf_err_bound, div_inrange ...) against a float64 evaluation of the exact quantity, and compares the difference with
+// the SAME bound expression the kernels use, minus the part of that bound which is reserved for the rounding of the
+// argument from double to float (stated per mode).
+#include "vgl_common.hip.h"
+
+enum {
+    VGL_BOUND_FAST_LN = 0,      // fast_ln / fast_ln_err on (0, 1]                      (normal_slow_test)
+    VGL_BOUND_GAMMA_LU = 1,     // gamma_test_lu / log part of gamma_test_margin on (0, 1]  (gamma_slow_test)
+    VGL_BOUND_GAMMA_SERIES = 2, // gamma_rhs_series against the analytic series, |s| <= 0.3333   (param = a1)
+    VGL_BOUND_GAMMA_REFEXPR = 3,// gamma_rhs_series against the reference's own double expression (param = a1)
+    VGL_BOUND_QS_TF = 4,        // qs_tf / qs_tf_margin on (1e-37, 1)                    (qs_decide_pf)
+    VGL_BOUND_RCP = 5,          // v_rcp_f32 within 1 ulp on every normal float           (qs_stage_pf)
+    VGL_BOUND_TANF = 6,         // tanf / tanf_err_bound on (0, VGL_PI]                   (poisson_attempt)
+    VGL_BOUND_EXP2 = 7,         // v_exp_f32 on [-126, 8]                                 (poisson_attempt)
+    VGL_BOUND_DIV = 8,          // div_inrange == IEEE quotient, operands shaped like the pool loop's (count = pairs)
+    VGL_BOUND_N
+};
+
+struct BoundAcc { unsigned long long n, viol, max_ratio_bits, arg_bits; };
+
+__device__ __forceinline__ void acc_update(double& mr, uint32_t& arg, unsigned long long& viol, const double err, const double bound, const uint32_t bits) {
+    // ratio err / bound; a non-positive bound with a non-zero error is a violation outright
+    const double r = (bound > 0.0) ? err / bound : (err > 0.0 ? 1e300 : 0.0);
+    if (!(r <= 1.0)) viol++;                                  // NaN counts as a violation
+    if (r > mr || r != r) { mr = (r != r) ? 1e300 : r; arg = bits; }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bound_sweep(const uint32_t lo, const unsigned long long count, const double param, BoundAcc* out) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    double mr = 0.0; uint32_t arg = 0; unsigned long long viol = 0, n = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const uint32_t bits = lo + (uint32_t)i;
+        const float x = __uint_as_float(bits);
+        const double xd = (double)x;
+        ++n;
+        if (MODE == VGL_BOUND_FAST_LN) {
+            // kernel: u double in (0,1), uf = (float)u, l = fast_ln(uf), claim |l - ln(u)| <= fast_ln_err(l).
+            // |ln(u) - ln(uf)| <= 2^-24 / (1 - 2^-24) < 5.97e-8 is the argument's share.
+            const double l = fast_ln(x);
+            acc_update(mr, arg, viol, fabs(l - log(xd)), fast_ln_err(l) - 5.97e-8, bits);
+        } else if (MODE == VGL_BOUND_GAMMA_LU) {
+            const float lu = gamma_test_lu(x);
+            const float b = fabsf(lu) * 0x1p-20f + 0x1p-21f;   // the log part of gamma_test_margin
+            // d = lu + g is rounded once more (2^-24 of the larger term, g <= |lu| near the decision): 2^-24 |lu| reserved
+            acc_update(mr, arg, viol, fabs((double)lu - log(xd)), (double)b - 5.97e-8 - fabs((double)lu) * 0x1p-24, bits);
+        } else if (MODE == VGL_BOUND_GAMMA_SERIES || MODE == VGL_BOUND_GAMMA_REFEXPR) {
+            if (!(fabsf(x) <= 0.3333f)) { --n; continue; }
+            const float a1f = (float)param;
+            const float g = gamma_rhs_series(x, a1f);
+            const double a1 = param, s = xd;
+            double exact;
+            if (MODE == VGL_BOUND_GAMMA_SERIES) {
+                double p = 0.0;                                   // sum_{k<60} (-s)^k / (k+4), Horner
+                for (int k = 59; k >= 0; --k) p = p * (-s) + 1.0 / (double)(k + 4);
+                exact = 3.0 * a1 * (s * s) * (s * s) * p;
+            } else {
+                // the reference's right-hand side as it computes it (rng.h:139-145), x = s / a2, a2 = 1/sqrt(9 a1)
+                const double a2 = 1.0 / sqrt(9.0 * a1);
+                const double xn = s / a2;
+                const double w = 1.0 + a2 * xn;
+                const double v = w * w * w;
+                exact = -(0.5 * (xn * xn) + a1 * (1.0 - v + log(v)));
+            }
+            // argument rounding: sf = (float)s and a1f = (float)a1 move g by <= (4.4 + 1) 2^-24 < 3.3e-7 relative
+            const double bound = (double)g * (4e-6 - 3.3e-7) + (MODE == VGL_BOUND_GAMMA_REFEXPR ? 1e-10 : 1e-30);
+            acc_update(mr, arg, viol, fabs((double)g - exact), bound, bits);
+        } else if (MODE == VGL_BOUND_QS_TF) {
+            // kernel: pf within 1.25 x 2^-22 relative of p (qs_stage_pf) => 10 log10(e) x 2.98e-7 < 1.3e-6 of the margin is the argument's
+            const float tf = qs_tf(x);
+            acc_update(mr, arg, viol, fabs((double)tf - (-10.0 * log10(xd))), (double)qs_tf_margin(tf) - 1.3e-6, bits);
+        } else if (MODE == VGL_BOUND_RCP) {
+            const float r = __builtin_amdgcn_rcpf(x);
+            const double ex = 1.0 / xd;
+            const float exf = (float)ex;
+            // result normal: within 1 ulp (2^-23 relative); where 1/x is below the normal range nothing is claimed
+            if (!(fabsf(exf) >= 0x1p-126f)) { --n; continue; }
+            acc_update(mr, arg, viol, fabs((double)r - ex), fabs(ex) * 0x1p-23, bits);
+        } else if (MODE == VGL_BOUND_TANF) {
+            const float yf = tanf(x);
+            const float y2 = yf * yf;
+            // half of the second term of tanf_err_bound belongs to the rounding of a to af
+            const double bound = (double)(fabsf(yf) * 0x1p-21f) + (double)((1.0f + y2) * x * 0x1p-24f);
+            acc_update(mr, arg, viol, fabs((double)yf - tan(xd)), bound, bits);
+        } else if (MODE == VGL_BOUND_EXP2) {
+            if (!(x >= -126.0f && x <= 8.0f)) { --n; continue; }
+            const float e = __builtin_amdgcn_exp2f(x);
+            const double ex = exp2(xd);
+            // poisson_t_rel_err grants 2^-19 beyond the argument's |z| 2^-22; 2^-22 of it covers the three float
+            // multiplications of tt = 0.9f (1 + y2) ex
+            acc_update(mr, arg, viol, fabs((double)e - ex), ex * (0x1p-19 - 0x1p-22), bits);
+        }
+    }
+    if (n) {
+        atomicAdd(&out->n, n);
+        if (viol) atomicAdd(&out->viol, viol);
+        const unsigned long long mb = (unsigned long long)__double_as_longlong(mr);      // non-negative doubles order like their bits
+        const unsigned long long old = atomicMax(&out->max_ratio_bits, mb);
+        if (mb > old) out->arg_bits = arg;                                                // diagnostic only (racy between equal maxima)
+    }
+}
+
+// splitmix-style hash -> 48-bit generator states shaped like the pool loop's operands
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x ^= x >> 33; x *= 0xFF51AFD7ED558CCDULL; x ^= x >> 33; x *= 0xC4CEB9FE1A85EC53ULL; x ^= x >> 33;
+    return x;
+}
+
+// div_inrange(v, u) against the compiler's IEEE division for v = 1.7156 (u' - 0.5), u, u' = X 2^-48 (rng.h:72-79):
+// every 8th pair draws u from the low end of the range (X < 2^k, k = 1..40), and pair 0 of each thread uses X = 1.
+__global__ __launch_bounds__(256) void k_bound_div(const unsigned long long count, BoundAcc* out) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long viol = 0, n = 0; uint32_t arg = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        uint64_t st1 = mix64(i * 2 + 1) & VGL_MASK48;
+        if ((i & 7) == 7) st1 >>= 8 + (uint32_t)((i >> 3) % 40);
+        if (i < stride) st1 = 1;
+        if (st1 == 0) st1 = 1;
+        const uint64_t st2 = (i & 1) ? lcg_next(st1) : (mix64(i * 2 + 2) & VGL_MASK48);
+        const double u = u01(st1);
+        const double v = 1.7156 * (u01(st2) - 0.5);
+        const double q0 = div_inrange(v, u);
+        const double q1 = v / u;
+        ++n;
+        if (__double_as_longlong(q0) != __double_as_longlong(q1)) { ++viol; arg = (uint32_t)i; }
+    }
+    atomicAdd(&out->n, n);
+    if (viol) { atomicAdd(&out->viol, viol); out->arg_bits = arg; }
+}
+
+extern "C" int vgl_dbg_bound_sweep(int mode, uint32_t lo_bits, unsigned long long count, double param, double out[4]) {
+    BoundAcc* d = nullptr;
+    if (hipMalloc((void**)&d, sizeof(BoundAcc)) != hipSuccess) return -1;
+    if (hipMemset(d, 0, sizeof(BoundAcc)) != hipSuccess) { (void)hipFree(d); return -1; }
+    const dim3 g(256 * 16), b(256);
+    switch (mode) {
+        case VGL_BOUND_FAST_LN: hipLaunchKernelGGL((k_bound_sweep<VGL_BOUND_FAST_LN>), g, b, 0, 0, lo_bits, count, param, d); break;
+        case VGL_BOUND_GAMMA_LU: hipLaunchKernelGGL((k_bound_sweep<VGL_BOUND_GAMMA_LU>), g, b, 0, 0, lo_bits, count, param, d); break;
+        case VGL_BOUND_GAMMA_SERIES: hipLaunchKernelGGL((k_bound_sweep<VGL_BOUND_GAMMA_SERIES>), g, b, 0, 0, lo_bits, count, param, d); break;
+        case VGL_BOUND_GAMMA_REFEXPR: hipLaunchKernelGGL((k_bound_sweep<VGL_BOUND_GAMMA_REFEXPR>), g, b, 0, 0, lo_bits, count, param, d); break;
+        case VGL_BOUND_QS_TF: hipLaunchKernelGGL((k_bound_sweep<VGL_BOUND_QS_TF>), g, b, 0, 0, lo_bits, count, param, d); break;
+        case VGL_BOUND_RCP: hipLaunchKernelGGL((k_bound_sweep<VGL_BOUND_RCP>), g, b, 0, 0, lo_bits, count, param, d); break;
+        case VGL_BOUND_TANF: hipLaunchKernelGGL((k_bound_sweep<VGL_BOUND_TANF>), g, b, 0, 0, lo_bits, count, param, d); break;
+        case VGL_BOUND_EXP2: hipLaunchKernelGGL((k_bound_sweep<VGL_BOUND_EXP2>), g, b, 0, 0, lo_bits, count, param, d); break;
+        case VGL_BOUND_DIV: hipLaunchKernelGGL(k_bound_div, g, b, 0, 0, count, d); break;
+        default: (void)hipFree(d); return -2;
+    }
+    BoundAcc h;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipFree(d); return -1; }
+    (void)hipFree(d);
+    out[0] = (double)h.n; out[1] = (double)h.viol;
+    out[2] = __builtin_bit_cast(double, h.max_ratio_bits);
+    out[3] = (double)h.arg_bits;
+    return 0;
+}

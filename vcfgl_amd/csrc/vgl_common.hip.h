@@ -88,6 +88,16 @@ static __device__ int poisson_draw(const VglPois& p, uint64_t& st, const double*
 // expressions are evaluated only inside the error band.  Bounds measured on MI355X
 // (tools/vlogcheck.py): |tanf(x) - tan(x)| <= 1.2 ulp, v_exp_f32 <= 0.71 ulp; 4x margins used.
 // Flat loop: one attempt per iteration for every lane that has not accepted yet.
+// The bounds themselves are the helpers below; tests/test_gpu_bounds.py sweeps every float32 argument of each
+// hardware function on the device and asserts them (vgl_bounds.hip), so a toolchain change that moves one fails the suite.
+// |tanf(af) - tan(a)| for af = (float)a: 4 ulp of the result + the argument's rounding (half of the second term) through tan' = 1 + y^2
+__device__ __forceinline__ float tanf_err_bound(const float yf, const float y2, const float af) {
+    return fabsf(yf) * 0x1p-21f + (1.0f + y2) * af * 0x1p-23f;
+}
+// relative error of tt = 0.9f (1 + y2) v_exp_f32((float)(z log2 e)) against 0.9 (1 + y^2) exp(z), given dy = tanf_err_bound()
+__device__ __forceinline__ float poisson_t_rel_err(const float yf, const float y2, const float dy, const float zf) {
+    return 2.0f * fabsf(yf) * dy / (1.0f + y2) + fabsf(zf) * 0x1p-22f + 0x1p-19f;
+}
 // one rejection attempt (rng.h:302-309) from the two generator states it would consume: `neg`: em < 0
 // (only st1 is consumed, no acceptance draw), else `rej` = the acceptance draw u(st2) exceeds t.
 __device__ __forceinline__ void poisson_attempt(const VglPois& p, const uint64_t st1, const uint64_t st2, const bool need,
@@ -96,7 +106,7 @@ __device__ __forceinline__ void poisson_attempt(const VglPois& p, const uint64_t
     const float af = (float)a;
     const float yf = tanf(af);
     const float y2 = yf * yf;
-    const float dy = fabsf(yf) * 0x1p-21f + (1.0f + y2) * af * 0x1p-23f;      // |yf - tan(a)|
+    const float dy = tanf_err_bound(yf, y2, af);                             // |yf - tan(a)|
     const double e0 = p.sq * (double)yf + p.lm;
     const double derr = p.sq * (double)dy + 1e-9;
     em = floor(e0);
@@ -107,7 +117,7 @@ __device__ __forceinline__ void poisson_attempt(const VglPois& p, const uint64_t
     const double z = em * p.alxm - gl - p.g;
     const float ex = __builtin_amdgcn_exp2f((float)(z * 1.4426950408889634));
     const float tt = 0.9f * (1.0f + y2) * ex;
-    const float rel_t = 2.0f * fabsf(yf) * dy / (1.0f + y2) + fabsf((float)z) * 0x1p-22f + 0x1p-19f;
+    const float rel_t = poisson_t_rel_err(yf, y2, dy, (float)z);
     const double u2 = u01(st2);
     rej = u2 > (double)tt;
     const bool amb_t = fabs(u2 - (double)tt) <= (double)(tt * rel_t) + 1e-30;
@@ -286,19 +296,13 @@ __device__ __forceinline__ bool normal_slow_test(const double v, const double u,
     return res;
 }
 
-// log(u) > 0.5*xsq + a1*(1.0 - v + log(v)),  v = fl(fl(w*w)*w), w = fl(1 + a2 x)    rng.h:139-145
-// With s = a2 x and a2^2 = 1/(9 a1) the quadratic terms cancel analytically:
-//     0.5 x^2 + a1 (1 - (1+s)^3 + 3 ln(1+s)) = -3 a1 s^4 (1/4 - s/5 + s^2/6 - s^3/7 + ...)
-// a well-conditioned series (no cancellation), so float32 is enough for the bounded decision:
-// |s| <= 1/3 => 11 terms leave < 2e-7 relative truncation; float32 evaluation < 1e-6 relative;
-// the reference's own double rounding of its expression is < 1e-12.  Outside the band (or for
-// |s| > 1/3) the exact double expression is evaluated.
-__device__ __forceinline__ bool gamma_slow_test(const double u, const double xsq, const double a1, const double v,
-                                                const double s, const bool need) {
-    const float uf = (float)u, sf = (float)s, a1f = (float)a1;
-    const float lu = __builtin_amdgcn_logf(uf) * 0.69314718f;
-    // Horner steps as explicit fused multiply-adds: this is the bounded estimate, not the reference's arithmetic
-    // (the translation unit is built with -ffp-contract=off), and a fused step only tightens the bound below
+// pieces of gamma_slow_test (asserted by tests/test_gpu_bounds.py over every float32 argument):
+// ln(u) from the float32 log2 and a float multiplication: |lu - ln(u)| <= |lu| 2^-20 + 2^-21 (argument rounding included)
+__device__ __forceinline__ float gamma_test_lu(const float uf) { return __builtin_amdgcn_logf(uf) * 0.69314718f; }
+// g = 3 a1 s^4 (1/4 - s/5 + ... + s^10/14) = -(0.5 x^2 + a1 (1 - v + log v)) for |s| <= 1/3, within 4e-6 g + 1e-10.
+// Horner steps as explicit fused multiply-adds: this is the bounded estimate, not the reference's arithmetic
+// (the translation unit is built with -ffp-contract=off), and a fused step only tightens the bound
+__device__ __forceinline__ float gamma_rhs_series(const float sf, const float a1f) {
     const float ns = -sf;
     float p = 1.0f / 14.0f;
     p = __builtin_fmaf(ns, p, 1.0f / 13.0f); p = __builtin_fmaf(ns, p, 1.0f / 12.0f); p = __builtin_fmaf(ns, p, 1.0f / 11.0f);
@@ -306,9 +310,27 @@ __device__ __forceinline__ bool gamma_slow_test(const double u, const double xsq
     p = __builtin_fmaf(ns, p, 1.0f / 7.0f); p = __builtin_fmaf(ns, p, 1.0f / 6.0f); p = __builtin_fmaf(ns, p, 1.0f / 5.0f);
     p = __builtin_fmaf(ns, p, 1.0f / 4.0f);
     const float s2 = sf * sf;
-    const float g = 3.0f * a1f * (s2 * s2) * p;                 // = -(rhs of the reference), >= 0
+    return 3.0f * a1f * (s2 * s2) * p;
+}
+__device__ __forceinline__ float gamma_test_margin(const float lu, const float g) {
+    return fabsf(lu) * 0x1p-20f + 0x1p-21f + g * 4e-6f + 1e-10f;
+}
+
+// log(u) > 0.5*xsq + a1*(1.0 - v + log(v)),  v = fl(fl(w*w)*w), w = fl(1 + a2 x)    rng.h:139-145
+// With s = a2 x and a2^2 = 1/(9 a1) the quadratic terms cancel analytically:
+//     0.5 x^2 + a1 (1 - (1+s)^3 + 3 ln(1+s)) = -3 a1 s^4 (1/4 - s/5 + s^2/6 - s^3/7 + ...)
+// a well-conditioned series (no cancellation), so float32 is enough for the bounded decision:
+// |s| <= 1/3 => 11 terms leave < 2e-6 relative truncation (first omitted term s^11/15 against P ~ 0.2); float32
+// evaluation < 1e-6 relative: together inside the 4e-6 g of the margin (swept: tests/test_gpu_bounds.py);
+// the reference's own double rounding of its expression is < 1e-12.  Outside the band (or for
+// |s| > 1/3) the exact double expression is evaluated.
+__device__ __forceinline__ bool gamma_slow_test(const double u, const double xsq, const double a1, const double v,
+                                                const double s, const bool need) {
+    const float uf = (float)u, sf = (float)s, a1f = (float)a1;
+    const float lu = gamma_test_lu(uf);
+    const float g = gamma_rhs_series(sf, a1f);                  // = -(rhs of the reference), >= 0
     const float d = lu + g;                                     // log(u) - rhs
-    const float m = fabsf(lu) * 0x1p-20f + 0x1p-21f + g * 4e-6f + 1e-10f;
+    const float m = gamma_test_margin(lu, g);
     const bool ok = (fabsf(d) > m) && (fabsf(sf) <= 0.3333f) && (uf > 0.0f);
     bool res = d > 0.0f;
     const bool amb = need && !ok;
@@ -327,14 +349,17 @@ __device__ __forceinline__ bool gamma_slow_test(const double u, const double xsq
 // log2 unless p sits within its error bound of an integer boundary (qs_decide_pf); those reads (about 1 in
 // 10^4) are drawn again in double by the lane that owns them (beta_draw + errprob_raw).
 // pf: v_rcp_f32 is 1 ulp, so its relative error is <= 2^-24 (gx) + 2^-24 (sum) + 2^-23 (rcp) + 2^-24 (product)
-// < 2^-22, i.e. < 1.1e-6 in tf; tf = -10 log10(p) within |tf| 2^-20 + 2.2e-6 (v_log_f32 bound + argument error).
+// = 1.25 x 2^-22 < 3.0e-7, i.e. < 1.3e-6 in tf; tf = -10 log10(p) within |tf| 2^-19 + 4e-6 of the exact value with that
+// argument error included (qs_tf_margin; v_rcp_f32 and this bound are swept over every float32 by tests/test_gpu_bounds.py).
 __device__ __forceinline__ float qs_stage_pf(const double gx, const double gy) {
     return (float)gx * __builtin_amdgcn_rcpf((float)(gx + gy));
 }
+__device__ __forceinline__ float qs_tf(const float pf) { return -3.0103f * __builtin_amdgcn_logf(pf); }
+__device__ __forceinline__ float qs_tf_margin(const float tf) { return tf * 0x1p-19f + 4e-6f; }
 // returns false where the float32 value cannot decide (the caller then needs the exact evaluation)
 __device__ __forceinline__ bool qs_decide_pf(const VglDevParams& P, const float pf, int& q, int& aq) {
-    const float tf = -3.0103f * __builtin_amdgcn_logf(pf);
-    const float m = tf * 0x1p-19f + 4e-6f;
+    const float tf = qs_tf(pf);
+    const float m = qs_tf_margin(tf);
     const float fl = floorf(tf);
     const float t2 = tf + (float)P.adjust_by;
     const float fl2 = floorf(t2);

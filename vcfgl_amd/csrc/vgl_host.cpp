@@ -54,6 +54,16 @@ extern "C" int vgl_default_rng_layout(const vgl_params* p, vgl_rng_layout* out) 
     return VGL_OK;
 }
 
+// Sites [0, max) a VGL_RNG_TILE job of this shape may address before its windows wrap around the 2^48 period of rand48
+// (evaluation e = site * n_samples + sample owns draws [e block, (e + 1) block)).
+extern "C" int vgl_rng_tile_max_sites(const vgl_params* p, int64_t* max_sites) {
+    if (!p || !max_sites || p->n_samples <= 0) return fail(VGL_E_ARG, "null argument");
+    vgl_rng_layout lay;
+    if (p->layout.block) lay = p->layout; else vgl_default_rng_layout(p, &lay);
+    *max_sites = (int64_t)((((unsigned __int128)1 << 48) / lay.block) / (uint64_t)p->n_samples);
+    return VGL_OK;
+}
+
 // ---- rand48 affine powers ---------------------------------------------------------------
 static VglAffine aff_compose(VglAffine f, VglAffine g) {      // f after g
     VglAffine r; r.a = (f.a * g.a) & VGL_MASK48; r.c = (f.a * g.c + f.c) & VGL_MASK48; return r;
@@ -568,6 +578,16 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     if (n_sites == 0) return VGL_OK;
     if (!gt || !o->site_status || !o->n_alleles || !o->alleles2acgt) return fail(VGL_E_ARG, "gt, site_status, n_alleles and alleles2acgt are required");
     if (site0 < 0) return fail(VGL_E_ARG, "site0 must be >= 0");
+    if (!c->dp.serial) {
+        // VGL_RNG_TILE windows are strided slices of ONE rand48 sequence of period 2^48: evaluation e owns draws
+        // [e block, (e + 1) block).  Past the period the windows would silently repeat earlier ones.
+        const unsigned __int128 end = (unsigned __int128)((uint64_t)site0 + (uint64_t)n_sites) * (uint64_t)c->dp.n_samples * c->p.layout.block;
+        if (end > ((unsigned __int128)1 << 48))
+            return fail(VGL_E_ARG, "VGL_RNG_TILE: sites [%lld, %lld) x %d samples x %llu draws per evaluation run past the 2^48 period of rand48 "
+                        "(at most %llu sites with this layout); split the job over seeds or use a smaller layout.block",
+                        (long long)site0, (long long)site0 + n_sites, c->dp.n_samples, (unsigned long long)c->p.layout.block,
+                        (unsigned long long)((((unsigned __int128)1 << 48) / c->p.layout.block) / (uint64_t)c->dp.n_samples));
+    }
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     const VglDevParams& D = c->dp;

@@ -461,8 +461,9 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
 }
 
 // ------------------------------------------------------------------------------------
-// debug hook (not part of the C ABI): raw v_log_f32 over a buffer, used by
-// tests/test_gpu_parity.py to check the error bound the fast decision paths assume
+// debug hook (not part of the C ABI): the raw hardware / ocml float32 functions over a buffer, for the exploratory scripts
+// tools/vlogcheck.py and tools/sincos_check.py.  The bounds the kernels rely on are asserted by tests/test_gpu_bounds.py
+// through vgl_dbg_bound_sweep (vgl_bounds.hip), over every float32 argument.
 __global__ void k_dbg_vlog(const float* in, float* out, int n, int mode) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

@@ -186,7 +186,7 @@ class VcfglArgs:
         p = _abi.Params()
         keep = []
         p.abi_version = _abi.ABI_VERSION
-        p.seed = int(np.int32(self.seed & 0xFFFFFFFF if self.seed >= 0 else self.seed))
+        p.seed = C.c_int32(int(self.seed) & 0xFFFFFFFF).value      # truncated like the reference's (int) / srand48 (io.cpp:1047-1061)
         p.n_samples = n_samples
         p.rng_mode = self.rng_mode
         p.beta_sampler = self.beta_sampler
