@@ -5,13 +5,22 @@ Workload (BASELINE.json configs[2], the depth-20 configuration the metric is quo
 1M sites x 1000 samples, --depth 20 -e 0.01 --error-qs 2 --beta-variance 1e-5 -GL 2, default tag
 surface (GL + DP, -doUnobserved 1 => G = 15).  One step = one pass of the hot path over the whole
 1e9-evaluation batch, tile by tile, with the packed true genotypes already resident in HBM and the
-outputs written to HBM.  Sites shard across ranks (weak scaling: every rank simulates its own
-1M-site range, addressed by absolute site index); the only collective is the end-of-step gather of
-the per-site records' index fields (status / allele count) to the writer rank over RCCL.
+outputs written to HBM.
+
+Multi-GPU: `python bench.py --gpus N` starts N ranks itself (one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* in their environment, before anything in this process touches a GPU); under `torch.distributed.run` it joins
+the ranks it is given and refuses to run when WORLD_SIZE differs from --gpus.  Sites shard across ranks by absolute
+site index: --scaling weak (default) gives every rank its own full-size range, --scaling strong splits the workload's
+sites with shard.site_range().  Collectives per step, over RCCL: the gather of the per-site record index to the writer
+rank and the all-reduce of the run summary's site counters; with --gather records also the tile-by-tile gather of the
+packed RECORDS of the kept sites (shard.pack_records / gather_records) -- at C3's volume (65 GB of tags per GPU and
+step) that gather is bound by the writer's links and is therefore a separate, labelled mode.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -19,20 +28,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-import synth  # noqa: E402
-from vcfgl_amd import Simulator, VcfglArgs, _abi  # noqa: E402
-from vcfgl_amd.shard import gather_site_index, reduce_site_counters  # noqa: E402
-
 try:
     METRIC = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]     # the reference's headline metric, verbatim
 except Exception:
     METRIC = "site-sample GL evals/s at depth 20, 1/2/4/8 MI355X; % HBM roofline"
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E vendor peak (MI355X_MICROARCH.md)
+# instruction roofline: 256 CUs x 4 SIMDs, 2.4 GHz, one wavefront instruction of the float64 / three-operand class this path
+# is made of per ~4 cycles of a SIMD (MI355X_MICROARCH.md "vector-instruction ISSUE cost"; tools/valu_rates.hip measured 4.3)
+VALU_PEAK_WAVE_INST_PER_S = 1024 * 2.4e9 / 4.0
 
-
+RTA3 = [(0, 2, 2), (3, 14, 12), (15, 30, 23), (31, 40, 37)]
 WORKLOADS = {
     # BASELINE.json configs[2]: the depth-20 configuration the metric is quoted on (default)
     "c3": dict(sites=1_000_000, samples=1000, flags=dict(depth=20.0, error_rate=0.01, error_qs=2, beta_variance=1e-5, gl_model=2),
@@ -41,8 +46,7 @@ WORKLOADS = {
     "c2": dict(sites=10_000, samples=100, flags=dict(depth=10.0, error_rate=0.01, gl_model=1),
                desc="--depth 10 -e 0.01 -GL 1"),
     # BASELINE.json configs[3], one GPU's share of the 8-GPU job (10M sites / 8)
-    "c4": dict(sites=1_250_000, samples=2000, flags=dict(depth=30.0, error_rate=0.01, error_qs=2, beta_variance=1e-5, gl_model=2,
-                                                         qs_bins=[(0, 2, 2), (3, 14, 12), (15, 30, 23), (31, 40, 37)]),
+    "c4": dict(sites=1_250_000, samples=2000, flags=dict(depth=30.0, error_rate=0.01, error_qs=2, beta_variance=1e-5, gl_model=2, qs_bins=RTA3),
                desc="--depth 30 -e 0.01 --error-qs 2 --beta-variance 1e-5 --qs-bins rta3 -GL 2"),
     # BASELINE.json configs[4]: exploded hom-ref sites, PL for the gVCF blocks.  2M of one GPU's 6.25M sites
     # (50M / 8): the tile layout keeps G = 15 planes of GL and PL, 120 B per evaluation resident in HBM
@@ -52,18 +56,27 @@ WORKLOADS = {
     "fixedq": dict(sites=1_000_000, samples=1000, flags=dict(depth=20.0, error_rate=0.01, gl_model=2),
                    desc="--depth 20 -e 0.01 --error-qs 0 -GL 2"),
 }
+KERNELS = ["k_depth", "k_sample", "k_site", "k_gl"]
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def workload_args(name="c3"):
+    from vcfgl_amd import VcfglArgs, _abi
     a = VcfglArgs(seed=42, **WORKLOADS[name]["flags"])
     a.rng_mode, a.beta_sampler = _abi.VGL_RNG_TILE, _abi.VGL_BETA_RAND48
     a._workload = name
     return a
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle = a port of the reference algorithm; test infrastructure used here only as the thing timed beside)
+
 def cpu_baseline(args, n_samples, budget_s=15.0):
     """The CPU oracle (a port of the reference algorithm, same inputs, one core) on a bounded sample."""
-    import subprocess
+    import synth
     so = os.path.join(ROOT, "oracle", "libvgl_oracle.so")
     if not os.path.exists(so):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libvgl_oracle.so"])
@@ -77,7 +90,9 @@ def cpu_baseline(args, n_samples, budget_s=15.0):
     gt = synth.binary_sites(0, n, n_samples)
     t0 = time.perf_counter(); o.simulate(0, gt, fields=fields); dt = time.perf_counter() - t0
     res = {"value": n * n_samples / dt, "unit": "site-sample GL evals/s", "cores": 1, "kind": "port",
-           "sample": f"first {n} sites x {n_samples} samples of the same workload, oracle/vgl_oracle.c (gcc -O2), {dt:.1f} s"}
+           "sample": f"first {n} sites x {n_samples} samples of the same workload, oracle/vgl_oracle.c (gcc -O2), {dt:.1f} s",
+           "sampler": "rand48 beta sampler (rng.h:426-446), as the GPU path in tile mode; the reference's default build draws quality "
+                      "scores from std::mt19937 + std::gamma_distribution, measured at ~2.0e5 evals/s on this configuration (BASELINE.md section 2)"}
     # All host cores, site-sharded in tile mode (NOT reference behaviour: the reference simulates on one
     # thread; SURVEY 8d asks for this figure beside the faithful one).  One process per core, each on its
     # own site range, about 8 s each.
@@ -98,6 +113,7 @@ def cpu_baseline(args, n_samples, budget_s=15.0):
 def cpu_worker(spec, args, n_samples):
     """One shard of the all-cores CPU leg: the oracle over sites [site0, site0 + n) in chunks."""
     import oracle_lib
+    import synth
     site0, n = (int(x) for x in spec.split(","))
     o = oracle_lib.Oracle(args, n_samples)
     fields = ["fmt_dp", "gl"]
@@ -109,41 +125,68 @@ def cpu_worker(spec, args, n_samples):
     print(json.dumps({"dt": time.perf_counter() - t0}))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
-    ap.add_argument("--sites", type=int, default=None)
-    ap.add_argument("--samples", type=int, default=None)
-    ap.add_argument("--tile-sites", type=int, default=65536)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)     # internal: one shard of the all-cores CPU leg
-    opt = ap.parse_args()
-    if opt.cpu_worker:                                         # never touches the GPU
-        cpu_worker(opt.cpu_worker, workload_args(opt.workload), opt.samples or WORKLOADS[opt.workload]["samples"])
-        return
+# ---------------------------------------------------------------------------------------------------------------------
+# launching the ranks
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):        # BENCH_FORCE_DIST: exercise the collective path at world 1
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+def spawn_ranks(opt):
+    """`python bench.py --gpus N` outside torch.distributed.run: start one process per GPU.  Nothing in this (parent)
+    process has touched a GPU: `import torch` alone does not initialise HIP, and the children are fresh interpreters."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(opt.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(opt.gpus), LOCAL_WORLD_SIZE=str(opt.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        for p in procs:
+            rc = max(rc, abs(p.wait()))
+            if rc:
+                break
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+    sys.exit(rc)
 
-    args = workload_args(opt.workload)
-    wl = WORKLOADS[opt.workload]
-    S = opt.sites if opt.sites is not None else wl["sites"]
-    N = opt.samples if opt.samples is not None else wl["samples"]
-    TS = min(opt.tile_sites, S)
-    site_base = rank * S                                      # this rank's absolute site range
-    sim = Simulator(args, N, device=local_rank, max_sites_per_tile=TS)
+
+# ---------------------------------------------------------------------------------------------------------------------
+
+def profile_entry(workload):
+    """committed PMC profile of this workload's kernels (profiles/pmc_traffic.json, written by tools/pmc_summary.py)"""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        prof = json.load(open(path))
+        return prof.get(workload, {})
+    except Exception:
+        return {}
+
+
+def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_cpu=False, gather="index"):
+    """K timed passes of the hot path over one workload; returns the result dictionary (rank 0) or None."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    import synth
+    from vcfgl_amd import Simulator, _abi
+    from vcfgl_amd.shard import gather_records, gather_site_index, pack_records, reduce_site_counters, site_range
+    rank, world, dist, dev, local_dev = env["rank"], env["world"], env["dist"], env["dev"], env["local_dev"]
+    args = workload_args(name)
+    wl = WORKLOADS[name]
+    S_wl = sites if sites is not None else wl["sites"]
+    N = samples if samples is not None else wl["samples"]
+    if opt.scaling == "strong":
+        site_base, site_end = site_range(rank, world, S_wl)          # the workload's sites split over the ranks
+        S, S_total = site_end - site_base, S_wl
+    else:
+        S, site_base, S_total = S_wl, rank * S_wl, S_wl * world      # every rank its own full-size range
+    TS = max(1, min(opt.tile_sites, S))
+    sim = Simulator(args, N, device=local_dev, max_sites_per_tile=TS)
     G = sim.G
+    log(f"{name}: rank {rank}/{world} sites [{site_base}, {site_base + S}) x {N} samples, tiles of {TS}")
 
     # ---- inputs resident in HBM before the timed region
     gt = torch.empty((S, N), dtype=torch.uint8, device=dev)
@@ -153,7 +196,7 @@ def main():
         for s0 in range(0, S, 65536):
             n = min(65536, S - s0)
             gt[s0:s0 + n] = synth.binary_sites_torch(site_base + s0, n, N, dev)
-    # ---- outputs: the whole job's tag arrays stay in HBM (65 B per evaluation)
+    # ---- outputs: the whole job's tag arrays stay in HBM (65 B per evaluation at C3)
     out = {
         "site_status": torch.empty((S,), dtype=torch.int32, device=dev),
         "n_alleles": torch.empty((S,), dtype=torch.int32, device=dev),
@@ -171,16 +214,27 @@ def main():
             setattr(t, k, v[s0:s0 + n].data_ptr())
         structs.append((s0, n, t))
     stream = torch.cuda.Stream(device=dev)
-    import ctypes as C
+    transport = torch.device("cpu") if (dist is not None and opt.backend == "gloo") else None
+    gathered_bytes = [0]
+
+    def to_transport(x):
+        return x if transport is None else x.to(transport)
 
     def step():
         for s0, n, t in structs:
             sim._check(sim.lib.vgl_simulate_tile_device(sim.ctx, site_base + s0, n, gt[s0:s0 + n].data_ptr(), C.byref(t),
                                                         C.c_void_p(stream.cuda_stream)))
-        if dist is not None:                                  # record-index gather to the writer rank
+            if dist is not None and gather == "records":           # the tile's records to the writer rank, variable length
+                with torch.cuda.stream(stream):
+                    p = pack_records({k: v[s0:s0 + n] for k, v in out.items()}, site0=site_base + s0)
+                    got = gather_records(p, world, rank, transport=transport, always_collective=True)
+                    if got is not None:
+                        gathered_bytes[0] += sum(q.nbytes() for q in got)
+        if dist is not None:                                      # record-index gather to the writer rank + the summary's counters
             stream.synchronize()
-            gather_site_index(out["site_status"], out["n_alleles"], world, rank, S * world, always_collective=True)
-            reduce_site_counters(out["site_status"], world, always_collective=True)             # the run summary's totals
+            gather_site_index(to_transport(out["site_status"]), to_transport(out["n_alleles"]), world, rank, S_total if opt.scaling == "strong" else S * world,
+                              always_collective=True)
+            reduce_site_counters(to_transport(out["site_status"]), world, always_collective=True)
 
     def barrier():
         stream.synchronize()
@@ -189,14 +243,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(opt.warmup):
+    for _ in range(warmup):
         step()
     barrier()
     sim.check(stream.cuda_stream)
     sim.timing(True)
     sim.kernel_ms(reset=True)
+    gathered_bytes[0] = 0
     t0 = time.perf_counter()
-    for _ in range(opt.steps):
+    for _ in range(steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
@@ -204,60 +259,202 @@ def main():
     kms, klaunch = sim.kernel_ms(reset=True)
     sim.timing(False)
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if transport is None else transport)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    evals_total = float(S) * N * world * opt.steps
-    value = evals_total / dt
+    res = None
     if rank == 0:
+        evals_total = float(S_total) * N * steps
         b_eval = 1 + 4 + 4 * G + (4 * G if args.add_pl else 0)  # packed GT in + DP out + GL (+ PL) out
-        names = ["k_sample", "k_site", "k_gl"]
         dom = int(np.argmax(kms))
         avg_ms = kms[dom] / max(klaunch[dom], 1)
-        evals_per_launch = float(S) * N * opt.steps / max(klaunch[dom], 1)     # average over the launches, partial last tile included
+        evals_per_launch = float(S) * N * steps / max(klaunch[dom], 1)     # average over the launches, partial last tile included
         achieved = b_eval * evals_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic = valu_busy = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                prof = json.load(open(tpath)).get(names[dom], {})
-                traffic, valu_busy = prof.get("hbm_bytes_per_launch"), prof.get("valu_busy_frac")
-            except Exception:
-                traffic = None
-        # the box's own device-copy bandwidth (read + write bytes of a 1 GiB device-to-device copy), the
-        # second denominator SURVEY 8d asks for beside the vendor peak
-        src = out["gl"].view(-1)[: min(out["gl"].numel(), 1 << 28)]
-        dst = torch.empty_like(src)
-        dst.copy_(src)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(4):
-            dst.copy_(src)
-        e1.record()
-        torch.cuda.synchronize()
-        copy_gbs = 4 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        del dst
-        line = {
-            "metric": METRIC if opt.workload in ("c3", "fixedq") else f"site-sample GL evals/s at depth {args.depth:g}", "value": value, "unit": "site-sample GL evals/s",
-            "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": dt / opt.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": f"{opt.workload}: {S} sites x {N} samples per GPU, {wl['desc']}, "
-                                   f"tags GL+DP{'+PL' if args.add_pl else ''} (G={G}), rng tile mode, rand48 beta sampler", "tile_sites": TS,
-                       "parallelism": f"site-sharded x{world}"},
-            "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "copy_bw_measured": copy_gbs, "frac_of_copy_bw": achieved / copy_gbs,
-                         "valu_busy_frac": valu_busy,     # from the committed PMC profile: what actually bounds this kernel
-                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_eval": b_eval,
-                         "kernel_ms_total": dict(zip(names, kms)), "launches": dict(zip(names, klaunch))},
+        prof = profile_entry(name)
+        kprof = prof.get("kernels", {}).get(KERNELS[dom], {})
+        # wavefronts per launch of the dominant kernel (launch geometry of vgl_sample.hip / vgl_gl.hip)
+        sites_per_launch = float(S) * steps / max(klaunch[dom], 1)
+        waves = sites_per_launch * N / 1024.0 if KERNELS[dom] == "k_depth" else sites_per_launch * ((N + 63) // 64)
+        valu = None
+        if kprof.get("valu_insts_per_wave"):
+            a = kprof["valu_insts_per_wave"] * waves / (avg_ms * 1e-3)
+            valu = {"achieved": a, "peak": VALU_PEAK_WAVE_INST_PER_S, "unit": "wavefront VALU instructions/s", "frac": a / VALU_PEAK_WAVE_INST_PER_S,
+                    "valu_insts_per_wave": kprof["valu_insts_per_wave"], "waves_per_launch": waves,
+                    "valu_busy_frac_pmc": kprof.get("valu_busy_frac"), "source": f"profiles/{prof.get('source')}_pmc_summary.json (not measured by this run)",
+                    "peak_note": "1024 SIMDs x 2.4 GHz / 4 cycles per wavefront instruction (float64 / three-operand class)"}
+        res = {
+            "value": evals_total / dt, "unit": "site-sample GL evals/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+            "workload": f"{name}: {S} sites x {N} samples per GPU, {wl['desc']}, tags GL+DP{'+PL' if args.add_pl else ''} (G={G}), rng tile mode, rand48 beta sampler",
+            "roofline": {"bound": "valu", "kernel": KERNELS[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "bound_note": "achieved / peak / frac are the ALGORITHMIC-bytes HBM figures the contract asks for; the kernel is bound by VALU issue, "
+                                       "see `valu` (SURVEY H7, DESIGN.md section 4)",
+                         "traffic": kprof.get("hbm_bytes_per_launch"),
+                         "traffic_source": f"profiles/{prof.get('source')}_pmc_summary.json, launches of 65536 sites (not measured by this run)" if kprof else None,
+                         "valu": valu, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_eval": b_eval,
+                         "kernel_ms_total": dict(zip(KERNELS, kms)), "launches": dict(zip(KERNELS, klaunch))},
         }
-        if not opt.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args, N)
-        print(json.dumps(line))
+        if dist is not None and gather == "records":
+            res["records_gather"] = {"bytes_per_step_at_writer": gathered_bytes[0] / steps, "GBps_into_writer": gathered_bytes[0] / dt / 1e9}
+        if name == opt.workload and not opt.no_pack_rate:
+            # device-side packing of one tile's records (what precedes the gather): an HBM-bound gather
+            s0, n, _ = structs[0]
+            tile = {k: v[s0:s0 + n] for k, v in out.items()}
+            p = pack_records(tile, site0=site_base + s0)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            p = pack_records(tile, site0=site_base + s0)
+            e1.record()
+            torch.cuda.synchronize()
+            res["record_packing"] = {"tile_sites": n, "kept_sites": p.n_kept, "packed_bytes": p.nbytes(), "ms": e0.elapsed_time(e1),
+                                     "GBps": 2 * p.nbytes() / (e0.elapsed_time(e1) * 1e-3) / 1e9, "note": "read + write bytes of shard.pack_records on one tile"}
+            del p
+        if with_cpu:
+            # the box's own device-copy bandwidth (read + write bytes of a 1 GiB device-to-device copy), the
+            # second denominator SURVEY 8d asks for beside the vendor peak
+            src = out["gl"].view(-1)[: min(out["gl"].numel(), 1 << 28)]
+            dst = torch.empty_like(src)
+            dst.copy_(src)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                dst.copy_(src)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbs = 4 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del dst
+            res["roofline"]["copy_bw_measured"] = copy_gbs
+            res["roofline"]["frac_of_copy_bw"] = achieved / copy_gbs
     sim.close()
+    del gt, out, structs
+    torch.cuda.empty_cache()
+    if res is not None and with_cpu:
+        log("cpu baseline ...")
+        res["cpu_baseline"] = cpu_baseline(args, N)
+    return res
+
+
+def host_path_rate(opt, env):
+    """PCIe-inclusive rate of the host-buffer entry point vgl_simulate_tile (pinned double-buffered staging inside the
+    library): never the bench value, reported beside it."""
+    import numpy as np
+    import synth
+    from vcfgl_amd import Simulator
+    args = workload_args("c3")
+    N, TS, tiles = 1000, 16384, 6
+    sim = Simulator(args, N, device=env["local_dev"], max_sites_per_tile=TS)
+    gts = [synth.binary_sites(k * TS, TS, N) for k in range(2)]
+    fields = ["fmt_dp", "gl"]
+    tile = sim.new_tile(TS, fields=fields)
+    sim._check(sim.lib.vgl_simulate_tile(sim.ctx, 0, TS, gts[0].ctypes.data, tile.byref()))
+    t0 = time.perf_counter()
+    for k in range(tiles):
+        sim._check(sim.lib.vgl_simulate_tile(sim.ctx, k * TS, TS, gts[k & 1].ctypes.data, tile.byref()))
+    dt = time.perf_counter() - t0
+    sim.close()
+    b = 4 + 4 * sim.G
+    return {"value": tiles * TS * N / dt, "unit": "site-sample GL evals/s", "GBps_over_pcie": tiles * TS * N * b / dt / 1e9,
+            "note": f"vgl_simulate_tile, host numpy buffers, {tiles} tiles of {TS} sites x {N} samples, GL+DP copied back; PCIe-inclusive, never the bench value"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--gather", choices=["index", "records"], default="index",
+                    help="N > 1: what the writer rank receives every step (records: the packed records of every tile as well)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL over xGMI; gloo stages through host memory (rehearsal)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a box with fewer GPUs than ranks: rank r uses device r %% device_count (needs --backend gloo)")
+    ap.add_argument("--sites", type=int, default=None)
+    ap.add_argument("--samples", type=int, default=None)
+    ap.add_argument("--tile-sites", type=int, default=65536)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other configurations attached as `extra`")
+    ap.add_argument("--no-pack-rate", action="store_true")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)     # internal: one shard of the all-cores CPU leg
+    opt = ap.parse_args()
+    if opt.cpu_worker:                                         # never touches the GPU
+        cpu_worker(opt.cpu_worker, workload_args(opt.workload), opt.samples or WORKLOADS[opt.workload]["samples"])
+        return
+    if opt.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+    if "RANK" not in os.environ and opt.gpus > 1:
+        spawn_ranks(opt)                                       # does not return
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != opt.gpus:
+        sys.exit(f"bench.py: --gpus {opt.gpus} but WORLD_SIZE is {world}: launch with --nproc-per-node {opt.gpus} (or plain `python bench.py --gpus {opt.gpus}`)")
+    import torch
+    ndev = torch.cuda.device_count()
+    if opt.share_gpu:
+        if opt.backend != "gloo":
+            sys.exit("--share-gpu needs --backend gloo (RCCL refuses two ranks on one device)")
+        local_dev = local_rank % max(ndev, 1)
+    else:
+        if local_rank >= ndev:
+            sys.exit(f"bench.py: rank {rank} needs GPU {local_rank} but this node shows {ndev} device(s)")
+        local_dev = local_rank
+    dist = None
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):        # BENCH_FORCE_DIST: exercise the collective path at world 1
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if opt.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_dev))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        if dist.get_world_size() != opt.gpus:
+            sys.exit(f"bench.py: the process group has {dist.get_world_size()} ranks, --gpus says {opt.gpus}")
+    torch.cuda.set_device(local_dev)
+    env = {"rank": rank, "world": world, "dist": dist, "dev": torch.device("cuda", local_dev), "local_dev": local_dev}
+
+    main_res = run_workload(opt.workload, opt, env, opt.steps, opt.warmup, sites=opt.sites, samples=opt.samples,
+                            with_cpu=(not opt.no_cpu_baseline and world == 1), gather=opt.gather)
+    extra = {}
+    if world == 1 and not opt.no_extra and opt.sites is None and opt.samples is None:
+        # the other BASELINE configurations on this GPU, a few passes each, attached to the same line (parity-test cases, not
+        # the headline: VERDICT r1 asked for driver-timed evidence of them)
+        for name in ("c5", "fixedq", "c4", "c2"):
+            if name == opt.workload:
+                continue
+            try:
+                r = run_workload(name, opt, env, steps=(20 if name == "c2" else 3), warmup=1, gather="index")
+                extra[name] = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "workload", "roofline")}
+            except Exception as e:                             # an extra must never cost the headline line
+                extra[name] = {"error": repr(e)[:300]}
+        try:
+            extra["host_path_c3"] = host_path_rate(opt, env)
+        except Exception as e:
+            extra["host_path_c3"] = {"error": repr(e)[:300]}
+
+    if rank == 0:
+        args = workload_args(opt.workload)
+        line = {
+            "metric": METRIC if opt.workload in ("c3", "fixedq") else f"site-sample GL evals/s at depth {args.depth:g}",
+            "value": main_res["value"], "unit": main_res["unit"],
+            "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": main_res["ms_per_step"],
+            "higher_is_better": True, "scaling": opt.scaling, "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": main_res["workload"], "tile_sites": opt.tile_sites,
+                       "parallelism": f"site-sharded x{world}" + (f", {opt.backend}" if world > 1 else ""),
+                       "gather": (opt.gather if world > 1 else None)},
+            "roofline": main_res["roofline"],
+        }
+        for k in ("cpu_baseline", "records_gather", "record_packing"):
+            if k in main_res:
+                line[k] = main_res[k]
+        if extra:
+            line["extra"] = extra
+        print(json.dumps(line), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

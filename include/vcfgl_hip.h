@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VGL_ABI_VERSION 2
+#define VGL_ABI_VERSION 3
 
 /* ---- error codes (returned by every entry point; 0 = success) ----------------------- */
 #define VGL_OK              0
@@ -217,9 +217,11 @@ int vgl_ctx_check(vgl_ctx* ctx, void* hip_stream);
 
 /* Kernel timing hook for bench.py: brackets the device work of every following
  * vgl_simulate_tile_device call with hipEvents on its stream.  vgl_ctx_kernel_ms returns
- * accumulated milliseconds and launch counts of the three kernels since the last reset. */
+ * accumulated milliseconds and launch counts since the last reset, in four buckets:
+ * [0] depth draws ahead of the sampling kernel (k_depth; the stream scouts in VGL_RNG_SERIAL), [1] k_sample,
+ * [2] k_site, [3] k_gl.  (ABI version 3: four buckets; version 2 had three and left the depth kernel untimed.) */
 int vgl_ctx_timing(vgl_ctx* ctx, int32_t enable);
-int vgl_ctx_kernel_ms(vgl_ctx* ctx, double ms[3], int64_t launches[3], int32_t reset);
+int vgl_ctx_kernel_ms(vgl_ctx* ctx, double ms[4], int64_t launches[4], int32_t reset);
 
 #ifdef __cplusplus
 }

@@ -6,7 +6,9 @@ HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE/WRITE_SI
 gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced streaming read (MI355X_MICROARCH.md,
 section HBM).  The raw (uncorrected) fetch figure is kept beside it: this path's loads are 1-8 bytes
 per lane, a width the guide marks as uncalibrated.
-usage: tools/pmc_summary.py <dir with FETCH_SIZE/ WRITE_SIZE/ SQ/ subdirs> <tag>"""
+profiles/pmc_traffic.json is keyed by bench workload: {workload: {"source": tag, "kernels": {kernel: {...}}}} -- bench.py
+quotes it (labelled with its source) beside the numbers it measures itself.
+usage: tools/pmc_summary.py <dir with FETCH_SIZE/ WRITE_SIZE/ SQ/ subdirs> <tag> [workload=c3] [sites per launch=65536]"""
 import collections
 import csv
 import glob
@@ -15,6 +17,8 @@ import os
 import sys
 
 root, tag = sys.argv[1], sys.argv[2]
+workload = sys.argv[3] if len(sys.argv) > 3 else "c3"
+sites_per_launch = int(sys.argv[4]) if len(sys.argv) > 4 else 65536
 out = collections.defaultdict(dict)
 for f in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -33,8 +37,8 @@ for k, v in out.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         v["hbm_bytes_per_launch"] = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
         v["hbm_bytes_per_launch_raw_fetch"] = (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
-        traffic[k.split("<")[0]] = {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"],
-                                    "raw_fetch_variant": v["hbm_bytes_per_launch_raw_fetch"], "source": tag}
+        traffic.setdefault(k.split("<")[0], {}).update({"hbm_bytes_per_launch": v["hbm_bytes_per_launch"],
+                                                        "raw_fetch_variant": v["hbm_bytes_per_launch_raw_fetch"]})
     if "SQ_ACTIVE_INST_VALU" in v and v.get("GRBM_GUI_ACTIVE"):
         # VALU pipes busy: SQ_ACTIVE_INST_VALU counts 4-cycle quads summed over the chip's 1024 SIMDs (256 CUs x 4);
         # GRBM_GUI_ACTIVE is summed over the 8 XCDs (value / 8 / duration = 2.39 GHz, the part's clock), so one XCD's
@@ -44,7 +48,17 @@ for k, v in out.items():
     if "SQ_INSTS_VALU" in v and "SQ_WAVES" in v:
         v["valu_insts_per_wave"] = v["SQ_INSTS_VALU"] / v["SQ_WAVES"]
         v["active_lanes_per_valu_inst"] = v.get("SQ_THREAD_CYCLES_VALU", 0) / v["SQ_INSTS_VALU"]
+        traffic.setdefault(k.split("<")[0], {}).update({"valu_insts_per_wave": v["valu_insts_per_wave"],
+                                                        "active_lanes_per_valu_inst": v["active_lanes_per_valu_inst"]})
 here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 json.dump(out, open(os.path.join(here, "profiles", f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
-json.dump(traffic, open(os.path.join(here, "profiles", "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+tpath = os.path.join(here, "profiles", "pmc_traffic.json")
+try:
+    allw = json.load(open(tpath))
+except Exception:
+    allw = {}
+for e in traffic.values():
+    e["sites_per_launch"] = sites_per_launch
+allw[workload] = {"source": tag, "kernels": traffic}
+json.dump(allw, open(tpath, "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True))

@@ -6,7 +6,7 @@ not been built -- the product path never falls back to a CPU implementation.
 import ctypes as C
 import os
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 VGL_OK = 0
 VGL_E_ARG, VGL_E_NODEVICE, VGL_E_NOMEM, VGL_E_CAPACITY, VGL_E_UNSUPPORTED, VGL_E_QSBIN, VGL_E_ADJQ = -1, -2, -3, -4, -5, -6, -7

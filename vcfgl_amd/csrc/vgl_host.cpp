@@ -175,8 +175,8 @@ struct vgl_ctx {
     double* d_pick_out = nullptr;
     // timing
     bool timing = false;
-    std::vector<hipEvent_t> ev;     // groups of 4
-    double ms[3] = {0, 0, 0}; int64_t launches[3] = {0, 0, 0};
+    std::vector<hipEvent_t> ev;     // groups of 5
+    double ms[4] = {0, 0, 0, 0}; int64_t launches[4] = {0, 0, 0, 0};    // k_depth, k_sample, k_site, k_gl
 };
 
 static int errprob_to_qs_fixed(const vgl_params* p, double ep, int* qs, int* adjqs) {
@@ -491,9 +491,9 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
 }
 
 static int resolve_timing(vgl_ctx* c) {
-    for (size_t i = 0; i + 3 < c->ev.size(); i += 4) {
-        HIPCHK(hipEventSynchronize(c->ev[i + 3]));
-        for (int k = 0; k < 3; k++) {
+    for (size_t i = 0; i + 4 < c->ev.size(); i += 5) {
+        HIPCHK(hipEventSynchronize(c->ev[i + 4]));
+        for (int k = 0; k < 4; k++) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, c->ev[i + k], c->ev[i + k + 1]));
             c->ms[k] += ms; c->launches[k] += 1;
@@ -510,13 +510,13 @@ extern "C" int vgl_ctx_timing(vgl_ctx* c, int32_t enable) {
     return VGL_OK;
 }
 
-extern "C" int vgl_ctx_kernel_ms(vgl_ctx* c, double ms[3], int64_t launches[3], int32_t reset) {
+extern "C" int vgl_ctx_kernel_ms(vgl_ctx* c, double ms[4], int64_t launches[4], int32_t reset) {
     if (!c) return fail(VGL_E_ARG, "null ctx");
     HIPCHK(hipSetDevice(c->device));
     int rc = resolve_timing(c);
     if (rc) return rc;
-    for (int k = 0; k < 3; k++) { ms[k] = c->ms[k]; launches[k] = c->launches[k]; }
-    if (reset) for (int k = 0; k < 3; k++) { c->ms[k] = 0; c->launches[k] = 0; }
+    for (int k = 0; k < 4; k++) { ms[k] = c->ms[k]; launches[k] = c->launches[k]; }
+    if (reset) for (int k = 0; k < 4; k++) { c->ms[k] = 0; c->launches[k] = 0; }
     return VGL_OK;
 }
 
@@ -622,9 +622,10 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     T.errp = (errp_always || dump_errp) ? c->d_errp : nullptr;
     T.site_pick_err = (D.error_qs == 1) ? o->site_pick_err : nullptr;
 
-    hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
-    if (c->timing) for (int k = 0; k < 4; k++) HIPCHK(hipEventCreate(&e[k]));
+    hipEvent_t e[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (c->timing) for (int k = 0; k < 5; k++) HIPCHK(hipEventCreate(&e[k]));
     HIPCHK(hipMemsetAsync(c->d_acc, 0, sizeof(int32_t) * VGL_ACC_STRIDE * (size_t)n_sites, st));
+    if (c->timing) HIPCHK(hipEventRecord(e[0], st));        // bucket 0: depth draws ahead of k_sample (k_depth; the scouts in serial mode)
     if (D.serial) {
         if (vgl_launch_scout(&D, &T, c->d_serial, st)) return fail(VGL_E_NODEVICE, "k_scout launch failed");
         c->serial_next_site = site0 + n_sites;
@@ -634,13 +635,13 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
             T.roff = c->d_roff; T.errp_lin = c->d_errp_lin;
         }
     } else if (D.depth_pre == 1 && vgl_launch_depth(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_depth launch failed");
-    if (c->timing) HIPCHK(hipEventRecord(e[0], st));
-    if (vgl_launch_sample(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_sample launch failed: %s", hipGetErrorString(hipGetLastError()));
     if (c->timing) HIPCHK(hipEventRecord(e[1], st));
-    if (vgl_launch_site(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_site launch failed");
+    if (vgl_launch_sample(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_sample launch failed: %s", hipGetErrorString(hipGetLastError()));
     if (c->timing) HIPCHK(hipEventRecord(e[2], st));
-    if (vgl_launch_gl(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_gl launch failed");
+    if (vgl_launch_site(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_site launch failed");
     if (c->timing) HIPCHK(hipEventRecord(e[3], st));
+    if (vgl_launch_gl(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_gl launch failed");
+    if (c->timing) HIPCHK(hipEventRecord(e[4], st));
     if (o->qs || o->i16) if (vgl_launch_siteagg(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_siteagg launch failed");
     if (dump_errp) {
         const size_t row = (size_t)n_sites * D.n_samples;
@@ -649,7 +650,7 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
         if ((size_t)o->read_capacity > rows)
             HIPCHK(hipMemsetAsync(o->read_errp + rows * row, 0xFF, ((size_t)o->read_capacity - rows) * row * sizeof(double), st));
     }
-    if (c->timing) for (int k = 0; k < 4; k++) c->ev.push_back(e[k]);
+    if (c->timing) for (int k = 0; k < 5; k++) c->ev.push_back(e[k]);
     return VGL_OK;
 }
 

@@ -83,8 +83,8 @@ class Simulator:
         self._check(self.lib.vgl_ctx_timing(self.ctx, 1 if enable else 0))
 
     def kernel_ms(self, reset=True):
-        ms = (C.c_double * 3)()
-        n = (C.c_int64 * 3)()
+        ms = (C.c_double * 4)()               # k_depth, k_sample, k_site, k_gl
+        n = (C.c_int64 * 4)()
         self._check(self.lib.vgl_ctx_kernel_ms(self.ctx, ms, n, 1 if reset else 0))
         return list(ms), list(n)
 
