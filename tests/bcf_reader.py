@@ -127,7 +127,7 @@ class Reader:
                         per.append(self._ints(t, n))
                 fmt.append((self.dict[k], t, per))
             assert self.off == end_indiv, "l_indiv does not match the individual block"
-            yield dict(chrom=self.contigs[chrom], pos0=pos, rlen=rlen, qual=qual, id=ident, alleles=alleles,
+            yield dict(chrom=self.contigs[chrom], pos0=pos, rlen=rlen, qual=qual, id=(ident if ident else "."), alleles=alleles,     # zero-length ID string = missing (htslib)
                        filter=[self.dict[f] for f in filt], info=info, fmt=fmt)
 
     def vcf_lines(self, fmt_float):

@@ -141,3 +141,64 @@ def test_run_log_is_written(tmp_path):
     out = run(tmp_path, "log", "v")                         # io.cpp:1031: <prefix>.arg
     txt = open(out + ".arg").read()
     assert "Command: vcfgl_hip" in txt and "Simulation finished successfully" in txt and out + ".vcf" in txt and "truth" in txt
+
+
+def test_bcf_in_bcf_out_with_an_info_key_defined_after_format_gt(tmp_path):
+    """A BCF input keeps its header lines, IDX= attributes included; the output drops FORMAT/GT, which shifts the index of
+    every key defined after it.  The indices written must be the ones the records are encoded with."""
+    src = tmp_path / "in.vcf"
+    src.write_text("##fileformat=VCFv4.2\n##FILTER=<ID=PASS,Description=\"All filters passed\">\n##contig=<ID=c1,length=9>\n"
+                   "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n"
+                   "##INFO=<ID=AC,Number=A,Type=Integer,Description=\"after GT\">\n##INFO=<ID=ZZ,Number=1,Type=Float,Description=\"after GT too\">\n"
+                   "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ts1\ts2\n"
+                   "c1\t2\t.\tA\tC\t.\tPASS\tAC=3;ZZ=0.5\tGT\t0|1\t1|1\n"
+                   "c1\t5\trs9\tG\tT\t.\tPASS\tAC=1\tGT\t0|0\t0|1\n")
+    base = ["--seed", "1", "--depth", "inf", "-e", "0", "-printTruth", "1", "-doUnobserved", "1", "--source", "1"]
+    first = str(tmp_path / "first")
+    r = subprocess.run([BIN, "-i", str(src), "-o", first, "-O", "u"] + base, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1500:]
+    hdr_in = bcf_reader.Reader(first + ".truth.bcf").header
+    gt_idx = [int(h.split(",IDX=")[1].rstrip(">")) for h in hdr_in if h.startswith("##FORMAT=<ID=GT,")][0]
+    ac_idx = [int(h.split(",IDX=")[1].rstrip(">")) for h in hdr_in if h.startswith("##INFO=<ID=AC,")][0]
+    assert gt_idx < ac_idx                                        # the situation of the finding: GT's index is below AC's
+    text = str(tmp_path / "text")
+    r = subprocess.run([BIN, "-i", first + ".truth.bcf", "-o", text, "-O", "v"] + base, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1500:]
+    for mode in ("u", "b"):
+        again = str(tmp_path / ("again_" + mode))
+        r = subprocess.run([BIN, "-i", first + ".truth.bcf", "-o", again, "-O", mode] + base, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-1500:]
+        rd = bcf_reader.Reader(again + ".bcf")
+        idx = {}
+        for h in rd.header:
+            if h.startswith(("##FILTER=", "##INFO=", "##FORMAT=")):
+                assert h.count(",IDX=") == 1, h
+                i = int(h.split(",IDX=")[1].rstrip(">"))
+                assert i not in idx, (h, idx[i])                  # no two dictionary lines share an index
+                idx[i] = h
+        recs = list(bcf_reader.Reader(again + ".bcf").records())
+        assert [[k for k, _, _ in r_["info"]] for r_ in recs] == [["AC", "ZZ"], ["AC"]]
+        assert [r_["info"][0][2] for r_ in recs] == [[3], [1]]
+        assert [r_["id"] for r_ in recs] == [".", "rs9"]
+        assert list(bcf_reader.Reader(again + ".bcf").vcf_lines(lambda b: {0.0: "0", 1.0: "1", float("-inf"): "-inf", 0.5: "0.5"}[struct.unpack("<f", struct.pack("<I", b))[0]])) == body(open(text + ".vcf"))
+
+
+def test_missing_id_is_a_zero_length_string(tmp_path):
+    """htslib encodes ID '.' as a typed string of length 0 (byte 0x07), not as the one-character string '.'"""
+    o = run(tmp_path, "id", "u")
+    raw = open(o + ".bcf", "rb").read()
+    l_text = struct.unpack_from("<I", raw, 5)[0]
+    off = 9 + l_text
+    assert raw[off + 8 + 24] == 0x07                           # l_shared, l_indiv, six fixed fields, then the ID
+
+
+def test_explode_refuses_unsorted_or_duplicate_positions(tmp_path):
+    """-explode 1 on a record that is not after its predecessor: the reference never leaves `while (n_in != pos)`
+    (vcfgl.cpp:1481); here it is an error message instead of an allocation until the machine runs out of memory."""
+    src = tmp_path / "dup.vcf"
+    src.write_text("##fileformat=VCFv4.2\n##contig=<ID=c1,length=9>\n##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n"
+                   "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ts1\n"
+                   "c1\t3\t.\t0\t1\t.\tPASS\t.\tGT\t0|1\nc1\t3\t.\t0\t1\t.\tPASS\t.\tGT\t1|1\n")
+    r = subprocess.run([BIN, "-i", str(src), "-o", str(tmp_path / "o"), "-O", "v", "--seed", "1", "--depth", "inf", "-e", "0", "-explode", "1"],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "cannot be exploded" in r.stderr

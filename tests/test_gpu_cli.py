@@ -245,3 +245,34 @@ def test_baseline_config_c1_cli_equals_oracle(oracle, mode, tmp_path):
     errs = gu.compare_with_golden(args, sites, tile, got)
     assert not errs, errs[:10]
     assert int(tile.numpy("fmt_dp").max()) >= 4            # depth-4 reads really reach GL model 1 (n up to ~10)
+
+
+@pytest.mark.parametrize("case", ["plain", "gvcf", "pileup"])
+def test_devices_do_not_change_the_output(case, tmp_path):
+    """--devices a,b,...: one context and one host thread per device, tiles dealt round robin and written in site order.
+    Every value depends only on the absolute site index, so the files must be byte-identical to the one-device run --
+    plain records, gVCF blocks that run across tiles simulated by different contexts, and the pileup.  (On a one-GPU box
+    the contexts share the device: the host-side machinery is the same.)"""
+    data = os.path.join(gu.REFVCF, "data")
+    flags = {"plain": ["-i", os.path.join(data, "data3.vcf"), "--depth", "6", "--error-rate", "0.01", "--error-qs", "2", "--beta-variance", "1e-5",
+                       "-explode", "1", "-doUnobserved", "2", "-addPL", "1", "-addGP", "1", "-addQS", "1", "-addFormatAD", "1", "-addInfoAD", "1", "-printTruth", "1"],
+             "gvcf": ["-i", os.path.join(data, "data2.vcf"), "--depth", "4", "--error-rate", "0.001", "-explode", "1", "-doUnobserved", "2", "-addPL", "1",
+                      "-doGVCF", "1", "--gvcf-dps", "1,3"],
+             "pileup": ["-i", os.path.join(data, "data3.vcf"), "--depth", "3", "--error-rate", "0.02", "--error-qs", "2", "--beta-variance", "1e-4",
+                        "-explode", "1", "-printPileup", "1", "-printQScores", "1"]}[case]
+    outs = {}
+    for name, dev in (("one", ["--device", "0"]), ("two", ["--devices", "0,0"]), ("three", ["--devices", "0,0,0"])):
+        out = str(tmp_path / name)
+        r = subprocess.run([BIN, "-o", out, "-O", "v", "--seed", "42", "--rng-mode", "0", "--tile-sites", "3"] + dev + flags, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        body = [l for l in open(out + ".vcf") if not l.startswith("##")]
+        extra = r.stdout
+        if case == "pileup":
+            extra += gzip.open(out + ".pileup.gz", "rt").read()
+        if case == "plain":
+            extra += "".join(l for l in open(out + ".truth.vcf") if not l.startswith("##"))
+        outs[name] = (body, extra)
+    assert len(outs["one"][0]) > 10
+    assert outs["one"] == outs["two"] == outs["three"]
+    r = subprocess.run([BIN, "-o", str(tmp_path / "x"), "-O", "v", "--seed", "42", "--rng-mode", "1", "--devices", "0,0"] + flags, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "does not shard" in r.stderr                     # the serial draw order is one stream

@@ -286,7 +286,14 @@ class Sink {
                 const int ht = (t == "Integer") ? HT_INT : (t == "Float") ? HT_FLOAT : (t == "Flag") ? HT_FLAG : HT_STR;
                 (inf ? info_type : fmt_type)[id] = ht;
             }
-            if (h.find(",IDX=") == std::string::npos && h.back() == '>') { char t[32]; snprintf(t, sizeof t, ",IDX=%d>", idx); h.pop_back(); h += t; }
+            // an input header (BCF in particular) may carry its own IDX= values: the index written is always the one the
+            // records are encoded with, so a stale attribute is replaced (FORMAT/GT is dropped from the output, which shifts
+            // every key that was defined after it)
+            for (size_t a; (a = h.find(",IDX=")) != std::string::npos;) {
+                size_t e = a + 5; while (e < h.size() && h[e] >= '0' && h[e] <= '9') e++;
+                h.erase(a, e - a);
+            }
+            if (h.back() == '>') { char t[32]; snprintf(t, sizeof t, ",IDX=%d>", idx); h.pop_back(); h += t; }
         }
     }
     int dict_id(const std::string& k) const {
@@ -366,7 +373,7 @@ class Sink {
         put_u32(out, col[5] == "." ? F32_MISSING : float_bits(col[5]));
         put_u32(out, (uint32_t)alleles.size() << 16 | n_info);
         put_u32(out, n_fmt << 24 | (uint32_t)N);
-        enc_str(out, col[2]);
+        if (col[2] == ".") enc_size(out, 0, BT_CHAR); else enc_str(out, col[2]);     // htslib writes a missing ID as a zero-length string
         for (const std::string& a : alleles) enc_str(out, a);
         std::vector<int32_t> fv;
         if (col[6] != "." && !col[6].empty()) { split(col[6], ';', filt); for (auto& f : filt) fv.push_back(dict_id(f)); }

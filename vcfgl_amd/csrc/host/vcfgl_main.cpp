@@ -22,25 +22,32 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/vcfgl_hip.h"
 #include "vcf_sink.h"
 
-[[noreturn]] static void die(const char* fmt, ...) {
-    va_list ap; va_start(ap, fmt);
+// Records are parsed, simulated and encoded on several threads, and any of them may hit a fatal input error: the first
+// one reports and leaves through _exit() (no static destructors run under the feet of the threads still working, which is
+// what exit() from two threads at once did), the others park.
+#include <atomic>
+#include <unistd.h>
+static std::atomic<bool> g_dying{false};
+[[noreturn]] static void die_v(const char* fmt, va_list ap) {
+    if (g_dying.exchange(true)) for (;;) pause();
+    fflush(stdout);
     fprintf(stderr, "\n\n*******\n[ERROR] "); vfprintf(stderr, fmt, ap); fprintf(stderr, "\n*******\n");
-    va_end(ap);
-    exit(1);                                   // shared.h:292-299
+    fflush(NULL);
+    _exit(1);                                  // shared.h:292-299 exit(1)
 }
-[[noreturn]] void vsink::fail(const char* fmt, ...) {
-    va_list ap; va_start(ap, fmt);
-    fprintf(stderr, "\n\n*******\n[ERROR] "); vfprintf(stderr, fmt, ap); fprintf(stderr, "\n*******\n");
-    va_end(ap);
-    exit(1);
-}
+[[noreturn]] static void die(const char* fmt, ...) { va_list ap; va_start(ap, fmt); die_v(fmt, ap); }
+[[noreturn]] void vsink::fail(const char* fmt, ...) { va_list ap; va_start(ap, fmt); die_v(fmt, ap); }
 
 // ---------------------------------------------------------------------------------------
 struct Args {
@@ -58,6 +65,7 @@ struct Args {
     std::vector<int32_t> qs_bins;
     std::string gvcf_dps_str;
     std::vector<int> gvcf_dps;
+    std::vector<int> devices;          // --devices 0,1,...: one context + host thread per GPU, tiles dealt round robin
 };
 
 static const char USAGE[] =
@@ -78,7 +86,8 @@ static const char USAGE[] =
     "  this program     --rng-mode 0|1 [0: counter-addressed windows of the rand48 sequence (fast, shards over GPUs);\n"
     "                                   1: the reference program's own draw order (reproduces its output)]\n"
     "                   --beta-sampler 0|1 [0: the rand48 sampler, 1: std::mt19937 (default with --rng-mode 1)]\n"
-    "                   --tile-sites INT [4096]    --device INT [0]    --encode-threads INT\n"
+    "                   --tile-sites INT [4096]    --device INT [0]    --devices INT,INT,... (several GPUs of the node: sites shard by\n"
+    "                   absolute index, the output does not depend on the device count; --rng-mode 0 only)    --encode-threads INT\n"
     "                   -v --version    -vv    -h --help\n\n";
 
 static Args parse_args(int argc, char** argv) {
@@ -155,6 +164,7 @@ static Args parse_args(int argc, char** argv) {
         else if (f == "--beta-sampler") a.beta_sampler = I(v);
         else if (f == "--tile-sites") a.tile_sites = I(v);
         else if (f == "--device") a.device = I(v);
+        else if (f == "--devices") { a.devices.clear(); for (const char* q = v; *q;) { char* e; const long d = strtol(q, &e, 10); if (e == q || d < 0) die("Could not parse --devices %s", v); a.devices.push_back((int)d); q = (*e == ',') ? e + 1 : e; if (*e && *e != ',') die("Could not parse --devices %s", v); } }
         else die("Unknown argument: %s", argv[i]);
     }
     // ---- validation (io.cpp:757-1000, the rules that concern the hot path)
@@ -528,11 +538,13 @@ static double host_qs_to_errprob(int q) {
     return strtod(b, nullptr);
 }
 
-struct Site { const Rec* rec; long pos0; std::string chrom; std::vector<uint8_t> gt; char ref_char; };
-static std::vector<std::string> g_truth_lines;      // -printTruth 1: records as check_rec_alleles() leaves them
+// One site in simulation order.  Its contig is rec->chrom: a record that -explode 1 synthesises keeps the contig of the
+// template record it was copied from (reference quirk, bcf_copy at vcfgl.cpp:1490, visible in test/reference/test18).
+struct SiteMeta { const Rec* rec; long pos0; char ref_char; };
 
-// check_rec_alleles (vcfgl.cpp:75-163) + the n_allele==1 filter (vcfgl.cpp:335-338); false = skipped
-static bool make_site(const Args& a, const Rec& rec, long pos0, bool blank, int N, Site& out) {
+// check_rec_alleles (vcfgl.cpp:75-163) + the n_allele==1 filter (vcfgl.cpp:335-338); false = skipped.
+// gt_row[N] receives the packed true genotypes; truth_line (when given) the record as -printTruth writes it.
+static bool make_site(const Args& a, const Rec& rec, long pos0, bool blank, int N, uint8_t* gt_row, SiteMeta& out, std::string* truth_line) {
     // (the n_allele == 1 filter below belongs to simulate_record_values and is not applied with --depth inf)
     const int n_alleles = (int)rec.alleles.size();
     if (n_alleles > 5) die("Multiallelic sites with more than 4 alleles are not supported.");
@@ -547,58 +559,77 @@ static bool make_site(const Args& a, const Rec& rec, long pos0, bool blank, int 
     }
     if (a.source == 0 && n_alleles > 2) die("Multiallelic sites are not supported when using binary GT source.");
     long allelesum = 0;
-    out.gt.assign(N, 0);
     for (int s = 0; s < N; s++) {
         int g0 = blank ? 0 : rec.gt[2 * s], g1 = blank ? 0 : rec.gt[2 * s + 1];
         int b0 = 0xF, b1 = 0xF;
         if (g0 >= 0) { if (g0 >= n_alleles) die("GT allele index out of range at position %ld", pos0 + 1); allelesum += g0; b0 = ra[g0] & 0xF; }
         if (g1 >= 0) { if (g1 >= n_alleles) die("GT allele index out of range at position %ld", pos0 + 1); allelesum += g1; b1 = ra[g1] & 0xF; }
-        out.gt[s] = (uint8_t)(b0 | (b1 << 4));
+        gt_row[s] = (uint8_t)(b0 | (b1 << 4));
     }
     if ((a.rm_invar & 1) && allelesum == 0) return false;
     if (a.rm_invar & 2) for (int k = 1; k < n_alleles; k++) if ((long)k * N * 2 == allelesum) return false;
-    if (a.print_truth) {                               // bcf_write(out_truth_fp, ...) at vcfgl.cpp:1518,1548,1607
-        std::string l = rec.chrom; char hb[48]; snprintf(hb, sizeof hb, "\t%ld\t", pos0 + 1); l += hb; l += rec.id; l += '\t';
+    if (truth_line) {                                  // bcf_write(out_truth_fp, ...) at vcfgl.cpp:1518,1548,1607
+        std::string& l = *truth_line;
+        l = rec.chrom; char hb[48]; snprintf(hb, sizeof hb, "\t%ld\t", pos0 + 1); l += hb; l += rec.id; l += '\t';
         if (a.source == 0) l += "A\tC";                // binary source: alleles become A,C (vcfgl.cpp:127)
         else { l += rec.alleles[0]; l += '\t'; if (n_alleles == 1) l += '.'; else for (int k = 1; k < n_alleles; k++) { if (k > 1) l += ','; l += rec.alleles[k]; } }
         l += '\t'; l += rec.qual; l += '\t'; l += rec.filt; l += '\t'; l += rec.info; l += "\tGT";
         for (int s = 0; s < N; s++) { l += '\t'; l += blank ? std::string("0|0") : rec.gt_str[s]; }
-        g_truth_lines.push_back(l);
     }
     if (!a.depth_inf && (a.rm_invar & 3) && n_alleles == 1) return false;
-    out.rec = &rec; out.pos0 = pos0; out.chrom = rec.chrom; out.ref_char = (a.source == 0) ? 'A' : rec.ref_char;
+    out.rec = &rec; out.pos0 = pos0; out.ref_char = (a.source == 0) ? 'A' : rec.ref_char;
     return true;
 }
 
-// main_simulate_record_values (vcfgl.cpp:1456-1639): sites in simulation order
-static std::vector<Site> build_sites(const Args& a, const Vcf& v) {
-    std::vector<Site> sites;
-    const int N = (int)v.samples.size();
-    const Rec* tpl = nullptr;
-    std::string last; long n_in = 0;
-    Site s;
-    for (const Rec& r : v.recs) {
-        if (r.chrom != last) { n_in = 0; last = r.chrom; }
-        while (a.explode == 1 && n_in != r.pos0) {
-            if (!tpl) tpl = &r;                                      // bcf_copy(explode_rec, in_rec): keeps its contig (reference quirk)
-            if (make_site(a, *tpl, n_in, true, N, s)) sites.push_back(s);
-            n_in++;
-        }
-        if (make_site(a, r, r.pos0, false, N, s)) sites.push_back(s);
-        n_in++;
+// main_simulate_record_values (vcfgl.cpp:1456-1639): the sites in simulation order, produced one at a time -- the sites that
+// -explode 1 adds are never materialised (BASELINE config C5: 50M exploded sites x 500 samples), the truth file is written
+// as the sites go by.
+struct SiteStream {
+    const Args& a; const Vcf& v; const int N;
+    vsink::Sink* truth = nullptr;
+    size_t ri = 0; const Rec* tpl = nullptr; std::string last; long n_in = 0, tail_size = -1; bool tail = false, done = false;
+    std::string tl;
+    SiteStream(const Args& a_, const Vcf& v_, int N_) : a(a_), v(v_), N(N_) {}
+    bool emit(const Rec& r, long pos0, bool blank, uint8_t* gt_row, SiteMeta& m) {
+        tl.clear();
+        const bool ok = make_site(a, r, pos0, blank, N, gt_row, m, truth ? &tl : nullptr);
+        if (truth && !tl.empty()) truth->write_line(tl);
+        return ok;
     }
-    if (a.explode == 1 && !v.recs.empty()) {
-        const Rec& r = v.recs.back();
-        auto it = v.contig_len.find(r.chrom);
-        const long size = (it == v.contig_len.end()) ? -1 : it->second;
-        while (size >= 0 && n_in != size) {
-            if (!tpl) tpl = &r;
-            if (make_site(a, *tpl, n_in, true, N, s)) sites.push_back(s);
-            n_in++;
+    bool next(uint8_t* gt_row, SiteMeta& m) {
+        while (!done) {
+            if (!tail) {
+                if (ri == v.recs.size()) {
+                    if (a.explode == 1 && !v.recs.empty()) {           // to the end of the last contig (vcfgl.cpp:1565-1625)
+                        auto it = v.contig_len.find(v.recs.back().chrom);
+                        tail_size = (it == v.contig_len.end()) ? -1 : it->second;
+                        tail = true;
+                        continue;
+                    }
+                    done = true; break;
+                }
+                const Rec& r = v.recs[ri];
+                if (r.chrom != last) { n_in = 0; last = r.chrom; }
+                if (a.explode == 1 && n_in != r.pos0) {
+                    // the reference's `while (n_in != pos)` (vcfgl.cpp:1481) never ends on such input
+                    if (r.pos0 < n_in) die("[-explode 1] Record %s:%ld is not after the previous record of its contig (duplicate or unsorted positions cannot be exploded).", r.chrom.c_str(), r.pos0 + 1);
+                    if (!tpl) tpl = &r;                                // bcf_copy(explode_rec, in_rec): keeps its contig (reference quirk)
+                    const long p0 = n_in++;
+                    if (emit(*tpl, p0, true, gt_row, m)) return true;
+                    continue;
+                }
+                ri++; n_in++;
+                if (emit(r, r.pos0, false, gt_row, m)) return true;
+            } else {
+                if (!(tail_size >= 0 && n_in < tail_size)) { done = true; break; }
+                if (!tpl) tpl = &v.recs.back();
+                const long p0 = n_in++;
+                if (emit(*tpl, p0, true, gt_row, m)) return true;
+            }
         }
+        return false;
     }
-    return sites;
-}
+};
 
 // ---------------------------------------------------------------------------------------
 // gVCF blocks: prepare_gvcf_block(), bcf_utils.cpp:662-942.  Invariant records (one observed
@@ -730,7 +761,7 @@ int main(int argc, char** argv) {
     Args a = parse_args(argc, argv);
     RunLog runlog; runlog.open(a);
     // --verbose 1: wall-clock seconds per stage on stderr at the end
-    double t_stage[6] = {0, 0, 0, 0, 0, 0};                   // read, sites, context, simulate, encode, write
+    double t_stage[6] = {0, 0, 0, 0, 0, 0};                   // read, sites, context, waiting for the device, encode, write
     auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
     double t_mark = now();
     auto lap = [&](int k) { const double t = now(); t_stage[k] += t - t_mark; t_mark = t; };
@@ -743,16 +774,14 @@ int main(int argc, char** argv) {
     const int N = (int)vcf.samples.size();
     if (N <= 0) die("no samples in %s", a.in_fn.c_str());
     if (!a.depths.empty() && (int)a.depths.size() != N) die("--depths-file must hold one depth per sample (%zu given, %d samples)", a.depths.size(), N);
-    std::vector<Site> sites = build_sites(a, vcf);
-    lap(1);
     const char mode = a.output_mode[0];
     const std::string ext = mode == 'v' ? ".vcf" : mode == 'z' ? ".vcf.gz" : ".bcf";
-    // binary output needs every contig / FILTER / INFO key of the records defined in the header
+    // binary output needs every contig / FILTER / INFO key of the records defined in the header (exploded sites carry the
+    // contig of an input record)
     auto complete_header = [&](std::vector<std::string>& hdr) {
         if (mode != 'u' && mode != 'b') return;
         std::vector<std::string> contigs, filters, keys, tmp;
         auto add = [](std::vector<std::string>& v, const std::string& x) { if (!x.empty() && std::find(v.begin(), v.end(), x) == v.end()) v.push_back(x); };
-        for (const Site& S : sites) add(contigs, S.chrom);
         for (const Rec& r : vcf.recs) {
             add(contigs, r.chrom);
             split(r.filt, ';', tmp); for (auto& f : tmp) add(filters, f);
@@ -760,15 +789,16 @@ int main(int argc, char** argv) {
         }
         vsink::Sink::define_missing(hdr, contigs, filters, keys);
     };
-    if (a.print_truth) {
-        vsink::Sink ts; ts.text_float = put_float;
+    SiteStream stream(a, vcf, N);
+    vsink::Sink truth_sink; truth_sink.text_float = put_float;
+    if (a.print_truth) {                                 // written as the sites go by (vcfgl.cpp:1518,1548,1607)
         std::vector<std::string> hdr = vcf.header;
         hdr.push_back("##source=vcfgl_hip"); hdr.push_back("##source=" + a.command);
         complete_header(hdr);
-        ts.open(a.out_prefix + ".truth" + ext, mode, hdr, vcf.samples);
-        for (const std::string& l : g_truth_lines) ts.write_line(l);
-        ts.close();
+        truth_sink.open(a.out_prefix + ".truth" + ext, mode, hdr, vcf.samples);
+        stream.truth = &truth_sink;
     }
+    size_t n_sites_total = 0;
 
     if (a.depth_inf) {                                   // simulate_record_true_values, vcfgl.cpp:1089-1262
         vsink::Sink out; out.text_float = put_float;
@@ -784,10 +814,13 @@ int main(int argc, char** argv) {
         const bool add_unobs = (a.do_unobserved == 1 || a.do_unobserved == 2 || a.do_unobserved == 4 || a.do_unobserved == 5);
         const char* nonref = (a.do_unobserved == 1 || a.do_unobserved == 4) ? "<*>" : "<NON_REF>";
         std::string line;
-        for (const Site& S : sites) {
+        std::vector<uint8_t> gtrow(N);
+        SiteMeta S;
+        while (stream.next(gtrow.data(), S)) {
+            n_sites_total++;
             int ac[4] = {0, 0, 0, 0};
             for (int s = 0; s < N; s++) {
-                const int b0 = S.gt[s] & 0xF, b1 = (S.gt[s] >> 4) & 0xF;
+                const int b0 = gtrow[s] & 0xF, b1 = (gtrow[s] >> 4) & 0xF;
                 if (b0 > 3 || b1 > 3) die("--depth inf needs complete A/C/G/T genotypes (position %ld)", S.pos0 + 1);
                 ac[b0]++; ac[b1]++;
             }
@@ -802,7 +835,7 @@ int main(int argc, char** argv) {
             for (int i = 0; i < n_acgt; i++) { idx_of[order[i]] = (int)al.size(); al.push_back(std::string(1, "ACGT"[order[i]])); }
             if (add_unobs) al.push_back(nonref);
             const int nA = (int)al.size(), nG = nA * (nA + 1) / 2;
-            line = S.chrom; char hb[64]; snprintf(hb, sizeof hb, "\t%ld\t", S.pos0 + 1); line += hb;
+            line = S.rec->chrom; char hb[64]; snprintf(hb, sizeof hb, "\t%ld\t", S.pos0 + 1); line += hb;
             line += S.rec->id; line += '\t'; line += al[0]; line += '\t';
             if (nA == 1) line += '.'; else for (int k = 1; k < nA; k++) { if (k > 1) line += ','; line += al[k]; }
             line += '\t'; line += S.rec->qual; line += '\t'; line += S.rec->filt; line += '\t'; line += S.rec->info; line += '\t';
@@ -810,7 +843,7 @@ int main(int argc, char** argv) {
             if (a.add_gl) fmt += "GL"; if (a.add_gp) { if (!fmt.empty()) fmt += ':'; fmt += "GP"; } if (a.add_pl) { if (!fmt.empty()) fmt += ':'; fmt += "PL"; }
             line += fmt.empty() ? "." : fmt;
             for (int s = 0; s < N; s++) {
-                const int i0 = idx_of[S.gt[s] & 0xF], i1 = idx_of[(S.gt[s] >> 4) & 0xF];
+                const int i0 = idx_of[gtrow[s] & 0xF], i1 = idx_of[(gtrow[s] >> 4) & 0xF];
                 const int tg = i0 > i1 ? i0 * (i0 + 1) / 2 + i1 : i1 * (i1 + 1) / 2 + i0;
                 line += '\t';
                 bool first = true;
@@ -823,7 +856,8 @@ int main(int argc, char** argv) {
             out.write_line(line);
         }
         out.close();
-        char sb[512]; snprintf(sb, sizeof sb, "\n\n-> Simulation finished successfully.\n\nSummary:\n\tNumber of samples: %d\n\tTotal number of sites simulated: %zu\n", N, sites.size());
+        if (a.print_truth) truth_sink.close();
+        char sb[512]; snprintf(sb, sizeof sb, "\n\n-> Simulation finished successfully.\n\nSummary:\n\tNumber of samples: %d\n\tTotal number of sites simulated: %zu\n", N, n_sites_total);
         fputs(sb, stderr);
         std::vector<std::string> files = {"-> Simulation output file: " + a.out_prefix + ext};
         if (a.print_truth) files.push_back("-> True genotypes output file: " + a.out_prefix + ".truth" + ext);
@@ -844,9 +878,15 @@ int main(int argc, char** argv) {
     int TS = a.tile_sites > 0 ? a.tile_sites : 4096;
     if (a.print_pileup || a.print_qs_err || a.print_gl_err || a.print_qscores)      // per-read dumps: bounded host / device staging
         TS = std::max(1, std::min(TS, (int)((64u << 20) / ((size_t)1024 * (size_t)std::max(N, 1)) + 1)));
-    vgl_ctx* ctx = nullptr;
+    // ---- devices: one context and one host thread per GPU; tiles are dealt to them round robin and come back to the writer
+    //      (this thread) in site order.  Every value depends only on the absolute site index (VGL_RNG_TILE), so the file does
+    //      not depend on the number of devices.  VGL_RNG_SERIAL consumes its streams in call order: one device.
+    std::vector<int> devices = a.devices.empty() ? std::vector<int>{a.device} : a.devices;
+    if (devices.size() > 1 && a.rng_mode == VGL_RNG_SERIAL) die("--devices: --rng-mode 1 (the reference's serial draw order) does not shard; use one device");
+    const int D = (int)devices.size();
+    std::vector<vgl_ctx*> ctxs(D, nullptr);
     t_mark = now();
-    if (vgl_ctx_create(&p, a.device, TS, &ctx) != VGL_OK) die("%s", vgl_last_error());
+    for (int d = 0; d < D; d++) if (vgl_ctx_create(&p, devices[d], TS, &ctxs[d]) != VGL_OK) die("%s", vgl_last_error());
     lap(2);
     const int A = vgl_max_alleles(&p), G = vgl_max_genotypes(&p);
 
@@ -879,8 +919,11 @@ int main(int argc, char** argv) {
         // BGZF compression threads: --threads as in the reference; when it is not given, up to 8 (same bytes either way)
         out.open(a.out_prefix + ext, mode, hdr, vcf.samples, a.threads_given ? a.threads : (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
     }
-    gzFile pile = nullptr;
-    if (a.print_pileup) { pile = gzopen((a.out_prefix + ".pileup.gz").c_str(), "wb"); if (!pile) die("Could not open pileup output"); }
+    FILE* pile_fp = nullptr; vsink::Bgzf pile;            // the reference writes the pileup through htslib's BGZF (vcfgl.cpp:1776-1783)
+    if (a.print_pileup) {
+        pile_fp = fopen((a.out_prefix + ".pileup.gz").c_str(), "wb"); if (!pile_fp) die("Could not open pileup output");
+        pile.open(pile_fp, 1);
+    }
     // ---- TSV lines on stdout (vcfgl.cpp:430-435, 533-554, 1745-1755)
     int pre_q = -1, pre_adjq = -1;                                              // preCalc->qScore / adj_qScore
     if (a.print_bpe && a.error_qs != 1) printf("base_pick_error_prob\tNA\tNA\tNA\tNA\t%f\n", a.error_rate);   // io.cpp:1089-1100
@@ -891,47 +934,81 @@ int main(int argc, char** argv) {
         if (a.print_qscores) printf("qs\tNA\tNA\tNA\tNA\t%d\n", a.adjust_qs ? pre_adjq : pre_q);
     }
     const bool dump_reads = a.error_qs == 2 && (a.print_qs_err || a.print_gl_err || a.print_qscores);
-    const bool want_errp = dump_reads || (a.error_qs == 2 && pile && (a.adjust_qs & 4));
+    const bool want_errp = dump_reads || (a.error_qs == 2 && pile_fp && (a.adjust_qs & 4));
     const bool dump_pick = a.error_qs == 1 && a.print_bpe;
-
-    // ---- tile buffers (host side of vgl_tile_out)
-    const size_t E = (size_t)TS * N;
-    std::vector<int32_t> st(TS), na(TS), nobs(TS), idp(TS), iad((size_t)TS * A), iadf((size_t)TS * A), iadr((size_t)TS * A);
-    std::vector<int8_t> a2b((size_t)TS * 5);
-    std::vector<float> qs((size_t)TS * A), i16((size_t)TS * 16);
-    std::vector<int32_t> dp(E), pl(a.add_pl ? E * G : 0), ad(E * A), adf(E * A), adr(E * A);
-    std::vector<float> gl(E * G), gp(a.add_gp ? E * G : 0);
     // per-read dump rows: the library's own staging capacity (vgl_host.cpp: depth + 8 sqrt(depth) + 16)
     double dmax = a.depth; for (double d : a.depths) dmax = std::max(dmax, d); if (!(dmax >= 0)) dmax = 0;
     const int pile_cap = (((int)ceil(dmax + 8.0 * sqrt(dmax) + 16.0)) + 3) & ~3;
-    std::vector<uint8_t> reads, gt_tile(E);
-    std::vector<double> errp, pick;
-    std::string tsv;
-    vgl_tile_out o; memset(&o, 0, sizeof o);
-    o.site_status = st.data(); o.n_alleles = na.data(); o.n_alleles_obs = nobs.data(); o.alleles2acgt = a2b.data();
-    o.info_dp = idp.data(); o.info_ad = iad.data(); o.info_adf = iadf.data(); o.info_adr = iadr.data();
-    if (a.add_qs) o.qs = qs.data();
-    if (a.add_i16) o.i16 = i16.data();
-    o.fmt_dp = dp.data(); o.gl = gl.data(); if (a.add_pl) o.pl = pl.data(); if (a.add_gp) o.gp = gp.data();
-    o.fmt_ad = ad.data(); o.fmt_adf = adf.data(); o.fmt_adr = adr.data();
     const char* nonref = (a.do_unobserved == 1 || a.do_unobserved == 4) ? "<*>" : "<NON_REF>";
 
+    // ---- tile buffers (host side of vgl_tile_out): only what this run prints is requested from the device
+    const bool want_dp = a.add_fmt_dp || a.do_gvcf || pile_fp || dump_reads;
+    struct TileBufs {
+        int ns = 0; int64_t t0 = 0; int dev = 0;
+        std::vector<SiteMeta> meta; std::vector<uint8_t> gt, reads;
+        std::vector<int32_t> st, na, nobs, idp, iad, iadf, iadr, dp, pl, ad, adf, adr;
+        std::vector<int8_t> a2b; std::vector<float> qs, i16, gl, gp; std::vector<double> errp, pick;
+        vgl_tile_out o;
+        std::mutex m; std::condition_variable cv; bool done = false;
+    };
+    const size_t E = (size_t)TS * N;
+    const int R = 2 * D;                                        // tiles in flight: two per device
+    std::vector<std::unique_ptr<TileBufs>> ring(R);
+    for (auto& up : ring) {
+        up.reset(new TileBufs());
+        TileBufs& B = *up;
+        B.meta.resize(TS); B.gt.resize(E);
+        B.st.resize(TS); B.na.resize(TS); B.nobs.resize(TS); B.a2b.resize((size_t)TS * 5);
+        memset(&B.o, 0, sizeof B.o);
+        B.o.site_status = B.st.data(); B.o.n_alleles = B.na.data(); B.o.n_alleles_obs = B.nobs.data(); B.o.alleles2acgt = B.a2b.data();
+        B.idp.resize(TS); B.o.info_dp = B.idp.data();           // also tells which sites reach the read loop (TSV dumps)
+        if (a.add_info_ad) { B.iad.resize((size_t)TS * A); B.o.info_ad = B.iad.data(); }
+        if (a.add_info_adf) { B.iadf.resize((size_t)TS * A); B.o.info_adf = B.iadf.data(); }
+        if (a.add_info_adr) { B.iadr.resize((size_t)TS * A); B.o.info_adr = B.iadr.data(); }
+        if (a.add_qs) { B.qs.resize((size_t)TS * A); B.o.qs = B.qs.data(); }
+        if (a.add_i16) { B.i16.resize((size_t)TS * 16); B.o.i16 = B.i16.data(); }
+        if (want_dp) { B.dp.resize(E); B.o.fmt_dp = B.dp.data(); }
+        if (a.add_gl) { B.gl.resize(E * G); B.o.gl = B.gl.data(); }
+        if (a.add_pl) { B.pl.resize(E * G); B.o.pl = B.pl.data(); }
+        if (a.add_gp) { B.gp.resize(E * G); B.o.gp = B.gp.data(); }
+        if (a.add_fmt_ad) { B.ad.resize(E * A); B.o.fmt_ad = B.ad.data(); }
+        if (a.add_fmt_adf) { B.adf.resize(E * A); B.o.fmt_adf = B.adf.data(); }
+        if (a.add_fmt_adr) { B.adr.resize(E * A); B.o.fmt_adr = B.adr.data(); }
+    }
+    // one worker per device: simulates the tiles handed to it, in order
+    struct Worker { std::thread th; std::mutex m; std::condition_variable cv; std::vector<TileBufs*> q; size_t head = 0; bool stop = false; };
+    std::vector<std::unique_ptr<Worker>> workers(D);
+    for (int d = 0; d < D; d++) {
+        workers[d].reset(new Worker());
+        Worker* W = workers[d].get();
+        vgl_ctx* ctx = ctxs[d];
+        W->th = std::thread([W, ctx]() {
+            for (;;) {
+                TileBufs* B = nullptr;
+                { std::unique_lock<std::mutex> lk(W->m); W->cv.wait(lk, [&] { return W->stop || W->head < W->q.size(); }); if (W->head == W->q.size()) return; B = W->q[W->head++]; }
+                if (vgl_simulate_tile(ctx, B->t0, B->ns, B->gt.data(), &B->o) != VGL_OK) die("%s", vgl_last_error());
+                { std::lock_guard<std::mutex> lk(B->m); B->done = true; }
+                B->cv.notify_all();
+            }
+        });
+    }
+
     long n_out = 0, n_skipped = 0;
-    std::string line;
+    std::string line, tsv;
     GvcfBlocker gv;
     std::vector<std::string> enc;
     gv.block_dps = a.gvcf_dps;
-    // one simulated record of the current tile: the eight fixed columns as text, the allele strings and the
+    // one simulated record of a tile: the eight fixed columns as text, the allele strings and the
     // typed FORMAT arrays (reads the tile buffers only: records of a tile are built on several threads)
-    auto build_record = [&](size_t t0, int i, std::string& line, std::vector<std::string>& al, std::vector<vsink::FmtDesc>& fmt) {
-        const Site& S = sites[t0 + i];
-        const int nA = na[i], nG = nA * (nA + 1) / 2;
+    auto build_record = [&](const TileBufs& B, int i, std::string& line, std::vector<std::string>& al, std::vector<vsink::FmtDesc>& fmt) {
+        const SiteMeta& S = B.meta[i];
+        const int nA = B.na[i], nG = nA * (nA + 1) / 2;
         char hb[64];
-        line += S.chrom; snprintf(hb, sizeof hb, "\t%ld\t", S.pos0 + 1); line += hb;
+        line += S.rec->chrom; snprintf(hb, sizeof hb, "\t%ld\t", S.pos0 + 1); line += hb;
         line += S.rec->id; line += '\t';
         // alleles (vcfgl.cpp:739-762; no-reads site :250-280)
         al.clear();
-        for (int k = 0; k < nA; k++) { const int b = a2b[(size_t)i * 5 + k]; al.push_back(b == 4 ? nonref : (b >= 0 ? std::string(1, "ACGT"[b]) : ".")); }
+        for (int k = 0; k < nA; k++) { const int b = B.a2b[(size_t)i * 5 + k]; al.push_back(b == 4 ? nonref : (b >= 0 ? std::string(1, "ACGT"[b]) : ".")); }
         if (al.empty()) al.push_back(".");
         line += al[0]; line += '\t';
         if (al.size() == 1) line += '.';
@@ -940,52 +1017,42 @@ int main(int argc, char** argv) {
         // INFO in add_tags() order: DP, QS, I16, AD, ADF, ADR (after the input record's own INFO)
         std::string info = (S.rec->info == ".") ? "" : S.rec->info;
         auto add_key = [&](const char* k) { if (!info.empty()) info += ';'; info += k; info += '='; };
-        if (a.add_info_dp) { add_key("DP"); put_int(info, idp[i]); }
-        if (a.add_qs) { add_key("QS"); for (int k = 0; k < nA; k++) { if (k) info += ','; out.put_float(info, qs[(size_t)i * A + k]); } }
-        if (a.add_i16) { add_key("I16"); for (int k = 0; k < 16; k++) { if (k) info += ','; out.put_float(info, i16[(size_t)i * 16 + k]); } }
-        if (a.add_info_ad) { add_key("AD"); for (int k = 0; k < nA; k++) { if (k) info += ','; put_int(info, iad[(size_t)i * A + k]); } }
-        if (a.add_info_adf) { add_key("ADF"); for (int k = 0; k < nA; k++) { if (k) info += ','; put_int(info, iadf[(size_t)i * A + k]); } }
-        if (a.add_info_adr) { add_key("ADR"); for (int k = 0; k < nA; k++) { if (k) info += ','; put_int(info, iadr[(size_t)i * A + k]); } }
+        if (a.add_info_dp) { add_key("DP"); put_int(info, B.idp[i]); }
+        if (a.add_qs) { add_key("QS"); for (int k = 0; k < nA; k++) { if (k) info += ','; out.put_float(info, B.qs[(size_t)i * A + k]); } }
+        if (a.add_i16) { add_key("I16"); for (int k = 0; k < 16; k++) { if (k) info += ','; out.put_float(info, B.i16[(size_t)i * 16 + k]); } }
+        if (a.add_info_ad) { add_key("AD"); for (int k = 0; k < nA; k++) { if (k) info += ','; put_int(info, B.iad[(size_t)i * A + k]); } }
+        if (a.add_info_adf) { add_key("ADF"); for (int k = 0; k < nA; k++) { if (k) info += ','; put_int(info, B.iadf[(size_t)i * A + k]); } }
+        if (a.add_info_adr) { add_key("ADR"); for (int k = 0; k < nA; k++) { if (k) info += ','; put_int(info, B.iadr[(size_t)i * A + k]); } }
         line += info.empty() ? "." : info;
         // FORMAT keys: DP, GL, PL, GP, AD, ADF, ADR; sample s, element k of a tag at plane[k * N + s]
         fmt.clear();
         const size_t sN = (size_t)N;
-        if (a.add_fmt_dp) fmt.push_back({"DP", false, 1, &dp[(size_t)i * N], 1, sN});
-        if (a.add_gl) fmt.push_back({"GL", true, nG, &gl[(size_t)i * G * N], 1, sN});
-        if (a.add_pl) fmt.push_back({"PL", false, nG, &pl[(size_t)i * G * N], 1, sN});
-        if (a.add_gp) fmt.push_back({"GP", true, nG, &gp[(size_t)i * G * N], 1, sN});
-        if (a.add_fmt_ad) fmt.push_back({"AD", false, nA, &ad[(size_t)i * A * N], 1, sN});
-        if (a.add_fmt_adf) fmt.push_back({"ADF", false, nA, &adf[(size_t)i * A * N], 1, sN});
-        if (a.add_fmt_adr) fmt.push_back({"ADR", false, nA, &adr[(size_t)i * A * N], 1, sN});
+        if (a.add_fmt_dp) fmt.push_back({"DP", false, 1, &B.dp[(size_t)i * N], 1, sN});
+        if (a.add_gl) fmt.push_back({"GL", true, nG, &B.gl[(size_t)i * G * N], 1, sN});
+        if (a.add_pl) fmt.push_back({"PL", false, nG, &B.pl[(size_t)i * G * N], 1, sN});
+        if (a.add_gp) fmt.push_back({"GP", true, nG, &B.gp[(size_t)i * G * N], 1, sN});
+        if (a.add_fmt_ad) fmt.push_back({"AD", false, nA, &B.ad[(size_t)i * A * N], 1, sN});
+        if (a.add_fmt_adf) fmt.push_back({"ADF", false, nA, &B.adf[(size_t)i * A * N], 1, sN});
+        if (a.add_fmt_adr) fmt.push_back({"ADR", false, nA, &B.adr[(size_t)i * A * N], 1, sN});
     };
-    for (size_t t0 = 0; t0 < sites.size(); t0 += TS) {
-        const int ns = (int)std::min((size_t)TS, sites.size() - t0);
-        for (int i = 0; i < ns; i++) memcpy(&gt_tile[(size_t)i * N], sites[t0 + i].gt.data(), N);
-        if (pile) {
-            // capacity of the per-read dump: the library stages at most read_cap reads; ask generously
-            reads.assign((size_t)pile_cap * ns * N, 0xFF);
-            o.reads = reads.data(); o.read_capacity = pile_cap;
-        }
-        if (want_errp) { errp.resize((size_t)pile_cap * ns * N); o.read_errp = errp.data(); o.read_capacity = pile_cap; }
-        if (dump_pick) { pick.resize(ns); o.site_pick_err = pick.data(); }
-        t_mark = now();
-        if (vgl_simulate_tile(ctx, (int64_t)t0, ns, gt_tile.data(), &o) != VGL_OK) die("%s", vgl_last_error());
-        lap(3);
+    // everything the writer does with one finished tile, in site order (TSV lines, pileup, gVCF blocks, records)
+    auto write_tile = [&](TileBufs& B) {
+        const int ns = B.ns;
         for (int i = 0; i < ns; i++) {
-            const Site& S = sites[t0 + i];
-            if ((dump_pick || dump_reads) && st[i] != VGL_SITE_SKIP_EMPTY && idp[i] > 0) {      // sites that reach the read loop (vcfgl.cpp:396-404)
+            const SiteMeta& S = B.meta[i];
+            if ((dump_pick || dump_reads) && B.st[i] != VGL_SITE_SKIP_EMPTY && B.idp[i] > 0) {      // sites that reach the read loop (vcfgl.cpp:396-404)
                 tsv.clear();
                 char hb[96];
                 if (dump_pick) for (int s = 0; s < N; s++) {                                   // vcfgl.cpp:430-435
-                    tsv += "base_pick_error_prob\t"; tsv += vcf.samples[s]; tsv += '\t'; tsv += S.chrom;
-                    snprintf(hb, sizeof hb, "\t%ld\tNA\t%f\n", S.pos0 + 1, pick[i]); tsv += hb;
+                    tsv += "base_pick_error_prob\t"; tsv += vcf.samples[s]; tsv += '\t'; tsv += S.rec->chrom;
+                    snprintf(hb, sizeof hb, "\t%ld\tNA\t%f\n", S.pos0 + 1, B.pick[i]); tsv += hb;
                 }
                 if (dump_reads) for (int s = 0; s < N; s++) {                                  // vcfgl.cpp:533-554
-                    const int n = dp[(size_t)i * N + s];
+                    const int n = B.dp[(size_t)i * N + s];
                     for (int r = 0; r < n; r++) {
-                        const double ep = errp[((size_t)r * ns + i) * N + s];
+                        const double ep = B.errp[((size_t)r * ns + i) * N + s];
                         int q, aq; host_errprob_to_qs(a, ep, q, aq);
-                        auto head = [&](const char* type) { tsv += type; tsv += '\t'; tsv += vcf.samples[s]; tsv += '\t'; tsv += S.chrom; snprintf(hb, sizeof hb, "\t%ld\t%d\t", S.pos0 + 1, r); tsv += hb; };
+                        auto head = [&](const char* type) { tsv += type; tsv += '\t'; tsv += vcf.samples[s]; tsv += '\t'; tsv += S.rec->chrom; snprintf(hb, sizeof hb, "\t%ld\t%d\t", S.pos0 + 1, r); tsv += hb; };
                         if (a.print_qs_err) { head("qs_error_prob"); snprintf(hb, sizeof hb, "%f\n", ep); tsv += hb; }
                         if (a.print_qscores) { head("qs"); snprintf(hb, sizeof hb, "%d\n", (a.adjust_qs & 8) ? aq : q); tsv += hb; }
                         if (a.print_gl_err) { head("gl_error_prob"); snprintf(hb, sizeof hb, "%f\n", a.precise_gl ? ep : host_qs_to_errprob((a.adjust_qs & 16) ? aq : q)); tsv += hb; }
@@ -993,33 +1060,34 @@ int main(int argc, char** argv) {
                 }
                 fwrite(tsv.data(), 1, tsv.size(), stdout);
             }
-            if (pile && st[i] != VGL_SITE_SKIP_EMPTY) {              // vcfgl.cpp:414-416, 616-634 (printed before skip decisions)
+            if (pile_fp && B.st[i] != VGL_SITE_SKIP_EMPTY) {              // vcfgl.cpp:414-416, 616-634 (printed before skip decisions)
                 line.clear();
                 char hb[64]; snprintf(hb, sizeof hb, "\t%ld\t%c", S.pos0 + 1, S.ref_char);
-                line += S.chrom; line += hb;
+                line += S.rec->chrom; line += hb;
                 for (int s = 0; s < N; s++) {
-                    const int n = dp[(size_t)i * N + s];
+                    const int n = B.dp[(size_t)i * N + s];
                     if (n == 0) { line += "\t0\t*\t*"; continue; }
                     snprintf(hb, sizeof hb, "\t%d\t", n); line += hb;
-                    for (int r = 0; r < n; r++) line += "ACGT"[reads[((size_t)r * ns + i) * N + s] & 3];
+                    for (int r = 0; r < n; r++) line += "ACGT"[B.reads[((size_t)r * ns + i) * N + s] & 3];
                     line += '\t';
-                    if (!(a.adjust_qs & 4)) for (int r = 0; r < n; r++) line += (char)((reads[((size_t)r * ns + i) * N + s] >> 2) + 33);
+                    if (!(a.adjust_qs & 4)) for (int r = 0; r < n; r++) line += (char)((B.reads[((size_t)r * ns + i) * N + s] >> 2) + 33);
                     else if (a.error_qs != 2) line.append((size_t)n, (char)(pre_adjq + 33));                  // PROGRAM_WILL_ADJUST_QS_FOR_PILEUP
-                    else for (int r = 0; r < n; r++) { int q, aq; host_errprob_to_qs(a, errp[((size_t)r * ns + i) * N + s], q, aq); line += (char)(aq + 33); }
+                    else for (int r = 0; r < n; r++) { int q, aq; host_errprob_to_qs(a, B.errp[((size_t)r * ns + i) * N + s], q, aq); line += (char)(aq + 33); }
                 }
                 line += '\n';
-                gzwrite(pile, line.data(), (unsigned)line.size());
+                pile.write(line.data(), line.size());
             }
-            if (st[i] < 0) { n_skipped++; continue; }
+            if (B.st[i] < 0) { n_skipped++; continue; }
             if (!a.do_gvcf) continue;                                    // plain records: encoded in parallel below
-            // gVCF: write_record_values (vcfgl.cpp:167-206) carries the open block from record to record
-            const int nA = na[i];
+            // gVCF: write_record_values (vcfgl.cpp:167-206) carries the open block from record to record (and from tile to
+            // tile, whichever device simulated it)
+            const int nA = B.na[i];
             std::vector<std::string> al; std::vector<vsink::FmtDesc> fmt;
             line.clear();
-            build_record(t0, i, line, al, fmt);
+            build_record(B, i, line, al, fmt);
             SiteView sv;
-            sv.chrom = &S.chrom; sv.pos0 = S.pos0; sv.n_obs = nobs[i]; sv.n_alleles = nA; sv.N = N; sv.G = G;
-            sv.dp = &dp[(size_t)i * N]; sv.pl = &pl[(size_t)i * G * N]; sv.qs = a.add_qs ? &qs[(size_t)i * A] : nullptr;
+            sv.chrom = &S.rec->chrom; sv.pos0 = S.pos0; sv.n_obs = B.nobs[i]; sv.n_alleles = nA; sv.N = N; sv.G = G;
+            sv.dp = &B.dp[(size_t)i * N]; sv.pl = &B.pl[(size_t)i * G * N]; sv.qs = a.add_qs ? &B.qs[(size_t)i * A] : nullptr;
             sv.alleles = al[0]; for (size_t k = 1; k < al.size(); k++) { sv.alleles += ','; sv.alleles += al[k]; }
             int ret = gv.prepare(&sv);
             if (ret == GvcfBlocker::FLUSH_BLOCK) { gv.emit(out, N); n_out++; ret = gv.prepare(&sv); }
@@ -1029,27 +1097,59 @@ int main(int argc, char** argv) {
             enc.resize(ns);
             vsink::parallel_for(ns, enc_threads, [&](int i) {
                 enc[i].clear();
-                if (st[i] < 0) return;
+                if (B.st[i] < 0) return;
                 std::string sh; std::vector<std::string> al; std::vector<vsink::FmtDesc> fmt;
-                build_record(t0, i, sh, al, fmt);
+                build_record(B, i, sh, al, fmt);
                 out.encode_rec(sh, fmt, enc[i]);
             });
             lap(4);
-            for (int i = 0; i < ns; i++) if (st[i] >= 0) { out.put(enc[i]); n_out++; }
+            for (int i = 0; i < ns; i++) if (B.st[i] >= 0) { out.put(enc[i]); n_out++; }
             lap(5);
         }
+    };
+
+    // ---- the tile ring: produce (decode sites, hand the tile to its device) up to R tiles ahead, write in order
+    size_t produced = 0, consumed = 0;
+    bool eof = false;
+    t_mark = now();
+    for (;;) {
+        while (!eof && produced - consumed < (size_t)R) {
+            TileBufs& B = *ring[produced % R];
+            B.ns = 0; B.t0 = (int64_t)n_sites_total; B.done = false; B.dev = (int)(produced % D);
+            while (B.ns < TS && stream.next(&B.gt[(size_t)B.ns * N], B.meta[B.ns])) B.ns++;
+            if (B.ns < TS) eof = true;
+            if (B.ns == 0) break;
+            n_sites_total += (size_t)B.ns;
+            if (pile_fp) { B.reads.assign((size_t)pile_cap * B.ns * N, 0xFF); B.o.reads = B.reads.data(); B.o.read_capacity = pile_cap; }   // capacity of the per-read dump: the library stages at most read_cap reads; ask generously
+            if (want_errp) { B.errp.resize((size_t)pile_cap * B.ns * N); B.o.read_errp = B.errp.data(); B.o.read_capacity = pile_cap; }
+            if (dump_pick) { B.pick.resize(B.ns); B.o.site_pick_err = B.pick.data(); }
+            Worker* W = workers[B.dev].get();
+            { std::lock_guard<std::mutex> lk(W->m); W->q.push_back(&B); }
+            W->cv.notify_one();
+            produced++;
+        }
+        lap(1);
+        if (consumed == produced) break;
+        TileBufs& B = *ring[consumed % R];
+        { std::unique_lock<std::mutex> lk(B.m); B.cv.wait(lk, [&] { return B.done; }); }
+        lap(3);
+        write_tile(B);
+        lap(5);
+        consumed++;
     }
+    for (auto& W : workers) { { std::lock_guard<std::mutex> lk(W->m); W->stop = true; } W->cv.notify_all(); W->th.join(); }
     if (a.do_gvcf && gv.prepare(nullptr) == GvcfBlocker::FLUSH_BLOCK) { gv.emit(out, N); n_out++; }
     t_mark = now();
     out.close();
+    if (a.print_truth) truth_sink.close();
     lap(5);
-    if (pile) gzclose(pile);
-    vgl_ctx_destroy(ctx);
-    if (a.verbose) fprintf(stderr, "\n[timing] read input %.3f s, sites %.3f s, device context %.3f s, simulate (incl. PCIe) %.3f s, encode %.3f s, write/compress %.3f s\n",
+    if (pile_fp) { pile.close(); fclose(pile_fp); }
+    for (vgl_ctx* c : ctxs) vgl_ctx_destroy(c);
+    if (a.verbose) fprintf(stderr, "\n[timing] read input %.3f s, decode sites %.3f s, device context(s) %.3f s, waiting for the device(s) (simulation incl. PCIe, overlapped with the writer) %.3f s, encode %.3f s, write/compress %.3f s\n",
                            t_stage[0], t_stage[1], t_stage[2], t_stage[3], t_stage[4], t_stage[5]);
     char sb[512];
     snprintf(sb, sizeof sb, "\n\n-> Simulation finished successfully.\n\nSummary:\n\tNumber of samples: %d\n\tTotal number of sites simulated: %zu\n"
-                            "\tNumber of sites included in simulation output file: %ld\n\tNumber of sites skipped: %ld\n", N, sites.size(), n_out, n_skipped);
+                            "\tNumber of sites included in simulation output file: %ld\n\tNumber of sites skipped: %ld\n", N, n_sites_total, n_out, n_skipped);
     fputs(sb, stderr);
     std::vector<std::string> files = {"-> Simulation output file: " + a.out_prefix + ext};
     if (a.print_pileup) files.push_back("-> Pileup output file: " + a.out_prefix + ".pileup.gz");
