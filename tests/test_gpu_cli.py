@@ -272,7 +272,7 @@ def test_devices_do_not_change_the_output(case, tmp_path):
         if case == "plain":
             extra += "".join(l for l in open(out + ".truth.vcf") if not l.startswith("##"))
         outs[name] = (body, extra)
-    assert len(outs["one"][0]) > 10
+    assert len(outs["one"][0]) > 5
     assert outs["one"] == outs["two"] == outs["three"]
     r = subprocess.run([BIN, "-o", str(tmp_path / "x"), "-O", "v", "--seed", "42", "--rng-mode", "1", "--devices", "0,0"] + flags, capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "does not shard" in r.stderr                     # the serial draw order is one stream

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 rm -rf gpurun_out/qtr; mkdir -p gpurun_out/qtr
 for g in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $g --output-format csv -d gpurun_out/qtr/$g -- python3 bench.py --sites 131072 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/qtr/$g.log 2>&1
+  rocprofv3 --pmc $g --output-format csv -d gpurun_out/qtr/$g -- python3 bench.py --sites 131072 --steps 1 --warmup 0 --no-cpu-baseline --no-extra --no-pack-rate > gpurun_out/qtr/$g.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, collections

@@ -44,6 +44,11 @@ __device__ __forceinline__ double u01(uint64_t x) {
     // exact for x < 2^48: the 48 bits become the top of the mantissa of 1.xxx (what glibc's erand48 does)
     return __longlong_as_double((long long)(0x3FF0000000000000ULL | (x << 4))) - 1.0;
 }
+// u01(x) - 0.5 in one subtraction: (1 + f) - 1.5 = f - 0.5 is a multiple of 2^-48 in [-0.5, 0.5), so it is exact, like the
+// two exact steps (1 + f) - 1.0 and f - 0.5 of the reference's `sample_uniform() - 0.5` (rng.h:74)
+__device__ __forceinline__ double u01_minus_half(uint64_t x) {
+    return __longlong_as_double((long long)(0x3FF0000000000000ULL | (x << 4))) - 1.5;
+}
 __device__ __forceinline__ double next_u(uint64_t& st) { st = lcg_next(st); return u01(st); }
 
 // gamma_ln, rng.h:38-43,60-64

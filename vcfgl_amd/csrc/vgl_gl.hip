@@ -70,6 +70,8 @@ __global__ __launch_bounds__(256) void k_site(const VglDevParams P, const VglTil
     }
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ float f32_missing() { return __uint_as_float(F32_MISSING_BITS); }
 __device__ __forceinline__ int nib(uint32_t v, int k) { return (int)((v >> (4 * k)) & 0xF); }
@@ -209,8 +211,18 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
                             else if (i < nA) mx = (v > mx) ? v : mx;
                         }
                     }
+                    // acc[i] -= mx, two genotypes per instruction (v_pk_add_f32: an IEEE float32 subtraction per half, the same
+                    // result as NG scalar subtractions)
+                    {
+                        const v2f m2 = {mx, mx};
 #pragma unroll
-                    for (int i = 0; i < NG; ++i) acc[i] -= mx;
+                        for (int i = 0; i + 1 < NG; i += 2) {
+                            v2f a = {acc[i], acc[i + 1]};
+                            a = a - m2;
+                            acc[i] = a.x; acc[i + 1] = a.y;
+                        }
+                        if (NG & 1) acc[NG - 1] -= mx;
+                    }
                 }
             };
             if (__ballot(nA != A) == 0) read_loop(std::true_type{}); else read_loop(std::false_type{});

@@ -71,7 +71,10 @@ __global__ __launch_bounds__(256) void k_depth(const VglDevParams P, const VglTi
 // EQS 2 is built for 4 wavefronts per SIMD (128 VGPRs, 32 spilled into rarely executed fallback code): with 3 the VALU
 // pipes were 86 % busy; the fourth wave hides the dependent f64 chains of the pool loop (+8 % on C3)
 // PREC: --precise-gl 1 with EQS 2 (the exact error probability of every read is staged for k_gl)
-template <int EQS, bool DBG, int DM, bool PREC>
+// LEAN: EQS 2 without per-base quality sums (-addQS / -addI16), strand draws, a per-read dump or --adjust-qs: the default tag
+// surface of the benchmark configurations.  The owners' state those options need (8 quality sums, the forward-strand depths, the
+// dump pointers) is then not carried across the pool loop, where the 128-register build would park it in scratch.
+template <int EQS, bool DBG, int DM, bool PREC, bool LEAN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 4 : 1, EQS == 2 ? 4 : 8))) void k_sample(const VglDevParams P, const VglTilePtrs T) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const WavePos wp = wave_pos(P, T);
@@ -93,6 +96,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
     unsigned long long c_t0 = 0, c_pois = 0, c_owner = 0, c_pool = 0, c_flush = 0, c_iter = 0, c_items = 0, c_tmp = 0;
     if (DBG) c_t0 = clock64();
     uint64_t err_thresh = P.err_thresh;
+    const bool k_strand = LEAN ? false : (P.sample_strand != 0);
+    const bool k_qsum = LEAN ? false : (P.need_qsum != 0);
+    const int k_adj = LEAN ? 0 : P.adjust_qs;
 
     // ---- stream states of this evaluation: J^(off_k) . J^(block*s) . J^(block*N*site) (x0)
     const uint64_t site_abs = (uint64_t)(T.site0 + ls);
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
         const bool stage = (P.gl_model != 1);      // GL model 1 with one fixed qScore needs only the per-base depths
         for (int r = 0; r < dp; ++r) {
             bool fwd;
-            const int r_base = sample_read_base(st_hap, st_base, a0, a1, err_thresh, P.sample_strand != 0, fwd);
+            const int r_base = sample_read_base(st_hap, st_base, a0, a1, err_thresh, k_strand, fwd);
             if (stage) T.reads[(size_t)r * plane + ev] = (uint8_t)((q_gl << 2) | r_base);
             if (T.reads_out && r < T.reads_out_cap) T.reads_out[(size_t)r * plane + ev] = (uint8_t)((q_i << 2) | r_base);
             const uint64_t one = 1ULL << (16 * r_base);
@@ -190,9 +196,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
         // reloads as a whole (v_readlane, VALU work) inside the loops below; the three values the flush
         // loop needs are therefore pinned to vector registers.
         uint8_t* reads_v = T.reads;
-        uint8_t* reads_out_v = T.reads_out;
-        int reads_out_cap_v = T.reads_out ? T.reads_out_cap : 0;
-        asm volatile("" : "+v"(reads_v), "+v"(reads_out_v), "+v"(reads_out_cap_v));
+        uint8_t* reads_out_v = LEAN ? nullptr : T.reads_out;
+        int reads_out_cap_v = (!LEAN && T.reads_out) ? T.reads_out_cap : 0;
+        if (LEAN) asm volatile("" : "+v"(reads_v));
+        else asm volatile("" : "+v"(reads_v), "+v"(reads_out_v), "+v"(reads_out_cap_v));
 
         for (int seg0 = 0; seg0 < total; seg0 += cap) {                 // normally one segment
             const int segT = (total - seg0 < cap) ? (total - seg0) : cap;
@@ -201,10 +208,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
             int r_end = seg0 + segT - offs; r_end = r_end > dp ? dp : r_end; r_end = r_end < rdone ? rdone : r_end;
             for (int r = rdone; r < r_end; ++r) {
                 bool fwd;
-                const int r_base = sample_read_base(st_hap, st_base, a0, a1, err_thresh, P.sample_strand != 0, fwd);
+                const int r_base = sample_read_base(st_hap, st_base, a0, a1, err_thresh, k_strand, fwd);
                 const uint64_t one = 1ULL << (16 * r_base);
                 ad4 += one;
-                if (fwd) adf4 += one;
+                if (!LEAN) { if (fwd) adf4 += one; }
                 const int k = offs + r - seg0;
                 l_it[k] = (uint32_t)((r << 6) | lane);
                 l_pb[k] = (uint8_t)r_base;
@@ -260,7 +267,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     const uint64_t st2 = lcg_next(st1);
                     const uint64_t st3 = lcg_next(st2);
                     const double u = u01(st1);
-                    const double v = 1.7156 * (u01(st2) - 0.5);
+                    const double v = 1.7156 * u01_minus_half(st2);
                     const double x = u - 0.449871;
                     const double y = fabs(v) + 0.386595;
                     const double q = (x * x) + y * (0.19600 * y - 0.25472 * x);
@@ -369,12 +376,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 const int r_base = l_pb[k];
                 const uint32_t qe = l_it[k];
                 const int q_i = (int)(qe & 0xFF);
-                const int aq_i = P.adjust_qs ? (int)((qe >> 8) & 0xFF) : -1;
-                const int q_gl = (P.adjust_qs & 1) ? aq_i : q_i;
+                const int aq_i = k_adj ? (int)((qe >> 8) & 0xFF) : -1;
+                const int q_gl = (k_adj & 1) ? aq_i : q_i;
                 reads_v[(size_t)r * plane + ev] = (uint8_t)((q_gl << 2) | r_base);
-                if (r < reads_out_cap_v) reads_out_v[(size_t)r * plane + ev] = (uint8_t)((q_i << 2) | r_base);
-                if (P.need_qsum) {
-                    const uint32_t qq = (uint32_t)((P.adjust_qs & 2) ? aq_i : q_i);
+                if (!LEAN) { if (r < reads_out_cap_v) reads_out_v[(size_t)r * plane + ev] = (uint8_t)((q_i << 2) | r_base); }
+                if (k_qsum) {
+                    const uint32_t qq = (uint32_t)((k_adj & 2) ? aq_i : q_i);
                     const uint32_t q2 = (uint32_t)qs_to_qssq((int)qq);
                     qs0 += (r_base == 0) ? qq : 0u; qs1 += (r_base == 1) ? qq : 0u;
                     qs2 += (r_base == 2) ? qq : 0u; qs3 += (r_base == 3) ? qq : 0u;
@@ -390,11 +397,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
     }
 
     if (active) {
-        if (!P.sample_strand) adf4 = ad4;
+        if (!k_strand) adf4 = ad4;
         if (T.fmt_dp) T.fmt_dp[ev] = dp;
         T.ad4[ev] = ad4;
-        if (P.need_adf) T.adf4[ev] = adf4;
-        if (P.need_qsum) {
+        if (!LEAN && P.need_adf) T.adf4[ev] = adf4;
+        if (!LEAN && P.need_qsum) {
             uint32_t* q = T.qsum + (size_t)ls * 4 * N + s;
             q[0] = qs0; q[(size_t)N] = qs1; q[(size_t)2 * N] = qs2; q[(size_t)3 * N] = qs3;
             if (P.need_qsumsq) {
@@ -402,7 +409,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 qq[0] = qq0; qq[(size_t)N] = qq1; qq[(size_t)2 * N] = qq2; qq[(size_t)3 * N] = qq3;
             }
         }
-        if (T.reads_out) for (int r = dp; r < T.reads_out_cap; ++r) T.reads_out[(size_t)r * plane + ev] = 0xFF;
+        if (!LEAN && T.reads_out) for (int r = dp; r < T.reads_out_cap; ++r) T.reads_out[(size_t)r * plane + ev] = 0xFF;
     }
 
     // ---- per-site sums: wave reduction, one atomic per wave and counter
@@ -445,17 +452,18 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
     const size_t lds = (size_t)wpb * p->pool_lds_bytes;
     hipStream_t s = (hipStream_t)stream;
     const int dm = p->depth_pre;                                  // 0 mixed / 1 k_depth / 2 product method only
-#define VGL_LAUNCH_SAMPLE(EQS, DBG, PREC, LDS) \
-    do { if (dm == 1) hipLaunchKernelGGL((k_sample<EQS, DBG, 1, PREC>), g, b, LDS, s, *p, *t); \
-         else if (dm == 2) hipLaunchKernelGGL((k_sample<EQS, DBG, 2, PREC>), g, b, LDS, s, *p, *t); \
-         else hipLaunchKernelGGL((k_sample<EQS, DBG, 0, PREC>), g, b, LDS, s, *p, *t); } while (0)
+#define VGL_LAUNCH_SAMPLE(EQS, DBG, PREC, LEAN, LDS) \
+    do { if (dm == 1) hipLaunchKernelGGL((k_sample<EQS, DBG, 1, PREC, LEAN>), g, b, LDS, s, *p, *t); \
+         else if (dm == 2) hipLaunchKernelGGL((k_sample<EQS, DBG, 2, PREC, LEAN>), g, b, LDS, s, *p, *t); \
+         else hipLaunchKernelGGL((k_sample<EQS, DBG, 0, PREC, LEAN>), g, b, LDS, s, *p, *t); } while (0)
+    const bool lean = !p->need_qsum && !p->sample_strand && !p->need_adf && !t->reads_out && p->adjust_qs == 0 && !getenv("VGL_NO_LEAN");
     if (p->error_qs == 2) {
-        if (dbg && !t->errp) VGL_LAUNCH_SAMPLE(2, true, false, lds);   // diagnostic build: --precise-gl 0 only
-        else if (t->errp) VGL_LAUNCH_SAMPLE(2, false, true, lds);     // --precise-gl 1, or the deviates were asked for
-        else VGL_LAUNCH_SAMPLE(2, false, false, lds);
+        if (dbg && !t->errp) VGL_LAUNCH_SAMPLE(2, true, false, false, lds);   // diagnostic build: --precise-gl 0 only
+        else if (t->errp) { if (lean) VGL_LAUNCH_SAMPLE(2, false, true, true, lds); else VGL_LAUNCH_SAMPLE(2, false, true, false, lds); }   // --precise-gl 1, or the deviates were asked for
+        else { if (lean) VGL_LAUNCH_SAMPLE(2, false, false, true, lds); else VGL_LAUNCH_SAMPLE(2, false, false, false, lds); }
     }
-    else if (p->error_qs == 1) VGL_LAUNCH_SAMPLE(1, false, false, 0);
-    else VGL_LAUNCH_SAMPLE(0, false, false, 0);
+    else if (p->error_qs == 1) VGL_LAUNCH_SAMPLE(1, false, false, false, 0);
+    else VGL_LAUNCH_SAMPLE(0, false, false, false, 0);
 #undef VGL_LAUNCH_SAMPLE
     return (int)hipGetLastError();
 }
