@@ -337,26 +337,60 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
 
 
 def host_path_rate(opt, env):
-    """PCIe-inclusive rate of the host-buffer entry point vgl_simulate_tile (pinned double-buffered staging inside the
-    library): never the bench value, reported beside it."""
+    """PCIe-inclusive rate of the host-buffer entry points (vgl_simulate_tile_async / vgl_tile_wait: page-locked destination
+    buffers, two tiles in flight, the copies of one tile beside the kernels of the next): never the bench value, reported
+    beside it.  The synchronous call on ordinary numpy buffers is timed too."""
+    import ctypes as C
     import numpy as np
     import synth
-    from vcfgl_amd import Simulator
+    from vcfgl_amd import Simulator, _abi
     args = workload_args("c3")
-    N, TS, tiles = 1000, 16384, 6
+    N, TS, tiles = 1000, 16384, 8
     sim = Simulator(args, N, device=env["local_dev"], max_sites_per_tile=TS)
+    lib = sim.lib
     gts = [synth.binary_sites(k * TS, TS, N) for k in range(2)]
-    fields = ["fmt_dp", "gl"]
-    tile = sim.new_tile(TS, fields=fields)
-    sim._check(sim.lib.vgl_simulate_tile(sim.ctx, 0, TS, gts[0].ctypes.data, tile.byref()))
-    t0 = time.perf_counter()
-    for k in range(tiles):
-        sim._check(sim.lib.vgl_simulate_tile(sim.ctx, k * TS, TS, gts[k & 1].ctypes.data, tile.byref()))
-    dt = time.perf_counter() - t0
-    sim.close()
     b = 4 + 4 * sim.G
+    # ---- page-locked destination buffers, two sets
+    sets = []
+    for _ in range(2):
+        t = _abi.TileOut()
+        keep = {}
+        for name, nbytes in (("site_status", TS * 4), ("n_alleles", TS * 4), ("alleles2acgt", TS * 5), ("fmt_dp", TS * N * 4), ("gl", TS * sim.G * N * 4)):
+            ptr = lib.vgl_host_alloc(nbytes)
+            assert ptr, lib.vgl_last_error()
+            keep[name] = ptr
+            setattr(t, name, ptr)
+        sets.append((t, keep))
+    tick = [C.c_int32(), C.c_int32()]
+
+    def run(n_tiles):
+        pending = None
+        for k in range(n_tiles):
+            sim._check(lib.vgl_simulate_tile_async(sim.ctx, k * TS, TS, gts[k & 1].ctypes.data, C.byref(sets[k & 1][0]), C.byref(tick[k & 1])))
+            if pending is not None:
+                sim._check(lib.vgl_tile_wait(sim.ctx, tick[pending]))
+            pending = k & 1
+        sim._check(lib.vgl_tile_wait(sim.ctx, tick[pending]))
+
+    run(2)
+    t0 = time.perf_counter(); run(tiles); dt = time.perf_counter() - t0
+    dp_sum = int(np.ctypeslib.as_array(C.cast(sets[(tiles - 1) & 1][1]["fmt_dp"], C.POINTER(C.c_int32)), shape=(TS * N,)).sum())
+    for _, keep in sets:
+        for ptr in keep.values():
+            lib.vgl_host_free(ptr)
+    # ---- the synchronous call on pageable numpy buffers
+    tile = sim.new_tile(TS, fields=["fmt_dp", "gl"])
+    sim._check(lib.vgl_simulate_tile(sim.ctx, 0, TS, gts[0].ctypes.data, tile.byref()))
+    t0 = time.perf_counter()
+    for k in range(3):
+        sim._check(lib.vgl_simulate_tile(sim.ctx, k * TS, TS, gts[k & 1].ctypes.data, tile.byref()))
+    dts = time.perf_counter() - t0
+    sim.close()
     return {"value": tiles * TS * N / dt, "unit": "site-sample GL evals/s", "GBps_over_pcie": tiles * TS * N * b / dt / 1e9,
-            "note": f"vgl_simulate_tile, host numpy buffers, {tiles} tiles of {TS} sites x {N} samples, GL+DP copied back; PCIe-inclusive, never the bench value"}
+            "mean_depth_check": dp_sum / (TS * N),
+            "sync_pageable": {"value": 3 * TS * N / dts, "GBps_over_pcie": 3 * TS * N * b / dts / 1e9},
+            "note": f"vgl_simulate_tile_async + vgl_tile_wait, page-locked host buffers, two tiles in flight, {tiles} tiles of {TS} sites x {N} samples, "
+                    "GL+DP copied back (64 B per evaluation); PCIe-inclusive, never the bench value"}
 
 
 def main():

@@ -44,7 +44,7 @@ extern "C" {
 #define VGL_E_NODEVICE     (-2)  /* no HIP device / HIP runtime error                            */
 #define VGL_E_NOMEM        (-3)  /* allocation failure                                           */
 #define VGL_E_CAPACITY     (-4)  /* a per-sample read depth exceeded the staging capacity        */
-#define VGL_E_UNSUPPORTED  (-5)  /* flag combination not implemented on the device path          */
+#define VGL_E_UNSUPPORTED  (-5)  /* flag combination not implemented on the device path (the mt19937 beta sampler in VGL_RNG_TILE) */
 #define VGL_E_QSBIN        (-6)  /* "Could not find a range for qs value" (vcfgl.cpp:63)         */
 #define VGL_E_ADJQ         (-7)  /* --adjust-qs 1|2 met a read without a valid adjusted quality score: error probability
                                     exactly 0 or 1, or a negative adjusted score (the reference exits on
@@ -200,6 +200,18 @@ int vgl_ctx_destroy(vgl_ctx* ctx);
  * Host variant: `gt` and every pointer in `out` are host memory; the call is synchronous. */
 int vgl_simulate_tile(vgl_ctx* ctx, int64_t site0, int32_t n_sites,
                       const uint8_t* gt, vgl_tile_out* out);
+
+/* Asynchronous host variant (the tags of a tile are 65 B per evaluation and must stream over PCIe while the next
+ * tile is computed).  vgl_simulate_tile_async() enqueues the tile -- its kernels on the context's compute stream, the copies of
+ * its outputs into the caller's host buffers on a second stream behind them -- and returns a ticket; vgl_tile_wait(ticket)
+ * returns once the outputs are complete (and reports the tile's device-side errors, like the synchronous call).  At most two
+ * tiles may be in flight per context, submitted in site order; the buffers of an in-flight tile must not be touched.
+ * Buffers obtained from vgl_host_alloc() are page-locked and are written by DMA at the link's rate; ordinary (pageable)
+ * buffers work too, more slowly.  vgl_simulate_tile() is the two calls back to back. */
+int   vgl_simulate_tile_async(vgl_ctx* ctx, int64_t site0, int32_t n_sites, const uint8_t* gt, vgl_tile_out* out, int32_t* ticket);
+int   vgl_tile_wait(vgl_ctx* ctx, int32_t ticket);
+void* vgl_host_alloc(size_t bytes);            /* page-locked host memory (NULL on failure); needs a HIP device */
+void  vgl_host_free(void* p);
 
 /* Device variant: `gt` and every pointer in `out` are device memory owned by the caller
  * (hipMalloc / a torch tensor's data_ptr); work is enqueued on `hip_stream` (a hipStream_t

@@ -316,16 +316,32 @@ static int cmp_u16(const void* a, const void* b) {
     return (int)*(const uint16_t*)a - (int)*(const uint16_t*)b;
 }
 
+/* htslib draws the shuffle of errmod_cal() from its OWN rand48 generator (hts_drand48, hts_os.c / os/rand.c: the drand48
+ * family restated for platforms that lack it, used on every platform), which no caller seeds: state {0x330e, 0xabcd, 0x1234},
+ * i.e. X0 = 0x1234ABCD330E, the same multiplier and increment as rand48.  The stream is process-wide: every errmod_cal() call
+ * with n > 255 continues it.  vcfgl's --seed does not reach it. */
+#define HTS_RAND48_X0 0x1234ABCD330EULL
+/* draws of that stream one evaluation owns in VGL_RNG_TILE mode: evaluation e starts at draw e * VGL_HTS_TILE_STRIDE */
+#define VGL_HTS_TILE_STRIDE 1024ULL
+
+/* ks_shuffle(uint16_t, n, a) of htslib's ksort.h: for (i = n; i > 1; --i) { j = (int)(hts_drand48() * i); swap(a[j], a[i-1]); } */
+static void ks_shuffle_u16(int n, uint16_t* a, uint64_t* st) {
+    for (int i = n; i > 1; --i) {
+        const int j = (int)(lcg_uniform(st) * i);
+        const uint16_t tmp = a[j]; a[j] = a[i - 1]; a[i - 1] = tmp;
+    }
+}
+
 /* errmod_cal(em, n, m=5, bases, q): bases[i] = qual<<5 | strand<<4 | base.
- * Returns -1 for n > 255 (htslib then subsamples with ks_shuffle/drand48: not restated). */
-static int errmod_cal5(const errmod_t* em, int n, uint16_t* bases, float* q) {
+ * n > 255: "if we exceed 255 bases, shuffle them to sample at random" -- ks_shuffle on `hts`, then the first 255. */
+static int errmod_cal5(const errmod_t* em, int n, uint16_t* bases, float* q, uint64_t* hts) {
     const int m = 5;
     double fsum[16], bsum[16];
     uint32_t c[16];
     int w[32];
     memset(q, 0, m * m * sizeof(float));
     if (n == 0) return 0;
-    if (n > 255) return -1;
+    if (n > 255) { ks_shuffle_u16(n, bases, hts); n = 255; }
     qsort(bases, n, sizeof(uint16_t), cmp_u16);
     memset(w, 0, sizeof w); memset(fsum, 0, sizeof fsum); memset(bsum, 0, sizeof bsum); memset(c, 0, sizeof c);
     for (int j = n - 1; j >= 0; --j) {
@@ -365,7 +381,8 @@ int vgl_oracle_errmod_cal(double depcorr, int n, const uint16_t* bases, float* q
     if (!em) return -3;
     uint16_t* tmp = (uint16_t*)malloc(sizeof(uint16_t) * (n > 0 ? n : 1));
     memcpy(tmp, bases, sizeof(uint16_t) * n);
-    int r = errmod_cal5(em, n, tmp, q25);
+    uint64_t hts = HTS_RAND48_X0;
+    int r = errmod_cal5(em, n, tmp, q25, &hts);
     free(tmp); errmod_free(em);
     return r;
 }
@@ -385,6 +402,7 @@ typedef struct vgl_oracle {
     mt19937_t mt;
     /* serial-mode stream states: rng0 (drand48), rng1, rng2 */
     uint64_t x0, st0, st1, st2;
+    uint64_t st_hts;           /* htslib's private rand48 stream (hts_drand48, default seed): ks_shuffle of errmod_cal at depth > 255 */
     /* preCalc (vcfgl.cpp:1661-1743) */
     int pre_q, pre_adjq;
     double pre_homT, pre_het, pre_homF;
@@ -505,6 +523,7 @@ int vgl_oracle_create(const vgl_params* p, vgl_oracle** out) {
     }
     o->x0 = vgl_oracle_rand48_seed(p->seed);
     o->st0 = o->st1 = o->st2 = o->x0;
+    o->st_hts = HTS_RAND48_X0;
     srand(1);                            /* the reference never seeds rand() (rng.h:12) */
 
     o->pre_q = o->pre_adjq = -1;
@@ -600,17 +619,25 @@ static void gl2_sample(const vgl_oracle* o, int s, int n, const int* acgt2allele
 }
 
 /* GL model 1, one sample: gl_methods.cpp:256-290 / :325-357 */
-static int gl1_sample(const vgl_oracle* o, int s, int n, const int* alleles2acgt, int nAlleles, float* g) {
+static int gl1_sample(vgl_oracle* o, int64_t site_abs, int s, int n, const int* alleles2acgt, int nAlleles, float* g) {
     const vgl_params* p = &o->p;
-    uint16_t ub[256]; float fpls[25];
-    if (n > 255) OFAIL(VGL_E_UNSUPPORTED, "GL model 1 with depth > 255 (htslib subsamples with drand48): not restated");
+    uint16_t* ub = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)(n > 0 ? n : 1)); float fpls[25];
+    if (!ub) OFAIL(VGL_E_NOMEM, "out of memory");
     for (int i = 0; i < n; i++) {
         int qs;
         if (p->error_qs == 2) qs = (p->adjust_qs & 1) ? o->adjq[(size_t)s * o->cap + i] : o->qsc[(size_t)s * o->cap + i];
         else qs = (p->adjust_qs & 1) ? o->pre_adjq : o->pre_q;
         ub[i] = (uint16_t)(qs << 5 | o->bases[(size_t)s * o->cap + i]);
     }
-    errmod_cal5(o->em, n, ub, fpls);
+    /* the shuffle stream of depth > 255: the process-wide stream in serial mode; a per-evaluation window of it in tile mode */
+    uint64_t hts_local, *hts = &o->st_hts;
+    if (p->rng_mode == VGL_RNG_TILE) {
+        const uint64_t e = (uint64_t)site_abs * (uint64_t)p->n_samples + (uint64_t)s;
+        hts_local = vgl_oracle_rand48_jump(HTS_RAND48_X0, e * VGL_HTS_TILE_STRIDE);
+        hts = &hts_local;
+    }
+    errmod_cal5(o->em, n, ub, fpls, hts);
+    free(ub);
     float max = -INFINITY; int gi = 0;
     for (int a2 = 0; a2 < nAlleles; ++a2) {
         int b2 = alleles2acgt[a2];
@@ -778,7 +805,7 @@ static int simulate_site(vgl_oracle* o, int64_t site_abs, int32_t ls, int32_t n_
         float* g = gl + (size_t)s * 15;
         if (0 == dp[s]) { for (int i = 0; i < nG; i++) g[i] = MISS; continue; }
         if (p->gl_model == 2) gl2_sample(o, s, dp[s], acgt2alleles, nAlleles, nG, g);
-        else if ((rc = gl1_sample(o, s, dp[s], alleles2acgt, nAlleles, g))) goto done;
+        else if ((rc = gl1_sample(o, site_abs, s, dp[s], alleles2acgt, nAlleles, g))) goto done;
     }
 
 write_site:

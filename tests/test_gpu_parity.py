@@ -399,3 +399,91 @@ def test_rng_period_guard():
         sim.simulate(mx.value - 1, gt, fields=["fmt_dp"])
     assert e.value.code == _abi.VGL_E_ARG and "2^48" in str(e.value)
     sim.close()
+
+
+@pytest.mark.parametrize("mode", [_abi.VGL_RNG_TILE, _abi.VGL_RNG_SERIAL])
+@pytest.mark.parametrize("eqs", [0, 2])
+def test_gl1_deeper_than_255_reads(oracle, mode, eqs):
+    """GL model 1 at depth > 255 (--depth goes to 500): htslib's errmod_cal() shuffles the pileup with ks_shuffle on its own
+    never-seeded rand48 stream (hts_drand48) and keeps the first 255 reads.  Samples below and above the limit mixed; in
+    serial mode that stream runs on from evaluation to evaluation and from tile to tile."""
+    depths = [300.0, 10.0, 262.0, 248.0, 420.0, 0.5, 256.0]
+    N, S = len(depths), 11
+    args = VcfglArgs(seed=42, depths=depths, error_rate=0.02, gl_model=1, error_qs=eqs, beta_variance=(1e-4 if eqs else -1.0),
+                     add_pl=1, add_fmt_ad=1, rm_invar_sites=0)
+    args.rng_mode = mode
+    args.beta_sampler = _abi.VGL_BETA_STD if mode == _abi.VGL_RNG_SERIAL else _abi.VGL_BETA_RAND48
+    gt = synth.acgt_sites(S, N, seed=5)
+    fields = ["site_status", "n_alleles", "alleles2acgt", "fmt_dp", "fmt_ad", "gl", "pl"]
+    want = oracle.Oracle(args, N).simulate(0, gt, fields=fields)
+    sim = Simulator(args, N, device=0, max_sites_per_tile=4)
+    parts = [sim.simulate(s0, gt[s0:s0 + 4], fields=fields) for s0 in range(0, S, 4)]          # three tiles
+    sim.close()
+    assert int(want.numpy("fmt_dp").max()) > 400 and int((want.numpy("fmt_dp") > 255).sum()) > 20
+    for f in fields:
+        got = np.concatenate([p.numpy(f) for p in parts], axis=0)
+        w = want.numpy(f)
+        assert np.array_equal(got.view(np.uint32) if got.dtype == np.float32 else got, w.view(np.uint32) if w.dtype == np.float32 else w), f
+
+
+def test_async_host_path_two_tiles_in_flight(oracle):
+    """vgl_simulate_tile_async / vgl_tile_wait: page-locked destination buffers, two tiles in flight -- the same
+    bytes as the synchronous call and as the oracle; a third submission without a wait is refused, a qs-bin miss is reported
+    by the wait of the tile it happened in."""
+    import ctypes as C
+    args = VcfglArgs(seed=42, depth=9, error_rate=0.01, error_qs=2, beta_variance=1e-5, add_pl=1)
+    args.rng_mode, args.beta_sampler = _abi.VGL_RNG_TILE, _abi.VGL_BETA_RAND48
+    N, TS, n_tiles = 130, 64, 5
+    sim = Simulator(args, N, device=0, max_sites_per_tile=TS)
+    lib = sim.lib
+    shapes = {"site_status": (TS,), "n_alleles": (TS,), "alleles2acgt": (TS, 5), "fmt_dp": (TS, N), "gl": (TS, sim.G, N), "pl": (TS, sim.G, N)}
+    dt = {"site_status": np.int32, "n_alleles": np.int32, "alleles2acgt": np.int8, "fmt_dp": np.int32, "gl": np.float32, "pl": np.int32}
+    sets = []
+    for _ in range(2):
+        t, arrs, ptrs = _abi.TileOut(), {}, []
+        for f, shp in shapes.items():
+            nbytes = int(np.prod(shp)) * np.dtype(dt[f]).itemsize
+            p = lib.vgl_host_alloc(nbytes)
+            assert p
+            ptrs.append(p)
+            arrs[f] = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(nbytes,)).view(dt[f]).reshape(shp)
+            setattr(t, f, p)
+        sets.append((t, arrs, ptrs))
+    gts = [synth.binary_sites(k * TS, TS, N) for k in range(n_tiles)]
+    ticks = [C.c_int32(), C.c_int32()]
+    got, pending = [], None
+    for k in range(n_tiles):
+        sim._check(lib.vgl_simulate_tile_async(sim.ctx, k * TS, TS, gts[k].ctypes.data, C.byref(sets[k & 1][0]), C.byref(ticks[k & 1])))
+        if pending is not None:
+            sim._check(lib.vgl_tile_wait(sim.ctx, ticks[pending & 1]))
+            got.append({f: a.copy() for f, a in sets[pending & 1][1].items()})
+        pending = k
+    sim._check(lib.vgl_tile_wait(sim.ctx, ticks[pending & 1]))
+    got.append({f: a.copy() for f, a in sets[pending & 1][1].items()})
+    assert lib.vgl_tile_wait(sim.ctx, 0) == _abi.VGL_E_ARG      # nothing in flight any more
+    t3 = [C.c_int32() for _ in range(3)]                        # two in flight is the limit: the third submission is refused
+    assert lib.vgl_simulate_tile_async(sim.ctx, 0, TS, gts[0].ctypes.data, C.byref(sets[0][0]), C.byref(t3[0])) == 0
+    assert lib.vgl_simulate_tile_async(sim.ctx, TS, TS, gts[1].ctypes.data, C.byref(sets[1][0]), C.byref(t3[1])) == 0
+    assert lib.vgl_simulate_tile_async(sim.ctx, 2 * TS, TS, gts[2].ctypes.data, C.byref(sets[0][0]), C.byref(t3[2])) == _abi.VGL_E_ARG
+    assert lib.vgl_tile_wait(sim.ctx, t3[0]) == 0 and lib.vgl_tile_wait(sim.ctx, t3[1]) == 0
+    orc = oracle.Oracle(args, N)
+    for k in range(n_tiles):
+        want = orc.simulate(k * TS, gts[k], fields=list(shapes))
+        sync = sim.simulate(k * TS, gts[k], fields=list(shapes))
+        for f in shapes:
+            w, g, s2 = want.numpy(f), got[k][f], sync.numpy(f)
+            v = lambda x: x.view(np.uint32) if x.dtype == np.float32 else x
+            assert np.array_equal(v(w), v(g)) and np.array_equal(v(w), v(s2)), (k, f)
+    for _, _, ptrs in sets:
+        for p in ptrs:
+            lib.vgl_host_free(p)
+    sim.close()
+    # a tile whose simulated quality scores fall outside --qs-bins: reported by that tile's wait, and only by it
+    bad = VcfglArgs(seed=42, depth=9, error_rate=0.01, error_qs=2, beta_variance=1e-5, qs_bins=[(0, 5, 3)])
+    bad.rng_mode, bad.beta_sampler = _abi.VGL_RNG_TILE, _abi.VGL_BETA_RAND48
+    sim = Simulator(bad, N, device=0, max_sites_per_tile=TS)
+    tile = sim.new_tile(TS, fields=["fmt_dp"])
+    tk = C.c_int32()
+    sim._check(lib.vgl_simulate_tile_async(sim.ctx, 0, TS, gts[0].ctypes.data, tile.byref(), C.byref(tk)))
+    assert lib.vgl_tile_wait(sim.ctx, tk) == _abi.VGL_E_QSBIN
+    sim.close()

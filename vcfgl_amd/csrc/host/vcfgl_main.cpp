@@ -631,6 +631,24 @@ struct SiteStream {
     }
 };
 
+// page-locked host array (vgl_host_alloc): grows, never shrinks
+template <class T> struct PBuf {
+    T* p = nullptr; size_t n = 0;
+    void resize(size_t m) {
+        if (m <= n) return;
+        if (p) vgl_host_free(p);
+        p = (T*)vgl_host_alloc(m * sizeof(T));
+        if (!p) die("%s", vgl_last_error());
+        n = m;
+    }
+    T* data() { return p; }
+    const T* data() const { return p; }
+    T& operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
+    PBuf() = default; PBuf(const PBuf&) = delete; PBuf& operator=(const PBuf&) = delete;
+    ~PBuf() { if (p) vgl_host_free(p); }
+};
+
 // ---------------------------------------------------------------------------------------
 // gVCF blocks: prepare_gvcf_block(), bcf_utils.cpp:662-942.  Invariant records (one observed
 // allele) whose minimum per-sample depth falls in the same --gvcf-dps range are merged into one
@@ -945,9 +963,11 @@ int main(int argc, char** argv) {
     const bool want_dp = a.add_fmt_dp || a.do_gvcf || pile_fp || dump_reads;
     struct TileBufs {
         int ns = 0; int64_t t0 = 0; int dev = 0;
-        std::vector<SiteMeta> meta; std::vector<uint8_t> gt, reads;
-        std::vector<int32_t> st, na, nobs, idp, iad, iadf, iadr, dp, pl, ad, adf, adr;
-        std::vector<int8_t> a2b; std::vector<float> qs, i16, gl, gp; std::vector<double> errp, pick;
+        std::vector<SiteMeta> meta; std::vector<uint8_t> gt;
+        // outputs live in page-locked memory (vgl_host_alloc): the device writes them by DMA while the next tile is computed
+        PBuf<uint8_t> reads;
+        PBuf<int32_t> st, na, nobs, idp, iad, iadf, iadr, dp, pl, ad, adf, adr;
+        PBuf<int8_t> a2b; PBuf<float> qs, i16, gl, gp; PBuf<double> errp, pick;
         vgl_tile_out o;
         std::mutex m; std::condition_variable cv; bool done = false;
     };
@@ -983,12 +1003,25 @@ int main(int argc, char** argv) {
         Worker* W = workers[d].get();
         vgl_ctx* ctx = ctxs[d];
         W->th = std::thread([W, ctx]() {
+            // a tile is submitted (vgl_simulate_tile_async) before the previous one is waited for: its kernels run while the
+            // previous tile's tags are still on their way to the host
+            TileBufs* prev = nullptr; int32_t prev_ticket = 0;
             for (;;) {
                 TileBufs* B = nullptr;
-                { std::unique_lock<std::mutex> lk(W->m); W->cv.wait(lk, [&] { return W->stop || W->head < W->q.size(); }); if (W->head == W->q.size()) return; B = W->q[W->head++]; }
-                if (vgl_simulate_tile(ctx, B->t0, B->ns, B->gt.data(), &B->o) != VGL_OK) die("%s", vgl_last_error());
-                { std::lock_guard<std::mutex> lk(B->m); B->done = true; }
-                B->cv.notify_all();
+                {
+                    std::unique_lock<std::mutex> lk(W->m);
+                    if (!prev) W->cv.wait(lk, [&] { return W->stop || W->head < W->q.size(); });
+                    if (W->head < W->q.size()) B = W->q[W->head++];
+                    else if (!prev) return;
+                }
+                int32_t ticket = 0;
+                if (B && vgl_simulate_tile_async(ctx, B->t0, B->ns, B->gt.data(), &B->o, &ticket) != VGL_OK) die("%s", vgl_last_error());
+                if (prev) {
+                    if (vgl_tile_wait(ctx, prev_ticket) != VGL_OK) die("%s", vgl_last_error());
+                    { std::lock_guard<std::mutex> lk(prev->m); prev->done = true; }
+                    prev->cv.notify_all();
+                }
+                prev = B; prev_ticket = ticket;
             }
         });
     }
@@ -1120,9 +1153,9 @@ int main(int argc, char** argv) {
             if (B.ns < TS) eof = true;
             if (B.ns == 0) break;
             n_sites_total += (size_t)B.ns;
-            if (pile_fp) { B.reads.assign((size_t)pile_cap * B.ns * N, 0xFF); B.o.reads = B.reads.data(); B.o.read_capacity = pile_cap; }   // capacity of the per-read dump: the library stages at most read_cap reads; ask generously
-            if (want_errp) { B.errp.resize((size_t)pile_cap * B.ns * N); B.o.read_errp = B.errp.data(); B.o.read_capacity = pile_cap; }
-            if (dump_pick) { B.pick.resize(B.ns); B.o.site_pick_err = B.pick.data(); }
+            if (pile_fp) { B.reads.resize((size_t)pile_cap * TS * N); memset(B.reads.data(), 0xFF, (size_t)pile_cap * B.ns * N); B.o.reads = B.reads.data(); B.o.read_capacity = pile_cap; }   // capacity of the per-read dump: the library stages at most read_cap reads; ask generously
+            if (want_errp) { B.errp.resize((size_t)pile_cap * TS * N); B.o.read_errp = B.errp.data(); B.o.read_capacity = pile_cap; }
+            if (dump_pick) { B.pick.resize(TS); B.o.site_pick_err = B.pick.data(); }
             Worker* W = workers[B.dev].get();
             { std::lock_guard<std::mutex> lk(W->m); W->q.push_back(&B); }
             W->cv.notify_one();

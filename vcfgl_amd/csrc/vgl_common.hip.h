@@ -40,6 +40,17 @@
 // rand48: X <- (A X + C) mod 2^48, u = X 2^-48   (glibc drand48/erand48; rng.h:8-10)
 __device__ __forceinline__ uint64_t lcg_next(uint64_t x) { return (x * VGL_LCG_A + VGL_LCG_C) & VGL_MASK48; }
 __device__ __forceinline__ uint64_t aff(const VglAffine m, uint64_t x) { return (m.a * x + m.c) & VGL_MASK48; }
+// state after n more steps (square-and-multiply on the affine map); rare paths only
+static __device__ uint64_t rand48_jump(uint64_t st, uint64_t n) {
+    uint64_t a = VGL_LCG_A, c = VGL_LCG_C, ra = 1, rc = 0;
+    while (n) {
+        if (n & 1) { ra = (ra * a) & VGL_MASK48; rc = (rc * a + c) & VGL_MASK48; }
+        c = ((a + 1) * c) & VGL_MASK48;
+        a = (a * a) & VGL_MASK48;
+        n >>= 1;
+    }
+    return (ra * st + rc) & VGL_MASK48;
+}
 __device__ __forceinline__ double u01(uint64_t x) {
     // exact for x < 2^48: the 48 bits become the top of the mantissa of 1.xxx (what glibc's erand48 does)
     return __longlong_as_double((long long)(0x3FF0000000000000ULL | (x << 4))) - 1.0;

@@ -9,6 +9,10 @@
 #define VGL_WAVE   64
 #define VGL_MAX_QS_BINS 32
 #define VGL_DEPTH_CHUNK 1024     // evaluations dealt to one wavefront of k_depth
+// htslib's errmod_cal() subsamples a pileup deeper than 255 reads with ks_shuffle() on htslib's OWN rand48 generator
+// (hts_drand48: never seeded by its callers, state {0x330e, 0xabcd, 0x1234}); GL model 1 reaches it with --depth > ~200
+#define VGL_HTS_RAND48_X0 0x1234ABCD330EULL
+#define VGL_HTS_TILE_STRIDE 1024ULL   // VGL_RNG_TILE: evaluation e owns draws [e * 1024, (e + 1) * 1024) of that stream
 
 // x -> a*x + c (mod 2^48): a power of the rand48 step
 struct VglAffine { uint64_t a, c; };
@@ -50,6 +54,8 @@ struct VglDevParams {
     int32_t rm_invar_sites, rm_empty_sites, sample_strand, per_sample_depth;
     int32_t need_qsum, need_qsumsq, need_adf, i16_mapq;
     int32_t add_i16;
+    int32_t gl1_deep;        // GL model 1 and the staging capacity exceeds 255 reads: reads are staged (also with one fixed
+                             // quality score) so that k_gl can subsample a deep evaluation the way errmod_cal() does
     int32_t serial;          // VGL_RNG_SERIAL
     int32_t scout_lds_bytes; // dynamic LDS of k_scout_wave (9 bytes per sample when the site fits)
     int32_t beta_std;        // VGL_BETA_STD (serial only)
@@ -129,6 +135,8 @@ struct VglTilePtrs {
     uint64_t* site_thresh;   // [n_sites] per-site base-pick error threshold (error_qs 1)
     int32_t*  scout_off;     // [N] scratch of the scout: first read index of each sample
     VglSiteTail* site_tail;  // [n_sites] (serial mode with -addI16)
+    const long long* hts_off; // [n_sites][N] serial mode, GL model 1 deeper than 255: first draw of an evaluation's shuffle in htslib's stream
+    const uint64_t* hts_base; // [1] state of that stream at the start of the tile (serial mode)
     const long long* roff;   // [n_sites][N] index of an evaluation's first read in draw order (serial --error-qs 2, std beta)
     const double* errp_lin;  // [reads of the tile] beta deviates in draw order (vgl_betachain.hip)
 };
@@ -153,6 +161,7 @@ struct VglSerialState {
     int32_t  rand_f, rand_r; // glibc rand() (TYPE_3 additive feedback, degree 31, separation 3)
     uint32_t rand_state[31]; // the reference draws I16 tail distances from the never-seeded rand() (rng.h:12)
     int32_t  pad;
+    uint64_t st_hts;         // htslib's private rand48 stream (hts_drand48), consumed by errmod_cal()'s shuffle at depth > 255
 };
 
 
@@ -166,6 +175,7 @@ int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, void* stream)
 int vgl_launch_site(const VglDevParams* p, const VglTilePtrs* t, void* stream);
 int vgl_launch_gl(const VglDevParams* p, const VglTilePtrs* t, void* stream);
 int vgl_launch_siteagg(const VglDevParams* p, const VglTilePtrs* t, void* stream);
+int vgl_launch_hts_offsets(const VglDevParams* p, const VglTilePtrs* t, struct VglSerialState* st, long long* hts_off, uint64_t* hts_base, void* stream);
 int vgl_launch_scout(const VglDevParams* p, const VglTilePtrs* t, struct VglSerialState* st, void* stream);
 int vgl_launch_sample_serial(const VglDevParams* p, const VglTilePtrs* t, void* stream);
 // vgl_betachain.hip

@@ -230,11 +230,30 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
             // GL model 1 with one fixed qScore: errmod_cal() reduces to table lookups on the
             // per-base depths (gl_methods.cpp:304-369; htslib errmod.c restated in vgl_host.cpp)
             int n = dp;
-            if (n > 255) { atomicOr(T.errflag, VGL_DEVERR_GL1DEPTH); n = 255; }
             int c[5]; double bs[5];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) { c[b] = (int)((ad4 >> (16 * b)) & 0xFFFF); if (c[b] > 255) c[b] = 255; }
+            for (int b = 0; b < 4; ++b) c[b] = (int)((ad4 >> (16 * b)) & 0xFFFF);
             c[4] = 0; bs[4] = 0.0;
+            if (__builtin_expect(n > 255, 0)) {
+                // errmod_cal(): "if we exceed 255 bases, shuffle them to sample at random" -- ks_shuffle (a Fisher-Yates pass from
+                // the end, j = (int)(hts_drand48() * i)) on htslib's private rand48 stream, then the first 255 reads.  The lane
+                // shuffles its own column of the staged reads in place (scratch of the context, 1 byte per read).
+                uint64_t st;
+                if (T.hts_off) st = rand48_jump(*T.hts_base, (uint64_t)T.hts_off[ev]);                      // serial: the process-wide stream
+                else st = rand48_jump(VGL_HTS_RAND48_X0, ((uint64_t)(T.site0 + ls) * (uint64_t)N + (uint64_t)s) * VGL_HTS_TILE_STRIDE);
+                uint8_t* col = T.reads + ev;
+                for (int i = n; i > 1; --i) {
+                    st = lcg_next(st);
+                    const int j = (int)(u01(st) * (double)i);
+                    const uint8_t tmp = col[(size_t)j * plane]; col[(size_t)j * plane] = col[(size_t)(i - 1) * plane]; col[(size_t)(i - 1) * plane] = tmp;
+                }
+                n = 255;
+                c[0] = c[1] = c[2] = c[3] = 0;
+                for (int r = 0; r < n; ++r) {
+                    const int b = (int)(col[(size_t)r * plane] & 3);
+                    c[0] += (b == 0); c[1] += (b == 1); c[2] += (b == 2); c[3] += (b == 3);
+                }
+            }
             if (P.error_qs != 2) {
 #pragma unroll
                 for (int b = 0; b < 4; ++b) bs[b] = P.gl1_bsum[n * 256 + c[b]];
@@ -275,8 +294,10 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
                     if (b1 == b2) q = tmp2 ? tmp1 : 0.0f;
                     else {
                         const int lo = b1 < b2 ? b1 : b2, hi = b1 < b2 ? b2 : b1;
-                        const int chi = cnt_of(ad4, hi) > 255 ? 255 : cnt_of(ad4, hi);
-                        int cjk = cnt_of(ad4, lo) + cnt_of(ad4, hi); if (cjk > 255) cjk = 255;
+                        int clo = 0, chi = 0;                              // counts of the (subsampled) pileup; the unobserved allele has none
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { clo = (k == lo) ? c[k] : clo; chi = (k == hi) ? c[k] : chi; }
+                        const int cjk = clo + chi;                         // <= n <= 255
                         const double lh = P.gl1_lhet[cjk << 8 | chi];
                         q = tmp2 ? (float)(-4.343 * lh + (double)tmp1) : (float)(-4.343 * lh);
                     }
@@ -411,6 +432,46 @@ __global__ __launch_bounds__(64) void k_siteagg(const VglDevParams P, const VglT
 }
 
 // ------------------------------------------------------------------------------------
+// VGL_RNG_SERIAL, GL model 1, evaluations deeper than 255 reads: the reference's process calls errmod_cal() sample by sample,
+// site by site (only for records that reach calculate_gls: status OK), and every call with n > 255 takes n - 1 draws of htslib's
+// stream.  Exclusive prefix of those counts = where each evaluation's shuffle starts; the stream then advances by the total.
+__global__ __launch_bounds__(1024) void k_hts_offsets(const VglDevParams P, const VglTilePtrs T, VglSerialState* S, long long* __restrict__ off, uint64_t* hts_base) {
+    __shared__ long long s_w[16];
+    __shared__ long long s_run;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long long n = (long long)T.n_sites * P.n_samples;
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    for (long long base = 0; base < n; base += 1024) {
+        const long long i = base + tid;
+        long long v = 0;
+        if (i < n && T.sinfo[i / P.n_samples].status == SITE_OK) {
+            const uint64_t a = T.ad4[i];
+            const long long d = (long long)((a & 0xFFFF) + ((a >> 16) & 0xFFFF) + ((a >> 32) & 0xFFFF) + ((a >> 48) & 0xFFFF));
+            v = d > 255 ? d - 1 : 0;
+        }
+        long long incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const long long t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        long long woff = 0;
+        for (int k = 0; k < wv; k++) woff += s_w[k];
+        const long long run = s_run;
+        if (i < n) off[i] = run + woff + incl - v;
+        __syncthreads();
+        if (tid == 1023) s_run = run + woff + incl;
+        __syncthreads();
+    }
+    if (tid == 0) { *hts_base = S->st_hts; S->st_hts = rand48_jump(S->st_hts, (uint64_t)s_run); }
+}
+
+extern "C" int vgl_launch_hts_offsets(const VglDevParams* p, const VglTilePtrs* t, VglSerialState* st, long long* hts_off, uint64_t* hts_base, void* stream) {
+    if (t->n_sites == 0) return 0;
+    hipLaunchKernelGGL(k_hts_offsets, dim3(1), dim3(1024), 0, (hipStream_t)stream, *p, *t, st, hts_off, hts_base);
+    return (int)hipGetLastError();
+}
+
 extern "C" int vgl_launch_site(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
     if (t->n_sites == 0) return 0;
     hipLaunchKernelGGL(k_site, dim3((t->n_sites + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p, *t);

@@ -166,13 +166,23 @@ struct vgl_ctx {
     long long chain_words_cap = 0;
     unsigned long long* d_dbg = nullptr;
     // VGL_RNG_SERIAL
+    long long* d_hts_off = nullptr; uint64_t* d_hts_base = nullptr;
     VglSerialState* d_serial = nullptr; uint64_t* d_sst = nullptr; uint64_t* d_site_thresh = nullptr; int32_t* d_scout_dp = nullptr; int32_t* d_sdp = nullptr; VglAffine* d_step_tab = nullptr; VglSiteTail* d_site_tail = nullptr;
     int64_t serial_next_site = 0;   // VGL_DEBUG_STAMPS=1 diagnostic counters
-    // host-variant mirrors
-    uint8_t* d_gt = nullptr; void* d_out[17] = {nullptr}; size_t d_out_bytes[17] = {0};
-    uint8_t* d_reads_out = nullptr; size_t d_reads_out_bytes = 0;
-    double* d_errp_out = nullptr; size_t d_errp_out_bytes = 0;     // host-variant staging of read_errp / site_pick_err
-    double* d_pick_out = nullptr;
+    // host variant (vgl_simulate_tile / _async): two slots of device mirrors, so that the copies of one tile's tags back to the
+    // host (copy stream) run beside the kernels of the next tile (compute stream) -- SURVEY H8
+    struct HostSlot {
+        uint8_t* d_gt = nullptr; uint8_t* h_gt = nullptr;          // h_gt: pinned staging of the packed genotypes
+        void* d_out[17] = {nullptr}; size_t d_out_bytes[17] = {0};
+        uint8_t* d_reads_out = nullptr; size_t d_reads_out_bytes = 0;
+        double* d_errp_out = nullptr; size_t d_errp_out_bytes = 0;
+        double* d_pick_out = nullptr;
+        uint32_t* h_flag = nullptr;                                 // pinned: the tile's device error flags
+        hipEvent_t ev_kernels = nullptr, ev_copied = nullptr;
+        bool busy = false; int rc = VGL_OK;
+    } slot[2];
+    hipStream_t s_compute = nullptr, s_copy = nullptr;
+    int next_slot = 0;
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;     // groups of 5
@@ -251,12 +261,23 @@ extern "C" int vgl_ctx_destroy(vgl_ctx* c) {
     if (!c) return VGL_OK;
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_gl1_fk, c->d_gl1_beta, c->d_gamma_ln, c->d_samp_tab, c->d_qs_read_tab, c->d_pois, c->d_q2gl, c->d_gl1_bsum, c->d_gl1_lhet, c->d_reads, c->d_errp, c->d_ad4,
-                    c->d_adf4, c->d_qsum, c->d_qsumsq, c->d_acc, c->d_sinfo, c->d_errflag, c->d_gt, c->d_reads_out, c->d_errp_out, c->d_pick_out, c->d_dbg,
+                    c->d_adf4, c->d_qsum, c->d_qsumsq, c->d_acc, c->d_sinfo, c->d_errflag, c->d_dbg,
                     c->d_serial, c->d_sst, c->d_site_thresh, c->d_scout_dp, c->d_site_tail, c->d_sdp, c->d_step_tab,
-                    c->d_chunk_tab, c->d_eval_pow, c->d_dp_pre, c->d_roff, c->d_rtotal, c->d_errp_lin, c->d_cw, c->d_ccons, c->d_cexit,
+                    c->d_chunk_tab, c->d_eval_pow, c->d_dp_pre, c->d_hts_off, c->d_hts_base, c->d_roff, c->d_rtotal, c->d_errp_lin, c->d_cw, c->d_ccons, c->d_cexit,
                     c->d_ccnt, c->d_centry, c->d_cbase, c->d_cpos, c->d_csnap, c->d_csnapw, c->d_cctl};
     for (void* q : ptrs) if (q) (void)hipFree(q);
-    for (void* q : c->d_out) if (q) (void)hipFree(q);
+    for (auto& S : c->slot) {
+        if (S.busy && S.ev_copied) (void)hipEventSynchronize(S.ev_copied);
+        for (void* q : S.d_out) if (q) (void)hipFree(q);
+        void* dq[] = {S.d_gt, S.d_reads_out, S.d_errp_out, S.d_pick_out};
+        for (void* q : dq) if (q) (void)hipFree(q);
+        if (S.h_gt) (void)hipHostFree(S.h_gt);
+        if (S.h_flag) (void)hipHostFree(S.h_flag);
+        if (S.ev_kernels) (void)hipEventDestroy(S.ev_kernels);
+        if (S.ev_copied) (void)hipEventDestroy(S.ev_copied);
+    }
+    if (c->s_compute) (void)hipStreamDestroy(c->s_compute);
+    if (c->s_copy) (void)hipStreamDestroy(c->s_copy);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     delete c;
     return VGL_OK;
@@ -321,6 +342,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     D.i16_mapq = p->i16_mapq; D.add_i16 = p->add_i16;
     D.adjust_by = p->adjust_by;
     D.serial = (p->rng_mode == VGL_RNG_SERIAL) ? 1 : 0;
+    D.gl1_deep = (p->gl_model == 1 && D.read_cap > 255) ? 1 : 0;
     D.scout_lds_bytes = ((size_t)p->n_samples * 9 <= 144 * 1024) ? (int32_t)(((size_t)p->n_samples * 9 + 15) & ~(size_t)15) : 0;
     D.beta_std = (p->beta_sampler == VGL_BETA_STD) ? 1 : 0;
     D.beta_chain = (D.serial && D.beta_std && p->error_qs == 2 && !getenv("VGL_NO_BETA_CHAIN")) ? 1 : 0;
@@ -465,6 +487,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
         hs.mt[0] = (uint32_t)p->seed;                            // io.cpp:1039, rng.h:400
         for (int i = 1; i < 624; i++) hs.mt[i] = 1812433253u * (hs.mt[i - 1] ^ (hs.mt[i - 1] >> 30)) + (uint32_t)i;
         hs.mt_idx = 624;
+        hs.st_hts = VGL_HTS_RAND48_X0;                           // htslib never seeds hts_drand48
         {   // glibc srandom_r(1) + the 310 discarded outputs: the state a process that never calls srand() starts from
             int32_t word = 1; hs.rand_state[0] = 1;
             for (int i = 1; i < 31; i++) { const long hi = word / 127773, lo = word % 127773; long w = 16807 * lo - 2836 * hi; if (w < 0) w += 2147483647; word = (int32_t)w; hs.rand_state[i] = (uint32_t)word; }
@@ -475,6 +498,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
             }
         }
         if (p->add_i16) TRY(dmalloc(&c->d_site_tail, (size_t)max_sites));
+        if (D.gl1_deep) { TRY(dmalloc(&c->d_hts_off, E)); TRY(dmalloc(&c->d_hts_base, (size_t)1)); }
         TRYHIP(hipMemcpy(c->d_serial, &hs, sizeof hs, hipMemcpyHostToDevice));
     }
     TRY(dmalloc(&c->d_ad4, E));
@@ -486,6 +510,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     TRY(dmalloc(&c->d_errflag, (size_t)1));
     TRYHIP(hipMemset(c->d_errflag, 0, sizeof(uint32_t)));
     if (getenv("VGL_DEBUG_STAMPS") || getenv("VGL_DEBUG_PHASE")) { TRY(dmalloc(&c->d_dbg, (size_t)16)); TRYHIP(hipMemset(c->d_dbg, 0, 128)); }
+    TRYHIP(hipDeviceSynchronize());          // tables and cleared words are in place before any (non-blocking) stream uses them
     *out = c;
     return VGL_OK;
 }
@@ -640,6 +665,10 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     if (c->timing) HIPCHK(hipEventRecord(e[2], st));
     if (vgl_launch_site(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_site launch failed");
     if (c->timing) HIPCHK(hipEventRecord(e[3], st));
+    if (D.serial && D.gl1_deep) {                            // where each deep evaluation's shuffle starts in htslib's stream
+        if (vgl_launch_hts_offsets(&D, &T, c->d_serial, c->d_hts_off, c->d_hts_base, st)) return fail(VGL_E_NODEVICE, "k_hts_offsets launch failed");
+        T.hts_off = c->d_hts_off; T.hts_base = c->d_hts_base;
+    }
     if (vgl_launch_gl(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_gl launch failed");
     if (c->timing) HIPCHK(hipEventRecord(e[4], st));
     if (o->qs || o->i16) if (vgl_launch_siteagg(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_siteagg launch failed");
@@ -682,7 +711,6 @@ extern "C" int vgl_ctx_check(vgl_ctx* c, void* stream) {
     if (flag) HIPCHK(hipMemsetAsync(c->d_errflag, 0, sizeof flag, (hipStream_t)stream));
     if (flag & VGL_DEVERR_CAPACITY) return fail(VGL_E_CAPACITY, "a simulated read depth exceeded the staging capacity of %d reads per sample", c->dp.read_cap);
     if (flag & VGL_DEVERR_QSBIN) return fail(VGL_E_QSBIN, "Could not find a range for a simulated qs value in --qs-bins");
-    if (flag & VGL_DEVERR_GL1DEPTH) return fail(VGL_E_UNSUPPORTED, "GL model 1 with depth > 255 (htslib subsamples with drand48) is not supported");
     if (flag & VGL_DEVERR_ADJQ) return fail(VGL_E_ADJQ, "--adjust-qs %d: a read has no valid adjusted quality score (error probability exactly 0 or 1, or a negative adjusted score)", c->dp.adjust_qs);
     return VGL_OK;
 }
@@ -710,64 +738,114 @@ static size_t field_count(const vgl_ctx* c, int kind, size_t n_sites) {
     }
 }
 
-extern "C" int vgl_simulate_tile(vgl_ctx* c, int64_t site0, int32_t n_sites, const uint8_t* gt, vgl_tile_out* o) {
-    if (!c || !o) return fail(VGL_E_ARG, "null argument");
+static int flags_to_rc(vgl_ctx* c, uint32_t flag) {
+    if (flag & VGL_DEVERR_CAPACITY) return fail(VGL_E_CAPACITY, "a simulated read depth exceeded the staging capacity of %d reads per sample", c->dp.read_cap);
+    if (flag & VGL_DEVERR_QSBIN) return fail(VGL_E_QSBIN, "Could not find a range for a simulated qs value in --qs-bins");
+    if (flag & VGL_DEVERR_ADJQ) return fail(VGL_E_ADJQ, "--adjust-qs %d: a read has no valid adjusted quality score (error probability exactly 0 or 1, or a negative adjusted score)", c->dp.adjust_qs);
+    return VGL_OK;
+}
+
+extern "C" void* vgl_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { fail(VGL_E_NOMEM, "hipHostMalloc of %zu bytes failed", bytes); return nullptr; }
+    return p;
+}
+extern "C" void vgl_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+// Host buffers in, host buffers out, asynchronously: the tile's kernels are enqueued on the context's compute stream, the copies of
+// its tags back to the host on its copy stream behind them; with two tiles in flight the copies of tile t overlap the kernels of
+// tile t + 1.  Destination buffers from vgl_host_alloc() (pinned) are written by DMA directly; pageable ones work, more slowly.
+extern "C" int vgl_simulate_tile_async(vgl_ctx* c, int64_t site0, int32_t n_sites, const uint8_t* gt, vgl_tile_out* o, int32_t* ticket) {
+    if (!c || !o || !ticket) return fail(VGL_E_ARG, "null argument");
     if (n_sites < 0 || n_sites > c->max_sites) return fail(VGL_E_ARG, "n_sites %d exceeds max_sites_per_tile %d", n_sites, c->max_sites);
-    if (n_sites == 0) return VGL_OK;
-    if (!gt) return fail(VGL_E_ARG, "null gt");
+    if (n_sites > 0 && !gt) return fail(VGL_E_ARG, "null gt");
     HIPCHK(hipSetDevice(c->device));
+    const int k = c->next_slot;
+    vgl_ctx::HostSlot& S = c->slot[k];
+    if (S.busy) return fail(VGL_E_ARG, "two tiles are already in flight: vgl_tile_wait() the older one first");
+    if (!c->s_compute) { HIPCHK(hipStreamCreateWithFlags(&c->s_compute, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking)); }
+    if (!S.ev_kernels) { HIPCHK(hipEventCreateWithFlags(&S.ev_kernels, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&S.ev_copied, hipEventDisableTiming)); }
     const size_t N = c->dp.n_samples;
-    if (!c->d_gt) HIPCHK(hipMalloc((void**)&c->d_gt, (size_t)c->max_sites * N));
-    HIPCHK(hipMemcpy(c->d_gt, gt, (size_t)n_sites * N, hipMemcpyHostToDevice));
+    if (!S.d_gt) { HIPCHK(hipMalloc((void**)&S.d_gt, (size_t)c->max_sites * N)); HIPCHK(hipHostMalloc((void**)&S.h_gt, (size_t)c->max_sites * N, hipHostMallocDefault));
+                   HIPCHK(hipHostMalloc((void**)&S.h_flag, sizeof(uint32_t), hipHostMallocDefault)); }
+    *ticket = k; c->next_slot = k ^ 1;
+    S.rc = VGL_OK; *S.h_flag = 0;
+    if (n_sites == 0) { S.busy = true; HIPCHK(hipEventRecord(S.ev_copied, c->s_copy)); return VGL_OK; }
+    memcpy(S.h_gt, gt, (size_t)n_sites * N);
+    HIPCHK(hipMemcpyAsync(S.d_gt, S.h_gt, (size_t)n_sites * N, hipMemcpyHostToDevice, c->s_compute));
     vgl_tile_out d;
     memset(&d, 0, sizeof d);
     for (int f = 0; f < 17; f++) {
         void* host = *(void**)((char*)o + FIELDS[f].off);
         if (!host) continue;
         const size_t need = field_count(c, FIELDS[f].kind, (size_t)c->max_sites) * FIELDS[f].esz;
-        if (c->d_out_bytes[f] < need) {
-            if (c->d_out[f]) (void)hipFree(c->d_out[f]);
-            c->d_out[f] = nullptr; c->d_out_bytes[f] = 0;
-            HIPCHK(hipMalloc(&c->d_out[f], need));
-            c->d_out_bytes[f] = need;
+        if (S.d_out_bytes[f] < need) {
+            if (S.d_out[f]) (void)hipFree(S.d_out[f]);
+            S.d_out[f] = nullptr; S.d_out_bytes[f] = 0;
+            HIPCHK(hipMalloc(&S.d_out[f], need));
+            S.d_out_bytes[f] = need;
         }
-        *(void**)((char*)&d + FIELDS[f].off) = c->d_out[f];
+        *(void**)((char*)&d + FIELDS[f].off) = S.d_out[f];
     }
     if (o->reads && o->read_capacity > 0) {
         const size_t need = (size_t)o->read_capacity * c->max_sites * N;
-        if (c->d_reads_out_bytes < need) {
-            if (c->d_reads_out) (void)hipFree(c->d_reads_out);
-            c->d_reads_out = nullptr; c->d_reads_out_bytes = 0;
-            HIPCHK(hipMalloc((void**)&c->d_reads_out, need));
-            c->d_reads_out_bytes = need;
+        if (S.d_reads_out_bytes < need) {
+            if (S.d_reads_out) (void)hipFree(S.d_reads_out);
+            S.d_reads_out = nullptr; S.d_reads_out_bytes = 0;
+            HIPCHK(hipMalloc((void**)&S.d_reads_out, need));
+            S.d_reads_out_bytes = need;
         }
-        d.reads = c->d_reads_out; d.read_capacity = o->read_capacity;
+        d.reads = S.d_reads_out; d.read_capacity = o->read_capacity;
     }
     if (o->read_errp && o->read_capacity > 0) {
         const size_t need = (size_t)o->read_capacity * c->max_sites * N * sizeof(double);
-        if (c->d_errp_out_bytes < need) {
-            if (c->d_errp_out) (void)hipFree(c->d_errp_out);
-            c->d_errp_out = nullptr; c->d_errp_out_bytes = 0;
-            HIPCHK(hipMalloc((void**)&c->d_errp_out, need));
-            c->d_errp_out_bytes = need;
+        if (S.d_errp_out_bytes < need) {
+            if (S.d_errp_out) (void)hipFree(S.d_errp_out);
+            S.d_errp_out = nullptr; S.d_errp_out_bytes = 0;
+            HIPCHK(hipMalloc((void**)&S.d_errp_out, need));
+            S.d_errp_out_bytes = need;
         }
-        d.read_errp = c->d_errp_out; d.read_capacity = o->read_capacity;
+        d.read_errp = S.d_errp_out; d.read_capacity = o->read_capacity;
     }
     if (o->site_pick_err) {
-        if (!c->d_pick_out) HIPCHK(hipMalloc((void**)&c->d_pick_out, (size_t)c->max_sites * sizeof(double)));
-        HIPCHK(hipMemset(c->d_pick_out, 0xFF, (size_t)n_sites * sizeof(double)));
-        d.site_pick_err = c->d_pick_out;
+        if (!S.d_pick_out) HIPCHK(hipMalloc((void**)&S.d_pick_out, (size_t)c->max_sites * sizeof(double)));
+        HIPCHK(hipMemsetAsync(S.d_pick_out, 0xFF, (size_t)n_sites * sizeof(double), c->s_compute));
+        d.site_pick_err = S.d_pick_out;
     }
-    int rc = vgl_simulate_tile_device(c, site0, n_sites, c->d_gt, &d, nullptr);
+    int rc = vgl_simulate_tile_device(c, site0, n_sites, S.d_gt, &d, c->s_compute);
     if (rc) return rc;
-    if ((rc = vgl_ctx_check(c, nullptr))) return rc;
+    // this tile's device error flags, then a clean word for the next tile
+    HIPCHK(hipMemcpyAsync(S.h_flag, c->d_errflag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->s_compute));
+    HIPCHK(hipMemsetAsync(c->d_errflag, 0, sizeof(uint32_t), c->s_compute));
+    HIPCHK(hipEventRecord(S.ev_kernels, c->s_compute));
+    HIPCHK(hipStreamWaitEvent(c->s_copy, S.ev_kernels, 0));
     for (int f = 0; f < 17; f++) {
         void* host = *(void**)((char*)o + FIELDS[f].off);
         if (!host) continue;
-        HIPCHK(hipMemcpy(host, c->d_out[f], field_count(c, FIELDS[f].kind, (size_t)n_sites) * FIELDS[f].esz, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpyAsync(host, S.d_out[f], field_count(c, FIELDS[f].kind, (size_t)n_sites) * FIELDS[f].esz, hipMemcpyDeviceToHost, c->s_copy));
     }
-    if (d.reads) HIPCHK(hipMemcpy(o->reads, d.reads, (size_t)o->read_capacity * n_sites * N, hipMemcpyDeviceToHost));
-    if (d.read_errp && c->dp.error_qs == 2) HIPCHK(hipMemcpy(o->read_errp, d.read_errp, (size_t)o->read_capacity * n_sites * N * sizeof(double), hipMemcpyDeviceToHost));
-    if (d.site_pick_err) HIPCHK(hipMemcpy(o->site_pick_err, d.site_pick_err, (size_t)n_sites * sizeof(double), hipMemcpyDeviceToHost));
+    if (d.reads) HIPCHK(hipMemcpyAsync(o->reads, d.reads, (size_t)o->read_capacity * n_sites * N, hipMemcpyDeviceToHost, c->s_copy));
+    if (d.read_errp && c->dp.error_qs == 2) HIPCHK(hipMemcpyAsync(o->read_errp, d.read_errp, (size_t)o->read_capacity * n_sites * N * sizeof(double), hipMemcpyDeviceToHost, c->s_copy));
+    if (d.site_pick_err) HIPCHK(hipMemcpyAsync(o->site_pick_err, d.site_pick_err, (size_t)n_sites * sizeof(double), hipMemcpyDeviceToHost, c->s_copy));
+    HIPCHK(hipEventRecord(S.ev_copied, c->s_copy));
+    S.busy = true;
     return VGL_OK;
+}
+
+extern "C" int vgl_tile_wait(vgl_ctx* c, int32_t ticket) {
+    if (!c || ticket < 0 || ticket > 1) return fail(VGL_E_ARG, "bad ticket");
+    vgl_ctx::HostSlot& S = c->slot[ticket];
+    if (!S.busy) return fail(VGL_E_ARG, "no tile in flight under this ticket");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventSynchronize(S.ev_copied));
+    S.busy = false;
+    return flags_to_rc(c, *S.h_flag);
+}
+
+extern "C" int vgl_simulate_tile(vgl_ctx* c, int64_t site0, int32_t n_sites, const uint8_t* gt, vgl_tile_out* o) {
+    if (c) for (int k = 0; k < 2; k++) if (c->slot[k].busy) return fail(VGL_E_ARG, "vgl_simulate_tile with a tile in flight: vgl_tile_wait() it first");
+    int32_t t = 0;
+    int rc = vgl_simulate_tile_async(c, site0, n_sites, gt, o, &t);
+    if (rc) return rc;
+    return vgl_tile_wait(c, t);
 }

@@ -156,7 +156,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
         const uint32_t q_gl = (uint32_t)((P.adjust_qs & 1) ? aq_i : q_i);
         const uint32_t qq = (uint32_t)((P.adjust_qs & 2) ? aq_i : q_i);
         const uint32_t q2 = (uint32_t)qs_to_qssq((int)qq);
-        const bool stage = (P.gl_model != 1);      // GL model 1 with one fixed qScore needs only the per-base depths
+        const bool stage = (P.gl_model != 1) || P.gl1_deep;   // GL model 1 with one fixed qScore needs only the per-base depths, unless
+                                                              // an evaluation may exceed 255 reads (k_gl then subsamples the staged reads)
         for (int r = 0; r < dp; ++r) {
             bool fwd;
             const int r_base = sample_read_base(st_hap, st_base, a0, a1, err_thresh, k_strand, fwd);
