@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
         const int offs = incl - dp;
-        const int total = __shfl(incl, 63, 64);
+        const int total = __builtin_amdgcn_readfirstlane(__shfl(incl, 63, 64));   // wave-uniform, and known to the compiler as such
         l_stq[lane] = st_qs;
         if (lane == 0) l_it[cap] = 0u;
         int rdone = 0;
@@ -202,8 +202,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
         if (LEAN) asm volatile("" : "+v"(reads_v));
         else asm volatile("" : "+v"(reads_v), "+v"(reads_out_v), "+v"(reads_out_cap_v));
 
-        for (int seg0 = 0; seg0 < total; seg0 += cap) {                 // normally one segment
-            const int segT = (total - seg0 < cap) ? (total - seg0) : cap;
+        // the pool holds `cap` items; a wavefront with more reads works through segments of equal length
+        const int nseg = (total + cap - 1) / (cap > 0 ? cap : 1);
+        const int seglen = nseg > 1 ? (total + nseg - 1) / nseg : cap;
+        for (int seg0 = 0; seg0 < total; seg0 += seglen) {              // normally one segment
+            const int segT = (total - seg0 < seglen) ? (total - seg0) : seglen;
             // -- owners: bases of their reads that fall into this segment
             if (DBG) c_tmp = clock64();
             int r_end = seg0 + segT - offs; r_end = r_end > dp ? dp : r_end; r_end = r_end < rdone ? rdone : r_end;
