@@ -747,7 +747,8 @@ static int flags_to_rc(vgl_ctx* c, uint32_t flag) {
 
 extern "C" void* vgl_host_alloc(size_t bytes) {
     void* p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { fail(VGL_E_NOMEM, "hipHostMalloc of %zu bytes failed", bytes); return nullptr; }
+    // portable: page-locked for every device of the node (one set of buffers may receive tiles of several contexts)
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) { fail(VGL_E_NOMEM, "hipHostMalloc of %zu bytes failed", bytes); return nullptr; }
     return p;
 }
 extern "C" void vgl_host_free(void* p) { if (p) (void)hipHostFree(p); }
