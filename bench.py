@@ -301,7 +301,9 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
             # device-side packing of one tile's records (what precedes the gather): an HBM-bound gather
             s0, n, _ = structs[0]
             tile = {k: v[s0:s0 + n] for k, v in out.items()}
-            p = pack_records(tile, site0=site_base + s0)
+            for _ in range(2):                                   # warm: the allocator then holds blocks of the packed sizes
+                p = pack_records(tile, site0=site_base + s0)
+                del p
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -411,9 +413,13 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the other configurations attached as `extra`")
     ap.add_argument("--no-pack-rate", action="store_true")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)     # internal: one shard of the all-cores CPU leg
+    ap.add_argument("--host-path-worker", default=None, help=argparse.SUPPRESS)   # internal: the PCIe-inclusive host path in a fresh process
     opt = ap.parse_args()
     if opt.cpu_worker:                                         # never touches the GPU
         cpu_worker(opt.cpu_worker, workload_args(opt.workload), opt.samples or WORKLOADS[opt.workload]["samples"])
+        return
+    if opt.host_path_worker is not None:
+        print(json.dumps(host_path_rate(opt, {"local_dev": int(opt.host_path_worker)})))
         return
     if opt.gpus < 1:
         sys.exit("--gpus must be >= 1")
@@ -464,7 +470,13 @@ def main():
             except Exception as e:                             # an extra must never cost the headline line
                 extra[name] = {"error": repr(e)[:300]}
         try:
-            extra["host_path_c3"] = host_path_rate(opt, env)
+            # in a process of its own: device buffers allocated after this process has allocated and freed 100+ GB through torch copy
+            # back at 35 GB/s instead of 53 (measured, tools/stream_alias_probe.py) -- a record loop creates its context at start
+            import torch
+            torch.cuda.empty_cache()
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--host-path-worker", str(env["local_dev"])],
+                                 capture_output=True, text=True, timeout=600)
+            extra["host_path_c3"] = json.loads(out.stdout.strip().splitlines()[-1])
         except Exception as e:
             extra["host_path_c3"] = {"error": repr(e)[:300]}
 
