@@ -455,6 +455,17 @@ def main():
     torch.cuda.set_device(local_dev)
     env = {"rank": rank, "world": world, "dist": dist, "dev": torch.device("cuda", local_dev), "local_dev": local_dev}
 
+    host_first = None
+    if world == 1 and not opt.no_extra and opt.sites is None and opt.samples is None:
+        # The PCIe-inclusive host path, in a process of its own and BEFORE the device-resident workloads: device memory that has
+        # been through 100+ GB of allocation and release (by this process or an earlier one on the GPU) copies back at 35 GB/s
+        # instead of 53 (measured: tools/stream_alias_probe.py) -- a record loop creates its context at start, like this.
+        try:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--host-path-worker", str(local_dev)],
+                                 capture_output=True, text=True, timeout=600)
+            host_first = json.loads(out.stdout.strip().splitlines()[-1])
+        except Exception as e:
+            host_first = {"error": repr(e)[:300]}
     main_res = run_workload(opt.workload, opt, env, opt.steps, opt.warmup, sites=opt.sites, samples=opt.samples,
                             with_cpu=(not opt.no_cpu_baseline and world == 1), gather=opt.gather)
     extra = {}
@@ -469,16 +480,7 @@ def main():
                 extra[name] = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "workload", "roofline")}
             except Exception as e:                             # an extra must never cost the headline line
                 extra[name] = {"error": repr(e)[:300]}
-        try:
-            # in a process of its own: device buffers allocated after this process has allocated and freed 100+ GB through torch copy
-            # back at 35 GB/s instead of 53 (measured, tools/stream_alias_probe.py) -- a record loop creates its context at start
-            import torch
-            torch.cuda.empty_cache()
-            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--host-path-worker", str(env["local_dev"])],
-                                 capture_output=True, text=True, timeout=600)
-            extra["host_path_c3"] = json.loads(out.stdout.strip().splitlines()[-1])
-        except Exception as e:
-            extra["host_path_c3"] = {"error": repr(e)[:300]}
+        extra["host_path_c3"] = host_first
 
     if rank == 0:
         args = workload_args(opt.workload)

@@ -108,15 +108,26 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
     __shared__ uint32_t s_x[NG * 256];                                  // gl_sort 2: one tag's planes of the workgroup, in natural order
     const int N = P.n_samples;
     const int tid = threadIdx.x;
-    const int64_t nwaves = (int64_t)T.n_sites * P.chunks;
+    const uint32_t nwaves = (uint32_t)T.n_sites * (uint32_t)P.chunks;                   // < 2^31 (checked by the launcher)
     const uint32_t bx = P.xcd_map ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x;     // logical workgroup (XCD-contiguous)
+    // wave k of this workgroup is wave 4 bx + k of the tile = (site, 64-sample chunk).  One scalar division per workgroup; a lane
+    // then finds the site of ANY of the four waves with three compares (a per-lane 64-bit division was 60+ vector instructions,
+    // three times per lane)
+    const uint32_t wg_ls = (bx * 4u) / (uint32_t)P.chunks, wg_rem = (bx * 4u) - wg_ls * (uint32_t)P.chunks;
+    auto wave_site = [&](const int k, int& ls_, int& s_base) {
+        const int t = (int)wg_rem + k, c = P.chunks;
+        const int add = (t >= c ? 1 : 0) + (t >= 2 * c ? 1 : 0) + (t >= 3 * c ? 1 : 0);
+        ls_ = (int)wg_ls + add;
+        s_base = (t - add * c) * 64;
+    };
     // ---- depth of the evaluation this thread would own in natural order
     int dp0 = -1;                                                      // -1: no evaluation (padding lane)
+    int ls0 = 0, s0 = N;
     {
-        const int64_t w = (int64_t)bx * 4 + (tid >> 6);
+        const uint32_t w = bx * 4u + (uint32_t)(tid >> 6);
         if (w < nwaves) {
-            const int ls0 = (int)(w / P.chunks);
-            const int s0 = (int)(w - (int64_t)ls0 * P.chunks) * 64 + (tid & 63);
+            int sb; wave_site(tid >> 6, ls0, sb);
+            s0 = sb + (tid & 63);
             if (s0 < N) {
                 const uint64_t a = T.ad4[(size_t)ls0 * N + s0];
                 dp0 = (int)((a & 0xFFFF) + ((a >> 16) & 0xFFFF) + ((a >> 32) & 0xFFFF) + ((a >> 48) & 0xFFFF));
@@ -154,10 +165,10 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
     }
     const int lane = tid & 63;
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t w = (int64_t)bx * 4 + (otid >> 6);
+    const uint32_t w = bx * 4u + (uint32_t)(otid >> 6);
     const bool xpose = (P.gl_sort == 2);                               // sorted lanes, natural-order stores through LDS
     int ls = 0, s = N;
-    if (w < nwaves) { ls = (int)(w / P.chunks); s = (int)(w - (int64_t)ls * P.chunks) * 64 + (otid & 63); }
+    if (w < nwaves) { int sb; wave_site(otid >> 6, ls, sb); s = sb + (otid & 63); }
     const bool live = s < N;
     if (!xpose && !live) return;                                       // with gl_sort 2 every thread reaches the barriers below
     if (!live) { ls = 0; s = 0; }                                      // padding lane: reads stay in range, nothing is stored
@@ -317,11 +328,8 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
     // but a plane's 256-evaluation window of the workgroup is written in natural order: the values pass through LDS
     // (s_x[plane][natural thread id]) so that every store of a wavefront is one contiguous segment.
     const bool sample_ok = have && dp > 0;
-    // this thread's own (natural-order) evaluation, for the stores of gl_sort 2
-    const int64_t w0 = (int64_t)bx * 4 + (tid >> 6);
-    const int ls0 = (int)(w0 / P.chunks);
-    const int s0 = (int)(w0 - (int64_t)ls0 * P.chunks) * 64 + (tid & 63);
-    const bool live0 = (w0 < nwaves) && (s0 < N);
+    // this thread's own (natural-order) evaluation, for the stores of gl_sort 2: (ls0, s0) from above
+    const bool live0 = (bx * 4u + (uint32_t)(tid >> 6) < nwaves) && (s0 < N);
     // VGL_PUT(base, NP, expr of i): the loops are spelled out here (not in a lambda) so that acc[] stays in registers
 #define VGL_PUT(BASE, NP, EXPR)                                                                          \
     do {                                                                                                 \
@@ -481,6 +489,7 @@ extern "C" int vgl_launch_site(const VglDevParams* p, const VglTilePtrs* t, void
 extern "C" int vgl_launch_gl(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
     const int64_t waves = (int64_t)t->n_sites * p->chunks;
     if (waves == 0) return 0;
+    if (waves + 4 >= (1LL << 31)) return (int)hipErrorInvalidValue;       // k_gl indexes the tile's wavefronts with 32 bits
     const unsigned blocks = (unsigned)((waves + 3) / 4);
     const size_t lds = (p->gl_model == 1 && p->error_qs == 2) ? (size_t)4 * 16384 : 0;   // (base,qual) histograms
     const dim3 g(blocks), b(256);
