@@ -60,6 +60,25 @@ __device__ __forceinline__ double u01(uint64_t x) {
 __device__ __forceinline__ double u01_minus_half(uint64_t x) {
     return __longlong_as_double((long long)(0x3FF0000000000000ULL | (x << 4))) - 1.5;
 }
+// The pool loop of k_sample<2> carries its generator states shifted left by 4 (x' = 16 x < 2^52): the 48 state bits then
+// already sit where the mantissa of 1.xxx wants them, and every uniform saves the 64-bit shift of u01().  Same generator:
+// x' <- (A x' + 16 C) mod 2^52.
+#define VGL_MASK52 0xFFFFFFFFFFFFFULL
+__device__ __forceinline__ uint64_t lcg_next52(uint64_t x) { return (x * VGL_LCG_A + (VGL_LCG_C << 4)) & VGL_MASK52; }
+// ... and without the reduction mod 2^52: bits 52-63 of the result are garbage that no later step looks at (a product's low 52
+// bits depend on the factors' low 52 bits only); u01_52r() masks while it builds the double
+__device__ __forceinline__ uint64_t lcg_next52r(uint64_t x) { return x * VGL_LCG_A + (VGL_LCG_C << 4); }
+// 1.xxx from a raw scaled state: the high word is (hi & 0xFFFFF) | 0x3FF00000 in ONE v_and_or_b32 (the compiler emits an and and
+// an or: it will not spend a register on the second constant, which the ISA needs there); `k3ff` = 0x3FF00000 in a VGPR
+__device__ __forceinline__ double bits_1xxx_52r(uint64_t x, uint32_t k3ff) {
+    uint32_t hi;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(hi) : "v"((uint32_t)(x >> 32)), "s"(0xFFFFFu), "v"(k3ff));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | (uint32_t)x));
+}
+// m = a jump of the generator with its constant already scaled (c' = 16 c): the per-read table of k_sample<2> is stored that way
+__device__ __forceinline__ uint64_t aff52(const VglAffine m, uint64_t x) { return (m.a * x + m.c) & VGL_MASK52; }
+__device__ __forceinline__ double u01_52(uint64_t x) { return __longlong_as_double((long long)(0x3FF0000000000000ULL | x)) - 1.0; }
+__device__ __forceinline__ double u01_52_minus_half(uint64_t x) { return __longlong_as_double((long long)(0x3FF0000000000000ULL | x)) - 1.5; }
 __device__ __forceinline__ double next_u(uint64_t& st) { st = lcg_next(st); return u01(st); }
 
 // gamma_ln, rng.h:38-43,60-64

@@ -183,6 +183,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
         uint64_t* l_stq = (uint64_t*)wl;
         uint32_t* l_it = (uint32_t*)(wl + 512);
         uint8_t* l_pb = wl + 512 + 4 * ((size_t)cap + 2);
+        // [2][3] f64 at the end: a1, a2 and 0.15 a2^2 of the two gamma samplers, looked up by a lane's stage in the pool loop (three
+        // LDS reads instead of four selects and two multiplications per iteration, and four fewer register pairs to carry)
+        double* l_gc = (double*)(wl + ((512 + 4 * ((size_t)cap + 2) + (size_t)cap + 7) & ~(size_t)7));
 
         // exclusive prefix sum of the depths = first pool index of each owner
         int incl = dp;
@@ -190,8 +193,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
         for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
         const int offs = incl - dp;
         const int total = __builtin_amdgcn_readfirstlane(__shfl(incl, 63, 64));   // wave-uniform, and known to the compiler as such
-        l_stq[lane] = st_qs;
-        if (lane == 0) l_it[cap] = 0u;
+        l_stq[lane] = st_qs << 4;                      // the pool loop works on states scaled by 16 (lcg_next52)
+        if (lane == 0) {
+            l_it[cap] = 0u;
+            l_gc[0] = P.gx.a1; l_gc[1] = P.gx.a2; l_gc[2] = (P.gx.a2 * P.gx.a2) * 0.15;
+            l_gc[3] = P.gy.a1; l_gc[4] = P.gy.a2; l_gc[5] = (P.gy.a2 * P.gy.a2) * 0.15;
+        }
         int rdone = 0;
         // Kernel arguments arrive in 16-dword scalar tuples that the register allocator spills and
         // reloads as a whole (v_readlane, VALU work) inside the loops below; the three values the flush
@@ -241,15 +248,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 bool have = k < segT;                        // == (k < segT) throughout: the loop tests that compare
                 bool stage1 = false;                         // false: first gamma deviate (x), true: second (y)
                 uint64_t st = 0; double gx = 0.0; int it_o = 0, it_r = 0;
-                if (have) { const uint32_t m = l_it[k]; it_o = m & 63; it_r = m >> 6; st = aff(P.qs_read_tab[it_r], l_stq[it_o]); }
+                if (have) { const uint32_t m = l_it[k]; it_o = m & 63; it_r = m >> 6; st = aff52(P.qs_read_tab[it_r], l_stq[it_o]); }
                 const bool any_changed = (P.gx.changed | P.gy.changed) != 0;
-                // the two gamma samplers' constants, kept in vector registers for the per-iteration selects
-                double gxa1 = P.gx.a1, gxa2 = P.gx.a2, gya1 = P.gy.a1, gya2 = P.gy.a2;
-                asm volatile("" : "+v"(gxa1), "+v"(gxa2), "+v"(gya1), "+v"(gya2));
                 // The bounded-log tests are needed by a few lanes per iteration but cost every lane of the
                 // wave; they run only every P.slow_period-th iteration.  In between, a lane that needs one
                 // holds: its state is left untouched, so the later iteration recomputes the same attempt.
                 int slow_cnt = P.slow_period, slow_cnt_n = P.slow_period_n;
+                uint32_t k3ff = 0x3FF00000u;                 // the exponent word of 1.xxx, in a vector register for v_and_or_b32
+                asm volatile("" : "+v"(k3ff));
                 while (__ballot(k < segT)) {
                     if (DBG) c_iter++;
                     const bool full = (--slow_cnt == 0);     // bounded gamma test (needed by ~0.2 % of the lanes of an iteration)
@@ -264,14 +270,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     const VglAffine tab_n = P.qs_read_tab[r_n];
                     const uint64_t base_n = l_stq[o_n];
 
-                    const double ga1 = stage1 ? gya1 : gxa1;
-                    const double ga2 = stage1 ? gya2 : gxa2;
+                    const double* gc = l_gc + (stage1 ? 3 : 0);
+                    const double ga1 = gc[0], ga2 = gc[1], ga2sq015 = gc[2];
                     // normal attempt
-                    const uint64_t st1 = lcg_next(st);
-                    const uint64_t st2 = lcg_next(st1);
-                    const uint64_t st3 = lcg_next(st2);
-                    const double u = u01(st1);
-                    const double v = 1.7156 * u01_minus_half(st2);
+                    const uint64_t st1 = lcg_next52r(st);        // raw: bits 52-63 are masked where a uniform is built
+                    const uint64_t st2 = lcg_next52r(st1);
+                    const uint64_t st3 = lcg_next52r(st2);
+                    const double u = bits_1xxx_52r(st1, k3ff) - 1.0;
+                    const double v = 1.7156 * (bits_1xxx_52r(st2, k3ff) - 1.5);
                     const double x = u - 0.449871;
                     const double y = fabs(v) + 0.386595;
                     const double q = (x * x) + y * (0.19600 * y - 0.25472 * x);
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     const double w = 1.0 + ga2 * xn;
                     const bool w_pos = w > 0.0;
                     const double vv = w * w * w;
-                    const double u2 = u01(st3);
+                    const double u2 = bits_1xxx_52r(st3, k3ff) - 1.0;
                     const double xsq = xn * xn;
                     const double x4 = xsq * xsq;
                     const bool sq_fail = u2 > 1.0 - 0.0331 * x4;
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     // 1 - u >= 0.15 a2^2 x^4 (+ P.sure_margin, far above the rounding of either side) is a sure accept: it settles 97 %
                     // of these cases (the sampler's rejection rate is 0.3 % for alpha ~ 10 and 0.003 % for alpha ~ 1000), and the
                     // bounded test below is left with ~0.2 % of the lanes of an iteration.
-                    const bool sure = (1.0 - u2 >= (ga2 * ga2) * 0.15 * x4 + P.sure_margin) && (w >= 0.5);
+                    const bool sure = (1.0 - u2 >= ga2sq015 * x4 + P.sure_margin) && (w >= 0.5);
                     const bool g_try = have && acc_n && w_pos && !hold;
                     const bool g_amb = g_try && sq_fail && !sure;
                     hold = hold || (g_amb && !full);
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                         asm volatile("" ::: "memory");       // (keeps the per-lane part of the test out of the common path)
                         if (acc_g && (stage1 ? P.gy.changed : P.gx.changed)) {
                             double u3;
-                            do { st = lcg_next(st); u3 = u01(st); } while (u3 == 0.0);
+                            do { st = lcg_next52r(st); u3 = bits_1xxx_52r(st, k3ff) - 1.0; } while (u3 == 0.0);
                             val = pow(u3, 1.0 / (stage1 ? P.gy.alpha0 : P.gx.alpha0)) * ga1 * vv;
                         }
                     }
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     // a lane that finished its item adopts kn and claims the next unclaimed item
                     const uint64_t fin_m = __ballot(fin);
                     const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fin_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fin_m, 0u));
-                    const uint64_t st_n = aff(tab_n, base_n);
+                    const uint64_t st_n = aff52(tab_n, base_n);
                     st = fin ? st_n : st;
                     it_o = fin ? o_n : it_o; it_r = fin ? r_n : it_r;
                     k = fin ? kn : k;
@@ -354,7 +360,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                         amb &= amb - 1;
                         const int Kb = seg0 + kb + b;                   // index of the read in the wave's pool
                         if (active && Kb >= offs && Kb < offs + dp) {
-                            uint64_t st_x = aff(P.qs_read_tab[Kb - offs], l_stq[lane]);
+                            VglAffine jr = P.qs_read_tab[Kb - offs]; jr.c >>= 4;     // the table carries 16 c (aff52)
+                            uint64_t st_x = aff(jr, l_stq[lane] >> 4);
                             const double ep = beta_draw(P, st_x);
                             int qe, aqe;
                             errprob_raw(P, ep, qe, aqe);
