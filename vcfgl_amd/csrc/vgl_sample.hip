@@ -179,10 +179,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
         //      probability of its read, then (dense pass) qScore | adjusted qScore << 8.  Slot [cap] stays 0: the
         //      prefetch of a lane that has no next item reads it.
         const int cap = P.pool_cap;
-        uint8_t* wl = lds_raw + (size_t)wp.wib * P.pool_lds_bytes;
+        uint8_t* wl = lds_raw;                         // one wavefront per workgroup (vgl_launch_sample): LDS offsets are compile-time
         uint64_t* l_stq = (uint64_t*)wl;
         uint32_t* l_it = (uint32_t*)(wl + 512);
         uint8_t* l_pb = wl + 512 + 4 * ((size_t)cap + 2);
+        uint32_t* l_ctr = l_it + cap + 1;             // pool loop: first unclaimed item
         // [2][3] f64 at the end: a1, a2 and 0.15 a2^2 of the two gamma samplers, looked up by a lane's stage in the pool loop (three
         // LDS reads instead of four selects and two multiplications per iteration, and four fewer register pairs to carry)
         double* l_gc = (double*)(wl + ((512 + 4 * ((size_t)cap + 2) + (size_t)cap + 7) & ~(size_t)7));
@@ -224,9 +225,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 ad4 += one;
                 if (!LEAN) { if (fwd) adf4 += one; }
                 const int k = offs + r - seg0;
-                l_it[k] = (uint32_t)((r << 6) | lane);
+                l_it[k] = ((uint32_t)lane << 26) | ((uint32_t)r << 4);   // slot: lane of the owner, 16 * read (byte offsets of l_stq / qs_read_tab by one shift / one mask)
                 l_pb[k] = (uint8_t)r_base;
             }
+            if (lane == 0) { l_it[segT] = 0u; *l_ctr = 128u; }   // the "no item" slot of this segment's prefetches; first unclaimed item
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -244,11 +246,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 // finishes an item adopts kn and claims the next unclaimed one.  Each item's stream is
                 // addressed by its read, so the result does not depend on who works on it.
                 int k = lane, kn = lane + 64;
-                int next_free = 128;                         // wave-uniform: first unclaimed item
                 bool have = k < segT;                        // == (k < segT) throughout: the loop tests that compare
                 bool stage1 = false;                         // false: first gamma deviate (x), true: second (y)
-                uint64_t st = 0; double gx = 0.0; int it_o = 0, it_r = 0;
-                if (have) { const uint32_t m = l_it[k]; it_o = m & 63; it_r = m >> 6; st = aff52(P.qs_read_tab[it_r], l_stq[it_o]); }
+                uint64_t st = 0; double gx = 0.0; uint32_t it_m = 0;
+                if (have) { it_m = l_it[k]; st = aff52(P.qs_read_tab[(it_m >> 4) & 0x3FF], l_stq[it_m >> 26]); }
                 const bool any_changed = (P.gx.changed | P.gy.changed) != 0;
                 // The bounded-log tests are needed by a few lanes per iteration but cost every lane of the
                 // wave; they run only every P.slow_period-th iteration.  In between, a lane that needs one
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 int slow_cnt = P.slow_period, slow_cnt_n = P.slow_period_n;
                 uint32_t k3ff = 0x3FF00000u;                 // the exponent word of 1.xxx, in a vector register for v_and_or_b32
                 asm volatile("" : "+v"(k3ff));
-                while (__ballot(k < segT)) {
+                do {                                         // segT >= 1: lane 0 has an item
                     if (DBG) c_iter++;
                     const bool full = (--slow_cnt == 0);     // bounded gamma test (needed by ~0.2 % of the lanes of an iteration)
                     if (full) slow_cnt = P.slow_period;
@@ -264,11 +265,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     if (full_n) slow_cnt_n = P.slow_period_n;
                     // operands of this lane's next item, fetched at the top of the iteration and consumed at
                     // the bottom (unconditional, clamped index: no divergent control flow in the loop)
-                    const bool hn = kn < segT;
-                    const uint32_t m_n = l_it[hn ? kn : cap];
-                    const int o_n = m_n & 63, r_n = m_n >> 6;
-                    const VglAffine tab_n = P.qs_read_tab[r_n];
-                    const uint64_t base_n = l_stq[o_n];
+                    const uint32_t m_n = l_it[kn < segT ? kn : segT];     // l_it[segT] = 0 (a valid slot) stands for "none"
+                    const VglAffine tab_n = *(const VglAffine*)((const uint8_t*)P.qs_read_tab + (m_n & 0x3FFFu << 4));
+                    const uint64_t base_n = *(const uint64_t*)((const uint8_t*)l_stq + (m_n >> 23));
 
                     const double* gc = l_gc + (stage1 ? 3 : 0);
                     const double ga1 = gc[0], ga2 = gc[1], ga2sq015 = gc[2];
@@ -285,7 +284,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     bool slow_n = false;
                     const bool n_amb = have && q_lo && !q_hi;
                     bool hold = n_amb && !full_n;
-                    if (full_n && __ballot(n_amb)) slow_n = normal_slow_test(v, u, n_amb);
+                    if (full_n && __builtin_amdgcn_ballot_w64(n_amb)) slow_n = normal_slow_test(v, u, n_amb);
                     const bool acc_n = !(q_lo && (q_hi || slow_n));
                     // gamma step on the accepted deviate
                     const double xn = div_inrange(v, u);
@@ -307,7 +306,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     const bool g_amb = g_try && sq_fail && !sure;
                     hold = hold || (g_amb && !full);
                     bool slow_g = false;
-                    if (full && __ballot(g_amb)) slow_g = gamma_slow_test(u2, xsq, ga1, vv, ga2 * xn, g_amb);
+                    if (full && __builtin_amdgcn_ballot_w64(g_amb)) slow_g = gamma_slow_test(u2, xsq, ga1, vv, ga2 * xn, g_amb);
                     const bool acc_g = g_try && !(g_amb && slow_g) && !hold;     // slow_g is meaningful on the lanes that asked for it
                     st = hold ? st : (g_try ? st3 : st2);    // u2 is drawn only when w > 0 (rng.h:140-142)
                     double val = ga1 * vv;
@@ -320,24 +319,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                         }
                     }
                     const bool fin = acc_g && stage1;
-                    // a finished read leaves its error probability (rng.h:438) as a float32 in the item's slot; the
-                    // quality scores are taken from it by the dense pass after the loop
-                    const float pf = qs_stage_pf(gx, val);
-                    if (fin) l_it[k] = __float_as_uint(pf);
-                    if (PREC) { if (fin) T.errp[(size_t)it_r * plane + ev0 + it_o] = gx / (gx + val); }
+                    const uint64_t st_n = tab_n.a * base_n + tab_n.c;     // raw, like st
+                    const double gx_prev = gx;
                     gx = (acc_g && !stage1) ? val : gx;
                     stage1 = stage1 != acc_g;
-                    // a lane that finished its item adopts kn and claims the next unclaimed item
-                    const uint64_t fin_m = __ballot(fin);
-                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fin_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fin_m, 0u));
-                    const uint64_t st_n = aff52(tab_n, base_n);
-                    st = fin ? st_n : st;
-                    it_o = fin ? o_n : it_o; it_r = fin ? r_n : it_r;
-                    k = fin ? kn : k;
-                    kn = fin ? next_free + rank : kn;
-                    next_free += __popcll(fin_m);
+                    if (fin) {
+                        // a finished read leaves its error probability (rng.h:438) as a float32 in the item's slot; the
+                        // quality scores are taken from it by the dense pass after the loop
+                        l_it[k] = __float_as_uint(qs_stage_pf(gx_prev, val));
+                        if (PREC) { T.errp[(size_t)((it_m >> 4) & 0x3FF) * plane + ev0 + (it_m >> 26)] = gx_prev / (gx_prev + val); it_m = m_n; }
+                        // the lane adopts kn and claims the next unclaimed item from the wave's counter (any assignment of
+                        // items to lanes gives the same result)
+                        st = st_n;
+                        k = kn;
+                        kn = (int)__hip_atomic_fetch_add(l_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    }
                     have = k < segT;
-                }
+                } while (__builtin_amdgcn_ballot_w64(have));
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -458,7 +456,7 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
     const bool dbg = t->dbg != nullptr;                         // VGL_DEBUG_STAMPS / VGL_DEBUG_PHASE
     // wavefronts never cooperate here, and a workgroup's wave slots and LDS are only handed on when its last
     // wavefront retires: one wavefront per workgroup keeps every SIMD at its full complement of waves
-    const int wpb = getenv("VGL_SAMPLE_WPB") ? atoi(getenv("VGL_SAMPLE_WPB")) : 1;
+    const int wpb = 1;
     const dim3 g((unsigned)((waves + wpb - 1) / wpb)), b(64 * wpb);
     const size_t lds = (size_t)wpb * p->pool_lds_bytes;
     hipStream_t s = (hipStream_t)stream;
