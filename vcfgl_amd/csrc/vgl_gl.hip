@@ -102,12 +102,19 @@ __device__ __forceinline__ int cnt_of(uint64_t ad4, int b) { return b < 4 ? (int
 template <int A, int GLM, bool PREC>
 __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTilePtrs T) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    __shared__ uint32_t s_hist[1026];
     __shared__ uint16_t s_perm[256];
     constexpr int NG = A * (A + 1) / 2;
-    __shared__ uint32_t s_x[NG * 256];                                  // gl_sort 2: one tag's planes of the workgroup, in natural order
+    __shared__ uint32_t s_x[15 * 256];                                  // gl_sort 2: one tag's planes of the workgroup, in natural order; GL model 2: the loop's accumulators (up to 15) on their way to genotype order
+    uint32_t* const s_hist = s_x;                                       // [1026] bins of the depth sort (done before s_x is used)
+    constexpr int QL = 96;                                              // quality scores below QL take their three terms from LDS
+    __shared__ double s_q2gl[(GLM == 2 && !PREC) ? 3 * QL : 1];
     const int N = P.n_samples;
     const int tid = threadIdx.x;
+    if (GLM == 2 && !PREC) {
+        if (P.error_qs == 2)
+            for (int i = tid; i < 3 * QL; i += 256) s_q2gl[i] = P.q2gl[(i / QL) * 257 + (i % QL)];
+        __syncthreads();
+    }
     const uint32_t nwaves = (uint32_t)T.n_sites * (uint32_t)P.chunks;                   // < 2^31 (checked by the launcher)
     const uint32_t bx = P.xcd_map ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x;     // logical workgroup (XCD-contiguous)
     // wave k of this workgroup is wave 4 bx + k of the tile = (site, 64-sample chunk).  One scalar division per workgroup; a lane
@@ -189,20 +196,43 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
 
     if (dp > 0) {
         if (GLM == 2) {
-            // gl_methods.cpp:22-59 / :94-139 / :171-220
+            // gl_methods.cpp:22-59 / :94-139 / :171-220.  The reference updates every genotype (i, j) per read with one of three
+            // terms chosen by (read allele == i, == j), then subtracts the maximum: genotypes that see the same sequence of
+            // choices hold the same value after every read.  For an evaluation whose reads show k distinct bases those
+            // sequences are: k homozygotes of a present allele, k (k - 1) / 2 heterozygotes of two present alleles, k "present /
+            // absent" heterozygotes, and ONE for every genotype of absent alleles (term homF at every read) -- 3 / 6 / 10 / 15
+            // accumulators for k = 1 .. 4 instead of A (A + 1) / 2 = 15, each updated by exactly the reference's operations.  A
+            // wavefront runs the loop built for the largest k among its lanes (a lane with fewer present bases leaves the higher
+            // slots to duplicates of its absent-allele sequences); the genotype-ordered values are read back through LDS.
             const bool per_read = (P.error_qs == 2);
-            // FULL: every lane of the wavefront is at a site with all A alleles (the usual case with
-            // -doUnobserved 1/2): the running maximum is then a plain v_max_f32 per genotype
-            auto read_loop = [&](auto full_tag) {
-                constexpr bool FULL = decltype(full_tag)::value;
+            const uint32_t p0 = (ad4 & 0xFFFFULL) != 0, p1 = ((ad4 >> 16) & 0xFFFF) != 0, p2 = ((ad4 >> 32) & 0xFFFF) != 0, p3 = (ad4 >> 48) != 0;
+            const int k_pres = (int)(p0 + p1 + p2 + p3);
+            const uint32_t cmap = (p0 << 2) | ((p0 + p1) << 4) | ((p0 + p1 + p2) << 6);          // 2 bits per base: its rank among the present bases
+            const uint32_t pmask = p0 | (p1 << 1) | (p2 << 2) | (p3 << 3);
+            const bool has_abs = nA > k_pres;                                                       // an allele of the site this evaluation has no read of
+            const int K = 1 + (__ballot(k_pres >= 2) != 0) + (__ballot(k_pres >= 3) != 0) + (__ballot(k_pres >= 4) != 0);   // wave-uniform
+            auto read_loop = [&](auto k_tag, auto full_tag) {
+                constexpr int KK = decltype(k_tag)::value;
+                constexpr bool FULL = decltype(full_tag)::value;                                  // every lane has an absent allele: all slots stand for real genotypes
+                constexpr int NH = KK * (KK - 1) / 2, NT = 2 * KK + NH + 1;                       // hom [0,KK) | het [KK, KK+NH) | present/absent [KK+NH, 2KK+NH) | absent
+                float tr[NT];
+#pragma unroll
+                for (int i = 0; i < NT; ++i) tr[i] = -0.0f;                                       // bcf_utils.h:310
                 double homT = P.pre_homT, het = P.pre_het, homF = P.pre_homF;
+                // the staged reads of an evaluation lie one plane (n_sites x n_samples bytes) apart: four loads are kept in flight
+                const uint8_t* col = T.reads + ev;
+                const int last = dp - 1;
+                uint32_t nx0 = col[0], nx1 = col[(size_t)(1 < last ? 1 : last) * plane], nx2 = col[(size_t)(2 < last ? 2 : last) * plane],
+                         nx3 = col[(size_t)(3 < last ? 3 : last) * plane];
                 for (int r = 0; r < dp; ++r) {
-                    const uint32_t rb = T.reads[(size_t)r * plane + ev];
-                    const int ao = nib(si.acgt2alleles, (int)(rb & 3));
+                    const uint32_t rb = nx0;
+                    nx0 = nx1; nx1 = nx2; nx2 = nx3; nx3 = col[(size_t)(r + 4 < last ? r + 4 : last) * plane];
+                    const int ci = (int)((cmap >> ((rb & 3) * 2)) & 3);                           // the read's base among the present ones
                     if (per_read) {
                         if (!PREC) {
                             const int q = (int)(rb >> 2);
-                            homT = P.q2gl[q]; het = P.q2gl[257 + q]; homF = P.q2gl[514 + q];
+                            if (__builtin_expect(q < QL, 1)) { homT = s_q2gl[q]; het = s_q2gl[QL + q]; homF = s_q2gl[2 * QL + q]; }
+                            else { homT = P.q2gl[q]; het = P.q2gl[257 + q]; homF = P.q2gl[514 + q]; }
                         } else {
                             const double e = T.errp[(size_t)r * plane + ev];
                             if (0.0 == e) { homT = 0.0; het = -0.30103; homF = -INFINITY; }
@@ -210,33 +240,71 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
                         }
                     }
                     float mx = -INFINITY;
+                    auto step = [&](float& a, const double t, const bool valid) {
+                        const float v = (float)((double)a + t);
+                        a = v;
+                        if (FULL) mx = __builtin_fmaxf(mx, v);                                    // = (v > mx) ? v : mx: v is never NaN-greater, mx never NaN
+                        else if (valid) mx = (v > mx) ? v : mx;
+                    };
 #pragma unroll
-                    for (int i = 0; i < A; ++i) {
+                    for (int c = 0; c < KK; ++c) step(tr[c], (KK == 1 || ci == c) ? homT : homF, c < k_pres || has_abs);
 #pragma unroll
-                        for (int j = 0; j <= i; ++j) {
-                            const int idx = i * (i + 1) / 2 + j;                         // bcf_alleles2gt
-                            const double t = (i == j) ? ((ao == i) ? homT : homF) : ((ao == i || ao == j) ? het : homF);
-                            const float v = (float)((double)acc[idx] + t);
-                            acc[idx] = v;
-                            if (FULL) mx = __builtin_fmaxf(mx, v);                       // = (v > mx) ? v : mx: v is never NaN-greater, mx never NaN
-                            else if (i < nA) mx = (v > mx) ? v : mx;
-                        }
+                    for (int d = 1; d < KK; ++d) {
+#pragma unroll
+                        for (int c = 0; c < d; ++c) step(tr[KK + d * (d - 1) / 2 + c], (KK == 2 || ci == c || ci == d) ? het : homF, d < k_pres || has_abs);
                     }
-                    // acc[i] -= mx, two genotypes per instruction (v_pk_add_f32: an IEEE float32 subtraction per half, the same
-                    // result as NG scalar subtractions)
+#pragma unroll
+                    for (int c = 0; c < KK; ++c) step(tr[KK + NH + c], (KK == 1 || ci == c) ? het : homF, has_abs);
+                    step(tr[NT - 1], homF, has_abs);
+                    // tr[i] -= mx, two per instruction (v_pk_add_f32: an IEEE float32 subtraction per half, the same result as scalar subtractions)
                     {
                         const v2f m2 = {mx, mx};
 #pragma unroll
-                        for (int i = 0; i + 1 < NG; i += 2) {
-                            v2f a = {acc[i], acc[i + 1]};
+                        for (int i = 0; i + 1 < NT; i += 2) {
+                            v2f a = {tr[i], tr[i + 1]};
                             a = a - m2;
-                            acc[i] = a.x; acc[i + 1] = a.y;
+                            tr[i] = a.x; tr[i + 1] = a.y;
                         }
-                        if (NG & 1) acc[NG - 1] -= mx;
+                        if (NT & 1) tr[NT - 1] -= mx;
                     }
                 }
+#pragma unroll
+                for (int i = 0; i < NT; ++i) s_x[i * 256 + otid] = __float_as_uint(tr[i]);       // column otid: this thread's, here and in VGL_PUT
             };
-            if (__ballot(nA != A) == 0) read_loop(std::true_type{}); else read_loop(std::false_type{});
+            const bool all_full = __ballot(!has_abs) == 0;
+            if (all_full) {
+                if (K == 1) read_loop(std::integral_constant<int, 1>{}, std::true_type{});
+                else if (K == 2) read_loop(std::integral_constant<int, 2>{}, std::true_type{});
+                else if (K == 3) read_loop(std::integral_constant<int, 3>{}, std::true_type{});
+                else read_loop(std::integral_constant<int, 4>{}, std::true_type{});
+            } else {
+                if (K == 1) read_loop(std::integral_constant<int, 1>{}, std::false_type{});
+                else if (K == 2) read_loop(std::integral_constant<int, 2>{}, std::false_type{});
+                else if (K == 3) read_loop(std::integral_constant<int, 3>{}, std::false_type{});
+                else read_loop(std::integral_constant<int, 4>{}, std::false_type{});
+            }
+            // genotype (i, j) -> its slot
+            const int oE = K, oP = K + K * (K - 1) / 2, oA = oP + K;
+            int pres[A];
+#pragma unroll
+            for (int i = 0; i < A; ++i) {
+                const int bb = nib(si.alleles2acgt, i);
+                pres[i] = (bb < 4 && ((pmask >> bb) & 1)) ? (int)((cmap >> (2 * bb)) & 3) : -1;
+            }
+#pragma unroll
+            for (int i = 0; i < A; ++i) {
+#pragma unroll
+                for (int j = 0; j <= i; ++j) {
+                    const int idx = i * (i + 1) / 2 + j;                                         // bcf_alleles2gt
+                    int m;
+                    if (i == j) m = pres[i] >= 0 ? pres[i] : oA;
+                    else {
+                        const int lo = pres[i] < pres[j] ? pres[i] : pres[j], hi = pres[i] < pres[j] ? pres[j] : pres[i];
+                        m = lo >= 0 ? oE + hi * (hi - 1) / 2 + lo : (hi >= 0 ? oP + hi : oA);
+                    }
+                    acc[idx] = __uint_as_float(s_x[m * 256 + otid]);
+                }
+            }
         } else {
             // GL model 1 with one fixed qScore: errmod_cal() reduces to table lookups on the
             // per-base depths (gl_methods.cpp:304-369; htslib errmod.c restated in vgl_host.cpp)
