@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
     };
     // ---- depth of the evaluation this thread would own in natural order
     int dp0 = -1;                                                      // -1: no evaluation (padding lane)
+    int k0 = 1;                                                        // GL model 2: distinct bases among its reads
     int ls0 = 0, s0 = N;
     {
         const uint32_t w = bx * 4u + (uint32_t)(tid >> 6);
@@ -139,15 +140,23 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
                 const uint64_t a = T.ad4[(size_t)ls0 * N + s0];
                 dp0 = (int)((a & 0xFFFF) + ((a >> 16) & 0xFFFF) + ((a >> 32) & 0xFFFF) + ((a >> 48) & 0xFFFF));
                 if (dp0 > 1023) dp0 = 1023;
+                if (GLM == 2) k0 = (int)((a & 0xFFFFULL) != 0) + (int)(((a >> 16) & 0xFFFF) != 0) + (int)(((a >> 32) & 0xFFFF) != 0) + (int)((a >> 48) != 0);
             }
         }
     }
     int otid = tid;
     if (P.gl_sort) {
-        const int nb = P.read_cap + 3;                                 // depths 0..read_cap, padding, one spare: <= 1026 bins
+        // order: (GL model 2) most distinct bases first -- the loop a wavefront runs is the one of its lane with the most -- then
+        // deepest first; evaluations without reads and padding lanes last.  At most 4 * 256 + 2 bins.
+        constexpr int NK = (GLM == 2) ? 4 : 1;
+        const int sh = P.read_cap > 511 ? 2 : (P.read_cap > 255 ? 1 : 0);
+        const int nbd = (P.read_cap >> sh) + 1;                        // depth bins
+        const int nb = NK * nbd + 2;
         for (int i = tid; i < nb; i += 256) s_hist[i] = 0;
         __syncthreads();
-        const int key = P.read_cap + 1 - (dp0 > P.read_cap ? P.read_cap : dp0);   // deepest first; padding (dp0 = -1) last
+        int key = nb - 1;
+        if (dp0 == 0) key = nb - 2;
+        else if (dp0 > 0) key = (NK - k0) * nbd + (nbd - 1 - ((dp0 > P.read_cap ? P.read_cap : dp0) >> sh));
         atomicAdd(&s_hist[key], 1u);
         __syncthreads();
         if (tid < 64) {                                                // exclusive scan of the bins by one wavefront
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
             auto read_loop = [&](auto k_tag, auto full_tag) {
                 constexpr int KK = decltype(k_tag)::value;
                 constexpr bool FULL = decltype(full_tag)::value;                                  // every lane has an absent allele: all slots stand for real genotypes
-                constexpr int NH = KK * (KK - 1) / 2, NT = 2 * KK + NH + 1;                       // hom [0,KK) | het [KK, KK+NH) | present/absent [KK+NH, 2KK+NH) | absent
+                constexpr int NT = (KK + 1) * (KK + 2) / 2;                                       // genotypes of KK + 1 "alleles": present base 0 .. KK-1, and KK = any absent allele
                 float tr[NT];
 #pragma unroll
                 for (int i = 0; i < NT; ++i) tr[i] = -0.0f;                                       // bcf_utils.h:310
@@ -247,15 +256,16 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
                         else if (valid) mx = (v > mx) ? v : mx;
                     };
 #pragma unroll
-                    for (int c = 0; c < KK; ++c) step(tr[c], (KK == 1 || ci == c) ? homT : homF, c < k_pres || has_abs);
+                    for (int b = 0; b <= KK; ++b) {
 #pragma unroll
-                    for (int d = 1; d < KK; ++d) {
-#pragma unroll
-                        for (int c = 0; c < d; ++c) step(tr[KK + d * (d - 1) / 2 + c], (KK == 2 || ci == c || ci == d) ? het : homF, d < k_pres || has_abs);
+                        for (int a = 0; a <= b; ++a) {
+                            double t;
+                            if (b == KK) t = (a == KK) ? homF : ((KK == 1 || ci == a) ? het : homF);            // one or both alleles absent
+                            else if (a == b) t = (KK == 1 || ci == a) ? homT : homF;
+                            else t = (KK == 2 || ci == a || ci == b) ? het : homF;
+                            step(tr[b * (b + 1) / 2 + a], t, b < k_pres || has_abs);
+                        }
                     }
-#pragma unroll
-                    for (int c = 0; c < KK; ++c) step(tr[KK + NH + c], (KK == 1 || ci == c) ? het : homF, has_abs);
-                    step(tr[NT - 1], homF, has_abs);
                     // tr[i] -= mx, two per instruction (v_pk_add_f32: an IEEE float32 subtraction per half, the same result as scalar subtractions)
                     {
                         const v2f m2 = {mx, mx};
@@ -283,26 +293,22 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
                 else if (K == 3) read_loop(std::integral_constant<int, 3>{}, std::false_type{});
                 else read_loop(std::integral_constant<int, 4>{}, std::false_type{});
             }
-            // genotype (i, j) -> its slot
-            const int oE = K, oP = K + K * (K - 1) / 2, oA = oP + K;
-            int pres[A];
+            // genotype (i, j) of the site's alleles -> slot of (rank of i's base or K, rank of j's base or K)
+            int pr[A], tri[A];
 #pragma unroll
             for (int i = 0; i < A; ++i) {
                 const int bb = nib(si.alleles2acgt, i);
-                pres[i] = (bb < 4 && ((pmask >> bb) & 1)) ? (int)((cmap >> (2 * bb)) & 3) : -1;
+                pr[i] = (bb < 4 && ((pmask >> bb) & 1)) ? (int)((cmap >> (2 * bb)) & 3) : K;
+                tri[i] = pr[i] * (pr[i] + 1) / 2;
             }
+            const uint32_t* colx = s_x + otid;
 #pragma unroll
             for (int i = 0; i < A; ++i) {
 #pragma unroll
                 for (int j = 0; j <= i; ++j) {
                     const int idx = i * (i + 1) / 2 + j;                                         // bcf_alleles2gt
-                    int m;
-                    if (i == j) m = pres[i] >= 0 ? pres[i] : oA;
-                    else {
-                        const int lo = pres[i] < pres[j] ? pres[i] : pres[j], hi = pres[i] < pres[j] ? pres[j] : pres[i];
-                        m = lo >= 0 ? oE + hi * (hi - 1) / 2 + lo : (hi >= 0 ? oP + hi : oA);
-                    }
-                    acc[idx] = __uint_as_float(s_x[m * 256 + otid]);
+                    const int m = (tri[i] > tri[j] ? tri[i] : tri[j]) + (pr[i] < pr[j] ? pr[i] : pr[j]);
+                    acc[idx] = __uint_as_float(colx[m * 256]);
                 }
             }
         } else {
