@@ -331,7 +331,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
         if (pc > 1920) pc = 1920;                      // 520 + 5 x 1920 B per wavefront: 16 wavefronts (the 4 per SIMD the kernel is
                                                        // built for) fit a CU's 160 KB LDS; larger pools run in several segments
         D.pool_cap = pc;
-        D.pool_lds_bytes = ((512 + 4 * (pc + 2) + pc + 7) & ~7) + 64;    // stream bases | item slots (+ the zero slot) | bases | gamma constants by stage
+        D.pool_lds_bytes = (576 + 4 * (pc + 2) + pc + 7) & ~7;         // stream bases | gamma constants by stage | item slots (+ zero slot, counter) | bases
     }
     D.error_qs = p->error_qs; D.gl_model = p->gl_model; D.precise_gl = p->precise_gl; D.adjust_qs = p->adjust_qs;
     D.n_qs_bins = p->n_qs_bins; D.do_unobserved = p->do_unobserved; D.rm_invar_sites = p->rm_invar_sites;

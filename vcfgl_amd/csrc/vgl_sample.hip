@@ -174,19 +174,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
             qq2 = q2 * (uint32_t)((ad4 >> 32) & 0xFFFF); qq3 = q2 * (uint32_t)((ad4 >> 48) & 0xFFFF);
         }
     } else {
-        // ---- LDS of this wave: [64] u64 qscore-stream bases | [cap + 2] u32 item slot | [cap] u8 base.
-        //      An item's slot holds (read << 6) | owner until the item is finished, then the float32 error
-        //      probability of its read, then (dense pass) qScore | adjusted qScore << 8.  Slot [cap] stays 0: the
-        //      prefetch of a lane that has no next item reads it.
+        // ---- LDS of this wave: [64] u64 qscore-stream bases | [2][4] f64 gamma constants | [cap + 2] u32 item slot | [cap] u8 base.
+        //      An item's slot holds owner << 26 | read << 4 until the item is finished, then the float32 error
+        //      probability of its read, then (dense pass) qScore | adjusted qScore << 8.  Slot [segT] of a segment is 0: the
+        //      prefetch of a lane that has no next item reads it.  Slot [cap + 1]: the pool loop's item counter.
         const int cap = P.pool_cap;
         uint8_t* wl = lds_raw;                         // one wavefront per workgroup (vgl_launch_sample): LDS offsets are compile-time
         uint64_t* l_stq = (uint64_t*)wl;
-        uint32_t* l_it = (uint32_t*)(wl + 512);
-        uint8_t* l_pb = wl + 512 + 4 * ((size_t)cap + 2);
+        // a1, a2, 0.15 a2^2 of the two gamma samplers and the sure-accept margin, looked up by a lane's stage in the pool loop (LDS
+        // reads instead of selects and multiplications per iteration, and fewer register pairs to carry)
+        double* l_gc = (double*)(wl + 512);
+        uint32_t* l_it = (uint32_t*)(wl + 576);
+        uint8_t* l_pb = wl + 576 + 4 * ((size_t)cap + 2);
         uint32_t* l_ctr = l_it + cap + 1;             // pool loop: first unclaimed item
-        // [2][3] f64 at the end: a1, a2 and 0.15 a2^2 of the two gamma samplers, looked up by a lane's stage in the pool loop (three
-        // LDS reads instead of four selects and two multiplications per iteration, and four fewer register pairs to carry)
-        double* l_gc = (double*)(wl + ((512 + 4 * ((size_t)cap + 2) + (size_t)cap + 7) & ~(size_t)7));
+        // the pool loop reads l_stq by LDS byte offsets taken from the item slots: the dynamic LDS block must start at 0
+        // (this kernel has no static LDS)
+        if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds_raw != 0u) __builtin_trap();
 
         // exclusive prefix sum of the depths = first pool index of each owner
         int incl = dp;
@@ -197,8 +200,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
         l_stq[lane] = st_qs << 4;                      // the pool loop works on states scaled by 16 (lcg_next52)
         if (lane == 0) {
             l_it[cap] = 0u;
-            l_gc[0] = P.gx.a1; l_gc[1] = P.gx.a2; l_gc[2] = (P.gx.a2 * P.gx.a2) * 0.15;
-            l_gc[3] = P.gy.a1; l_gc[4] = P.gy.a2; l_gc[5] = (P.gy.a2 * P.gy.a2) * 0.15;
+            l_gc[0] = P.gx.a1; l_gc[1] = P.gx.a2; l_gc[2] = (P.gx.a2 * P.gx.a2) * 0.15; l_gc[3] = P.sure_margin;
+            l_gc[4] = P.gy.a1; l_gc[5] = P.gy.a2; l_gc[6] = (P.gy.a2 * P.gy.a2) * 0.15; l_gc[7] = P.sure_margin;
         }
         int rdone = 0;
         // Kernel arguments arrive in 16-dword scalar tuples that the register allocator spills and
@@ -267,10 +270,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     // the bottom (unconditional, clamped index: no divergent control flow in the loop)
                     const uint32_t m_n = l_it[kn < segT ? kn : segT];     // l_it[segT] = 0 (a valid slot) stands for "none"
                     const VglAffine tab_n = *(const VglAffine*)((const uint8_t*)P.qs_read_tab + (m_n & 0x3FFFu << 4));
-                    const uint64_t base_n = *(const uint64_t*)((const uint8_t*)l_stq + (m_n >> 23));
+                    const uint64_t base_n = *(__attribute__((address_space(3))) const uint64_t*)(uintptr_t)(m_n >> 23);   // l_stq[owner]
 
-                    const double* gc = l_gc + (stage1 ? 3 : 0);
-                    const double ga1 = gc[0], ga2 = gc[1], ga2sq015 = gc[2];
+                    const double* gc = l_gc + (stage1 ? 4 : 0);
+                    const double ga1 = gc[0], ga2 = gc[1], ga2sq015 = gc[2], sure_margin = gc[3];
                     // normal attempt
                     const uint64_t st1 = lcg_next52r(st);        // raw: bits 52-63 are masked where a uniform is built
                     const uint64_t st2 = lcg_next52r(st1);
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     // 1 - u >= 0.15 a2^2 x^4 (+ P.sure_margin, far above the rounding of either side) is a sure accept: it settles 97 %
                     // of these cases (the sampler's rejection rate is 0.3 % for alpha ~ 10 and 0.003 % for alpha ~ 1000), and the
                     // bounded test below is left with ~0.2 % of the lanes of an iteration.
-                    const bool sure = (1.0 - u2 >= ga2sq015 * x4 + P.sure_margin) && (w >= 0.5);
+                    const bool sure = (1.0 - u2 >= ga2sq015 * x4 + sure_margin) && (w >= 0.5);
                     const bool g_try = have && acc_n && w_pos && !hold;
                     const bool g_amb = g_try && sq_fail && !sure;
                     hold = hold || (g_amb && !full);
