@@ -87,6 +87,22 @@ def test_unobserved_and_skip_modes(oracle, du, rm):
     assert_parity(want, got)
 
 
+@pytest.mark.parametrize("du", [0, 1, 3, 5])
+@pytest.mark.parametrize("e,depth", [(0.0, 9), (0.03, 14), (0.35, 25)])
+@pytest.mark.parametrize("eqs,precise", [(0, 0), (2, 0), (2, 1)])
+def test_gl2_accumulator_classes(oracle, du, e, depth, eqs, precise):
+    """GL model 2 keeps one accumulator per distinct update sequence (k_gl: 3 / 6 / 10 / 15 for 1 .. 4 distinct bases among an
+    evaluation's reads, the loop chosen per wavefront, lanes ordered by that count): error rates from 0 (one or two bases per
+    evaluation) to 0.35 (mostly four), with (du 1, 5) and without (du 0, 3) an allele that no read of the site shows, 4- and
+    5-allele kernels, fixed / per-read / exact-log terms.  300 samples: several wavefronts per site and a ragged last one."""
+    kw = dict(error_qs=2, beta_variance=1e-4) if eqs == 2 else {}
+    if e == 0.0 and eqs == 2:
+        pytest.skip("the beta sampler needs a mean error rate > 0")
+    args = VcfglArgs(seed=31 + du, depth=depth, error_rate=e, do_unobserved=du, precise_gl=precise, add_pl=1, add_fmt_ad=1, **kw)
+    want, got = run_both(oracle, args, synth.acgt_sites(12, 300, seed=7 + du, missing=0.02))
+    assert_parity(want, got, exact_gl=(precise == 0), check_gp=False)
+
+
 @pytest.mark.parametrize("e", [0.0, 0.2, 0.9])
 def test_error_rates_incl_low_qscore(oracle, e):
     """e=0 -> q 63; e=0.9 -> q 0 (homT = -inf in the LUT)"""
