@@ -259,19 +259,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 // holds: its state is left untouched, so the later iteration recomputes the same attempt.
                 int slow_cnt = P.slow_period, slow_cnt_n = P.slow_period_n;
                 uint32_t k3ff = 0x3FF00000u;                 // the exponent word of 1.xxx, in a vector register for v_and_or_b32
-                asm volatile("" : "+v"(k3ff));
+                // a lane that finishes an item claims the next one with an LDS atomic whose result (`claimed`) is first looked at in
+                // the next iteration (kn = fin_prev ? claimed : kn), so no wait stands behind the atomic
+                uint32_t claimed = 0; bool fin_prev = false;
                 do {                                         // segT >= 1: lane 0 has an item
                     if (DBG) c_iter++;
                     const bool full = (--slow_cnt == 0);     // bounded gamma test (needed by ~0.2 % of the lanes of an iteration)
                     if (full) slow_cnt = P.slow_period;
                     const bool full_n = (--slow_cnt_n == 0); // bounded normal-deviate test (~1.2 %)
                     if (full_n) slow_cnt_n = P.slow_period_n;
-                    // operands of this lane's next item, fetched at the top of the iteration and consumed at
-                    // the bottom (unconditional, clamped index: no divergent control flow in the loop)
-                    const uint32_t m_n = l_it[kn < segT ? kn : segT];     // l_it[segT] = 0 (a valid slot) stands for "none"
-                    const VglAffine tab_n = *(const VglAffine*)((const uint8_t*)P.qs_read_tab + (m_n & 0x3FFFu << 4));
-                    const uint64_t base_n = *(__attribute__((address_space(3))) const uint64_t*)(uintptr_t)(m_n >> 23);   // l_stq[owner]
-
                     const double* gc = l_gc + (stage1 ? 4 : 0);
                     const double ga1 = gc[0], ga2 = gc[1], ga2sq015 = gc[2], sure_margin = gc[3];
                     // normal attempt
@@ -289,6 +285,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     bool hold = n_amb && !full_n;
                     if (full_n && __builtin_amdgcn_ballot_w64(n_amb)) slow_n = normal_slow_test(v, u, n_amb);
                     const bool acc_n = !(q_lo && (q_hi || slow_n));
+                    // operands of this lane's next item, fetched here -- far enough behind the claim of the previous iteration and
+                    // ahead of their use at the bottom (unconditional, clamped index: no divergent control flow in the loop)
+                    kn = fin_prev ? (int)claimed : kn;
+                    const uint32_t m_n = l_it[kn < segT ? kn : segT];     // l_it[segT] = 0 (a valid slot) stands for "none"
+                    const VglAffine tab_n = *(const VglAffine*)((const uint8_t*)P.qs_read_tab + (m_n & 0x3FFFu << 4));
+                    const uint64_t base_n = *(__attribute__((address_space(3))) const uint64_t*)(uintptr_t)(m_n >> 23);   // l_stq[owner]
                     // gamma step on the accepted deviate
                     const double xn = div_inrange(v, u);
                     const double w = 1.0 + ga2 * xn;
@@ -335,8 +337,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                         // items to lanes gives the same result)
                         st = st_n;
                         k = kn;
-                        kn = (int)__hip_atomic_fetch_add(l_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        claimed = __hip_atomic_fetch_add(l_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     }
+                    fin_prev = fin;
                     have = k < segT;
                 } while (__builtin_amdgcn_ballot_w64(have));
             }
