@@ -268,10 +268,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     if (full) slow_cnt = P.slow_period;
                     const bool full_n = (--slow_cnt_n == 0); // bounded normal-deviate test (~1.2 %)
                     if (full_n) slow_cnt_n = P.slow_period_n;
-                    const double* gc = l_gc + (stage1 ? 4 : 0);
+                    uint32_t goff = stage1 ? 32u : 0u;                         // l_gc[stage] = LDS byte 512 + goff (the dynamic LDS block starts at 0)
+                    asm volatile("" : "+v"(goff));                              // one select, not one per element
+                    const __attribute__((address_space(3))) double* gc = (const __attribute__((address_space(3))) double*)(uintptr_t)goff + 64;
                     const double ga1 = gc[0], ga2 = gc[1], ga2sq015 = gc[2], sure_margin = gc[3];
                     // normal attempt
-                    const uint64_t st1 = lcg_next52r(st);        // raw: bits 52-63 are masked where a uniform is built
+                    uint64_t st1 = lcg_next52r(st);              // raw: bits 52-63 are masked where a uniform is built
+                    asm volatile("" : "+v"(st1));                // (st2 from st1, not from a second product of st: one multiply-add fewer)
                     const uint64_t st2 = lcg_next52r(st1);
                     const uint64_t st3 = lcg_next52r(st2);
                     const double u = bits_1xxx_52r(st1, k3ff) - 1.0;
