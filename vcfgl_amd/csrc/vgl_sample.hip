@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 l_it[k] = ((uint32_t)lane << 26) | ((uint32_t)r << 4);   // slot: lane of the owner, 16 * read (byte offsets of l_stq / qs_read_tab by one shift / one mask)
                 l_pb[k] = (uint8_t)r_base;
             }
-            if (lane == 0) { l_it[segT] = 0u; *l_ctr = 128u; }   // the "no item" slot of this segment's prefetches; first unclaimed item
+            if (lane == 0) { l_it[segT] = 0u; *l_ctr = 128u * 4u; }   // the "no item" slot of this segment's prefetches; first unclaimed item
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -248,11 +248,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 // item ahead (so that kn's operands are in flight while k is worked on); a lane that
                 // finishes an item adopts kn and claims the next unclaimed one.  Each item's stream is
                 // addressed by its read, so the result does not depend on who works on it.
-                int k = lane, kn = lane + 64;
-                bool have = k < segT;                        // == (k < segT) throughout: the loop tests that compare
+                // k, kn: the lane's item and the one claimed ahead, as BYTE offsets of their slots (4 x item index: the counter is
+                // bumped by 4, so a claim is an LDS address without a shift)
+                typedef __attribute__((address_space(3))) uint32_t lds_u32;
+                const int segT4 = segT * 4;
+                int k = lane * 4, kn = (lane + 64) * 4;
+                bool have = k < segT4;                       // == (k < segT4) throughout: the loop tests that compare
                 bool stage1 = false;                         // false: first gamma deviate (x), true: second (y)
                 uint64_t st = 0; double gx = 0.0; uint32_t it_m = 0;
-                if (have) { it_m = l_it[k]; st = aff52(P.qs_read_tab[(it_m >> 4) & 0x3FF], l_stq[it_m >> 26]); }
+                if (have) { it_m = l_it[lane]; st = aff52(P.qs_read_tab[(it_m >> 4) & 0x3FF], l_stq[it_m >> 26]); }
                 const bool any_changed = (P.gx.changed | P.gy.changed) != 0;
                 // The bounded-log tests are needed by a few lanes per iteration but cost every lane of the
                 // wave; they run only every P.slow_period-th iteration.  In between, a lane that needs one
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     // operands of this lane's next item, fetched here -- far enough behind the claim of the previous iteration and
                     // ahead of their use at the bottom (unconditional, clamped index: no divergent control flow in the loop)
                     kn = fin_prev ? (int)claimed : kn;
-                    const uint32_t m_n = l_it[kn < segT ? kn : segT];     // l_it[segT] = 0 (a valid slot) stands for "none"
+                    const uint32_t m_n = *(const lds_u32*)(uintptr_t)(576u + (uint32_t)(kn < segT4 ? kn : segT4));   // l_it[...]; l_it[segT] = 0 (a valid slot) stands for "none"
                     const VglAffine tab_n = *(const VglAffine*)((const uint8_t*)P.qs_read_tab + (m_n & 0x3FFFu << 4));
                     const uint64_t base_n = *(__attribute__((address_space(3))) const uint64_t*)(uintptr_t)(m_n >> 23);   // l_stq[owner]
                     // gamma step on the accepted deviate
@@ -334,16 +338,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     if (fin) {
                         // a finished read leaves its error probability (rng.h:438) as a float32 in the item's slot; the
                         // quality scores are taken from it by the dense pass after the loop
-                        l_it[k] = __float_as_uint(qs_stage_pf(gx_prev, val));
+                        *(lds_u32*)(uintptr_t)(576u + (uint32_t)k) = __float_as_uint(qs_stage_pf(gx_prev, val));   // l_it[item]
                         if (PREC) { T.errp[(size_t)((it_m >> 4) & 0x3FF) * plane + ev0 + (it_m >> 26)] = gx_prev / (gx_prev + val); it_m = m_n; }
                         // the lane adopts kn and claims the next unclaimed item from the wave's counter (any assignment of
                         // items to lanes gives the same result)
                         st = st_n;
                         k = kn;
-                        claimed = __hip_atomic_fetch_add(l_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        claimed = __hip_atomic_fetch_add(l_ctr, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     }
                     fin_prev = fin;
-                    have = k < segT;
+                    have = k < segT4;
                 } while (__builtin_amdgcn_ballot_w64(have));
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
