@@ -427,6 +427,24 @@ __device__ __forceinline__ void qs_finish(const VglDevParams& P, int& q, int& aq
     }
 }
 
+// sample_read_base() on states carried shifted left by 16 bits: 64-bit wraparound is then the generator's mod 2^48 (no masking
+// per step), u < 0.5 is the sign bit, floor(4u) the top two bits.  err_thresh16 = err_thresh << 16, saturated (sample_thresh16).
+__device__ __forceinline__ uint64_t lcg_next16(const uint64_t x) { return x * VGL_LCG_A + (VGL_LCG_C << 16); }
+__device__ __forceinline__ uint64_t sample_thresh16(const uint64_t t) { return t >= (1ULL << 48) ? ~0ULL : (t << 16); }
+__device__ __forceinline__ int sample_read_base16(uint64_t& st_hap, uint64_t& st_base, const int a0, const int a1,
+                                                  const uint64_t err_thresh16, const bool sample_strand, bool& fwd) {
+    st_hap = lcg_next16(st_hap);
+    const int true_base = ((int64_t)st_hap >= 0) ? a0 : a1;
+    int r_base = true_base;
+    st_base = lcg_next16(st_base);
+    if (st_base < err_thresh16) {
+        do { st_base = lcg_next16(st_base); r_base = (int)(st_base >> 62); } while (r_base == true_base);
+    }
+    fwd = true;
+    if (sample_strand) { st_base = lcg_next16(st_base); fwd = (int64_t)st_base >= 0; }
+    return r_base;
+}
+
 // one read: haplotype pick, base-call error, strand (vcfgl.cpp:473,486-488,581-586); all compares
 // are exact integer restatements on the 48-bit state: u<0.5 <=> X<2^47, u<e <=> X<ceil(e 2^48),
 // floor(4u) = X>>46

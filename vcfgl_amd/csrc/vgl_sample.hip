@@ -204,6 +204,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
             l_gc[4] = P.gy.a1; l_gc[5] = P.gy.a2; l_gc[6] = (P.gy.a2 * P.gy.a2) * 0.15; l_gc[7] = P.sure_margin;
         }
         int rdone = 0;
+        uint64_t st_hap16 = st_hap << 16, st_base16 = st_base << 16;      // sample_read_base16
+        const uint64_t err_thresh16 = sample_thresh16(err_thresh);
         // Kernel arguments arrive in 16-dword scalar tuples that the register allocator spills and
         // reloads as a whole (v_readlane, VALU work) inside the loops below; the three values the flush
         // loop needs are therefore pinned to vector registers.
@@ -221,15 +223,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
             // -- owners: bases of their reads that fall into this segment
             if (DBG) c_tmp = clock64();
             int r_end = seg0 + segT - offs; r_end = r_end > dp ? dp : r_end; r_end = r_end < rdone ? rdone : r_end;
-            for (int r = rdone; r < r_end; ++r) {
-                bool fwd;
-                const int r_base = sample_read_base(st_hap, st_base, a0, a1, err_thresh, k_strand, fwd);
-                const uint64_t one = 1ULL << (16 * r_base);
-                ad4 += one;
-                if (!LEAN) { if (fwd) adf4 += one; }
-                const int k = offs + r - seg0;
-                l_it[k] = ((uint32_t)lane << 26) | ((uint32_t)r << 4);   // slot: lane of the owner, 16 * read (byte offsets of l_stq / qs_read_tab by one shift / one mask)
-                l_pb[k] = (uint8_t)r_base;
+            {
+                // slot value (owner << 26 | read << 4), slot address and base address advance by constants per read
+                typedef __attribute__((address_space(3))) uint32_t lds_u32o;
+                typedef __attribute__((address_space(3))) uint8_t lds_u8o;
+                uint32_t sv = ((uint32_t)lane << 26) | ((uint32_t)rdone << 4);
+                const uint32_t sv_end = ((uint32_t)lane << 26) | ((uint32_t)r_end << 4);
+                uint32_t ka = 576u + 4u * (uint32_t)(offs + rdone - seg0);                     // l_it[k]  (the dynamic LDS block starts at 0)
+                uint32_t pa = 576u + 4u * ((uint32_t)cap + 2u) + (uint32_t)(offs + rdone - seg0);   // l_pb[k]
+                while (sv < sv_end) {
+                    bool fwd;
+                    const int r_base = sample_read_base16(st_hap16, st_base16, a0, a1, err_thresh16, k_strand, fwd);
+                    const uint64_t one = 1ULL << (16 * r_base);
+                    ad4 += one;
+                    if (!LEAN) { if (fwd) adf4 += one; }
+                    *(lds_u32o*)(uintptr_t)ka = sv;
+                    *(lds_u8o*)(uintptr_t)pa = (uint8_t)r_base;
+                    sv += 16u; ka += 4u; pa += 1u;
+                }
             }
             if (lane == 0) { l_it[segT] = 0u; *l_ctr = 128u * 4u; }   // the "no item" slot of this segment's prefetches; first unclaimed item
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
