@@ -28,6 +28,7 @@ struct VglGamma1 { double alpha0, a1, a2; int32_t changed; int32_t pad; };
 #define VGL_DEVERR_QSBIN    2u
 #define VGL_DEVERR_GL1DEPTH 4u
 #define VGL_DEVERR_ADJQ     8u
+#define VGL_DEVERR_INTERNAL 16u   /* a layout assumption of a kernel does not hold (k_sample<2>: dynamic LDS must start at offset 0) */
 
 // per-site accumulator layout (int32 x 16): [0] INFO/DP, [1..4] ACGT depth,
 // [5..8] forward-strand ACGT depth, [9..12] reverse-strand ACGT depth

@@ -712,6 +712,7 @@ extern "C" int vgl_ctx_check(vgl_ctx* c, void* stream) {
     if (flag & VGL_DEVERR_CAPACITY) return fail(VGL_E_CAPACITY, "a simulated read depth exceeded the staging capacity of %d reads per sample", c->dp.read_cap);
     if (flag & VGL_DEVERR_QSBIN) return fail(VGL_E_QSBIN, "Could not find a range for a simulated qs value in --qs-bins");
     if (flag & VGL_DEVERR_ADJQ) return fail(VGL_E_ADJQ, "--adjust-qs %d: a read has no valid adjusted quality score (error probability exactly 0 or 1, or a negative adjusted score)", c->dp.adjust_qs);
+    if (flag & VGL_DEVERR_INTERNAL) return fail(VGL_E_NODEVICE, "internal: a kernel's LDS layout assumption does not hold on this build (k_sample<2>)");
     return VGL_OK;
 }
 
@@ -742,6 +743,7 @@ static int flags_to_rc(vgl_ctx* c, uint32_t flag) {
     if (flag & VGL_DEVERR_CAPACITY) return fail(VGL_E_CAPACITY, "a simulated read depth exceeded the staging capacity of %d reads per sample", c->dp.read_cap);
     if (flag & VGL_DEVERR_QSBIN) return fail(VGL_E_QSBIN, "Could not find a range for a simulated qs value in --qs-bins");
     if (flag & VGL_DEVERR_ADJQ) return fail(VGL_E_ADJQ, "--adjust-qs %d: a read has no valid adjusted quality score (error probability exactly 0 or 1, or a negative adjusted score)", c->dp.adjust_qs);
+    if (flag & VGL_DEVERR_INTERNAL) return fail(VGL_E_NODEVICE, "internal: a kernel's LDS layout assumption does not hold on this build (k_sample<2>)");
     return VGL_OK;
 }
 

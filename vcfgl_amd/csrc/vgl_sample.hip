@@ -158,14 +158,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
         const uint32_t q2 = (uint32_t)qs_to_qssq((int)qq);
         const bool stage = (P.gl_model != 1) || P.gl1_deep;   // GL model 1 with one fixed qScore needs only the per-base depths, unless
                                                               // an evaluation may exceed 255 reads (k_gl then subsamples the staged reads)
+        uint64_t st_hap16 = st_hap << 16, st_base16 = st_base << 16;      // sample_read_base16: states carried shifted by 16
+        const uint64_t err_thresh16 = sample_thresh16(err_thresh);
         for (int r = 0; r < dp; ++r) {
             bool fwd;
-            const int r_base = sample_read_base(st_hap, st_base, a0, a1, err_thresh, k_strand, fwd);
+            const int r_base = sample_read_base16(st_hap16, st_base16, a0, a1, err_thresh16, k_strand, fwd);
             if (stage) T.reads[(size_t)r * plane + ev] = (uint8_t)((q_gl << 2) | r_base);
             if (T.reads_out && r < T.reads_out_cap) T.reads_out[(size_t)r * plane + ev] = (uint8_t)((q_i << 2) | r_base);
             const uint64_t one = 1ULL << (16 * r_base);
             ad4 += one;
-            if (fwd) adf4 += one;
+            if (k_strand) { if (fwd) adf4 += one; }                       // without strand draws adf4 = ad4 (set after the loops)
         }
         if (P.need_qsum) {
             qs0 = qq * (uint32_t)(ad4 & 0xFFFF); qs1 = qq * (uint32_t)((ad4 >> 16) & 0xFFFF);
@@ -189,7 +191,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
         uint32_t* l_ctr = l_it + cap + 1;             // pool loop: first unclaimed item
         // the pool loop reads l_stq by LDS byte offsets taken from the item slots: the dynamic LDS block must start at 0
         // (this kernel has no static LDS)
-        if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds_raw != 0u) __builtin_trap();
+        if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds_raw != 0u) {      // (vgl_launch_sample checks the same on the host)
+            if (lane == 0) atomicOr(T.errflag, VGL_DEVERR_INTERNAL);
+            return;
+        }
 
         // exclusive prefix sum of the depths = first pool index of each owner
         int incl = dp;
@@ -491,6 +496,22 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
          else hipLaunchKernelGGL((k_sample<EQS, DBG, 0, PREC, LEAN>), g, b, LDS, s, *p, *t); } while (0)
     const bool lean = !p->need_qsum && !p->sample_strand && !p->need_adf && !t->reads_out && p->adjust_qs == 0 && !getenv("VGL_NO_LEAN");
     if (p->error_qs == 2) {
+        // the pool loop addresses LDS by integer offsets from 0: none of its instantiations may own static LDS
+        static const bool static_lds_free = [] {
+            size_t worst = 0;
+            hipFuncAttributes a;
+#define VGL_STATIC_LDS(DBG, DM, PREC, LEAN) \
+            if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_sample<2, DBG, DM, PREC, LEAN>)) != hipSuccess) return false; \
+            worst = a.sharedSizeBytes > worst ? a.sharedSizeBytes : worst;
+            VGL_STATIC_LDS(true, 0, false, false) VGL_STATIC_LDS(true, 1, false, false) VGL_STATIC_LDS(true, 2, false, false)
+            VGL_STATIC_LDS(false, 0, true, true) VGL_STATIC_LDS(false, 1, true, true) VGL_STATIC_LDS(false, 2, true, true)
+            VGL_STATIC_LDS(false, 0, true, false) VGL_STATIC_LDS(false, 1, true, false) VGL_STATIC_LDS(false, 2, true, false)
+            VGL_STATIC_LDS(false, 0, false, true) VGL_STATIC_LDS(false, 1, false, true) VGL_STATIC_LDS(false, 2, false, true)
+            VGL_STATIC_LDS(false, 0, false, false) VGL_STATIC_LDS(false, 1, false, false) VGL_STATIC_LDS(false, 2, false, false)
+#undef VGL_STATIC_LDS
+            return worst == 0;
+        }();
+        if (!static_lds_free) return (int)hipErrorInvalidConfiguration;
         if (dbg && !t->errp) VGL_LAUNCH_SAMPLE(2, true, false, false, lds);   // diagnostic build: --precise-gl 0 only
         else if (t->errp) { if (lean) VGL_LAUNCH_SAMPLE(2, false, true, true, lds); else VGL_LAUNCH_SAMPLE(2, false, true, false, lds); }   // --precise-gl 1, or the deviates were asked for
         else { if (lean) VGL_LAUNCH_SAMPLE(2, false, false, true, lds); else VGL_LAUNCH_SAMPLE(2, false, false, false, lds); }
