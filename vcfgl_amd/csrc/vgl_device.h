@@ -24,6 +24,14 @@ struct VglPois { double lm, sq, alxm, g; int32_t st12; int32_t pad; };
 struct VglGamma1 { double alpha0, a1, a2; int32_t changed; int32_t pad; };
 
 // Device error flag bits (sticky, OR-ed by kernels)
+// Staged reads (VglTilePtrs::reads, 1 byte per read: qScore << 2 | base): read r of evaluation ev is byte (r & 3) of the 32-bit
+// word [(r >> 2) * plane + ev], plane = n_sites * n_samples -- four reads of an evaluation per word, so that the wavefronts of
+// k_sample store and those of k_gl load whole 256-byte rows per instruction.  read_cap is a multiple of 4.
+#if defined(__HIPCC__)
+__device__ __forceinline__ size_t vgl_read_byte(const int r, const size_t plane, const size_t ev) {
+    return ((((size_t)(r >> 2)) * plane + ev) << 2) | (size_t)(r & 3);
+}
+#endif
 #define VGL_DEVERR_CAPACITY 1u
 #define VGL_DEVERR_QSBIN    2u
 #define VGL_DEVERR_GL1DEPTH 4u

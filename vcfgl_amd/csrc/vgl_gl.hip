@@ -228,14 +228,20 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
 #pragma unroll
                 for (int i = 0; i < NT; ++i) tr[i] = -0.0f;                                       // bcf_utils.h:310
                 double homT = P.pre_homT, het = P.pre_het, homF = P.pre_homF;
-                // the staged reads of an evaluation lie one plane (n_sites x n_samples bytes) apart: four loads are kept in flight
-                const uint8_t* col = T.reads + ev;
-                const int last = dp - 1;
-                uint32_t nx0 = col[0], nx1 = col[(size_t)(1 < last ? 1 : last) * plane], nx2 = col[(size_t)(2 < last ? 2 : last) * plane],
-                         nx3 = col[(size_t)(3 < last ? 3 : last) * plane];
+                // the staged reads of an evaluation: four per 32-bit word, words one plane (n_sites x n_samples words) apart
+                // (vgl_read_byte); three words = 12 reads are kept in flight
+                const uint32_t* colw = (const uint32_t*)T.reads + ev;
+                const int lastw = (dp - 1) >> 2;
+                uint32_t w0 = colw[0], w1 = colw[(size_t)(1 < lastw ? 1 : lastw) * plane], w2 = colw[(size_t)(2 < lastw ? 2 : lastw) * plane];
+                uint32_t cur = 0;
                 for (int r = 0; r < dp; ++r) {
-                    const uint32_t rb = nx0;
-                    nx0 = nx1; nx1 = nx2; nx2 = nx3; nx3 = col[(size_t)(r + 4 < last ? r + 4 : last) * plane];
+                    if ((r & 3) == 0) {                                                           // (r is the same in every active lane)
+                        cur = w0; w0 = w1; w1 = w2;
+                        const int nw = (r >> 2) + 3;
+                        w2 = colw[(size_t)(nw < lastw ? nw : lastw) * plane];
+                    }
+                    const uint32_t rb = cur & 0xFFu;
+                    cur >>= 8;
                     const int ci = (int)((cmap >> ((rb & 3) * 2)) & 3);                           // the read's base among the present ones
                     if (per_read) {
                         if (!PREC) {
@@ -326,16 +332,17 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
                 uint64_t st;
                 if (T.hts_off) st = rand48_jump(*T.hts_base, (uint64_t)T.hts_off[ev]);                      // serial: the process-wide stream
                 else st = rand48_jump(VGL_HTS_RAND48_X0, ((uint64_t)(T.site0 + ls) * (uint64_t)N + (uint64_t)s) * VGL_HTS_TILE_STRIDE);
-                uint8_t* col = T.reads + ev;
+                uint8_t* const rd = T.reads;
                 for (int i = n; i > 1; --i) {
                     st = lcg_next(st);
                     const int j = (int)(u01(st) * (double)i);
-                    const uint8_t tmp = col[(size_t)j * plane]; col[(size_t)j * plane] = col[(size_t)(i - 1) * plane]; col[(size_t)(i - 1) * plane] = tmp;
+                    const size_t pj = vgl_read_byte(j, plane, ev), pi = vgl_read_byte(i - 1, plane, ev);
+                    const uint8_t tmp = rd[pj]; rd[pj] = rd[pi]; rd[pi] = tmp;
                 }
                 n = 255;
                 c[0] = c[1] = c[2] = c[3] = 0;
                 for (int r = 0; r < n; ++r) {
-                    const int b = (int)(col[(size_t)r * plane] & 3);
+                    const int b = (int)(rd[vgl_read_byte(r, plane, ev)] & 3);
                     c[0] += (b == 0); c[1] += (b == 1); c[2] += (b == 2); c[3] += (b == 3);
                 }
             }
@@ -349,7 +356,7 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
                 uint8_t* h = lds_raw + (size_t)wib * 16384 + lane;
                 for (int bin = 0; bin < 256; ++bin) h[bin * 64] = 0;
                 for (int r = 0; r < n; ++r) {
-                    const uint32_t rb = T.reads[(size_t)r * plane + ev];
+                    const uint32_t rb = T.reads[vgl_read_byte(r, plane, ev)];
                     const int bin = (int)(((rb & 3) << 6) | (rb >> 2));
                     h[bin * 64] = (uint8_t)(h[bin * 64] + 1);
                 }

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
         for (int r = 0; r < dp; ++r) {
             bool fwd;
             const int r_base = sample_read_base16(st_hap16, st_base16, a0, a1, err_thresh16, k_strand, fwd);
-            if (stage) T.reads[(size_t)r * plane + ev] = (uint8_t)((q_gl << 2) | r_base);
+            if (stage) T.reads[vgl_read_byte(r, plane, ev)] = (uint8_t)((q_gl << 2) | r_base);
             if (T.reads_out && r < T.reads_out_cap) T.reads_out[(size_t)r * plane + ev] = (uint8_t)((q_i << 2) | r_base);
             const uint64_t one = 1ULL << (16 * r_base);
             ad4 += one;
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 const int q_i = (int)(qe & 0xFF);
                 const int aq_i = k_adj ? (int)((qe >> 8) & 0xFF) : -1;
                 const int q_gl = (k_adj & 1) ? aq_i : q_i;
-                reads_v[(size_t)r * plane + ev] = (uint8_t)((q_gl << 2) | r_base);
+                reads_v[vgl_read_byte(r, plane, ev)] = (uint8_t)((q_gl << 2) | r_base);
                 if (!LEAN) { if (r < reads_out_cap_v) reads_out_v[(size_t)r * plane + ev] = (uint8_t)((q_i << 2) | r_base); }
                 if (k_qsum) {
                     const uint32_t qq = (uint32_t)((k_adj & 2) ? aq_i : q_i);

@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void k_sample_serial(const VglDevParams P, con
                 if (aq_i < 0 && (P.adjust_qs & 3)) atomicOr(T.errflag, VGL_DEVERR_ADJQ);               // vcfgl.cpp:558, gl_methods.cpp:101
             }
             const int q_gl = (P.adjust_qs & 1) ? aq_i : q_i;
-            T.reads[(size_t)r * plane + ev] = (uint8_t)((q_gl << 2) | r_base);
+            T.reads[vgl_read_byte(r, plane, ev)] = (uint8_t)((q_gl << 2) | r_base);
             if (T.reads_out && r < T.reads_out_cap) T.reads_out[(size_t)r * plane + ev] = (uint8_t)((q_i << 2) | r_base);
             if (P.need_qsum) {
                 const uint32_t qv = (uint32_t)((P.adjust_qs & 2) ? aq_i : q_i);
