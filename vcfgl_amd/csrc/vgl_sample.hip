@@ -160,14 +160,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                                                               // an evaluation may exceed 255 reads (k_gl then subsamples the staged reads)
         uint64_t st_hap16 = st_hap << 16, st_base16 = st_base << 16;      // sample_read_base16: states carried shifted by 16
         const uint64_t err_thresh16 = sample_thresh16(err_thresh);
-        for (int r = 0; r < dp; ++r) {
-            bool fwd;
-            const int r_base = sample_read_base16(st_hap16, st_base16, a0, a1, err_thresh16, k_strand, fwd);
-            if (stage) T.reads[vgl_read_byte(r, plane, ev)] = (uint8_t)((q_gl << 2) | r_base);
-            if (T.reads_out && r < T.reads_out_cap) T.reads_out[(size_t)r * plane + ev] = (uint8_t)((q_i << 2) | r_base);
-            const uint64_t one = 1ULL << (16 * r_base);
-            ad4 += one;
-            if (k_strand) { if (fwd) adf4 += one; }                       // without strand draws adf4 = ad4 (set after the loops)
+        // four reads per trip: one 32-bit store of the staged word (vgl_read_byte) instead of four byte stores
+        uint32_t* const reads_w = (uint32_t*)T.reads;
+        for (int r0 = 0; r0 < dp; r0 += 4) {
+            uint32_t rw = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = r0 + j;
+                if (r < dp) {
+                    bool fwd;
+                    const int r_base = sample_read_base16(st_hap16, st_base16, a0, a1, err_thresh16, k_strand, fwd);
+                    rw |= ((q_gl << 2) | (uint32_t)r_base) << (8 * j);
+                    if (T.reads_out && r < T.reads_out_cap) T.reads_out[(size_t)r * plane + ev] = (uint8_t)((q_i << 2) | r_base);
+                    const uint64_t one = 1ULL << (16 * r_base);
+                    ad4 += one;
+                    if (k_strand) { if (fwd) adf4 += one; }               // without strand draws adf4 = ad4 (set after the loops)
+                }
+            }
+            if (stage) reads_w[(size_t)(r0 >> 2) * plane + ev] = rw;
         }
         if (P.need_qsum) {
             qs0 = qq * (uint32_t)(ad4 & 0xFFFF); qs1 = qq * (uint32_t)((ad4 >> 16) & 0xFFFF);
