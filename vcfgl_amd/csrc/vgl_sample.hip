@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
             l_gc[4] = P.gy.a1; l_gc[5] = P.gy.a2; l_gc[6] = (P.gy.a2 * P.gy.a2) * 0.15; l_gc[7] = P.sure_margin;
         }
         int rdone = 0;
+        uint32_t carry_w = 0;                          // the staged word the last segment ended in
         uint64_t st_hap16 = st_hap << 16, st_base16 = st_base << 16;      // sample_read_base16
         const uint64_t err_thresh16 = sample_thresh16(err_thresh);
         // Kernel arguments arrive in 16-dword scalar tuples that the register allocator spills and
@@ -419,23 +420,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
             // -- owners: combine base + quality score, stage the read, quality sums (vcfgl.cpp:525-564)
-            for (int r = rdone; r < r_end; ++r) {
-                const int k = offs + r - seg0;
-                const int r_base = l_pb[k];
-                const uint32_t qe = l_it[k];
-                const int q_i = (int)(qe & 0xFF);
-                const int aq_i = k_adj ? (int)((qe >> 8) & 0xFF) : -1;
-                const int q_gl = (k_adj & 1) ? aq_i : q_i;
-                reads_v[vgl_read_byte(r, plane, ev)] = (uint8_t)((q_gl << 2) | r_base);
-                if (!LEAN) { if (r < reads_out_cap_v) reads_out_v[(size_t)r * plane + ev] = (uint8_t)((q_i << 2) | r_base); }
-                if (k_qsum) {
-                    const uint32_t qq = (uint32_t)((k_adj & 2) ? aq_i : q_i);
-                    const uint32_t q2 = (uint32_t)qs_to_qssq((int)qq);
-                    qs0 += (r_base == 0) ? qq : 0u; qs1 += (r_base == 1) ? qq : 0u;
-                    qs2 += (r_base == 2) ? qq : 0u; qs3 += (r_base == 3) ? qq : 0u;
-                    qq0 += (r_base == 0) ? q2 : 0u; qq1 += (r_base == 1) ? q2 : 0u;
-                    qq2 += (r_base == 2) ? q2 : 0u; qq3 += (r_base == 3) ? q2 : 0u;
+            // four reads per trip, one 32-bit store of the staged word (vgl_read_byte); a word cut by a segment boundary is
+            // stored again, complete, by the next segment (carry_w)
+            for (int r0 = rdone & ~3; r0 < r_end; r0 += 4) {
+                uint32_t rw = (r0 < rdone) ? carry_w : 0u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = r0 + j;
+                    if (r >= rdone && r < r_end) {
+                        const int k = offs + r - seg0;
+                        const int r_base = l_pb[k];
+                        const uint32_t qe = l_it[k];
+                        const int q_i = (int)(qe & 0xFF);
+                        const int aq_i = k_adj ? (int)((qe >> 8) & 0xFF) : -1;
+                        const int q_gl = (k_adj & 1) ? aq_i : q_i;
+                        rw |= (uint32_t)((q_gl << 2) | r_base) << (8 * j);
+                        if (!LEAN) { if (r < reads_out_cap_v) reads_out_v[(size_t)r * plane + ev] = (uint8_t)((q_i << 2) | r_base); }
+                        if (k_qsum) {
+                            const uint32_t qq = (uint32_t)((k_adj & 2) ? aq_i : q_i);
+                            const uint32_t q2 = (uint32_t)qs_to_qssq((int)qq);
+                            qs0 += (r_base == 0) ? qq : 0u; qs1 += (r_base == 1) ? qq : 0u;
+                            qs2 += (r_base == 2) ? qq : 0u; qs3 += (r_base == 3) ? qq : 0u;
+                            qq0 += (r_base == 0) ? q2 : 0u; qq1 += (r_base == 1) ? q2 : 0u;
+                            qq2 += (r_base == 2) ? q2 : 0u; qq3 += (r_base == 3) ? q2 : 0u;
+                        }
+                    }
                 }
+                ((uint32_t*)reads_v)[(size_t)(r0 >> 2) * plane + ev] = rw;
+                carry_w = rw;
             }
             rdone = r_end;
             __builtin_amdgcn_wave_barrier();
