@@ -427,6 +427,20 @@ __device__ __forceinline__ void qs_finish(const VglDevParams& P, int& q, int& aq
     }
 }
 
+// inclusive prefix sum over the 64 lanes of a wavefront in seven DPP adds (row_shr 1/2/3 of the input, row_shr 4 and 8 of the
+// running sums on the upper banks, row_bcast 15 and 31 across the rows) instead of six ds_bpermute round trips
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(const uint32_t x) {
+    uint32_t v = x;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);      // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);      // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x113, 0xf, 0xf, true);      // row_shr:3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xe, true);      // row_shr:4, banks 1-3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xc, true);      // row_shr:8, banks 2-3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 // sample_read_base() on states carried shifted left by 16 bits: 64-bit wraparound is then the generator's mod 2^48 (no masking
 // per step), u < 0.5 is the sign bit, floor(4u) the top two bits.  err_thresh16 = err_thresh << 16, saturated (sample_thresh16).
 __device__ __forceinline__ uint64_t lcg_next16(const uint64_t x) { return x * VGL_LCG_A + (VGL_LCG_C << 16); }

@@ -156,7 +156,12 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
         __syncthreads();
         int key = nb - 1;
         if (dp0 == 0) key = nb - 2;
-        else if (dp0 > 0) key = (NK - k0) * nbd + (nbd - 1 - ((dp0 > P.read_cap ? P.read_cap : dp0) >> sh));
+        else if (dp0 > 0) {
+            const int dq = (dp0 > P.read_cap ? P.read_cap : dp0) >> sh;
+            // deepest first, except the two-base group: its shallow end shares a wavefront with the (few, expensive) evaluations of
+            // three or four bases, whose loop then ends sooner; its deep end joins the cheap one-base loop's wavefronts
+            key = (NK - k0) * nbd + ((GLM == 2 && k0 == 2 && P.gl_flip2) ? dq : nbd - 1 - dq);
+        }
         atomicAdd(&s_hist[key], 1u);
         __syncthreads();
         if (tid < 64) {                                                // exclusive scan of the bins by one wavefront
@@ -164,11 +169,9 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
             for (int base = 0; base < nb; base += 64) {
                 const int i = base + tid;
                 const uint32_t v = (i < nb) ? s_hist[i] : 0u;
-                uint32_t incl = v;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d, 64); if (tid >= d) incl += t; }
+                const uint32_t incl = wave_incl_scan_u32(v);
                 if (i < nb) s_hist[i] = run + incl - v;
-                run += __shfl(incl, 63, 64);
+                run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             }
         }
         __syncthreads();

@@ -355,6 +355,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     // k_gl lane order: 0 natural, 1 depth-sorted lanes storing their own evaluations (4-byte pieces), 2 depth-sorted lanes and
     // natural-order stores through LDS -- the last is at least as fast as the others from depth 5 (config C5) to depth 30
     D.gl_sort = getenv("VGL_GL_SORT") ? atoi(getenv("VGL_GL_SORT")) : (dmax >= 1.0 ? 2 : 0);
+    D.gl_flip2 = getenv("VGL_GL_FLIP2") ? atoi(getenv("VGL_GL_FLIP2")) : 1;
     D.slow_period = getenv("VGL_SLOW_PERIOD") ? atoi(getenv("VGL_SLOW_PERIOD")) : 4;
     if (D.slow_period < 1) D.slow_period = 1;
     D.slow_period_n = getenv("VGL_SLOW_PERIOD_N") ? atoi(getenv("VGL_SLOW_PERIOD_N")) : 4;

@@ -207,11 +207,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
         }
 
         // exclusive prefix sum of the depths = first pool index of each owner
-        int incl = dp;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        const int incl = (int)wave_incl_scan_u32((uint32_t)dp);
         const int offs = incl - dp;
-        const int total = __builtin_amdgcn_readfirstlane(__shfl(incl, 63, 64));   // wave-uniform, and known to the compiler as such
+        const int total = __builtin_amdgcn_readlane(incl, 63);          // wave-uniform, and known to the compiler as such
         l_stq[lane] = st_qs << 4;                      // the pool loop works on states scaled by 16 (lcg_next52)
         if (lane == 0) {
             l_it[cap] = 0u;
