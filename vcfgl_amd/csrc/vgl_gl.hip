@@ -99,12 +99,13 @@ __device__ __forceinline__ int cnt_of(uint64_t ad4, int b) { return b < 4 ? (int
 // Which wavefront of a workgroup takes the deepest 64 evaluations rotates with the workgroup index.
 // GLM, PREC: the GL model (1 / 2) and --precise-gl as template parameters -- the paths share no code, and the
 // model-1 tables and the double log10 of --precise-gl 1 would cost the plain model-2 loop registers (occupancy)
-template <int A, int GLM, bool PREC>
-__global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTilePtrs T) {
+template <int A, int GLM, bool PREC, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const VglTilePtrs T) {
+    constexpr int WG = 64 * WPB;                                        // evaluations (threads) per workgroup: 256 or 512
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    __shared__ uint16_t s_perm[256];
+    __shared__ uint16_t s_perm[WG];
     constexpr int NG = A * (A + 1) / 2;
-    __shared__ uint32_t s_x[15 * 256];                                  // gl_sort 2: one tag's planes of the workgroup, in natural order; GL model 2: the loop's accumulators (up to 15) on their way to genotype order
+    __shared__ uint32_t s_x[15 * WG];                                  // gl_sort 2: one tag's planes of the workgroup, in natural order; GL model 2: the loop's accumulators (up to 15) on their way to genotype order
     uint32_t* const s_hist = s_x;                                       // [1026] bins of the depth sort (done before s_x is used)
     constexpr int QL = 96;                                              // quality scores below QL take their three terms from LDS
     __shared__ double s_q2gl[(GLM == 2 && !PREC) ? 3 * QL : 1];
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
     const int tid = threadIdx.x;
     if (GLM == 2 && !PREC) {
         if (P.error_qs == 2)
-            for (int i = tid; i < 3 * QL; i += 256) s_q2gl[i] = P.q2gl[(i / QL) * 257 + (i % QL)];
+            for (int i = tid; i < 3 * QL; i += WG) s_q2gl[i] = P.q2gl[(i / QL) * 257 + (i % QL)];
         __syncthreads();
     }
     const uint32_t nwaves = (uint32_t)T.n_sites * (uint32_t)P.chunks;                   // < 2^31 (checked by the launcher)
@@ -120,10 +121,12 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
     // wave k of this workgroup is wave 4 bx + k of the tile = (site, 64-sample chunk).  One scalar division per workgroup; a lane
     // then finds the site of ANY of the four waves with three compares (a per-lane 64-bit division was 60+ vector instructions,
     // three times per lane)
-    const uint32_t wg_ls = (bx * 4u) / (uint32_t)P.chunks, wg_rem = (bx * 4u) - wg_ls * (uint32_t)P.chunks;
+    const uint32_t wg_ls = (bx * (uint32_t)WPB) / (uint32_t)P.chunks, wg_rem = (bx * (uint32_t)WPB) - wg_ls * (uint32_t)P.chunks;
     auto wave_site = [&](const int k, int& ls_, int& s_base) {
         const int t = (int)wg_rem + k, c = P.chunks;
-        const int add = (t >= c ? 1 : 0) + (t >= 2 * c ? 1 : 0) + (t >= 3 * c ? 1 : 0);
+        int add = 0;
+#pragma unroll
+        for (int j = 1; j < WPB; ++j) add += (t >= j * c) ? 1 : 0;
         ls_ = (int)wg_ls + add;
         s_base = (t - add * c) * 64;
     };
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
     int k0 = 1;                                                        // GL model 2: distinct bases among its reads
     int ls0 = 0, s0 = N;
     {
-        const uint32_t w = bx * 4u + (uint32_t)(tid >> 6);
+        const uint32_t w = bx * (uint32_t)WPB + (uint32_t)(tid >> 6);
         if (w < nwaves) {
             int sb; wave_site(tid >> 6, ls0, sb);
             s0 = sb + (tid & 63);
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
         const int sh = P.read_cap > 511 ? 2 : (P.read_cap > 255 ? 1 : 0);
         const int nbd = (P.read_cap >> sh) + 1;                        // depth bins
         const int nb = NK * nbd + 2;
-        for (int i = tid; i < nb; i += 256) s_hist[i] = 0;
+        for (int i = tid; i < nb; i += WG) s_hist[i] = 0;
         __syncthreads();
         int key = nb - 1;
         if (dp0 == 0) key = nb - 2;
@@ -180,11 +183,11 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
         // thread id whose evaluation this lane processes.  Which wavefront of the workgroup takes the deepest 64 evaluations
         // rotates with the workgroup index: wavefront k of every workgroup tends to land on the same SIMD of its CU, and
         // the deep groups must not all queue on one of them
-        otid = s_perm[(tid + 64 * (int)(bx & 3)) & 255];
+        otid = s_perm[(tid + 64 * (int)(bx & (WPB - 1))) & (WG - 1)];
     }
     const int lane = tid & 63;
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t w = bx * 4u + (uint32_t)(otid >> 6);
+    const uint32_t w = bx * (uint32_t)WPB + (uint32_t)(otid >> 6);
     const bool xpose = (P.gl_sort == 2);                               // sorted lanes, natural-order stores through LDS
     int ls = 0, s = N;
     if (w < nwaves) { int sb; wave_site(otid >> 6, ls, sb); s = sb + (otid & 63); }
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < NT; ++i) s_x[i * 256 + otid] = __float_as_uint(tr[i]);       // column otid: this thread's, here and in VGL_PUT
+                for (int i = 0; i < NT; ++i) s_x[i * WG + otid] = __float_as_uint(tr[i]);       // column otid: this thread's, here and in VGL_PUT
             };
             const bool all_full = __ballot(!has_abs) == 0;
             if (all_full) {
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
                 for (int j = 0; j <= i; ++j) {
                     const int idx = i * (i + 1) / 2 + j;                                         // bcf_alleles2gt
                     const int m = (tri[i] > tri[j] ? tri[i] : tri[j]) + (pr[i] < pr[j] ? pr[i] : pr[j]);
-                    acc[idx] = __uint_as_float(colx[m * 256]);
+                    acc[idx] = __uint_as_float(colx[m * WG]);
                 }
             }
         } else {
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
     // (s_x[plane][natural thread id]) so that every store of a wavefront is one contiguous segment.
     const bool sample_ok = have && dp > 0;
     // this thread's own (natural-order) evaluation, for the stores of gl_sort 2: (ls0, s0) from above
-    const bool live0 = (bx * 4u + (uint32_t)(tid >> 6) < nwaves) && (s0 < N);
+    const bool live0 = (bx * (uint32_t)WPB + (uint32_t)(tid >> 6) < nwaves) && (s0 < N);
     // VGL_PUT(base, NP, expr of i): the loops are spelled out here (not in a lambda) so that acc[] stays in registers
 #define VGL_PUT(BASE, NP, EXPR)                                                                          \
     do {                                                                                                 \
@@ -422,10 +425,10 @@ __global__ __launch_bounds__(256) void k_gl(const VglDevParams P, const VglTileP
             if (!xpose) {                                                                                \
                 _Pragma("unroll") for (int i = 0; i < (NP); ++i) base_[((size_t)ls * (NP) + i) * N + s] = (EXPR); \
             } else {                                                                                     \
-                _Pragma("unroll") for (int i = 0; i < (NP); ++i) s_x[i * 256 + otid] = (EXPR);           \
+                _Pragma("unroll") for (int i = 0; i < (NP); ++i) s_x[i * WG + otid] = (EXPR);           \
                 __syncthreads();                                                                         \
                 if (live0) {                                                                             \
-                    _Pragma("unroll") for (int i = 0; i < (NP); ++i) base_[((size_t)ls0 * (NP) + i) * N + s0] = s_x[i * 256 + tid]; \
+                    _Pragma("unroll") for (int i = 0; i < (NP); ++i) base_[((size_t)ls0 * (NP) + i) * N + s0] = s_x[i * WG + tid]; \
                 }                                                                                        \
                 __syncthreads();                                                                         \
             }                                                                                            \
@@ -573,18 +576,21 @@ extern "C" int vgl_launch_site(const VglDevParams* p, const VglTilePtrs* t, void
 extern "C" int vgl_launch_gl(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
     const int64_t waves = (int64_t)t->n_sites * p->chunks;
     if (waves == 0) return 0;
-    if (waves + 4 >= (1LL << 31)) return (int)hipErrorInvalidValue;       // k_gl indexes the tile's wavefronts with 32 bits
-    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    if (waves + 8 >= (1LL << 31)) return (int)hipErrorInvalidValue;       // k_gl indexes the tile's wavefronts with 32 bits
+    // 8 wavefronts (512 evaluations) per workgroup for GL model 2 at depth: the evaluations with three or four distinct bases, whose
+    // loop is the expensive one, then fill one wavefront in 512 rather than one in 256 (P.gl_wpb: vgl_ctx_create, VGL_GL_WPB; measured
+    // at C3 / fixed-q / C4: 4 -> 8 wavefronts -7 / -6 / -10 % of the kernel's time, 16 is slower again; equal at depth 5)
+    const int wpb = (p->gl_model == 2 && p->gl_wpb == 8) ? 8 : 4;
+    const unsigned blocks = (unsigned)((waves + wpb - 1) / wpb);
     const size_t lds = (p->gl_model == 1 && p->error_qs == 2) ? (size_t)4 * 16384 : 0;   // (base,qual) histograms
-    const dim3 g(blocks), b(256);
+    const dim3 g(blocks), b(64 * wpb);
     hipStream_t s = (hipStream_t)stream;
-    if (p->gl_model == 2 && p->precise_gl) {
-        if (p->A == 5) hipLaunchKernelGGL((k_gl<5, 2, true>), g, b, lds, s, *p, *t); else hipLaunchKernelGGL((k_gl<4, 2, true>), g, b, lds, s, *p, *t);
-    } else if (p->gl_model == 2) {
-        if (p->A == 5) hipLaunchKernelGGL((k_gl<5, 2, false>), g, b, lds, s, *p, *t); else hipLaunchKernelGGL((k_gl<4, 2, false>), g, b, lds, s, *p, *t);
-    } else {
-        if (p->A == 5) hipLaunchKernelGGL((k_gl<5, 1, false>), g, b, lds, s, *p, *t); else hipLaunchKernelGGL((k_gl<4, 1, false>), g, b, lds, s, *p, *t);
-    }
+#define VGL_LAUNCH_GL(GLM, PREC, WPB) \
+    do { if (p->A == 5) hipLaunchKernelGGL((k_gl<5, GLM, PREC, WPB>), g, b, lds, s, *p, *t); else hipLaunchKernelGGL((k_gl<4, GLM, PREC, WPB>), g, b, lds, s, *p, *t); } while (0)
+    if (p->gl_model == 2 && p->precise_gl) { if (wpb == 8) VGL_LAUNCH_GL(2, true, 8); else VGL_LAUNCH_GL(2, true, 4); }
+    else if (p->gl_model == 2) { if (wpb == 8) VGL_LAUNCH_GL(2, false, 8); else VGL_LAUNCH_GL(2, false, 4); }
+    else VGL_LAUNCH_GL(1, false, 4);
+#undef VGL_LAUNCH_GL
     return (int)hipGetLastError();
 }
 

@@ -356,6 +356,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     // natural-order stores through LDS -- the last is at least as fast as the others from depth 5 (config C5) to depth 30
     D.gl_sort = getenv("VGL_GL_SORT") ? atoi(getenv("VGL_GL_SORT")) : (dmax >= 1.0 ? 2 : 0);
     D.gl_flip2 = getenv("VGL_GL_FLIP2") ? atoi(getenv("VGL_GL_FLIP2")) : 1;
+    D.gl_wpb = getenv("VGL_GL_WPB") ? atoi(getenv("VGL_GL_WPB")) : (D.gl_sort ? 8 : 4);
     D.slow_period = getenv("VGL_SLOW_PERIOD") ? atoi(getenv("VGL_SLOW_PERIOD")) : 4;
     if (D.slow_period < 1) D.slow_period = 1;
     D.slow_period_n = getenv("VGL_SLOW_PERIOD_N") ? atoi(getenv("VGL_SLOW_PERIOD_N")) : 4;
