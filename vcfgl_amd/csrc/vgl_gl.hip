@@ -134,13 +134,14 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
     int dp0 = -1;                                                      // -1: no evaluation (padding lane)
     int k0 = 1;                                                        // GL model 2: distinct bases among its reads
     int ls0 = 0, s0 = N;
+    uint64_t a = 0;                                                    // its per-base depths (kept for the epilogue, which runs in natural order)
     {
         const uint32_t w = bx * (uint32_t)WPB + (uint32_t)(tid >> 6);
         if (w < nwaves) {
             int sb; wave_site(tid >> 6, ls0, sb);
             s0 = sb + (tid & 63);
             if (s0 < N) {
-                const uint64_t a = T.ad4[(size_t)ls0 * N + s0];
+                a = T.ad4[(size_t)ls0 * N + s0];
                 dp0 = (int)((a & 0xFFFF) + ((a >> 16) & 0xFFFF) + ((a >> 32) & 0xFFFF) + ((a >> 48) & 0xFFFF));
                 if (dp0 > 1023) dp0 = 1023;
                 if (GLM == 2) k0 = (int)((a & 0xFFFFULL) != 0) + (int)(((a >> 16) & 0xFFFF) != 0) + (int)(((a >> 32) & 0xFFFF) != 0) + (int)((a >> 48) != 0);
@@ -188,17 +189,15 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
     const int lane = tid & 63;
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t w = bx * (uint32_t)WPB + (uint32_t)(otid >> 6);
-    const bool xpose = (P.gl_sort == 2);                               // sorted lanes, natural-order stores through LDS
+    const VglSiteInfo si_n = T.sinfo[ls0];                             // the natural evaluation's site (epilogue); in flight during the loop
     int ls = 0, s = N;
     if (w < nwaves) { int sb; wave_site(otid >> 6, ls, sb); s = sb + (otid & 63); }
     const bool live = s < N;
-    if (!xpose && !live) return;                                       // with gl_sort 2 every thread reaches the barriers below
-    if (!live) { ls = 0; s = 0; }                                      // padding lane: reads stay in range, nothing is stored
+    if (!live) { ls = 0; s = 0; }                                      // padding lane: reads stay in range, nothing is deposited
     const size_t ev = (size_t)ls * N + s;
     const size_t plane = (size_t)T.n_sites * N;
     const VglSiteInfo si = T.sinfo[ls];
     const int nA = si.n_alleles;
-    const int nG = nA * (nA + 1) / 2;
     const bool have = (si.status == SITE_OK);
     const float MISS = f32_missing();
 
@@ -223,7 +222,6 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
             const uint32_t p0 = (ad4 & 0xFFFFULL) != 0, p1 = ((ad4 >> 16) & 0xFFFF) != 0, p2 = ((ad4 >> 32) & 0xFFFF) != 0, p3 = (ad4 >> 48) != 0;
             const int k_pres = (int)(p0 + p1 + p2 + p3);
             const uint32_t cmap = (p0 << 2) | ((p0 + p1) << 4) | ((p0 + p1 + p2) << 6);          // 2 bits per base: its rank among the present bases
-            const uint32_t pmask = p0 | (p1 << 1) | (p2 << 2) | (p3 << 3);
             const bool has_abs = nA > k_pres;                                                       // an allele of the site this evaluation has no read of
             const int K = 1 + (__ballot(k_pres >= 2) != 0) + (__ballot(k_pres >= 3) != 0) + (__ballot(k_pres >= 4) != 0);   // wave-uniform
             auto read_loop = [&](auto k_tag, auto full_tag) {
@@ -290,8 +288,16 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
                         if (NT & 1) tr[NT - 1] -= mx;
                     }
                 }
+                // deposit: column otid (= the evaluation's natural position in the workgroup), rows = genotype index over (present
+                // base ranks 0..3, 4 = absent) whatever KK this wavefront ran with, so that the reader needs no KK
 #pragma unroll
-                for (int i = 0; i < NT; ++i) s_x[i * WG + otid] = __float_as_uint(tr[i]);       // column otid: this thread's, here and in VGL_PUT
+                for (int b = 0; b <= KK; ++b) {
+#pragma unroll
+                    for (int a_ = 0; a_ <= b; ++a_) {
+                        const int row = (b < KK) ? b * (b + 1) / 2 + a_ : (a_ < KK ? 10 + a_ : 14);
+                        s_x[row * WG + otid] = __float_as_uint(tr[b * (b + 1) / 2 + a_]);
+                    }
+                }
             };
             const bool all_full = __ballot(!has_abs) == 0;
             if (all_full) {
@@ -304,24 +310,6 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
                 else if (K == 2) read_loop(std::integral_constant<int, 2>{}, std::false_type{});
                 else if (K == 3) read_loop(std::integral_constant<int, 3>{}, std::false_type{});
                 else read_loop(std::integral_constant<int, 4>{}, std::false_type{});
-            }
-            // genotype (i, j) of the site's alleles -> slot of (rank of i's base or K, rank of j's base or K)
-            int pr[A], tri[A];
-#pragma unroll
-            for (int i = 0; i < A; ++i) {
-                const int bb = nib(si.alleles2acgt, i);
-                pr[i] = (bb < 4 && ((pmask >> bb) & 1)) ? (int)((cmap >> (2 * bb)) & 3) : K;
-                tri[i] = pr[i] * (pr[i] + 1) / 2;
-            }
-            const uint32_t* colx = s_x + otid;
-#pragma unroll
-            for (int i = 0; i < A; ++i) {
-#pragma unroll
-                for (int j = 0; j <= i; ++j) {
-                    const int idx = i * (i + 1) / 2 + j;                                         // bcf_alleles2gt
-                    const int m = (tri[i] > tri[j] ? tri[i] : tri[j]) + (pr[i] < pr[j] ? pr[i] : pr[j]);
-                    acc[idx] = __uint_as_float(colx[m * WG]);
-                }
             }
         } else {
             // GL model 1 with one fixed qScore: errmod_cal() reduces to table lookups on the
@@ -406,51 +394,73 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
                 }
             }
 #pragma unroll
-            for (int i = 0; i < NG; ++i) acc[i] -= mx;
+            for (int i = 0; i < NG; ++i) s_x[i * WG + otid] = __float_as_uint(acc[i] - mx);     // deposit: column otid, rows = genotypes
         }
     }
 
     // ---- GL / PL / GP planes (vcfgl.cpp:907-970; no-reads site :297-305), FORMAT/AD, ADF, ADR (vcfgl.cpp:806-843).
-    // put(): element i of this lane's evaluation -> plane i of a tag.  With gl_sort 2 the lanes have worked in depth order,
-    // but a plane's 256-evaluation window of the workgroup is written in natural order: the values pass through LDS
-    // (s_x[plane][natural thread id]) so that every store of a wavefront is one contiguous segment.
-    const bool sample_ok = have && dp > 0;
-    // this thread's own (natural-order) evaluation, for the stores of gl_sort 2: (ls0, s0) from above
+    // The lanes have worked in sorted order and left their accumulators in LDS column (natural position); from here every
+    // thread handles the evaluation at its own natural position, so that each store of a wavefront is one contiguous segment of
+    // a plane and no tag needs a transposition of its own.
+    __syncthreads();
     const bool live0 = (bx * (uint32_t)WPB + (uint32_t)(tid >> 6) < nwaves) && (s0 < N);
+    const int nA0 = si_n.n_alleles, nG0 = nA0 * (nA0 + 1) / 2;
+    const bool have0 = (si_n.status == SITE_OK);
+    const int dpn = (int)((a & 0xFFFF) + ((a >> 16) & 0xFFFF) + ((a >> 32) & 0xFFFF) + ((a >> 48) & 0xFFFF));
+    const bool sample_ok = have0 && live0 && dpn > 0;
+    if (sample_ok) {
+        const uint32_t* colx = s_x + tid;
+        if (GLM == 2) {
+            // genotype (i, j) of the site's alleles -> row of (rank of i's base among this evaluation's present bases or 4, same for j)
+            const uint32_t p0 = (a & 0xFFFFULL) != 0, p1 = ((a >> 16) & 0xFFFF) != 0, p2 = ((a >> 32) & 0xFFFF) != 0, p3 = (a >> 48) != 0;
+            const uint32_t cmap = (p0 << 2) | ((p0 + p1) << 4) | ((p0 + p1 + p2) << 6);
+            const uint32_t pmask = p0 | (p1 << 1) | (p2 << 2) | (p3 << 3);
+            int pr[A], tri[A];
+#pragma unroll
+            for (int i = 0; i < A; ++i) {
+                const int bb = nib(si_n.alleles2acgt, i);
+                pr[i] = (bb < 4 && ((pmask >> bb) & 1)) ? (int)((cmap >> (2 * bb)) & 3) : 4;
+                tri[i] = pr[i] * (pr[i] + 1) / 2;
+            }
+#pragma unroll
+            for (int i = 0; i < A; ++i) {
+#pragma unroll
+                for (int j = 0; j <= i; ++j) {
+                    const int idx = i * (i + 1) / 2 + j;                                         // bcf_alleles2gt
+                    const int m = (tri[i] > tri[j] ? tri[i] : tri[j]) + (pr[i] < pr[j] ? pr[i] : pr[j]);
+                    acc[idx] = __uint_as_float(colx[m * WG]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NG; ++i) acc[i] = __uint_as_float(colx[i * WG]);
+        }
+    }
     // VGL_PUT(base, NP, expr of i): the loops are spelled out here (not in a lambda) so that acc[] stays in registers
 #define VGL_PUT(BASE, NP, EXPR)                                                                          \
     do {                                                                                                 \
         uint32_t* const base_ = (uint32_t*)(BASE);                                                       \
-        if (base_) {                                                                                     \
-            if (!xpose) {                                                                                \
-                _Pragma("unroll") for (int i = 0; i < (NP); ++i) base_[((size_t)ls * (NP) + i) * N + s] = (EXPR); \
-            } else {                                                                                     \
-                _Pragma("unroll") for (int i = 0; i < (NP); ++i) s_x[i * WG + otid] = (EXPR);           \
-                __syncthreads();                                                                         \
-                if (live0) {                                                                             \
-                    _Pragma("unroll") for (int i = 0; i < (NP); ++i) base_[((size_t)ls0 * (NP) + i) * N + s0] = s_x[i * WG + tid]; \
-                }                                                                                        \
-                __syncthreads();                                                                         \
-            }                                                                                            \
+        if (base_ && live0) {                                                                            \
+            _Pragma("unroll") for (int i = 0; i < (NP); ++i) base_[((size_t)ls0 * (NP) + i) * N + s0] = (EXPR); \
         }                                                                                                \
     } while (0)
-    VGL_PUT(T.gl, NG, __float_as_uint((sample_ok && i < nG) ? acc[i] : MISS));
-    VGL_PUT(T.pl, NG, pl_of(acc[i], sample_ok && i < nG));
+    VGL_PUT(T.gl, NG, __float_as_uint((sample_ok && i < nG0) ? acc[i] : MISS));
+    VGL_PUT(T.pl, NG, pl_of(acc[i], sample_ok && i < nG0));
     if (T.gp) {                                                          // GP = 10^GL normalised by its float32 sum in genotype order
         float sum_gps = 0.0f;
 #pragma unroll
         for (int i = 0; i < NG; ++i) {                                   // (the likelihoods are not needed any more: reuse their registers)
-            const bool valid = sample_ok && i < nG;
+            const bool valid = sample_ok && i < nG0;
             acc[i] = valid ? (float)pow(10.0, (double)acc[i]) : 0.0f;
             if (valid) sum_gps += acc[i];
         }
-        VGL_PUT(T.gp, NG, __float_as_uint((sample_ok && i < nG) ? acc[i] / sum_gps : MISS));
+        VGL_PUT(T.gp, NG, __float_as_uint((sample_ok && i < nG0) ? acc[i] / sum_gps : MISS));
     }
     if (T.fmt_ad || T.fmt_adf || T.fmt_adr) {
-        const uint64_t adf4 = P.need_adf ? T.adf4[ev] : ad4;
-        VGL_PUT(T.fmt_ad, A, (uint32_t)cnt_of(ad4, (have && i < nA) ? nib(si.alleles2acgt, i) : 0xF));
-        VGL_PUT(T.fmt_adf, A, (uint32_t)cnt_of(adf4, (have && i < nA) ? nib(si.alleles2acgt, i) : 0xF));
-        VGL_PUT(T.fmt_adr, A, (uint32_t)(cnt_of(ad4, (have && i < nA) ? nib(si.alleles2acgt, i) : 0xF) - cnt_of(adf4, (have && i < nA) ? nib(si.alleles2acgt, i) : 0xF)));
+        const uint64_t adf4 = (P.need_adf && live0) ? T.adf4[(size_t)ls0 * N + s0] : a;
+        VGL_PUT(T.fmt_ad, A, (uint32_t)cnt_of(a, (have0 && i < nA0) ? nib(si_n.alleles2acgt, i) : 0xF));
+        VGL_PUT(T.fmt_adf, A, (uint32_t)cnt_of(adf4, (have0 && i < nA0) ? nib(si_n.alleles2acgt, i) : 0xF));
+        VGL_PUT(T.fmt_adr, A, (uint32_t)(cnt_of(a, (have0 && i < nA0) ? nib(si_n.alleles2acgt, i) : 0xF) - cnt_of(adf4, (have0 && i < nA0) ? nib(si_n.alleles2acgt, i) : 0xF)));
     }
 #undef VGL_PUT
 }
