@@ -1,8 +1,8 @@
 #!/bin/bash
-# usage (on the GPU box): tools/quick_pmc.sh  -> per-kernel VALU instruction counts of one bench tile
+# usage (on the GPU box): tools/quick_pmc.sh [workload]  -> per-kernel VALU instruction counts of one bench tile
 export TMPDIR=/tmp
 rm -rf gpurun_out/qpmc; mkdir -p gpurun_out/qpmc
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/qpmc/SQ -- python3 bench.py --sites 131072 --steps 1 --warmup 0 --no-cpu-baseline --no-extra --no-pack-rate > gpurun_out/qpmc/log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/qpmc/SQ -- python3 bench.py --workload ${1:-c3} --sites 131072 --steps 1 --warmup 0 --no-cpu-baseline --no-extra --no-pack-rate > gpurun_out/qpmc/log 2>&1
 python3 - <<'PY'
 import csv, glob, collections
 f = glob.glob("gpurun_out/qpmc/SQ/*/*counter_collection.csv")[0]
