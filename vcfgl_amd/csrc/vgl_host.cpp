@@ -317,7 +317,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     D.A = vgl_max_alleles(p); D.G = vgl_max_genotypes(p);
     int cap = (int)ceil(dmax + 8.0 * sqrt(dmax) + 16.0);
     D.read_cap = (cap + 3) & ~3;
-    if (getenv("VGL_DEBUG_READ_CAP")) D.read_cap = atoi(getenv("VGL_DEBUG_READ_CAP"));   // test hook: force the overflow path
+    if (getenv("VGL_DEBUG_READ_CAP")) D.read_cap = (atoi(getenv("VGL_DEBUG_READ_CAP")) + 3) & ~3;   // test hook: force the overflow path (a multiple of 4: staged reads are packed four per word)
     if (D.read_cap > 1023) { delete c; return fail(VGL_E_ARG, "mean depth too large for the staging layout"); }
     {   // quality-score pool of one wavefront: the summed depth of its (up to) 64 samples
         double lmax = 0.0;
