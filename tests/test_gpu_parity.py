@@ -388,6 +388,22 @@ def test_undecided_quality_scores_are_redrawn_exactly(oracle, monkeypatch, depth
     assert_parity(want, got)
 
 
+@pytest.mark.parametrize("every", [0, 3, 7])
+@pytest.mark.parametrize("depth,N,bins", [(20, 300, False), (30, 130, True), (70, 64, False)])
+def test_deferred_reads_are_redrawn_by_k_redo(oracle, monkeypatch, every, depth, N, bins):
+    """The default tag surface runs k_sample<2> without any double-precision fallback code: a read that one of the float32
+    bounds cannot settle (pool loop: the two bounded log tests; dense pass: the quality score) is appended to a list and drawn
+    again in double by k_redo, which patches the staged read.  VGL_DEBUG_REDO_EVERY=k sends every k-th candidate of each of the
+    three sources down that path (0: only the genuine ones); the GLs -- which are all that depends on the scores here -- must not
+    change.  Cases: one segment per wavefront, --qs-bins (k_redo applies them), several LDS segments per wavefront."""
+    if every:
+        monkeypatch.setenv("VGL_DEBUG_REDO_EVERY", str(every))
+    kw = dict(qs_bins=[(0, 2, 2), (3, 14, 12), (15, 30, 23), (31, 40, 37)]) if bins else {}          # the rta3 bins (doc/error_qs.MD)
+    args = VcfglArgs(seed=77, depth=depth, error_rate=0.01, error_qs=2, beta_variance=1e-5, add_pl=1, **kw)
+    want, got = run_both(oracle, args, synth.binary_sites(0, 10, N))
+    assert_parity(want, got, check_gp=False)
+
+
 @pytest.mark.parametrize("var", [1e-9, 1e-12])
 def test_error_qs2_very_large_shape_parameters(oracle, var):
     """beta shape parameters of 1e4 .. 1e10 (--beta-variance 1e-9 / 1e-12): the gamma sampler's second test compares

@@ -313,7 +313,10 @@ __device__ __forceinline__ double fast_ln_err(const double l) { return fabs(l) *
 
 // (v*v) > -4.0*log(u)*(u*u)                                              rng.h:78
 // `need` = lanes whose result is used; only those can force the exact evaluation.
-__device__ __forceinline__ bool normal_slow_test(const double v, const double u, const bool need) {
+// DEFER: the lanes the bound cannot decide are reported in `undecided` instead of being settled by the double log here (k_sample<2>
+// hands their reads to k_redo: the exact code then costs this kernel neither registers nor scratch)
+template <bool DEFER>
+__device__ __forceinline__ bool normal_slow_test_t(const double v, const double u, const bool need, bool& undecided) {
     const double lhs = v * v;
     const float uf = (float)u;
     const double l = fast_ln(uf);
@@ -323,12 +326,19 @@ __device__ __forceinline__ bool normal_slow_test(const double v, const double u,
     const bool hi = lhs > rhs + m, lo = lhs < rhs - m;
     bool res = hi;
     const bool amb = need && !((hi || lo) && (uf > 0.0f));
-    if (__builtin_expect(__ballot(amb) != 0, 0)) {          // wave-uniform and rare: a real branch
-        asm volatile("" ::: "memory");                      // (keeps the compiler from speculating the double log)
-        const bool ex = lhs > -4.0 * log(u) * (u * u);
-        res = amb ? ex : res;
+    undecided = DEFER && amb;
+    if (!DEFER) {
+        if (__builtin_expect(__ballot(amb) != 0, 0)) {      // wave-uniform and rare: a real branch
+            asm volatile("" ::: "memory");                  // (keeps the compiler from speculating the double log)
+            const bool ex = lhs > -4.0 * log(u) * (u * u);
+            res = amb ? ex : res;
+        }
     }
     return res;
+}
+__device__ __forceinline__ bool normal_slow_test(const double v, const double u, const bool need) {
+    bool und;
+    return normal_slow_test_t<false>(v, u, need, und);
 }
 
 // pieces of gamma_slow_test (asserted by tests/test_gpu_bounds.py over every float32 argument):
@@ -359,8 +369,9 @@ __device__ __forceinline__ float gamma_test_margin(const float lu, const float g
 // evaluation < 1e-6 relative: together inside the 4e-6 g of the margin (swept: tests/test_gpu_bounds.py);
 // the reference's own double rounding of its expression is < 1e-12.  Outside the band (or for
 // |s| > 1/3) the exact double expression is evaluated.
-__device__ __forceinline__ bool gamma_slow_test(const double u, const double xsq, const double a1, const double v,
-                                                const double s, const bool need) {
+template <bool DEFER>
+__device__ __forceinline__ bool gamma_slow_test_t(const double u, const double xsq, const double a1, const double v,
+                                                  const double s, const bool need, bool& undecided) {
     const float uf = (float)u, sf = (float)s, a1f = (float)a1;
     const float lu = gamma_test_lu(uf);
     const float g = gamma_rhs_series(sf, a1f);                  // = -(rhs of the reference), >= 0
@@ -369,12 +380,20 @@ __device__ __forceinline__ bool gamma_slow_test(const double u, const double xsq
     const bool ok = (fabsf(d) > m) && (fabsf(sf) <= 0.3333f) && (uf > 0.0f);
     bool res = d > 0.0f;
     const bool amb = need && !ok;
-    if (__builtin_expect(__ballot(amb) != 0, 0)) {          // wave-uniform and rare: a real branch
-        asm volatile("" ::: "memory");
-        const bool ex = log(u) > 0.5 * xsq + a1 * (1.0 - v + log(v));
-        res = amb ? ex : res;
+    undecided = DEFER && amb;
+    if (!DEFER) {
+        if (__builtin_expect(__ballot(amb) != 0, 0)) {      // wave-uniform and rare: a real branch
+            asm volatile("" ::: "memory");
+            const bool ex = log(u) > 0.5 * xsq + a1 * (1.0 - v + log(v));
+            res = amb ? ex : res;
+        }
     }
     return res;
+}
+__device__ __forceinline__ bool gamma_slow_test(const double u, const double xsq, const double a1, const double v,
+                                                const double s, const bool need) {
+    bool und;
+    return gamma_slow_test_t<false>(u, xsq, a1, v, s, need, und);
 }
 
 // error probability -> qScore / adjusted qScore (vcfgl.cpp:500-523) in two steps.  k_sample<2> leaves

@@ -37,6 +37,7 @@ __device__ __forceinline__ size_t vgl_read_byte(const int r, const size_t plane,
 #define VGL_DEVERR_GL1DEPTH 4u
 #define VGL_DEVERR_ADJQ     8u
 #define VGL_DEVERR_INTERNAL 16u   /* a layout assumption of a kernel does not hold (k_sample<2>: dynamic LDS must start at offset 0) */
+#define VGL_DEVERR_REDO     32u   /* k_sample<2, deferred>: more undecided reads than the tile's redo list holds */
 
 // per-site accumulator layout (int32 x 16): [0] INFO/DP, [1..4] ACGT depth,
 // [5..8] forward-strand ACGT depth, [9..12] reverse-strand ACGT depth
@@ -82,6 +83,8 @@ struct VglDevParams {
                              // bound by its arithmetic, measured 1-3 % slower with it and keeps the hardware order)
     int32_t dbg_phase;       // diagnostic (VGL_DEBUG_PHASE=n): k_sample returns after phase n; 0 = off
     int32_t dbg_qs_exact;    // test hook (VGL_DEBUG_QS_EXACT=1): k_sample<2> treats every read as undecided in float32
+    int32_t dbg_redo_every;  // test hook (VGL_DEBUG_REDO_EVERY=k): the deferred build sends every k-th read and slow-test lane to k_redo
+    int32_t defer_ok;        // the flag set allows the deferred build of k_sample<2> (vgl_ctx_create; VGL_NO_DEFER=1 turns it off)
     int32_t pre_q, pre_adjq;           // preCalc qScore / adj_qScore (vcfgl.cpp:1697-1702)
     double  adjust_by;
     double  pre_homT, pre_het, pre_homF;
@@ -121,7 +124,10 @@ struct VglTilePtrs {
     int32_t n_sites;
     const uint8_t* gt;
     // staging / scratch (ctx owned)
-    uint8_t* reads;          // [read_cap][n_sites][N]
+    uint8_t* reads;          // [read_cap / 4][n_sites][N] words, four reads each (vgl_read_byte)
+    unsigned long long* redo_list;   // k_sample<2, deferred>: (evaluation << 10 | read) of the reads whose quality score k_redo draws in double
+    uint32_t* redo_count;    // entries appended this tile (may exceed redo_cap: overflow = VGL_DEVERR_INTERNAL)
+    uint32_t redo_cap;
     double*  errp;           // [read_cap][n_sites][N]   (precise_gl with error_qs 2)
     uint64_t* ad4;           // [n_sites][N]  4 x u16 ACGT depth
     uint64_t* adf4;          // [n_sites][N]  4 x u16 forward-strand depth

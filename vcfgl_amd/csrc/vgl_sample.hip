@@ -74,8 +74,13 @@ __global__ __launch_bounds__(256) void k_depth(const VglDevParams P, const VglTi
 // LEAN: EQS 2 without per-base quality sums (-addQS / -addI16), strand draws, a per-read dump or --adjust-qs: the default tag
 // surface of the benchmark configurations.  The owners' state those options need (8 quality sums, the forward-strand depths, the
 // dump pointers) is then not carried across the pool loop, where the 128-register build would park it in scratch.
-template <int EQS, bool DBG, int DM, bool PREC, bool LEAN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 4 : 1, EQS == 2 ? 4 : 8))) void k_sample(const VglDevParams P, const VglTilePtrs T) {
+// LEAN 2 = LEAN with the double-precision fallbacks deferred: a read whose quality score a float32 bound cannot settle (in the
+// pool loop's two bounded tests or in the dense pass; about one read in 10^4) is appended to T.redo_list and drawn again in double
+// by k_redo.  Without log() / pow() / the double gamma sampler the kernel needs 92 VGPRs and no scratch, and is built for 5
+// wavefronts per SIMD (+6.5 % on C3).
+template <int EQS, bool DBG, int DM, bool PREC, int LEAN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? (LEAN == 2 ? 5 : 4) : 1, EQS == 2 ? (LEAN == 2 ? 5 : 4) : 8))) void k_sample(const VglDevParams P, const VglTilePtrs T) {
+    constexpr bool DEFER = (LEAN == 2);
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const WavePos wp = wave_pos(P, T);
     if (!wp.valid) return;
@@ -315,7 +320,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     bool slow_n = false;
                     const bool n_amb = have && q_lo && !q_hi;
                     bool hold = n_amb && !full_n;
-                    if (full_n && __builtin_amdgcn_ballot_w64(n_amb)) slow_n = normal_slow_test(v, u, n_amb);
+                    bool redo = false;                                              // DEFER: this item goes to k_redo
+                    if (full_n && __builtin_amdgcn_ballot_w64(n_amb)) {
+                        bool und;
+                        slow_n = normal_slow_test_t<DEFER>(v, u, n_amb, und);
+                        if (DEFER) redo = und || (n_amb && P.dbg_redo_every && ((uint32_t)(st1 >> 8) % (uint32_t)P.dbg_redo_every) == 0u);
+                    }
                     const bool acc_n = !(q_lo && (q_hi || slow_n));
                     // operands of this lane's next item, fetched here -- far enough behind the claim of the previous iteration and
                     // ahead of their use at the bottom (unconditional, clamped index: no divergent control flow in the loop)
@@ -343,11 +353,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     const bool g_amb = g_try && sq_fail && !sure;
                     hold = hold || (g_amb && !full);
                     bool slow_g = false;
-                    if (full && __builtin_amdgcn_ballot_w64(g_amb)) slow_g = gamma_slow_test(u2, xsq, ga1, vv, ga2 * xn, g_amb);
+                    if (full && __builtin_amdgcn_ballot_w64(g_amb)) {
+                        bool und;
+                        slow_g = gamma_slow_test_t<DEFER>(u2, xsq, ga1, vv, ga2 * xn, g_amb, und);
+                        if (DEFER) redo = redo || und || (g_amb && P.dbg_redo_every && ((uint32_t)(st3 >> 8) % (uint32_t)P.dbg_redo_every) == 1u);
+                    }
                     const bool acc_g = g_try && !(g_amb && slow_g) && !hold;     // slow_g is meaningful on the lanes that asked for it
                     st = hold ? st : (g_try ? st3 : st2);    // u2 is drawn only when w > 0 (rng.h:140-142)
                     double val = ga1 * vv;
-                    if (__builtin_expect(any_changed, 0)) {  // alpha < 1 (rng.h:146-148); wave-uniform guard
+                    if (!DEFER && __builtin_expect(any_changed, 0)) {  // alpha < 1 (rng.h:146-148); wave-uniform guard (never with DEFER)
                         asm volatile("" ::: "memory");       // (keeps the per-lane part of the test out of the common path)
                         if (acc_g && (stage1 ? P.gy.changed : P.gx.changed)) {
                             double u3;
@@ -355,15 +369,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                             val = pow(u3, 1.0 / (stage1 ? P.gy.alpha0 : P.gx.alpha0)) * ga1 * vv;
                         }
                     }
-                    const bool fin = acc_g && stage1;
+                    const bool fin = (acc_g && stage1) || redo;               // redo (DEFER): the item is dropped here, k_redo draws its read
                     const uint64_t st_n = tab_n.a * base_n + tab_n.c;     // raw, like st
                     const double gx_prev = gx;
                     gx = (acc_g && !stage1) ? val : gx;
-                    stage1 = stage1 != acc_g;
+                    stage1 = (stage1 != acc_g) && !redo;
                     if (fin) {
                         // a finished read leaves its error probability (rng.h:438) as a float32 in the item's slot; the
                         // quality scores are taken from it by the dense pass after the loop
                         *(lds_u32*)(uintptr_t)(576u + (uint32_t)k) = __float_as_uint(qs_stage_pf(gx_prev, val));   // l_it[item]
+                        if (DEFER) { if (redo) *(lds_u32*)(uintptr_t)(576u + (uint32_t)k) = 0x7FC00000u; }        // NaN: undecided for the dense pass
                         if (PREC) { T.errp[(size_t)((it_m >> 4) & 0x3FF) * plane + ev0 + (it_m >> 26)] = gx_prev / (gx_prev + val); it_m = m_n; }
                         // the lane adopts kn and claims the next unclaimed item from the wave's counter (any assignment of
                         // items to lanes gives the same result)
@@ -387,30 +402,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 const bool inb = kk < segT;
                 const float pf = __uint_as_float(l_it[inb ? kk : cap]);
                 int q_i, aq_i;
-                const bool ok = qs_decide_pf(P, pf, q_i, aq_i) && !P.dbg_qs_exact;
+                bool ok = qs_decide_pf(P, pf, q_i, aq_i) && !P.dbg_qs_exact;
+                if (DEFER) { if (P.dbg_redo_every) ok = ok && ((uint32_t)(seg0 + kk) % (uint32_t)P.dbg_redo_every) != 2u; }    // test hook
                 uint64_t amb = __ballot(inb && !ok);
                 if (__builtin_expect(amb != 0, 0)) {
-                    // undecided in float32: the owner of the read draws its deviate again in double (rng.h:433-444)
+                    // undecided in float32: the owner of the read draws its deviate again in double (rng.h:433-444) -- here, or (DEFER)
+                    // in k_redo, which patches the staged read: the owner appends (evaluation, read) to the tile's list
                     while (amb) {
                         const int b = __builtin_ctzll(amb);
                         amb &= amb - 1;
                         const int Kb = seg0 + kb + b;                   // index of the read in the wave's pool
                         if (active && Kb >= offs && Kb < offs + dp) {
-                            VglAffine jr = P.qs_read_tab[Kb - offs]; jr.c >>= 4;     // the table carries 16 c (aff52)
-                            uint64_t st_x = aff(jr, l_stq[lane] >> 4);
-                            const double ep = beta_draw(P, st_x);
-                            int qe, aqe;
-                            errprob_raw(P, ep, qe, aqe);
-                            if (aqe < 0 && (P.adjust_qs & 3)) atomicOr(T.errflag, VGL_DEVERR_ADJQ);   // vcfgl.cpp:558, gl_methods.cpp:101
-                            l_it[kb + b] = (uint32_t)(uint16_t)qe | ((uint32_t)(uint16_t)aqe << 16);
+                            if (DEFER) {
+                                const uint32_t idx = atomicAdd(T.redo_count, 1u);
+                                if (idx < T.redo_cap) T.redo_list[idx] = ((unsigned long long)ev << 10) | (unsigned long long)(Kb - offs);
+                                else atomicOr(T.errflag, VGL_DEVERR_REDO);
+                            } else {
+                                VglAffine jr = P.qs_read_tab[Kb - offs]; jr.c >>= 4;     // the table carries 16 c (aff52)
+                                uint64_t st_x = aff(jr, l_stq[lane] >> 4);
+                                const double ep = beta_draw(P, st_x);
+                                int qe, aqe;
+                                errprob_raw(P, ep, qe, aqe);
+                                if (aqe < 0 && (P.adjust_qs & 3)) atomicOr(T.errflag, VGL_DEVERR_ADJQ);   // vcfgl.cpp:558, gl_methods.cpp:101
+                                l_it[kb + b] = (uint32_t)(uint16_t)qe | ((uint32_t)(uint16_t)aqe << 16);
+                            }
                         }
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    if (inb && !ok) { const uint32_t e = l_it[kk]; q_i = (int)(int16_t)(e & 0xFFFF); aq_i = (int)(int16_t)(e >> 16); }
+                    if (!DEFER) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        if (inb && !ok) { const uint32_t e = l_it[kk]; q_i = (int)(int16_t)(e & 0xFFFF); aq_i = (int)(int16_t)(e >> 16); }
+                    } else if (inb && !ok) { q_i = 0; aq_i = -1; }      // placeholder: k_redo writes the read's score
                 }
-                qs_finish(P, q_i, aq_i, T.errflag, inb);
+                qs_finish(P, q_i, aq_i, T.errflag, DEFER ? (inb && ok) : inb);
                 if (inb) l_it[kk] = (uint32_t)(q_i & 0xFF) | ((uint32_t)(aq_i & 0xFF) << 8);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -498,6 +523,38 @@ extern "C" int vgl_launch_depth(const VglDevParams* p, const VglTilePtrs* t, voi
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------
+// The reads k_sample<2, ., ., ., 2> could not settle in float32: one lane per list entry draws the read's error probability again
+// in double from the read's own stream (rng.h:433-444: the stream of a read does not depend on who works on it), takes the
+// quality score the exact way (vcfgl.cpp:500-523) and writes it into the staged read (the base bits stay).  Default tag surface
+// only (no quality sums, no --adjust-qs, no per-read dump): nothing else depends on the score.
+__global__ __launch_bounds__(64) void k_redo(const VglDevParams P, const VglTilePtrs T) {
+    const uint32_t cnt = *T.redo_count;
+    const uint32_t n = cnt < T.redo_cap ? cnt : T.redo_cap;
+    const size_t N = (size_t)P.n_samples, plane = (size_t)T.n_sites * N;
+    for (uint32_t i = blockIdx.x * 64u + threadIdx.x; i < n; i += gridDim.x * 64u) {
+        const unsigned long long e = T.redo_list[i];
+        const size_t ev = (size_t)(e >> 10);
+        const int r = (int)(e & 1023u);
+        const size_t ls = ev / N, s = ev - ls * N;
+        const uint64_t site_abs = (uint64_t)(T.site0 + (int64_t)ls);
+        uint64_t xb = P.x0;
+#pragma unroll 1
+        for (int b = 0; b < 40; ++b)
+            if ((site_abs >> b) & 1) xb = aff(P.site_pow[b], xb);
+        const uint64_t xe = aff(P.samp_tab[s], xb);
+        const uint64_t st_qs = aff(P.off[3], xe);
+        VglAffine jr = P.qs_read_tab[r]; jr.c >>= 4;                     // the table carries 16 c (aff52)
+        uint64_t st_x = aff(jr, st_qs);
+        const double ep = beta_draw(P, st_x);
+        int q, aq;
+        errprob_raw(P, ep, q, aq);
+        qs_finish(P, q, aq, T.errflag, true);
+        uint8_t* const p = T.reads + vgl_read_byte(r, plane, ev);
+        *p = (uint8_t)(((uint32_t)q << 2) | (*p & 3u));
+    }
+}
+
 extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
     const int64_t waves = (int64_t)t->n_sites * p->chunks;
     if (waves == 0) return 0;
@@ -523,21 +580,26 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
 #define VGL_STATIC_LDS(DBG, DM, PREC, LEAN) \
             if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_sample<2, DBG, DM, PREC, LEAN>)) != hipSuccess) return false; \
             worst = a.sharedSizeBytes > worst ? a.sharedSizeBytes : worst;
-            VGL_STATIC_LDS(true, 0, false, false) VGL_STATIC_LDS(true, 1, false, false) VGL_STATIC_LDS(true, 2, false, false)
-            VGL_STATIC_LDS(false, 0, true, true) VGL_STATIC_LDS(false, 1, true, true) VGL_STATIC_LDS(false, 2, true, true)
-            VGL_STATIC_LDS(false, 0, true, false) VGL_STATIC_LDS(false, 1, true, false) VGL_STATIC_LDS(false, 2, true, false)
-            VGL_STATIC_LDS(false, 0, false, true) VGL_STATIC_LDS(false, 1, false, true) VGL_STATIC_LDS(false, 2, false, true)
-            VGL_STATIC_LDS(false, 0, false, false) VGL_STATIC_LDS(false, 1, false, false) VGL_STATIC_LDS(false, 2, false, false)
+            VGL_STATIC_LDS(true, 0, false, 0) VGL_STATIC_LDS(true, 1, false, 0) VGL_STATIC_LDS(true, 2, false, 0)
+            VGL_STATIC_LDS(false, 0, true, 1) VGL_STATIC_LDS(false, 1, true, 1) VGL_STATIC_LDS(false, 2, true, 1)
+            VGL_STATIC_LDS(false, 0, true, 0) VGL_STATIC_LDS(false, 1, true, 0) VGL_STATIC_LDS(false, 2, true, 0)
+            VGL_STATIC_LDS(false, 0, false, 1) VGL_STATIC_LDS(false, 1, false, 1) VGL_STATIC_LDS(false, 2, false, 1)
+            VGL_STATIC_LDS(false, 0, false, 2) VGL_STATIC_LDS(false, 1, false, 2) VGL_STATIC_LDS(false, 2, false, 2)
+            VGL_STATIC_LDS(false, 0, false, 0) VGL_STATIC_LDS(false, 1, false, 0) VGL_STATIC_LDS(false, 2, false, 0)
 #undef VGL_STATIC_LDS
             return worst == 0;
         }();
         if (!static_lds_free) return (int)hipErrorInvalidConfiguration;
-        if (dbg && !t->errp) VGL_LAUNCH_SAMPLE(2, true, false, false, lds);   // diagnostic build: --precise-gl 0 only
-        else if (t->errp) { if (lean) VGL_LAUNCH_SAMPLE(2, false, true, true, lds); else VGL_LAUNCH_SAMPLE(2, false, true, false, lds); }   // --precise-gl 1, or the deviates were asked for
-        else { if (lean) VGL_LAUNCH_SAMPLE(2, false, false, true, lds); else VGL_LAUNCH_SAMPLE(2, false, false, false, lds); }
+        if (dbg && !t->errp) VGL_LAUNCH_SAMPLE(2, true, false, 0, lds);   // diagnostic build: --precise-gl 0 only
+        else if (t->errp) { if (lean) VGL_LAUNCH_SAMPLE(2, false, true, 1, lds); else VGL_LAUNCH_SAMPLE(2, false, true, 0, lds); }   // --precise-gl 1, or the deviates were asked for
+        else if (lean && p->defer_ok && t->redo_list) {
+            VGL_LAUNCH_SAMPLE(2, false, false, 2, lds);
+            hipLaunchKernelGGL(k_redo, dim3(2048), dim3(64), 0, s, *p, *t);
+        }
+        else { if (lean) VGL_LAUNCH_SAMPLE(2, false, false, 1, lds); else VGL_LAUNCH_SAMPLE(2, false, false, 0, lds); }
     }
-    else if (p->error_qs == 1) VGL_LAUNCH_SAMPLE(1, false, false, false, 0);
-    else VGL_LAUNCH_SAMPLE(0, false, false, false, 0);
+    else if (p->error_qs == 1) VGL_LAUNCH_SAMPLE(1, false, false, 0, 0);
+    else VGL_LAUNCH_SAMPLE(0, false, false, 0, 0);
 #undef VGL_LAUNCH_SAMPLE
     return (int)hipGetLastError();
 }
