@@ -388,16 +388,19 @@ def test_undecided_quality_scores_are_redrawn_exactly(oracle, monkeypatch, depth
     assert_parity(want, got)
 
 
-@pytest.mark.parametrize("every", [0, 3, 7])
+@pytest.mark.parametrize("every,cap", [(0, None), (3, None), (7, None), (3, 16)])
 @pytest.mark.parametrize("depth,N,bins", [(20, 300, False), (30, 130, True), (70, 64, False)])
-def test_deferred_reads_are_redrawn_by_k_redo(oracle, monkeypatch, every, depth, N, bins):
+def test_deferred_reads_are_redrawn_by_k_redo(oracle, monkeypatch, every, cap, depth, N, bins):
     """The default tag surface runs k_sample<2> without any double-precision fallback code: a read that one of the float32
     bounds cannot settle (pool loop: the two bounded log tests; dense pass: the quality score) is appended to a list and drawn
     again in double by k_redo, which patches the staged read.  VGL_DEBUG_REDO_EVERY=k sends every k-th candidate of each of the
     three sources down that path (0: only the genuine ones); the GLs -- which are all that depends on the scores here -- must not
-    change.  Cases: one segment per wavefront, --qs-bins (k_redo applies them), several LDS segments per wavefront."""
+    change.  Cases: one segment per wavefront, --qs-bins (k_redo applies them), several LDS segments per wavefront; cap 16: the
+    list overflows and the rest of the reads travels through the bitmap."""
     if every:
         monkeypatch.setenv("VGL_DEBUG_REDO_EVERY", str(every))
+    if cap is not None:
+        monkeypatch.setenv("VGL_DEBUG_REDO_CAP", str(cap))
     kw = dict(qs_bins=[(0, 2, 2), (3, 14, 12), (15, 30, 23), (31, 40, 37)]) if bins else {}          # the rta3 bins (doc/error_qs.MD)
     args = VcfglArgs(seed=77, depth=depth, error_rate=0.01, error_qs=2, beta_variance=1e-5, add_pl=1, **kw)
     want, got = run_both(oracle, args, synth.binary_sites(0, 10, N))

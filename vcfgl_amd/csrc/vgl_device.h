@@ -37,7 +37,6 @@ __device__ __forceinline__ size_t vgl_read_byte(const int r, const size_t plane,
 #define VGL_DEVERR_GL1DEPTH 4u
 #define VGL_DEVERR_ADJQ     8u
 #define VGL_DEVERR_INTERNAL 16u   /* a layout assumption of a kernel does not hold (k_sample<2>: dynamic LDS must start at offset 0) */
-#define VGL_DEVERR_REDO     32u   /* k_sample<2, deferred>: more undecided reads than the tile's redo list holds */
 
 // per-site accumulator layout (int32 x 16): [0] INFO/DP, [1..4] ACGT depth,
 // [5..8] forward-strand ACGT depth, [9..12] reverse-strand ACGT depth
@@ -126,8 +125,9 @@ struct VglTilePtrs {
     // staging / scratch (ctx owned)
     uint8_t* reads;          // [read_cap / 4][n_sites][N] words, four reads each (vgl_read_byte)
     unsigned long long* redo_list;   // k_sample<2, deferred>: (evaluation << 10 | read) of the reads whose quality score k_redo draws in double
-    uint32_t* redo_count;    // entries appended this tile (may exceed redo_cap: overflow = VGL_DEVERR_INTERNAL)
+    uint32_t* redo_count;    // entries appended this tile (may exceed redo_cap: the rest is marked in redo_bits)
     uint32_t redo_cap;
+    uint32_t* redo_bits;     // one bit per (evaluation, read) of the tile, all zero between tiles: overflow of the list
     double*  errp;           // [read_cap][n_sites][N]   (precise_gl with error_qs 2)
     uint64_t* ad4;           // [n_sites][N]  4 x u16 ACGT depth
     uint64_t* adf4;          // [n_sites][N]  4 x u16 forward-strand depth

@@ -159,7 +159,7 @@ struct vgl_ctx {
     uint8_t* d_reads = nullptr; double* d_errp = nullptr; uint64_t* d_ad4 = nullptr; uint64_t* d_adf4 = nullptr;
     uint32_t* d_qsum = nullptr; uint32_t* d_qsumsq = nullptr; int32_t* d_acc = nullptr; VglSiteInfo* d_sinfo = nullptr;
     uint32_t* d_errflag = nullptr;
-    unsigned long long* d_redo_list = nullptr; uint32_t* d_redo_count = nullptr; uint32_t redo_cap = 0;   // k_sample<2, deferred> -> k_redo
+    unsigned long long* d_redo_list = nullptr; uint32_t* d_redo_count = nullptr; uint32_t redo_cap = 0; uint32_t* d_redo_bits = nullptr;   // k_sample<2, deferred> -> k_redo
     // beta chain of VGL_RNG_SERIAL with --error-qs 2 and the std beta sampler (vgl_betachain.hip); grow-only buffers
     long long* d_roff = nullptr; long long* d_rtotal = nullptr; double* d_errp_lin = nullptr; size_t errp_lin_cap = 0;
     uint32_t* d_cw = nullptr; uint8_t* d_ccons = nullptr; uint8_t* d_cexit = nullptr; int32_t* d_ccnt = nullptr; uint8_t* d_centry = nullptr;
@@ -262,7 +262,7 @@ extern "C" int vgl_ctx_destroy(vgl_ctx* c) {
     if (!c) return VGL_OK;
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_gl1_fk, c->d_gl1_beta, c->d_gamma_ln, c->d_samp_tab, c->d_qs_read_tab, c->d_pois, c->d_q2gl, c->d_gl1_bsum, c->d_gl1_lhet, c->d_reads, c->d_errp, c->d_ad4,
-                    c->d_adf4, c->d_qsum, c->d_qsumsq, c->d_acc, c->d_sinfo, c->d_errflag, c->d_dbg, c->d_redo_list, c->d_redo_count,
+                    c->d_adf4, c->d_qsum, c->d_qsumsq, c->d_acc, c->d_sinfo, c->d_errflag, c->d_dbg, c->d_redo_list, c->d_redo_count, c->d_redo_bits,
                     c->d_serial, c->d_sst, c->d_site_thresh, c->d_scout_dp, c->d_site_tail, c->d_sdp, c->d_step_tab,
                     c->d_chunk_tab, c->d_eval_pow, c->d_dp_pre, c->d_hts_off, c->d_hts_base, c->d_roff, c->d_rtotal, c->d_errp_lin, c->d_cw, c->d_ccons, c->d_cexit,
                     c->d_ccnt, c->d_centry, c->d_cbase, c->d_cpos, c->d_csnap, c->d_csnapw, c->d_cctl};
@@ -523,10 +523,12 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     TRY(dmalloc(&c->d_sinfo, (size_t)max_sites));
     TRY(dmalloc(&c->d_errflag, (size_t)1));
     if (D.defer_ok) {
-        // about 6 reads in 10^4 take this path at C3 / C4 (tools/redo_rate.py); room for 1 in 64 of the staging capacity, for every read
-        // under the test hook
+        // about 6 reads in 10^4 take this path at C3 / C4 (tools/redo_rate.py); the list has room for 1 in 64 of the staging capacity
+        // (VGL_DEBUG_REDO_CAP: test hook), what does not fit is marked in a bitmap over the staged reads (all zero between tiles)
         const size_t reads = E * (size_t)D.read_cap;
-        c->redo_cap = (uint32_t)std::min<size_t>(0xFFFFFFF0u, D.dbg_redo_every ? reads : std::max<size_t>(65536, reads / 64));
+        c->redo_cap = (uint32_t)std::min<size_t>(0xFFFFFFF0u, getenv("VGL_DEBUG_REDO_CAP") ? (size_t)atol(getenv("VGL_DEBUG_REDO_CAP")) : std::max<size_t>(65536, reads / 64));
+        TRY(dmalloc(&c->d_redo_bits, (reads + 31) / 32));
+        TRYHIP(hipMemset(c->d_redo_bits, 0, sizeof(uint32_t) * ((reads + 31) / 32)));
         TRY(dmalloc(&c->d_redo_list, (size_t)c->redo_cap));
         TRY(dmalloc(&c->d_redo_count, (size_t)1));
         TRYHIP(hipMemset(c->d_redo_count, 0, sizeof(uint32_t)));
@@ -644,7 +646,7 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     T.site0 = site0; T.n_sites = n_sites; T.gt = gt;
     T.reads = c->d_reads; T.errp = c->d_errp; T.ad4 = c->d_ad4; T.adf4 = c->d_adf4; T.qsum = c->d_qsum; T.qsumsq = c->d_qsumsq;
     T.acc = c->d_acc; T.sinfo = c->d_sinfo; T.errflag = c->d_errflag; T.dbg = c->d_dbg; T.dp_pre = c->d_dp_pre;
-    T.redo_list = c->d_redo_list; T.redo_count = c->d_redo_count; T.redo_cap = c->redo_cap;
+    T.redo_list = c->d_redo_list; T.redo_count = c->d_redo_count; T.redo_cap = c->redo_cap; T.redo_bits = c->d_redo_bits;
     if (D.serial) {
         const size_t E = (size_t)c->max_sites * D.n_samples;
         T.sst_hap = c->d_sst; T.sst_base = c->d_sst + E; T.sdp = c->d_sdp;
@@ -749,7 +751,6 @@ extern "C" int vgl_ctx_check(vgl_ctx* c, void* stream) {
     if (flag & VGL_DEVERR_QSBIN) return fail(VGL_E_QSBIN, "Could not find a range for a simulated qs value in --qs-bins");
     if (flag & VGL_DEVERR_ADJQ) return fail(VGL_E_ADJQ, "--adjust-qs %d: a read has no valid adjusted quality score (error probability exactly 0 or 1, or a negative adjusted score)", c->dp.adjust_qs);
     if (flag & VGL_DEVERR_INTERNAL) return fail(VGL_E_NODEVICE, "internal: a kernel's LDS layout assumption does not hold on this build (k_sample<2>)");
-    if (flag & VGL_DEVERR_REDO) return fail(VGL_E_CAPACITY, "more reads than expected needed the double-precision quality-score path (list of %u per tile): set VGL_NO_DEFER=1 to run the kernel that carries that path inline", c->redo_cap);
     return VGL_OK;
 }
 
@@ -781,7 +782,6 @@ static int flags_to_rc(vgl_ctx* c, uint32_t flag) {
     if (flag & VGL_DEVERR_QSBIN) return fail(VGL_E_QSBIN, "Could not find a range for a simulated qs value in --qs-bins");
     if (flag & VGL_DEVERR_ADJQ) return fail(VGL_E_ADJQ, "--adjust-qs %d: a read has no valid adjusted quality score (error probability exactly 0 or 1, or a negative adjusted score)", c->dp.adjust_qs);
     if (flag & VGL_DEVERR_INTERNAL) return fail(VGL_E_NODEVICE, "internal: a kernel's LDS layout assumption does not hold on this build (k_sample<2>)");
-    if (flag & VGL_DEVERR_REDO) return fail(VGL_E_CAPACITY, "more reads than expected needed the double-precision quality-score path (list of %u per tile): set VGL_NO_DEFER=1 to run the kernel that carries that path inline", c->redo_cap);
     return VGL_OK;
 }
 

@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                             if (DEFER) {
                                 const uint32_t idx = atomicAdd(T.redo_count, 1u);
                                 if (idx < T.redo_cap) T.redo_list[idx] = ((unsigned long long)ev << 10) | (unsigned long long)(Kb - offs);
-                                else atomicOr(T.errflag, VGL_DEVERR_REDO);
+                                else { const size_t bit = ev * (size_t)P.read_cap + (size_t)(Kb - offs); atomicOr(&T.redo_bits[bit >> 5], 1u << (bit & 31)); }   // list full: the bitmap
                             } else {
                                 VglAffine jr = P.qs_read_tab[Kb - offs]; jr.c >>= 4;     // the table carries 16 c (aff52)
                                 uint64_t st_x = aff(jr, l_stq[lane] >> 4);
@@ -528,30 +528,47 @@ extern "C" int vgl_launch_depth(const VglDevParams* p, const VglTilePtrs* t, voi
 // in double from the read's own stream (rng.h:433-444: the stream of a read does not depend on who works on it), takes the
 // quality score the exact way (vcfgl.cpp:500-523) and writes it into the staged read (the base bits stay).  Default tag surface
 // only (no quality sums, no --adjust-qs, no per-read dump): nothing else depends on the score.
+__device__ __forceinline__ void redo_read(const VglDevParams& P, const VglTilePtrs& T, const size_t ev, const int r) {
+    const size_t N = (size_t)P.n_samples, plane = (size_t)T.n_sites * N;
+    const size_t ls = ev / N, s = ev - ls * N;
+    const uint64_t site_abs = (uint64_t)(T.site0 + (int64_t)ls);
+    uint64_t xb = P.x0;
+#pragma unroll 1
+    for (int b = 0; b < 40; ++b)
+        if ((site_abs >> b) & 1) xb = aff(P.site_pow[b], xb);
+    const uint64_t xe = aff(P.samp_tab[s], xb);
+    const uint64_t st_qs = aff(P.off[3], xe);
+    VglAffine jr = P.qs_read_tab[r]; jr.c >>= 4;                         // the table carries 16 c (aff52)
+    uint64_t st_x = aff(jr, st_qs);
+    const double ep = beta_draw(P, st_x);
+    int q, aq;
+    errprob_raw(P, ep, q, aq);
+    qs_finish(P, q, aq, T.errflag, true);
+    uint8_t* const p = T.reads + vgl_read_byte(r, plane, ev);
+    *p = (uint8_t)(((uint32_t)q << 2) | (*p & 3u));
+}
 __global__ __launch_bounds__(64) void k_redo(const VglDevParams P, const VglTilePtrs T) {
     const uint32_t cnt = *T.redo_count;
     const uint32_t n = cnt < T.redo_cap ? cnt : T.redo_cap;
-    const size_t N = (size_t)P.n_samples, plane = (size_t)T.n_sites * N;
     for (uint32_t i = blockIdx.x * 64u + threadIdx.x; i < n; i += gridDim.x * 64u) {
         const unsigned long long e = T.redo_list[i];
-        const size_t ev = (size_t)(e >> 10);
-        const int r = (int)(e & 1023u);
-        const size_t ls = ev / N, s = ev - ls * N;
-        const uint64_t site_abs = (uint64_t)(T.site0 + (int64_t)ls);
-        uint64_t xb = P.x0;
-#pragma unroll 1
-        for (int b = 0; b < 40; ++b)
-            if ((site_abs >> b) & 1) xb = aff(P.site_pow[b], xb);
-        const uint64_t xe = aff(P.samp_tab[s], xb);
-        const uint64_t st_qs = aff(P.off[3], xe);
-        VglAffine jr = P.qs_read_tab[r]; jr.c >>= 4;                     // the table carries 16 c (aff52)
-        uint64_t st_x = aff(jr, st_qs);
-        const double ep = beta_draw(P, st_x);
-        int q, aq;
-        errprob_raw(P, ep, q, aq);
-        qs_finish(P, q, aq, T.errflag, true);
-        uint8_t* const p = T.reads + vgl_read_byte(r, plane, ev);
-        *p = (uint8_t)(((uint32_t)q << 2) | (*p & 3u));
+        redo_read(P, T, (size_t)(e >> 10), (int)(e & 1023u));
+    }
+    // More undecided reads than the list holds (never seen with the flag sets this build is chosen for, but then the result must
+    // still be right): the owners marked the rest in a bitmap over (evaluation, read), which is walked and cleared here.
+    if (cnt > T.redo_cap) {
+        const size_t words = ((size_t)T.n_sites * (size_t)P.n_samples * (size_t)P.read_cap + 31) >> 5;
+        for (size_t w = (size_t)blockIdx.x * 64u + threadIdx.x; w < words; w += (size_t)gridDim.x * 64u) {
+            uint32_t m = T.redo_bits[w];
+            if (!m) continue;
+            T.redo_bits[w] = 0u;
+            while (m) {
+                const int b = __builtin_ctz(m);
+                m &= m - 1;
+                const size_t bit = (w << 5) + (size_t)b;
+                redo_read(P, T, bit / (size_t)P.read_cap, (int)(bit % (size_t)P.read_cap));
+            }
+        }
     }
 }
 
