@@ -296,6 +296,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 // a lane that finishes an item claims the next one with an LDS atomic whose result (`claimed`) is first looked at in
                 // the next iteration (kn = fin_prev ? claimed : kn), so no wait stands behind the atomic
                 uint32_t claimed = 0; bool fin_prev = false;
+                // address of the counter and the increment live in vector registers across the loop (the compiler would otherwise
+                // rebuild both with two moves in front of every atomic)
+                __attribute__((address_space(3))) uint32_t* ctr_p = (__attribute__((address_space(3))) uint32_t*)l_ctr;
+                uint32_t four_v = 4u;
+                asm volatile("" : "+v"(ctr_p), "+v"(four_v));
                 do {                                         // segT >= 1: lane 0 has an item
                     if (DBG) c_iter++;
                     const bool full = (--slow_cnt == 0);     // bounded gamma test (needed by ~0.2 % of the lanes of an iteration)
@@ -384,7 +389,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                         // items to lanes gives the same result)
                         st = st_n;
                         k = kn;
-                        claimed = __hip_atomic_fetch_add(l_ctr, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        claimed = __hip_atomic_fetch_add(ctr_p, four_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     }
                     fin_prev = fin;
                     have = k < segT4;
