@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 out=gpurun_out/kglprobe; rm -rf $out; mkdir -p $out
 Q="--no-cpu-baseline --no-extra --no-pack-rate"
 for wl in c5 c3; do
-  for gs in 2 0 1; do
+  for gs in 2 0; do
     VGL_GL_SORT=$gs python3 bench.py --workload $wl --steps 3 --warmup 1 $Q 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']

@@ -86,17 +86,14 @@ __device__ __forceinline__ uint32_t pl_of(const float v, const bool valid) {
 }
 __device__ __forceinline__ int cnt_of(uint64_t ad4, int b) { return b < 4 ? (int)((ad4 >> (16 * b)) & 0xFFFF) : 0; }
 
-// Evaluations differ in depth, and the likelihood loop runs once per read: a wavefront is busy for
-// its deepest evaluation (Poisson(5) depths keep 38 of 64 lanes active, Poisson(20) about 45).  The 256
-// evaluations of a workgroup are therefore re-dealt to the lanes in depth order (P.gl_sort: LDS counting
-// sort of the thread ids), so each wavefront works on evaluations of similar depth.  Loads and stores
-// stay inside the workgroup's 256-evaluation window of each plane:
-//   gl_sort 1  a lane stores its own evaluation: a store instruction writes 4-byte pieces of the window
-//              (2x the algorithmic write bytes in the PMC, and 1.5x the time at low depth);
-//   gl_sort 2  (default) the values of one tag pass through LDS back into natural order, and every store
-//              of a wavefront is one contiguous segment;
-//   gl_sort 0  natural order throughout (no sort).
-// Which wavefront of a workgroup takes the deepest 64 evaluations rotates with the workgroup index.
+// Evaluations differ in depth -- and, for GL model 2, in how many distinct bases their reads show, which decides how many
+// accumulators their loop carries (below) -- and the likelihood loop runs once per read: a wavefront is busy for its deepest,
+// most diverse evaluation.  The 64 x WPB evaluations of a workgroup are therefore re-dealt to the lanes in (distinct bases, depth)
+// order (P.gl_sort != 0: LDS counting sort of the thread ids), so that each wavefront works on similar evaluations.  The sorted
+// lanes leave their accumulators in LDS, column = the evaluation's natural position; after one barrier every thread computes and
+// stores all tags of the evaluation at its OWN natural position, so every store of a wavefront is one contiguous segment of a
+// plane.  gl_sort 0: natural order throughout (the same path with the identity permutation).
+// Which wavefront of a workgroup takes the heaviest 64 evaluations rotates with the workgroup index.
 // GLM, PREC: the GL model (1 / 2) and --precise-gl as template parameters -- the paths share no code, and the
 // model-1 tables and the double log10 of --precise-gl 1 would cost the plain model-2 loop registers (occupancy)
 template <int A, int GLM, bool PREC, int WPB>
