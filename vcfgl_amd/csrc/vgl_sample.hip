@@ -441,7 +441,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     } else if (inb && !ok) { q_i = 0; aq_i = -1; }      // placeholder: k_redo writes the read's score
                 }
                 qs_finish(P, q_i, aq_i, T.errflag, DEFER ? (inb && ok) : inb);
-                if (inb) l_it[kk] = (uint32_t)(q_i & 0xFF) | ((uint32_t)(aq_i & 0xFF) << 8);
+                if (LEAN) { if (inb) l_pb[kk] = (uint8_t)((q_i << 2) | l_pb[kk]); }        // the staged byte itself: score << 2 | base
+                else if (inb) l_it[kk] = (uint32_t)(q_i & 0xFF) | ((uint32_t)(aq_i & 0xFF) << 8);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -450,6 +451,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
             // -- owners: combine base + quality score, stage the read, quality sums (vcfgl.cpp:525-564)
             // four reads per trip, one 32-bit store of the staged word (vgl_read_byte); a word cut by a segment boundary is
             // stored again, complete, by the next segment (carry_w)
+            if (LEAN) {
+                // the dense pass has left the staged bytes in l_pb: one (unaligned) 32-bit LDS read per word, masked to the reads of
+                // this segment
+                for (int r0 = rdone & ~3; r0 < r_end; r0 += 4) {
+                    uint32_t w4;
+                    __builtin_memcpy(&w4, l_pb + (offs + r0 - seg0), 4);       // bytes before / after the lane's reads are masked below
+                    const int lo = rdone > r0 ? rdone - r0 : 0, hi = r_end - r0 < 4 ? r_end - r0 : 4;
+                    const uint32_t mask = (0xFFFFFFFFu << (8 * lo)) & (0xFFFFFFFFu >> (8 * (4 - hi)));
+                    const uint32_t rw = (w4 & mask) | ((r0 < rdone) ? carry_w : 0u);
+                    ((uint32_t*)reads_v)[(size_t)(r0 >> 2) * plane + ev] = rw;
+                    carry_w = rw;
+                }
+            } else
             for (int r0 = rdone & ~3; r0 < r_end; r0 += 4) {
                 uint32_t rw = (r0 < rdone) ? carry_w : 0u;
 #pragma unroll
