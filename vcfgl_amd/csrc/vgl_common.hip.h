@@ -411,15 +411,19 @@ __device__ __forceinline__ float qs_stage_pf(const double gx, const double gy) {
 __device__ __forceinline__ float qs_tf(const float pf) { return -3.0103f * __builtin_amdgcn_logf(pf); }
 __device__ __forceinline__ float qs_tf_margin(const float tf) { return tf * 0x1p-19f + 4e-6f; }
 // returns false where the float32 value cannot decide (the caller then needs the exact evaluation)
-__device__ __forceinline__ bool qs_decide_pf(const VglDevParams& P, const float pf, int& q, int& aq) {
+// adj: P.adjust_qs, or 0 where the caller knows it at compile time (the lean builds of k_sample<2>)
+__device__ __forceinline__ bool qs_decide_pf(const VglDevParams& P, const float pf, int& q, int& aq, const int adj) {
     const float tf = qs_tf(pf);
     const float m = qs_tf_margin(tf);
     const float fl = floorf(tf);
-    const float t2 = tf + (float)P.adjust_by;
-    const float fl2 = floorf(t2);
     bool ok = (pf > 1.0e-37f) && (pf < 1.0f) && (tf - fl > m) && (fl + 1.0f - tf > m);
-    if (P.adjust_qs) ok = ok && (t2 > m) && (t2 - fl2 > m) && (fl2 + 1.0f - t2 > m);
-    q = (int)fl; aq = P.adjust_qs ? (int)fl2 : -1;
+    q = (int)fl; aq = -1;
+    if (adj) {
+        const float t2 = tf + (float)P.adjust_by;
+        const float fl2 = floorf(t2);
+        ok = ok && (t2 > m) && (t2 - fl2 > m) && (fl2 + 1.0f - t2 > m);
+        aq = (int)fl2;
+    }
     return ok;
 }
 // vcfgl.cpp:500-507, exact

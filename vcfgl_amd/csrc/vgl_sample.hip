@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 const bool inb = kk < segT;
                 const float pf = __uint_as_float(l_it[inb ? kk : cap]);
                 int q_i, aq_i;
-                bool ok = qs_decide_pf(P, pf, q_i, aq_i) && !P.dbg_qs_exact;
+                bool ok = qs_decide_pf(P, pf, q_i, aq_i, k_adj) && !P.dbg_qs_exact;
                 if (DEFER) { if (P.dbg_redo_every) ok = ok && ((uint32_t)(seg0 + kk) % (uint32_t)P.dbg_redo_every) != 2u; }    // test hook
                 uint64_t amb = __ballot(inb && !ok);
                 if (__builtin_expect(amb != 0, 0)) {
