@@ -76,13 +76,15 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float f32_missing() { return __uint_as_float(F32_MISSING_BITS); }
 __device__ __forceinline__ int nib(uint32_t v, int k) { return (int)((v >> (4 * k)) & 0xF); }
 // PL of one likelihood (vcfgl.cpp:907-939)
+// lroundf(-10.0 * gl) capped at MAXPL, MAXPL for gl = -inf.  The double product of a float and -10 is exact, so its conversion to
+// float is the float product x; gl <= 0 (the maximum has been subtracted), so x >= 0 and lroundf(x) = trunc(x) + (x - trunc(x) >= 0.5)
+// (the difference is exact); x = +inf gives NaN in the compare (false) and +inf in the sum, which the cap takes.  Branch-free.
 __device__ __forceinline__ uint32_t pl_of(const float v, const bool valid) {
-    int32_t x;
-    if (!valid) x = I32_MISSING;
-    else if (v == -INFINITY) x = MAXPL;
-    // lroundf(-10.0 * gl): the double product of a float and -10 is exact, so its conversion to float is the float product
-    else { x = (int32_t)lroundf(v * -10.0f); if (x > MAXPL) x = MAXPL; }
-    return (uint32_t)x;
+    const float x = v * -10.0f;
+    const float t = truncf(x);
+    float r = t + (((x - t) >= 0.5f) ? 1.0f : 0.0f);
+    r = __builtin_fminf(r, (float)MAXPL);
+    return valid ? (uint32_t)(int32_t)r : (uint32_t)I32_MISSING;
 }
 __device__ __forceinline__ int cnt_of(uint64_t ad4, int b) { return b < 4 ? (int)((ad4 >> (16 * b)) & 0xFFFF) : 0; }
 
