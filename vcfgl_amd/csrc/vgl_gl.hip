@@ -86,6 +86,25 @@ __device__ __forceinline__ uint32_t pl_of(const float v, const bool valid) {
     r = __builtin_fminf(r, (float)MAXPL);
     return valid ? (uint32_t)(int32_t)r : (uint32_t)I32_MISSING;
 }
+// log10(x) for 0 < x <= 1 (--precise-gl 1: three per read, gl_methods.cpp:171-220), relative error < 1e-15 -- the mode is held to 1e-6,
+// like the device log10() it replaces: x = m 2^e with m in [sqrt(1/2), sqrt(2)), ln m = 2 atanh((m - 1) / (m + 1)) by its series up to
+// s^19 (|s| <= 0.172: remainder 2e-17 relative), log10 x = (e ln 2 + ln m) log10(e).  x <= 0 gives -inf (log10(0) of a certain base).
+__device__ __forceinline__ double log10_unit(const double x) {
+    if (!(x > 0.0)) return -INFINITY;
+    int e;
+    double m = frexp(x, &e);                                         // [1/2, 1)
+    const bool lo = m < 0.70710678118654752;
+    m = lo ? m + m : m;
+    e = lo ? e - 1 : e;
+    const double s = (m - 1.0) / (m + 1.0);
+    const double z = s * s;
+    double p = 1.0 / 19.0;
+    p = __builtin_fma(p, z, 1.0 / 17.0); p = __builtin_fma(p, z, 1.0 / 15.0); p = __builtin_fma(p, z, 1.0 / 13.0);
+    p = __builtin_fma(p, z, 1.0 / 11.0); p = __builtin_fma(p, z, 1.0 / 9.0); p = __builtin_fma(p, z, 1.0 / 7.0);
+    p = __builtin_fma(p, z, 1.0 / 5.0); p = __builtin_fma(p, z, 1.0 / 3.0); p = __builtin_fma(p, z, 1.0);
+    const double ln = __builtin_fma((double)e, 0.69314718055994531, (s + s) * p);
+    return ln * 0.43429448190325183;
+}
 // 10^x for x <= 0 (GP = 10^GL, vcfgl.cpp:941-970), relative error 2e-16 (numpy check of the same steps against 10**x) -- GP is held to 1e-6, like the device pow()
 // it replaces (≈200 vector instructions per call, fifteen calls per evaluation): 2^n 2^f with n = rint(x log2 10), f in [-1/2, 1/2]
 // taken as x log2 10 - n in two pieces, 2^f = e^(f ln 2) by a degree-13 Taylor polynomial (|f ln 2| <= 0.35: remainder < 2e-17).
@@ -271,7 +290,7 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
                         } else {
                             const double e = T.errp[(size_t)r * plane + ev];
                             if (0.0 == e) { homT = 0.0; het = -0.30103; homF = -INFINITY; }
-                            else { homT = log10(1.0 - e); het = log10((1.0 - e) / 2.0 + e / 6.0); homF = log10(e / 3.0); }
+                            else { homT = log10_unit(1.0 - e); het = log10_unit((1.0 - e) / 2.0 + e / 6.0); homF = log10_unit(e / 3.0); }
                         }
                     }
                     float mx = -INFINITY;
