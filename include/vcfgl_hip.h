@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VGL_ABI_VERSION 3
+#define VGL_ABI_VERSION 4
 
 /* ---- error codes (returned by every entry point; 0 = success) ----------------------- */
 #define VGL_OK              0
@@ -78,10 +78,17 @@ extern "C" {
 #define VGL_BETA_STD    1  /* rng.h:353-421, std::mt19937 + std::gamma_distribution (default
                               reference build; one global stream => VGL_RNG_SERIAL only)       */
 
-/* Window layout of VGL_RNG_TILE.  Evaluation e = site_abs * n_samples + sample owns draws
+/* Window layout of VGL_RNG_TILE.  Evaluation e = H(site_abs) * n_samples + sample owns draws
  * [e*block, (e+1)*block) of the rand48 sequence; stream k of that evaluation starts at
  * e*block + off[k].  A consumer that needs more draws than its sub-window simply keeps
  * stepping the generator (deterministic, only statistically overlapping).
+ * H is a fixed permutation of the site indices [0, 2^W), 2^W = vgl_rng_tile_max_sites() (ABI version 4; H(0) = 0):
+ *     sh = (W + 1) / 2;  x ^= x >> sh;  x = x * 0xBF58476D1CE4E5B9 mod 2^W;  x ^= x >> sh;
+ *                        x = x * 0x94D049BB133111EB mod 2^W;  x ^= x >> sh            (identity for W <= 1)
+ * (vgl_rng_tile_site_hash() evaluates it).  It breaks the regular spacing of the sites' windows: rand48 is a linear
+ * congruential generator mod 2^48, and at offsets that are multiples of a high power of two its states are linearly
+ * related (sites s, s + 2^k, s + 2^(k+1) at equal spacing would give u(s) - 2 u(s + 2^k) + u(s + 2^(k+1)) = const for
+ * large k).  Results still depend only on (seed, absolute site index, sample): tiling and sharding never change a value.
  *   k=0 depth        rng1, Poisson draws                  (vcfgl.cpp:364-368, rng.h:284-351)
  *   k=1 haplotype    rng1, one draw per read              (vcfgl.cpp:473)
  *   k=2 base/strand  rng0, error test, wrong base, strand (vcfgl.cpp:486-488,582)
@@ -178,9 +185,12 @@ int32_t vgl_max_alleles(const vgl_params* p);      /* 4 or 5:  shared.h:148-152 
 int32_t vgl_max_genotypes(const vgl_params* p);    /* 10 or 15: lut_nAlleles_to_nGenotypes    */
 int     vgl_default_rng_layout(const vgl_params* p, vgl_rng_layout* out);
 /* VGL_RNG_TILE addresses one rand48 sequence of period 2^48: a job may use sites [0, *max_sites) before its windows
- * would repeat (BASELINE config C4, 1e7 sites x 2000 samples at depth 30, uses 48 % of it).  vgl_simulate_tile* return
- * VGL_E_ARG beyond that.  The reference's serial streams have no such limit (rng.h:8-10) -- VGL_RNG_SERIAL neither. */
+ * would repeat; *max_sites = 2^W, the largest power of two with 2^W * n_samples * block <= 2^48 (BASELINE config C4, 1e7
+ * sites x 2000 samples at depth 30: 2^24 = 1.68e7).  vgl_simulate_tile* return VGL_E_ARG beyond that.  The reference's
+ * serial streams have no such limit (rng.h:8-10) -- VGL_RNG_SERIAL neither. */
 int     vgl_rng_tile_max_sites(const vgl_params* p, int64_t* max_sites);
+/* H(site) of the window layout above (pure host arithmetic; VGL_E_ARG outside [0, max_sites)). */
+int     vgl_rng_tile_site_hash(const vgl_params* p, int64_t site, int64_t* hashed);
 int     vgl_abi_version(void);
 const char* vgl_last_error(void);
 

@@ -60,6 +60,24 @@ uint64_t vgl_oracle_rand48_jump(uint64_t st, uint64_t n) {
     return (ra * st + rc) & MASK48;
 }
 
+/* VGL_RNG_TILE: position of a site's windows in the rand48 sequence, as include/vcfgl_hip.h (vgl_rng_layout) specifies it:
+ * a permutation of [0, 2^W), 2^W * n_samples * block <= 2^48.  Restated from that specification, not shared with the product. */
+uint64_t vgl_oracle_site_hash(uint64_t x, int W) {
+    if (W <= 1) return x;
+    const uint64_t mask = ((uint64_t)1 << W) - 1;
+    const int sh = (W + 1) / 2;
+    x ^= x >> sh; x = (x * 0xBF58476D1CE4E5B9ULL) & mask;
+    x ^= x >> sh; x = (x * 0x94D049BB133111EBULL) & mask;
+    x ^= x >> sh;
+    return x;
+}
+int vgl_oracle_site_hash_bits(uint64_t block, uint64_t n_samples) {
+    const uint64_t raw = (uint64_t)((((unsigned __int128)1 << 48) / block) / n_samples);
+    int W = 0;
+    while (W < 40 && ((uint64_t)2 << W) <= raw) ++W;
+    return W;
+}
+
 uint64_t vgl_oracle_rand48_seed(int32_t seed) {      /* io.cpp:1054-1061, shared.h:22 */
     return ((((uint64_t)(uint32_t)seed) << 16) | 0x330EULL) & MASK48;
 }
@@ -408,6 +426,7 @@ typedef struct vgl_oracle {
     double pre_homT, pre_het, pre_homF;
     errmod_t* em;
     vgl_rng_layout lay;
+    int hash_bits;             /* W of vgl_oracle_site_hash() */
     int A, G;                  /* max alleles / genotypes of the tile layout */
     /* scratch */
     int cap;                   /* reads capacity per sample */
@@ -552,6 +571,7 @@ int vgl_oracle_create(const vgl_params* p, vgl_oracle** out) {
         if (!o->em) { vgl_oracle_destroy(o); OFAIL(VGL_E_NOMEM, "out of memory"); }
     }
     if (p->layout.block) o->lay = p->layout; else vgl_oracle_default_layout(p, &o->lay);
+    o->hash_bits = vgl_oracle_site_hash_bits(o->lay.block, (uint64_t)N);
     o->A = max_alleles(p);
     o->G = N_GT_OF_ALLELES[o->A];
     o->cap = 0;
@@ -632,7 +652,7 @@ static int gl1_sample(vgl_oracle* o, int64_t site_abs, int s, int n, const int* 
     /* the shuffle stream of depth > 255: the process-wide stream in serial mode; a per-evaluation window of it in tile mode */
     uint64_t hts_local, *hts = &o->st_hts;
     if (p->rng_mode == VGL_RNG_TILE) {
-        const uint64_t e = (uint64_t)site_abs * (uint64_t)p->n_samples + (uint64_t)s;
+        const uint64_t e = vgl_oracle_site_hash((uint64_t)site_abs, o->hash_bits) * (uint64_t)p->n_samples + (uint64_t)s;
         hts_local = vgl_oracle_rand48_jump(HTS_RAND48_X0, e * VGL_HTS_TILE_STRIDE);
         hts = &hts_local;
     }
@@ -686,7 +706,7 @@ static int simulate_site(vgl_oracle* o, int64_t site_abs, int32_t ls, int32_t n_
         uint64_t* st_depth;
         uint64_t local_depth;
         if (tile) {
-            uint64_t e = (uint64_t)site_abs * (uint64_t)N + (uint64_t)s;
+            uint64_t e = vgl_oracle_site_hash((uint64_t)site_abs, o->hash_bits) * (uint64_t)N + (uint64_t)s;
             uint64_t base = e * o->lay.block;
             local_depth = vgl_oracle_rand48_jump(o->x0, base + o->lay.off[0]);
             st_hap[s] = vgl_oracle_rand48_jump(o->x0, base + o->lay.off[1]);
@@ -925,6 +945,8 @@ done:
 
 int vgl_oracle_simulate(vgl_oracle* o, int64_t site0, int32_t n_sites, const uint8_t* gt, vgl_tile_out* out) {
     if (!o || !gt || !out || !out->site_status || !out->n_alleles || !out->alleles2acgt) OFAIL(VGL_E_ARG, "null argument");
+    if (o->p.rng_mode == VGL_RNG_TILE && (site0 < 0 || (uint64_t)site0 + (uint64_t)n_sites > ((uint64_t)1 << o->hash_bits)))
+        OFAIL(VGL_E_ARG, "VGL_RNG_TILE: sites beyond 2^%d run past the 2^48 period of rand48", o->hash_bits);
     for (int32_t i = 0; i < n_sites; i++) {
         int rc = simulate_site(o, site0 + i, i, n_sites, gt + (size_t)i * o->p.n_samples, out);
         if (rc) return rc;

@@ -90,7 +90,8 @@ def test_flag_parser_matches_reference_surface():
 
 def test_rng_period_limit_of_tile_mode():
     """VGL_RNG_TILE windows are slices of one rand48 sequence (period 2^48): the library states how many sites a job of a
-    given shape may address.  BASELINE config C4 (1e7 sites x 2000 samples, depth 30, --error-qs 2) uses 48 % of it."""
+    given shape may address -- 2^W, the domain of the site permutation H (include/vcfgl_hip.h, vgl_rng_layout).  BASELINE
+    config C4 (1e7 sites x 2000 samples, depth 30, --error-qs 2) fits."""
     lib = _abi.load_library()
     a = VcfglArgs(seed=42, depth=30.0, error_rate=0.01, error_qs=2, beta_variance=1e-5)
     p, _ = a.to_struct(2000)
@@ -98,9 +99,9 @@ def test_rng_period_limit_of_tile_mode():
     assert lib.vgl_default_rng_layout(C.byref(p), C.byref(lay)) == 0
     mx = C.c_int64()
     assert lib.vgl_rng_tile_max_sites(C.byref(p), C.byref(mx)) == 0
-    assert mx.value == (2 ** 48 // lay.block) // 2000
-    assert 10_000_000 < mx.value < 25_000_000                    # C4 fits, a job 2.1x larger does not
-    assert abs(10_000_000 / mx.value - 0.48) < 0.02
+    raw = (2 ** 48 // lay.block) // 2000
+    assert mx.value == 1 << (raw.bit_length() - 1) == 2 ** 24    # the largest power of two whose windows fit the period
+    assert 10_000_000 < mx.value < 25_000_000                    # C4 fits, a job twice as large does not
     a3 = VcfglArgs(seed=42, depth=20.0, error_rate=0.01, error_qs=2, beta_variance=1e-5)
     p3, _ = a3.to_struct(1000)
     assert lib.vgl_rng_tile_max_sites(C.byref(p3), C.byref(mx)) == 0 and mx.value > 8 * 1_000_000      # C3 on 8 GPUs, weak scaling

@@ -6,7 +6,7 @@ not been built -- the product path never falls back to a CPU implementation.
 import ctypes as C
 import os
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 VGL_OK = 0
 VGL_E_ARG, VGL_E_NODEVICE, VGL_E_NOMEM, VGL_E_CAPACITY, VGL_E_UNSUPPORTED, VGL_E_QSBIN, VGL_E_ADJQ = -1, -2, -3, -4, -5, -6, -7
@@ -68,7 +68,7 @@ TILE_FIELDS = [
 EXPORTS = [
     "vgl_max_alleles", "vgl_max_genotypes", "vgl_default_rng_layout", "vgl_abi_version",
     "vgl_last_error", "vgl_ctx_create", "vgl_ctx_destroy", "vgl_simulate_tile",
-    "vgl_simulate_tile_device", "vgl_ctx_check", "vgl_ctx_timing", "vgl_ctx_kernel_ms", "vgl_rng_tile_max_sites",
+    "vgl_simulate_tile_device", "vgl_ctx_check", "vgl_ctx_timing", "vgl_ctx_kernel_ms", "vgl_rng_tile_max_sites", "vgl_rng_tile_site_hash",
     "vgl_simulate_tile_async", "vgl_tile_wait", "vgl_host_alloc", "vgl_host_free",
 ]
 
@@ -102,6 +102,7 @@ def load_library():
     lib.vgl_default_rng_layout.argtypes = [C.POINTER(Params), C.POINTER(RngLayout)]
     lib.vgl_last_error.restype = C.c_char_p
     lib.vgl_rng_tile_max_sites.argtypes = [C.POINTER(Params), C.POINTER(C.c_int64)]
+    lib.vgl_rng_tile_site_hash.argtypes = [C.POINTER(Params), C.c_int64, C.POINTER(C.c_int64)]
     lib.vgl_ctx_create.argtypes = [C.POINTER(Params), C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
     lib.vgl_ctx_destroy.argtypes = [C.c_void_p]
     lib.vgl_simulate_tile.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.POINTER(TileOut)]

@@ -17,6 +17,28 @@
 // x -> a*x + c (mod 2^48): a power of the rand48 step
 struct VglAffine { uint64_t a, c; };
 
+// VGL_RNG_TILE, where the windows of a site lie in the rand48 sequence: site index -> H(site), a bijection of [0, 2^W)
+// (xorshift / odd multiply / xorshift / odd multiply / xorshift on W bits, every step invertible; H(0) = 0, so site 0 / sample 0
+// still starts on the reference's first draws).  Evaluation (site, sample) owns the draws [e block, (e + 1) block) with
+// e = H(site) * n_samples + sample.  Without H, sites 2^k apart sit at offsets 2^k * N * block of ONE linear congruential
+// sequence mod 2^48, and a^(2^k) = 1 mod 2^(k+2) makes the states at sites s, s + 2^k, s + 2^(k+1) linearly dependent (for
+// k >= 19 at 1000 samples, depth 20: u(s) - 2 u(s + 2^k) + u(s + 2^(k+1)) is one constant for every sample and read).  H removes
+// the regular spacing: the windows of neighbouring sites and of sites 2^k apart are at pseudo-random offsets of each other.
+// W = floor(log2(2^48 / block / n_samples)): the 2^W site groups fill at most the generator's period.
+// The oracle (oracle/vgl_oracle.c: site_hash) and the tests restate this function; vgl_rng_tile_site_hash() exports it.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline uint64_t vgl_site_hash(uint64_t x, const int W) {
+    if (W <= 1) return x;
+    const uint64_t mask = (1ULL << W) - 1ULL;
+    const int sh = (W + 1) >> 1;
+    x ^= x >> sh; x = (x * 0xBF58476D1CE4E5B9ULL) & mask;
+    x ^= x >> sh; x = (x * 0x94D049BB133111EBULL) & mask;
+    x ^= x >> sh;
+    return x;
+}
+
 // PoissonSampler (rng.h:249-280), one per run or one per sample
 struct VglPois { double lm, sq, alxm, g; int32_t st12; int32_t pad; };
 
@@ -91,12 +113,13 @@ struct VglDevParams {
     // rand48 addressing
     uint64_t x0;
     VglAffine off[4];                  // J^(off[k])
-    VglAffine site_pow[40];            // J^(block * N * 2^b)
+    VglAffine site_pow[40];            // J^(block * N * 2^b)  (k_sitebase)
+    int32_t site_hash_bits;            // W of vgl_site_hash(): sites [0, 2^W) are addressable
+    uint32_t depth_magic;              // k_depth, N < 1024: floor(2^32 / N) + 1, so that t / N = mulhi(t, magic) for t < 2048
     const VglAffine* samp_tab;         // [N] J^(block * s)
     const VglAffine* qs_read_tab;      // [read_cap] J^(qs_read_stride * r)
     const VglAffine* step_tab;         // [192] J^k (serial-mode scout)
-    const VglAffine* chunk_tab;        // [VGL_DEPTH_CHUNK] J^(block * i)  (k_depth)
-    const VglAffine* eval_pow_tab;     // [64] J^(block * 2^b)             (k_depth)
+    const VglAffine* depth_tab;        // [N] J^(off[0] + block * s)       (k_depth)
     // samplers
     VglPois pois0;
     const VglPois* pois;               // [N] when per_sample_depth
@@ -137,6 +160,8 @@ struct VglTilePtrs {
     VglSiteInfo* sinfo;      // [n_sites]
     uint32_t* errflag;
     int32_t*  dp_pre;        // [n_sites][N] depth draws of k_depth (tile mode)
+    uint64_t* site_base;     // [n_sites] tile mode: J^(block N H(site)) (x0), the generator state in front of the site's windows (k_sitebase)
+    uint64_t* site_hash;     // [n_sites] tile mode: H(site) (GL model 1 deeper than 255 reads addresses htslib's stream by it)
     // outputs (caller owned device memory; may be null)
     int32_t* site_status; int32_t* n_alleles; int32_t* n_alleles_obs; int8_t* alleles2acgt;
     int32_t* info_dp; int32_t* info_ad; int32_t* info_adf; int32_t* info_adr;
@@ -187,6 +212,7 @@ extern "C" {
 #endif
 // launch wrappers implemented beside their kernels in vgl_sample.hip / vgl_serial.hip / vgl_gl.hip
 // (stream = hipStream_t)
+int vgl_launch_sitebase(const VglDevParams* p, const VglTilePtrs* t, void* stream);
 int vgl_launch_depth(const VglDevParams* p, const VglTilePtrs* t, void* stream);
 int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, void* stream);
 int vgl_launch_site(const VglDevParams* p, const VglTilePtrs* t, void* stream);

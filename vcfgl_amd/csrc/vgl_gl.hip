@@ -360,7 +360,7 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
                 // shuffles its own column of the staged reads in place (scratch of the context, 1 byte per read).
                 uint64_t st;
                 if (T.hts_off) st = rand48_jump(*T.hts_base, (uint64_t)T.hts_off[ev]);                      // serial: the process-wide stream
-                else st = rand48_jump(VGL_HTS_RAND48_X0, ((uint64_t)(T.site0 + ls) * (uint64_t)N + (uint64_t)s) * VGL_HTS_TILE_STRIDE);
+                else st = rand48_jump(VGL_HTS_RAND48_X0, (T.site_hash[ls] * (uint64_t)N + (uint64_t)s) * VGL_HTS_TILE_STRIDE);
                 uint8_t* const rd = T.reads;
                 for (int i = n; i > 1; --i) {
                     st = lcg_next(st);

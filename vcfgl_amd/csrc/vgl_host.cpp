@@ -54,13 +54,29 @@ extern "C" int vgl_default_rng_layout(const vgl_params* p, vgl_rng_layout* out) 
     return VGL_OK;
 }
 
-// Sites [0, max) a VGL_RNG_TILE job of this shape may address before its windows wrap around the 2^48 period of rand48
-// (evaluation e = site * n_samples + sample owns draws [e block, (e + 1) block)).
-extern "C" int vgl_rng_tile_max_sites(const vgl_params* p, int64_t* max_sites) {
-    if (!p || !max_sites || p->n_samples <= 0) return fail(VGL_E_ARG, "null argument");
+// W of vgl_site_hash(): the largest W with 2^W * n_samples * block <= 2^48, the period of rand48
+static int site_hash_bits(const vgl_params* p) {
     vgl_rng_layout lay;
     if (p->layout.block) lay = p->layout; else vgl_default_rng_layout(p, &lay);
-    *max_sites = (int64_t)((((unsigned __int128)1 << 48) / lay.block) / (uint64_t)p->n_samples);
+    const uint64_t raw = (uint64_t)((((unsigned __int128)1 << 48) / lay.block) / (uint64_t)p->n_samples);
+    int W = 0;
+    while (W < 40 && (2ULL << W) <= raw) ++W;
+    return W;
+}
+
+// Sites [0, max) a VGL_RNG_TILE job of this shape may address: evaluation (site, sample) owns draws [e block, (e + 1) block),
+// e = H(site) * n_samples + sample, and H (vgl_site_hash, vgl_device.h) permutes [0, 2^W) with 2^W * n_samples * block <= 2^48.
+extern "C" int vgl_rng_tile_max_sites(const vgl_params* p, int64_t* max_sites) {
+    if (!p || !max_sites || p->n_samples <= 0) return fail(VGL_E_ARG, "null argument");
+    *max_sites = (int64_t)1 << site_hash_bits(p);
+    return VGL_OK;
+}
+
+extern "C" int vgl_rng_tile_site_hash(const vgl_params* p, int64_t site, int64_t* hashed) {
+    if (!p || !hashed || p->n_samples <= 0) return fail(VGL_E_ARG, "null argument");
+    const int W = site_hash_bits(p);
+    if (site < 0 || site >= ((int64_t)1 << W)) return fail(VGL_E_ARG, "site %lld outside [0, 2^%d)", (long long)site, W);
+    *hashed = (int64_t)vgl_site_hash((uint64_t)site, W);
     return VGL_OK;
 }
 
@@ -152,7 +168,7 @@ struct vgl_ctx {
     int max_sites;
     VglDevParams dp;
     // device tables
-    VglAffine* d_chunk_tab = nullptr; VglAffine* d_eval_pow = nullptr; int32_t* d_dp_pre = nullptr;
+    VglAffine* d_depth_tab = nullptr; int32_t* d_dp_pre = nullptr; uint64_t* d_site_base = nullptr; uint64_t* d_site_hash = nullptr;
     VglAffine* d_samp_tab = nullptr; VglAffine* d_qs_read_tab = nullptr; VglPois* d_pois = nullptr;
     double* d_q2gl = nullptr; double* d_gamma_ln = nullptr; double* d_gl1_fk = nullptr; double* d_gl1_beta = nullptr; double* d_gl1_bsum = nullptr; double* d_gl1_lhet = nullptr;
     // workspace
@@ -264,7 +280,7 @@ extern "C" int vgl_ctx_destroy(vgl_ctx* c) {
     void* ptrs[] = {c->d_gl1_fk, c->d_gl1_beta, c->d_gamma_ln, c->d_samp_tab, c->d_qs_read_tab, c->d_pois, c->d_q2gl, c->d_gl1_bsum, c->d_gl1_lhet, c->d_reads, c->d_errp, c->d_ad4,
                     c->d_adf4, c->d_qsum, c->d_qsumsq, c->d_acc, c->d_sinfo, c->d_errflag, c->d_dbg, c->d_redo_list, c->d_redo_count, c->d_redo_bits,
                     c->d_serial, c->d_sst, c->d_site_thresh, c->d_scout_dp, c->d_site_tail, c->d_sdp, c->d_step_tab,
-                    c->d_chunk_tab, c->d_eval_pow, c->d_dp_pre, c->d_hts_off, c->d_hts_base, c->d_roff, c->d_rtotal, c->d_errp_lin, c->d_cw, c->d_ccons, c->d_cexit,
+                    c->d_depth_tab, c->d_site_base, c->d_site_hash, c->d_dp_pre, c->d_hts_off, c->d_hts_base, c->d_roff, c->d_rtotal, c->d_errp_lin, c->d_cw, c->d_ccons, c->d_cexit,
                     c->d_ccnt, c->d_centry, c->d_cbase, c->d_cpos, c->d_csnap, c->d_csnapw, c->d_cctl};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     for (auto& S : c->slot) {
@@ -425,14 +441,15 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
 
 #define TRY(x) do { if ((rc = (x))) { vgl_ctx_destroy(c); return rc; } } while (0)
 #define TRYHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { vgl_ctx_destroy(c); return fail(e_ == hipErrorOutOfMemory ? VGL_E_NOMEM : VGL_E_NODEVICE, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
-    if (!D.serial) {                                               // k_depth: J^(block*i) and J^(block*2^b)
-        std::vector<VglAffine> ct(VGL_DEPTH_CHUNK), ep(64);
-        { VglAffine cur = {1, 0}; for (int i = 0; i < VGL_DEPTH_CHUNK; i++) { ct[i] = cur; cur = aff_compose(jb, cur); } }
-        { VglAffine cur = jb; for (int b = 0; b < 64; b++) { ep[b] = cur; cur = aff_compose(cur, cur); } }
-        TRY(dmalloc(&c->d_chunk_tab, (size_t)VGL_DEPTH_CHUNK)); TRY(dmalloc(&c->d_eval_pow, (size_t)64));
-        TRYHIP(hipMemcpy(c->d_chunk_tab, ct.data(), sizeof(VglAffine) * ct.size(), hipMemcpyHostToDevice));
-        TRYHIP(hipMemcpy(c->d_eval_pow, ep.data(), sizeof(VglAffine) * ep.size(), hipMemcpyHostToDevice));
-        D.chunk_tab = c->d_chunk_tab; D.eval_pow_tab = c->d_eval_pow;
+    if (!D.serial) {                                               // k_sitebase's outputs; k_depth: J^(off0 + block*s)
+        D.site_hash_bits = site_hash_bits(&c->p);
+        D.depth_magic = (uint32_t)((1ULL << 32) / (uint64_t)N + 1ULL);
+        std::vector<VglAffine> dt(N);
+        for (int s = 0; s < N; s++) dt[s] = aff_compose(D.off[0], samp[s]);
+        TRY(dmalloc(&c->d_depth_tab, (size_t)N));
+        TRYHIP(hipMemcpy(c->d_depth_tab, dt.data(), sizeof(VglAffine) * N, hipMemcpyHostToDevice));
+        D.depth_tab = c->d_depth_tab;
+        TRY(dmalloc(&c->d_site_base, (size_t)max_sites)); TRY(dmalloc(&c->d_site_hash, (size_t)max_sites));
     }
     TRY(dmalloc(&c->d_samp_tab, (size_t)N));
     TRYHIP(hipMemcpy(c->d_samp_tab, samp.data(), sizeof(VglAffine) * N, hipMemcpyHostToDevice));
@@ -629,14 +646,14 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     if (!gt || !o->site_status || !o->n_alleles || !o->alleles2acgt) return fail(VGL_E_ARG, "gt, site_status, n_alleles and alleles2acgt are required");
     if (site0 < 0) return fail(VGL_E_ARG, "site0 must be >= 0");
     if (!c->dp.serial) {
-        // VGL_RNG_TILE windows are strided slices of ONE rand48 sequence of period 2^48: evaluation e owns draws
-        // [e block, (e + 1) block).  Past the period the windows would silently repeat earlier ones.
-        const unsigned __int128 end = (unsigned __int128)((uint64_t)site0 + (uint64_t)n_sites) * (uint64_t)c->dp.n_samples * c->p.layout.block;
-        if (end > ((unsigned __int128)1 << 48))
+        // VGL_RNG_TILE windows are slices of ONE rand48 sequence of period 2^48: evaluation (site, sample) owns draws
+        // [e block, (e + 1) block), e = H(site) n_samples + sample, H a permutation of [0, 2^W).  Past 2^W sites the windows would
+        // silently repeat earlier ones.
+        if ((uint64_t)site0 + (uint64_t)n_sites > (1ULL << c->dp.site_hash_bits))
             return fail(VGL_E_ARG, "VGL_RNG_TILE: sites [%lld, %lld) x %d samples x %llu draws per evaluation run past the 2^48 period of rand48 "
                         "(at most %llu sites with this layout); split the job over seeds or use a smaller layout.block",
                         (long long)site0, (long long)site0 + n_sites, c->dp.n_samples, (unsigned long long)c->p.layout.block,
-                        (unsigned long long)((((unsigned __int128)1 << 48) / c->p.layout.block) / (uint64_t)c->dp.n_samples));
+                        (unsigned long long)(1ULL << c->dp.site_hash_bits));
     }
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
@@ -646,6 +663,7 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     T.site0 = site0; T.n_sites = n_sites; T.gt = gt;
     T.reads = c->d_reads; T.errp = c->d_errp; T.ad4 = c->d_ad4; T.adf4 = c->d_adf4; T.qsum = c->d_qsum; T.qsumsq = c->d_qsumsq;
     T.acc = c->d_acc; T.sinfo = c->d_sinfo; T.errflag = c->d_errflag; T.dbg = c->d_dbg; T.dp_pre = c->d_dp_pre;
+    T.site_base = c->d_site_base; T.site_hash = c->d_site_hash;
     T.redo_list = c->d_redo_list; T.redo_count = c->d_redo_count; T.redo_cap = c->redo_cap; T.redo_bits = c->d_redo_bits;
     if (D.serial) {
         const size_t E = (size_t)c->max_sites * D.n_samples;
@@ -686,7 +704,10 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
             if (rc != VGL_OK) return rc;
             T.roff = c->d_roff; T.errp_lin = c->d_errp_lin;
         }
-    } else if (D.depth_pre == 1 && vgl_launch_depth(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_depth launch failed");
+    } else {
+        if (vgl_launch_sitebase(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_sitebase launch failed");
+        if (D.depth_pre == 1 && vgl_launch_depth(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_depth launch failed");
+    }
     if (c->timing) HIPCHK(hipEventRecord(e[1], st));
     if (vgl_launch_sample(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_sample launch failed: %s", hipGetErrorString(hipGetLastError()));
     if (c->timing) HIPCHK(hipEventRecord(e[2], st));
@@ -718,6 +739,15 @@ extern "C" long long vgl_dbg_chain(vgl_ctx* c, double* out, long long n) {
     if (n > R) n = R;
     if (hipMemcpy(out, c->d_errp_lin, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return R;
+}
+
+// diagnostic (not in the public header): the generator states in front of the windows of the last tile's sites (k_sitebase)
+extern "C" int vgl_dbg_site_base(vgl_ctx* c, uint64_t* out, int n) {
+    if (!c || !c->d_site_base || n > c->max_sites) return VGL_E_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, c->d_site_base, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost));
+    return VGL_OK;
 }
 
 // diagnostic (not in the public header): read and clear the VGL_DEBUG_STAMPS counters

@@ -16,32 +16,53 @@
 // lane's work does not depend on its own evaluation's depth; each lane runs the nested
 // rejection loops of the gamma sampler as one flat state machine (one normal-deviate attempt
 // per iteration) so that lanes at different stages share every iteration.
+// Where the windows of each site of the tile start in the rand48 sequence (VGL_RNG_TILE): one lane per site computes
+// H(site) (vgl_site_hash, vgl_device.h) and the generator state J^(block N H(site)) (x0) in front of the site's N evaluation
+// blocks from the 40-entry power table.  k_depth, k_sample and k_redo start from that state (one load per wavefront / lane);
+// samples and reads stay additive inside a site.
+__global__ __launch_bounds__(256) void k_sitebase(const VglDevParams P, const VglTilePtrs T) {
+    const int ls = blockIdx.x * 256 + threadIdx.x;
+    if (ls >= T.n_sites) return;
+    const uint64_t h = vgl_site_hash((uint64_t)(T.site0 + ls), P.site_hash_bits);
+    uint64_t xb = P.x0;
+#pragma unroll 1
+    for (int b = 0; b < 40; ++b)
+        if ((h >> b) & 1) xb = aff(P.site_pow[b], xb);
+    T.site_base[ls] = xb;
+    T.site_hash[ls] = h;
+}
+
 // Depth draws of a tile (vcfgl.cpp:364-389; rng.h:284-351), ahead of k_sample.  The rejection sampler
 // needs 2 attempts on average but about 7 for the slowest of 64 lanes, so evaluations are not tied to
-// lanes here: a wavefront owns VGL_DEPTH_CHUNK consecutive evaluations and deals them to its lanes as
+// lanes here: a wavefront owns VGL_DEPTH_CHUNK consecutive evaluations of the tile and deals them to its lanes as
 // lanes finish; one rejection attempt of every busy lane per iteration, lane state advanced by selects
-// (launched only when every sample's mean depth is >= 12; the short product-method loops stay in k_sample).  Evaluation e = site_abs * N + sample starts its depth stream at
-// J^(off0) J^(block e) (X0): J^(block e_chunk) per wavefront from a power table, one table jump per evaluation.
+// (launched only when every sample's mean depth is >= 12; the short product-method loops stay in k_sample).  Evaluation
+// (site, sample) starts its depth stream at J^(off0 + block sample) (site_base[site]): the site's state from k_sitebase, one table
+// jump per evaluation.  A chunk spans sites: the site of item i is found from the chunk's first (site, sample) by one compare
+// (N >= 1024) or one multiply-high (P.depth_magic).
 __global__ __launch_bounds__(256) void k_depth(const VglDevParams P, const VglTilePtrs T) {
     const int lane = threadIdx.x & 63;
-    const int N = P.n_samples;
+    const uint32_t N = (uint32_t)P.n_samples;
     const int64_t E = (int64_t)T.n_sites * N;
     const int64_t c0 = ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * VGL_DEPTH_CHUNK;
     if (c0 >= E) return;
     const int cn = (int)((E - c0 < VGL_DEPTH_CHUNK) ? (E - c0) : VGL_DEPTH_CHUNK);
-    const uint64_t e_abs0 = (uint64_t)T.site0 * (uint64_t)N + (uint64_t)c0;
-    uint64_t xc = P.x0;
-#pragma unroll 1
-    for (int b = 0; b < 64; ++b)
-        if ((e_abs0 >> b) & 1) xc = aff(P.eval_pow_tab[b], xc);
-    xc = aff(P.off[0], xc);
-    const uint32_t s_of_c0 = (uint32_t)(e_abs0 % (uint64_t)N);          // sample index of the chunk's first evaluation
+    const uint32_t ls_c0 = (uint32_t)(c0 / (int64_t)N);                  // site and sample of the chunk's first evaluation (wave-uniform)
+    const uint32_t s_c0 = (uint32_t)(c0 - (int64_t)ls_c0 * N);
+    const bool big_n = N >= (uint32_t)VGL_DEPTH_CHUNK;
+    auto start_of = [&](const int i, uint32_t& s_out) -> uint64_t {      // stream start of the chunk's item i (i < cn)
+        const uint32_t t = s_c0 + (uint32_t)i;                           // < N + 1024
+        const uint32_t add = big_n ? (uint32_t)(t >= N) : __umulhi(t, P.depth_magic);
+        s_out = t - add * N;
+        return aff(P.depth_tab[s_out], T.site_base[ls_c0 + add]);
+    };
 
     int i = lane, next_free = 64;
     bool busy = i < cn;
-    uint64_t st = aff(P.chunk_tab[busy ? i : 0], xc);
+    uint32_t s_i;
+    uint64_t st = start_of(busy ? i : 0, s_i);
     VglPois pp = P.pois0;
-    if (P.per_sample_depth) pp = P.pois[(s_of_c0 + (uint32_t)(busy ? i : 0)) % (uint32_t)N];
+    if (P.per_sample_depth) pp = P.pois[s_i];
     while (__ballot(busy)) {
         // one rejection attempt (rng.h:300-312); k_depth runs only when every sample uses this method
         const uint64_t st1 = lcg_next(st), st2 = lcg_next(st1);
@@ -57,8 +78,9 @@ __global__ __launch_bounds__(256) void k_depth(const VglDevParams P, const VglTi
         const int i_n = done ? next_free + rank : i;
         next_free += __popcll(dm);
         const bool busy_n = done ? (i_n < cn) : busy;
-        const uint64_t st_n = aff(P.chunk_tab[busy_n ? i_n : 0], xc);
-        if (P.per_sample_depth) { const VglPois pn = P.pois[(s_of_c0 + (uint32_t)(busy_n ? i_n : 0)) % (uint32_t)N]; if (done) pp = pn; }
+        uint32_t s_n;
+        const uint64_t st_n = start_of(busy_n ? i_n : 0, s_n);
+        if (P.per_sample_depth) { const VglPois pn = P.pois[s_n]; if (done) pp = pn; }
         st = done ? st_n : st;
         i = i_n; busy = busy_n;
     }
@@ -105,12 +127,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
     const bool k_qsum = LEAN ? false : (P.need_qsum != 0);
     const int k_adj = LEAN ? 0 : P.adjust_qs;
 
-    // ---- stream states of this evaluation: J^(off_k) . J^(block*s) . J^(block*N*site) (x0)
-    const uint64_t site_abs = (uint64_t)(T.site0 + ls);
-    uint64_t xb = P.x0;
-#pragma unroll 1
-    for (int b = 0; b < 40; ++b)
-        if ((site_abs >> b) & 1) xb = aff(P.site_pow[b], xb);
+    // ---- stream states of this evaluation: J^(off_k) . J^(block*s) . J^(block*N*H(site)) (x0); the site factor comes from k_sitebase
+    const uint64_t xb = T.site_base[ls];
 
     if (active) {
         const VglAffine ms = P.samp_tab[s];
@@ -534,6 +552,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
 }
 
 // ------------------------------------------------------------------------------------
+extern "C" int vgl_launch_sitebase(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
+    if (t->n_sites == 0) return 0;
+    hipLaunchKernelGGL(k_sitebase, dim3((unsigned)((t->n_sites + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p, *t);
+    return (int)hipGetLastError();
+}
+
 extern "C" int vgl_launch_depth(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
     const int64_t E = (int64_t)t->n_sites * p->n_samples;
     if (E == 0) return 0;
@@ -550,12 +574,7 @@ extern "C" int vgl_launch_depth(const VglDevParams* p, const VglTilePtrs* t, voi
 __device__ __forceinline__ void redo_read(const VglDevParams& P, const VglTilePtrs& T, const size_t ev, const int r) {
     const size_t N = (size_t)P.n_samples, plane = (size_t)T.n_sites * N;
     const size_t ls = ev / N, s = ev - ls * N;
-    const uint64_t site_abs = (uint64_t)(T.site0 + (int64_t)ls);
-    uint64_t xb = P.x0;
-#pragma unroll 1
-    for (int b = 0; b < 40; ++b)
-        if ((site_abs >> b) & 1) xb = aff(P.site_pow[b], xb);
-    const uint64_t xe = aff(P.samp_tab[s], xb);
+    const uint64_t xe = aff(P.samp_tab[s], T.site_base[ls]);
     const uint64_t st_qs = aff(P.off[3], xe);
     VglAffine jr = P.qs_read_tab[r]; jr.c >>= 4;                         // the table carries 16 c (aff52)
     uint64_t st_x = aff(jr, st_qs);
