@@ -72,3 +72,17 @@ def acgt_sites(n_sites, n_samples, seed=7, missing=0.0, n_alleles=4):
     if missing > 0:
         al = np.where(rng.random((n_sites, n_samples, 2)) < missing, 0xF, al).astype(np.uint8)
     return (al[:, :, 0] | (al[:, :, 1] << 4)).astype(np.uint8)
+
+
+def acgt_range(site0, n_sites, n_samples, missing=0.02, block=128):
+    """acgt_sites() addressable by absolute site index: sites [128 b, 128 (b + 1)) come from the generator seeded with b, so any
+    range, however it is chunked, sees the same bytes."""
+    out = np.empty((n_sites, n_samples), dtype=np.uint8)
+    s = site0
+    while s < site0 + n_sites:
+        b = s // block
+        blk = acgt_sites(block, n_samples, seed=1000 + b, missing=missing)
+        lo, hi = s - b * block, min(block, site0 + n_sites - b * block)
+        out[s - site0:s - site0 + hi - lo] = blk[lo:hi]
+        s += hi - lo
+    return out

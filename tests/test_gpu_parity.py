@@ -1,7 +1,10 @@
 """Parity of the HIP path (through the C ABI) with the CPU oracle on identical seeded inputs,
 VGL_RNG_TILE addressing.  Integer fields must be bit-exact.  GL is bit-exact wherever the
-per-read terms come from constants or the qScore LUT; where a per-read log10()/pow() is
-evaluated on the device (precise-gl 1, GP) the north-star tolerance of 1e-6 applies."""
+per-read terms come from constants or the qScore LUT.  Where the device evaluates a logarithm or a power itself
+(--precise-gl 1: log10_unit, three per read; GP: exp10_nonpos -- both within ~1e-15 relative of glibc's) a float32 result may
+fall on the other side of a rounding boundary: GL then has to be within ONE unit in the last place of float32 of the oracle's,
+with at most 1e-5 of the values not identical (expected ~1e-7: the count is printed), and GP within 1e-6 absolute
+(`north_star`'s tolerance).  tests/test_gpu_scale_oracle.py applies the same criterion to 1.5e8 GL values."""
 import numpy as np
 import pytest
 
@@ -14,6 +17,14 @@ pytestmark = pytest.mark.gpu
 INT_FIELDS = ["site_status", "n_alleles", "n_alleles_obs", "alleles2acgt", "info_dp", "info_ad", "info_adf",
               "info_adr", "fmt_dp", "pl", "fmt_ad", "fmt_adf", "fmt_adr"]
 TOL = 1e-6
+
+
+def ulps32(a, b):
+    """distance of two finite float32 arrays in units in the last place (monotone integer image of the floats)"""
+    def key(x):
+        i = x.view(np.int32).astype(np.int64)
+        return np.where(i < 0, -(i & 0x7FFFFFFF), i)
+    return np.abs(key(np.ascontiguousarray(a)) - key(np.ascontiguousarray(b)))
 
 
 def bits(a):
@@ -42,15 +53,24 @@ def assert_parity(want, got, exact_gl=True, i16=False, qs=True, check_gp=True):
     if exact_gl:
         assert np.array_equal(wb, gb), f"GL not bit-exact: {np.sum(wb != gb)} of {wb.size} differ"
     else:
-        a, b = wgl[~miss].astype(np.float64), ggl[~miss].astype(np.float64)
+        a, b = wgl[~miss], ggl[~miss]
         fin = np.isfinite(a)
         assert np.array_equal(fin, np.isfinite(b)) and np.array_equal(a[~fin], b[~fin])
-        assert np.all(np.abs(a[fin] - b[fin]) <= TOL * np.maximum(1.0, np.abs(a[fin])))
+        d = ulps32(a[fin], b[fin])
+        nonid = int((d > 0).sum())
+        print(f"GL (device log10): {nonid} of {d.size} values not identical to the oracle's, worst {int(d.max()) if d.size else 0} ulp")
+        assert d.size == 0 or d.max() <= 1, f"GL {int(d.max())} units in the last place from the oracle"
+        assert nonid <= max(1, int(np.ceil(1e-5 * d.size))), f"{nonid} of {d.size} GL values differ from the oracle"
     if check_gp:
         wgp, ggp = want.numpy("gp"), got.numpy("gp")
         m = wgp.view(np.uint32) == _abi.FLOAT_MISSING_BITS
         assert np.array_equal(m, ggp.view(np.uint32) == _abi.FLOAT_MISSING_BITS)
-        assert np.all(np.abs(wgp[~m].astype(np.float64) - ggp[~m].astype(np.float64)) <= TOL)
+        dg = np.abs(wgp[~m].astype(np.float64) - ggp[~m].astype(np.float64))
+        nonid = int((wgp[~m].view(np.uint32) != ggp[~m].view(np.uint32)).sum())
+        if nonid:
+            print(f"GP (device 10^x): {nonid} of {dg.size} values not identical to the oracle's, worst {dg.max():.3g} absolute")
+        assert np.all(dg <= TOL)
+        assert nonid <= max(1, int(np.ceil(1e-5 * dg.size))), f"{nonid} of {dg.size} GP values differ from the oracle"
     if qs and "qs" in got.arrays:
         assert np.array_equal(want.numpy("qs").view(np.uint32), got.numpy("qs").view(np.uint32)), "QS"
     if i16 and "i16" in got.arrays:
@@ -77,6 +97,18 @@ def test_depth_branches(oracle, depth):
     assert_parity(want, got)
     if depth == 0.0:
         assert (got.numpy("site_status") == _abi.VGL_SITE_NO_READS).all()
+
+
+@pytest.mark.parametrize("N,n_sites", [(1, 2500), (2, 1300), (3, 700), (7, 300), (63, 40), (100, 25), (1023, 5), (1024, 5), (1025, 5), (2047, 3), (2500, 3)])
+def test_depth_kernel_chunks_span_sites(oracle, N, n_sites):
+    """k_depth deals 1024 consecutive evaluations of the tile per wavefront: with few samples a chunk spans hundreds of sites,
+    whose windows start at unrelated (hashed) positions -- the site of every dealt item is looked up (one compare for N >= 1024,
+    a multiply-high below, N = 1 on its own)"""
+    args = VcfglArgs(seed=3, depth=14.0, error_rate=0.01, add_fmt_ad=1)
+    want, got = run_both(oracle, args, synth.binary_sites(77, n_sites, N), site0=77)
+    for f in ("site_status", "fmt_dp", "info_dp", "fmt_ad"):
+        assert np.array_equal(want.numpy(f), got.numpy(f)), f
+    assert np.array_equal(want.numpy("gl").view(np.uint32), got.numpy("gl").view(np.uint32))
 
 
 @pytest.mark.parametrize("du", [0, 1, 2, 3, 4, 5])

@@ -115,7 +115,7 @@ struct VglDevParams {
     VglAffine off[4];                  // J^(off[k])
     VglAffine site_pow[40];            // J^(block * N * 2^b)  (k_sitebase)
     int32_t site_hash_bits;            // W of vgl_site_hash(): sites [0, 2^W) are addressable
-    uint32_t depth_magic;              // k_depth, N < 1024: floor(2^32 / N) + 1, so that t / N = mulhi(t, magic) for t < 2048
+    uint32_t depth_magic;              // k_depth, 2 <= N < 1024: floor(2^32 / N) + 1, so that t / N = mulhi(t, magic) for t < 2048
     const VglAffine* samp_tab;         // [N] J^(block * s)
     const VglAffine* qs_read_tab;      // [read_cap] J^(qs_read_stride * r)
     const VglAffine* step_tab;         // [192] J^k (serial-mode scout)

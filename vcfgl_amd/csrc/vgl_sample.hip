@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void k_depth(const VglDevParams P, const VglTi
     const bool big_n = N >= (uint32_t)VGL_DEPTH_CHUNK;
     auto start_of = [&](const int i, uint32_t& s_out) -> uint64_t {      // stream start of the chunk's item i (i < cn)
         const uint32_t t = s_c0 + (uint32_t)i;                           // < N + 1024
-        const uint32_t add = big_n ? (uint32_t)(t >= N) : __umulhi(t, P.depth_magic);
+        const uint32_t add = big_n ? (uint32_t)(t >= N) : (N == 1u ? t : __umulhi(t, P.depth_magic));   // t / N (the magic number needs N >= 2 to fit 32 bits)
         s_out = t - add * N;
         return aff(P.depth_tab[s_out], T.site_base[ls_c0 + add]);
     };
