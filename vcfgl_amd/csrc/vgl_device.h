@@ -132,8 +132,8 @@ struct VglDevParams {
     int32_t gamma_ln_n;
     const double* gl1_bsum;            // [256][256]  sum_{i<c} fk[i]*beta[q][n][i]   (fixed qScore)
     const double* gl1_lhet;            // [256][256]
-    const double* gl1_fk;              // [256]            (per-read qScores only)
-    const double* gl1_beta;            // [64][256][256]   (per-read qScores only)
+    const double* gl1_fkbeta;          // [60][gl1_nc][gl1_nc] fk[i] * beta[q][n][i] at [q - 4][n][i]  (per-read qScores only)
+    int32_t gl1_nc;                    // min(255, read_cap) + 1: the table is compact in n and i, so that the part a run touches stays in L2
 };
 
 // per-site I16 tail-distance sums (vcfgl.cpp:647-663): all of a site's draws are credited to the base of

@@ -96,7 +96,7 @@ __device__ __forceinline__ double log10_unit(const double x) {
     const bool lo = m < 0.70710678118654752;
     m = lo ? m + m : m;
     e = lo ? e - 1 : e;
-    const double s = (m - 1.0) / (m + 1.0);
+    const double s = div_inrange(m - 1.0, m + 1.0);                  // the correctly rounded quotient without the exponent handling of the IEEE sequence (|m - 1| < 0.42, m + 1 in [1.7, 2.42))
     const double z = s * s;
     double p = 1.0 / 19.0;
     p = __builtin_fma(p, z, 1.0 / 17.0); p = __builtin_fma(p, z, 1.0 / 15.0); p = __builtin_fma(p, z, 1.0 / 13.0);
@@ -140,7 +140,8 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     __shared__ uint16_t s_perm[WG];
     constexpr int NG = A * (A + 1) / 2;
-    __shared__ uint32_t s_x[15 * WG];                                  // gl_sort 2: one tag's planes of the workgroup, in natural order; GL model 2: the loop's accumulators (up to 15) on their way to genotype order
+    __shared__ uint32_t s_x[(GLM == 1 ? 16 : 15) * WG];                // the accumulators (up to 15 rows) of the workgroup's evaluations on their way from sorted to natural order; before that, GL model 1
+                                                                        // with per-read scores: a (base, quality) histogram per lane, 64 one-byte rows per wavefront
     uint32_t* const s_hist = s_x;                                       // [1026] bins of the depth sort (done before s_x is used)
     constexpr int QL = 96;                                              // quality scores below QL take their three terms from LDS
     __shared__ double s_q2gl[(GLM == 2 && !PREC) ? 3 * QL : 1];
@@ -243,8 +244,8 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
 #pragma unroll
     for (int i = 0; i < NG; ++i) acc[i] = -0.0f;                                     // bcf_utils.h:310
 
-    if (dp > 0) {
-        if (GLM == 2) {
+    if (GLM == 2) {
+        if (dp > 0) {
             // gl_methods.cpp:22-59 / :94-139 / :171-220.  The reference updates every genotype (i, j) per read with one of three
             // terms chosen by (read allele == i, == j), then subtracts the maximum: genotypes that see the same sequence of
             // choices hold the same value after every read.  For an evaluation whose reads show k distinct bases those
@@ -290,7 +291,14 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
                         } else {
                             const double e = T.errp[(size_t)r * plane + ev];
                             if (0.0 == e) { homT = 0.0; het = -0.30103; homF = -INFINITY; }
-                            else { homT = log10_unit(1.0 - e); het = log10_unit((1.0 - e) / 2.0 + e / 6.0); homF = log10_unit(e / 3.0); }
+                            else {
+                                // e / 3.0 and e / 6.0 correctly rounded, as the reference's divisions are: q0 = e RN(1/3), one residual and one
+                                // correction (Markstein: exact for a correctly rounded reciprocal), and e / 6 = (e / 3) / 2 (halving is exact)
+                                const double third = 0.33333333333333331;
+                                const double q0 = e * third;
+                                const double e3 = __builtin_fma(__builtin_fma(-3.0, q0, e), third, q0);
+                                homT = log10_unit(1.0 - e); het = log10_unit((1.0 - e) / 2.0 + e3 * 0.5); homF = log10_unit(e3);
+                            }
                         }
                     }
                     float mx = -INFINITY;
@@ -346,61 +354,128 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
                 else if (K == 3) read_loop(std::integral_constant<int, 3>{}, std::false_type{});
                 else read_loop(std::integral_constant<int, 4>{}, std::false_type{});
             }
-        } else {
-            // GL model 1 with one fixed qScore: errmod_cal() reduces to table lookups on the
-            // per-base depths (gl_methods.cpp:304-369; htslib errmod.c restated in vgl_host.cpp)
-            int n = dp;
-            int c[5]; double bs[5];
+        }
+    } else {
+        // GL model 1 (gl_methods.cpp:233-369; htslib errmod.c restated in vgl_host.cpp).  With one fixed qScore errmod_cal() reduces
+        // to table lookups on the per-base depths; with per-read scores each base accumulates fk[i] beta[q][n][i] over its own reads
+        // in descending quality (below).  `on`: the lane has an evaluation with reads (wave-level loops run for every lane).
+        const bool on = dp > 0;
+        int n = dp;
+        int c[5]; double bs[5];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) c[b] = (int)((ad4 >> (16 * b)) & 0xFFFF);
-            c[4] = 0; bs[4] = 0.0;
-            if (__builtin_expect(n > 255, 0)) {
-                // errmod_cal(): "if we exceed 255 bases, shuffle them to sample at random" -- ks_shuffle (a Fisher-Yates pass from
-                // the end, j = (int)(hts_drand48() * i)) on htslib's private rand48 stream, then the first 255 reads.  The lane
-                // shuffles its own column of the staged reads in place (scratch of the context, 1 byte per read).
-                uint64_t st;
-                if (T.hts_off) st = rand48_jump(*T.hts_base, (uint64_t)T.hts_off[ev]);                      // serial: the process-wide stream
-                else st = rand48_jump(VGL_HTS_RAND48_X0, (T.site_hash[ls] * (uint64_t)N + (uint64_t)s) * VGL_HTS_TILE_STRIDE);
-                uint8_t* const rd = T.reads;
-                for (int i = n; i > 1; --i) {
-                    st = lcg_next(st);
-                    const int j = (int)(u01(st) * (double)i);
-                    const size_t pj = vgl_read_byte(j, plane, ev), pi = vgl_read_byte(i - 1, plane, ev);
-                    const uint8_t tmp = rd[pj]; rd[pj] = rd[pi]; rd[pi] = tmp;
-                }
-                n = 255;
-                c[0] = c[1] = c[2] = c[3] = 0;
-                for (int r = 0; r < n; ++r) {
-                    const int b = (int)(rd[vgl_read_byte(r, plane, ev)] & 3);
-                    c[0] += (b == 0); c[1] += (b == 1); c[2] += (b == 2); c[3] += (b == 3);
-                }
+        for (int b = 0; b < 4; ++b) { c[b] = (int)((ad4 >> (16 * b)) & 0xFFFF); bs[b] = 0.0; }
+        c[4] = 0; bs[4] = 0.0;
+        if (__builtin_expect(n > 255, 0)) {
+            // errmod_cal(): "if we exceed 255 bases, shuffle them to sample at random" -- ks_shuffle (a Fisher-Yates pass from
+            // the end, j = (int)(hts_drand48() * i)) on htslib's private rand48 stream, then the first 255 reads.  The lane
+            // shuffles its own column of the staged reads in place (scratch of the context, 1 byte per read).
+            uint64_t st;
+            if (T.hts_off) st = rand48_jump(*T.hts_base, (uint64_t)T.hts_off[ev]);                      // serial: the process-wide stream
+            else st = rand48_jump(VGL_HTS_RAND48_X0, (T.site_hash[ls] * (uint64_t)N + (uint64_t)s) * VGL_HTS_TILE_STRIDE);
+            uint8_t* const rd = T.reads;
+            for (int i = n; i > 1; --i) {
+                st = lcg_next(st);
+                const int j = (int)(u01(st) * (double)i);
+                const size_t pj = vgl_read_byte(j, plane, ev), pi = vgl_read_byte(i - 1, plane, ev);
+                const uint8_t tmp = rd[pj]; rd[pj] = rd[pi]; rd[pi] = tmp;
             }
-            if (P.error_qs != 2) {
+            n = 255;
+            c[0] = c[1] = c[2] = c[3] = 0;
+            for (int r = 0; r < n; ++r) {
+                const int b = (int)(rd[vgl_read_byte(r, plane, ev)] & 3);
+                c[0] += (b == 0); c[1] += (b == 1); c[2] += (b == 2); c[3] += (b == 3);
+            }
+        }
+        if (P.error_qs != 2) {
+            if (on) {
 #pragma unroll
                 for (int b = 0; b < 4; ++b) bs[b] = P.gl1_bsum[n * 256 + c[b]];
-            } else {
-                // per-read qScores (gl_methods.cpp:233-302): errmod_cal() walks the reads in descending
-                // (qual, base) order, so each base accumulates fk[i]*beta[q][n][i] over its own reads in
-                // descending quality: a per-lane (base, qual) histogram in LDS replaces the sort
-                uint8_t* h = lds_raw + (size_t)wib * 16384 + lane;
-                for (int bin = 0; bin < 256; ++bin) h[bin * 64] = 0;
-                for (int r = 0; r < n; ++r) {
-                    const uint32_t rb = T.reads[vgl_read_byte(r, plane, ev)];
-                    const int bin = (int)(((rb & 3) << 6) | (rb >> 2));
-                    h[bin * 64] = (uint8_t)(h[bin * 64] + 1);
-                }
+            }
+        } else {
+            // per-read qScores (gl_methods.cpp:233-302): errmod_cal() walks the reads in descending (qual, base) order and adds, per
+            // base, fk[i] beta[qual][n][i] for the base's i-th read in that order (qual clamped to [4, 63]).  A counting sort per
+            // lane replaces the sort: (1) the quality range [qbot, qtop] of the wavefront's reads; (2) per window of 16 quality
+            // values from the top, a one-byte (base, quality) histogram per lane in LDS (64 rows x 64 lanes per wavefront, laid
+            // over s_x) and a 64-bit presence mask in registers (a bin's count is only read where its bit is set: no zeroing);
+            // (3) per base, a flat loop over the base's reads in descending quality: the next non-empty bin by a count-trailing-
+            // zeros of the mask, one 8-byte gather of fk[i] beta[q][n][i] (host table, compact in n and i: L2 resident) and one
+            // double add per read.  Each lane takes its bases in the order of their depth, so that the first loop carries the
+            // lanes' main base and the others are short.  (Round 2: 256 zeroed bins per lane in 16 KB of LDS per wavefront, a scan
+            // of all 256 bins with a divergent inner loop, gathers from a 32 MB table.)
+            uint8_t* const hw = (uint8_t*)s_x + (size_t)wib * 4096 + lane;                     // row r of this lane: hw[64 r]
+            const uint32_t* const colw = (const uint32_t*)T.reads + ev;
+            const int nwords = on ? (n + 3) >> 2 : 0;
+            int qhi = 0, qlo = 63;
+            for (int w = 0; w < nwords; ++w) {
+                const uint32_t word = colw[(size_t)w * plane];
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    double acc_b = 0.0; int i = 0;
-                    for (int q = 63; q >= 0; --q) {
-                        const int cnt = h[(b * 64 + q) * 64];
-                        const int qq = q < 4 ? 4 : q;                          // errmod_cal clamps qual to [4,63]
-                        for (int j = 0; j < cnt; ++j) { acc_b += P.gl1_fk[i] * P.gl1_beta[((size_t)qq << 16) | ((size_t)n << 8) | (size_t)i]; ++i; }
-                    }
-                    bs[b] = acc_b;
+                for (int j = 0; j < 4; ++j) {
+                    int q = (int)((word >> (8 * j + 2)) & 63u);
+                    q = q < 4 ? 4 : q;
+                    const bool in = 4 * w + j < n;
+                    qhi = (in && q > qhi) ? q : qhi; qlo = (in && q < qlo) ? q : qlo;
                 }
             }
-            float mx = -INFINITY;
+#pragma unroll
+            for (int m_ = 32; m_ >= 1; m_ >>= 1) { const int a_ = __shfl_xor(qhi, m_, 64), b_ = __shfl_xor(qlo, m_, 64); qhi = a_ > qhi ? a_ : qhi; qlo = b_ < qlo ? b_ : qlo; }
+            const int qtop = __builtin_amdgcn_readfirstlane(qhi), qbot = __builtin_amdgcn_readfirstlane(qlo);
+            // the lane's bases by descending depth (a 5-exchange sorting network on depth << 2 | base)
+            uint32_t k0_ = ((uint32_t)c[0] << 2) | 0u, k1_ = ((uint32_t)c[1] << 2) | 1u, k2_ = ((uint32_t)c[2] << 2) | 2u, k3_ = ((uint32_t)c[3] << 2) | 3u;
+            auto cx = [](uint32_t& a_, uint32_t& b_) { const uint32_t hi_ = a_ > b_ ? a_ : b_, lo_ = a_ > b_ ? b_ : a_; a_ = hi_; b_ = lo_; };
+            cx(k0_, k1_); cx(k2_, k3_); cx(k0_, k2_); cx(k1_, k3_); cx(k1_, k2_);
+            const uint32_t ob[4] = {k0_ & 3u, k1_ & 3u, k2_ & 3u, k3_ & 3u};
+            int ik[4] = {0, 0, 0, 0};                                   // reads of the lane's k-th base taken so far = the next read's rank
+            double acck[4] = {0.0, 0.0, 0.0, 0.0};
+            const uint32_t NC = (uint32_t)P.gl1_nc;
+            const uint32_t row_n = (uint32_t)n * NC;
+            const double* const tab = P.gl1_fkbeta;
+            for (int wtop = qtop; wtop >= qbot; wtop -= 16) {          // wave-uniform; one round unless the scores span more than 16 values
+                uint64_t pm = 0;                                        // bit (16 base + wtop - q): the bin holds reads
+                for (int w = 0; w < nwords; ++w) {
+                    const uint32_t word = colw[(size_t)w * plane];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t rb = (word >> (8 * j)) & 0xFFu;
+                        int q = (int)(rb >> 2);
+                        q = q < 4 ? 4 : q;
+                        const int qi = wtop - q;
+                        if (4 * w + j < n && qi >= 0 && qi < 16) {
+                            const uint32_t row = ((rb & 3u) << 4) | (uint32_t)qi;
+                            const uint64_t bit = 1ULL << row;
+                            const uint32_t h = hw[row * 64u];
+                            hw[row * 64u] = (uint8_t)((pm & bit) ? h + 1u : 1u);
+                            pm |= bit;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t b = ob[k];
+                    uint32_t m = (uint32_t)(pm >> (16u * b)) & 0xFFFFu;
+                    if (m) {
+                        uint32_t left = 0, rowq = 0;
+                        int i = ik[k];
+                        double acc_b = acck[k];
+                        do {
+                            const bool refill = left == 0u;             // then m != 0 (loop condition)
+                            const uint32_t qi = (uint32_t)__builtin_ctz(m | 0x10000u);
+                            const uint32_t hcnt = hw[((b << 4) | (qi & 15u)) * 64u];
+                            m = refill ? (m & (m - 1u)) : m;
+                            left = refill ? hcnt : left;
+                            rowq = refill ? ((uint32_t)(wtop - 4) - qi) * NC * NC + row_n : rowq;
+                            acc_b += tab[rowq + (uint32_t)i];
+                            ++i; --left;
+                        } while (m != 0u || left != 0u);
+                        ik[k] = i; acck[k] = acc_b;
+                    }
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                bs[b] = (ob[0] == (uint32_t)b) ? acck[0] : ((ob[1] == (uint32_t)b) ? acck[1] : ((ob[2] == (uint32_t)b) ? acck[2] : acck[3]));
+        }
+        float mx = -INFINITY;
+        if (on) {
 #pragma unroll
             for (int i = 0; i < A; ++i) {
 #pragma unroll
@@ -428,6 +503,9 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
                     if (i < nA) mx = (v > mx) ? v : mx;
                 }
             }
+        }
+        if (P.error_qs == 2) __syncthreads();                           // the histograms lay over s_x: every wavefront is done with its own before the deposits
+        if (on) {
 #pragma unroll
             for (int i = 0; i < NG; ++i) s_x[i * WG + otid] = __float_as_uint(acc[i] - mx);     // deposit: column otid, rows = genotypes
         }
@@ -627,7 +705,7 @@ extern "C" int vgl_launch_gl(const VglDevParams* p, const VglTilePtrs* t, void* 
     // at C3 / fixed-q / C4: 4 -> 8 wavefronts -7 / -6 / -10 % of the kernel's time, 16 is slower again; equal at depth 5)
     const int wpb = (p->gl_model == 2 && p->gl_wpb == 8) ? 8 : 4;
     const unsigned blocks = (unsigned)((waves + wpb - 1) / wpb);
-    const size_t lds = (p->gl_model == 1 && p->error_qs == 2) ? (size_t)4 * 16384 : 0;   // (base,qual) histograms
+    const size_t lds = 0;
     const dim3 g(blocks), b(64 * wpb);
     hipStream_t s = (hipStream_t)stream;
 #define VGL_LAUNCH_GL(GLM, PREC, WPB) \

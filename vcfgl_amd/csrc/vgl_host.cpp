@@ -415,11 +415,12 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
         D.beta_a = a; D.beta_b = b;
     }
     // The deferred build of k_sample<2> (5 wavefronts per SIMD, no double-precision fallback code in the kernel: the reads a float32
-    // bound cannot settle go to k_redo) serves the default tag surface of the benchmark configurations; everything else
-    // (--precise-gl 1, -addQS / -addI16, strand tags, --adjust-qs, a per-read dump, a beta shape parameter below 8 -- the gamma sampler's
+    // bound cannot settle go to k_redo) serves the default tag surface of the benchmark configurations, with or without --precise-gl 1
+    // (k_redo then also rewrites the read's staged error probability); everything else
+    // (-addQS / -addI16, strand tags, --adjust-qs, a per-read dump, a beta shape parameter below 8 -- the gamma sampler's
     // bounded test then leaves its series' range |a2 x| <= 1/3 too often) runs the build with the fallbacks inline.
     D.dbg_redo_every = getenv("VGL_DEBUG_REDO_EVERY") ? atoi(getenv("VGL_DEBUG_REDO_EVERY")) : 0;
-    D.defer_ok = (!D.serial && p->error_qs == 2 && !p->precise_gl && !D.need_qsum && !D.sample_strand && !D.need_adf && p->adjust_qs == 0 &&
+    D.defer_ok = (!D.serial && p->error_qs == 2 && !D.need_qsum && !D.sample_strand && !D.need_adf && p->adjust_qs == 0 &&
                   !D.gx.changed && !D.gy.changed && D.gx.alpha0 >= 8.0 && D.gy.alpha0 >= 8.0 && !getenv("VGL_NO_DEFER") && !getenv("VGL_DEBUG_QS_EXACT") && !getenv("VGL_NO_LEAN")) ? 1 : 0;
     if (D.defer_ok && D.pool_cap > 1472) {      // 20 wavefronts' pools in a CU's 160 KB of LDS: 576 + 5 x 1472 + 8 B each
         D.pool_cap = 1472;
@@ -486,10 +487,17 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
         std::vector<double> bsum, lhet, fkv, betav;
         if (p->error_qs == 2) {                                    // gl_methods.cpp:233-302: per-read qScores
             build_gl1_tables(1.0 - p->gl1_theta, -1, bsum, lhet, &fkv, &betav);
-            TRY(dmalloc(&c->d_gl1_fk, fkv.size())); TRY(dmalloc(&c->d_gl1_beta, betav.size()));
-            TRYHIP(hipMemcpy(c->d_gl1_fk, fkv.data(), sizeof(double) * fkv.size(), hipMemcpyHostToDevice));
-            TRYHIP(hipMemcpy(c->d_gl1_beta, betav.data(), sizeof(double) * betav.size(), hipMemcpyHostToDevice));
-            D.gl1_fk = c->d_gl1_fk; D.gl1_beta = c->d_gl1_beta;
+            // errmod_cal()'s per-read term fk[w] * beta[q << 16 | n << 8 | c] (one double product, the same bits wherever it is
+            // formed), q in [4, 63], n <= min(255, staging capacity), c < n: compact in n and c
+            const int nc = std::min(255, D.read_cap) + 1;
+            std::vector<double> fb((size_t)60 * nc * nc, 0.0);
+            for (int q = 4; q < 64; ++q)
+                for (int n = 1; n < nc; ++n)
+                    for (int i = 0; i < n; ++i)
+                        fb[((size_t)(q - 4) * nc + n) * nc + i] = fkv[i] * betav[(size_t)q << 16 | (size_t)n << 8 | (size_t)i];
+            TRY(dmalloc(&c->d_gl1_beta, fb.size()));
+            TRYHIP(hipMemcpy(c->d_gl1_beta, fb.data(), sizeof(double) * fb.size(), hipMemcpyHostToDevice));
+            D.gl1_fkbeta = c->d_gl1_beta; D.gl1_nc = nc;
         } else
         build_gl1_tables(1.0 - p->gl1_theta, (p->adjust_qs & 1) ? D.pre_adjq : D.pre_q, bsum, lhet);   // io.cpp:1276, gl_methods.cpp:318
         TRY(dmalloc(&c->d_gl1_bsum, bsum.size())); TRY(dmalloc(&c->d_gl1_lhet, lhet.size()));

@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                         // quality scores are taken from it by the dense pass after the loop
                         *(lds_u32*)(uintptr_t)(576u + (uint32_t)k) = __float_as_uint(qs_stage_pf(gx_prev, val));   // l_it[item]
                         if (DEFER) { if (redo) *(lds_u32*)(uintptr_t)(576u + (uint32_t)k) = 0x7FC00000u; }        // NaN: undecided for the dense pass
-                        if (PREC) { T.errp[(size_t)((it_m >> 4) & 0x3FF) * plane + ev0 + (it_m >> 26)] = gx_prev / (gx_prev + val); it_m = m_n; }
+                        if (PREC) { T.errp[(size_t)((it_m >> 4) & 0x3FF) * plane + ev0 + (it_m >> 26)] = (DEFER ? div_inrange(gx_prev, gx_prev + val) : gx_prev / (gx_prev + val)); it_m = m_n; }   // DEFER: both shape parameters >= 8, the operands are far from the exponent limits
                         // the lane adopts kn and claims the next unclaimed item from the wave's counter (any assignment of
                         // items to lanes gives the same result)
                         st = st_n;
@@ -582,6 +582,7 @@ __device__ __forceinline__ void redo_read(const VglDevParams& P, const VglTilePt
     int q, aq;
     errprob_raw(P, ep, q, aq);
     qs_finish(P, q, aq, T.errflag, true);
+    if (T.errp) T.errp[(size_t)r * plane + ev] = ep;                     // --precise-gl 1 / the deviate dump: the read's exact error probability
     uint8_t* const p = T.reads + vgl_read_byte(r, plane, ev);
     *p = (uint8_t)(((uint32_t)q << 2) | (*p & 3u));
 }
@@ -640,12 +641,17 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
             VGL_STATIC_LDS(false, 0, true, 0) VGL_STATIC_LDS(false, 1, true, 0) VGL_STATIC_LDS(false, 2, true, 0)
             VGL_STATIC_LDS(false, 0, false, 1) VGL_STATIC_LDS(false, 1, false, 1) VGL_STATIC_LDS(false, 2, false, 1)
             VGL_STATIC_LDS(false, 0, false, 2) VGL_STATIC_LDS(false, 1, false, 2) VGL_STATIC_LDS(false, 2, false, 2)
+            VGL_STATIC_LDS(false, 0, true, 2) VGL_STATIC_LDS(false, 1, true, 2) VGL_STATIC_LDS(false, 2, true, 2)
             VGL_STATIC_LDS(false, 0, false, 0) VGL_STATIC_LDS(false, 1, false, 0) VGL_STATIC_LDS(false, 2, false, 0)
 #undef VGL_STATIC_LDS
             return worst == 0;
         }();
         if (!static_lds_free) return (int)hipErrorInvalidConfiguration;
         if (dbg && !t->errp) VGL_LAUNCH_SAMPLE(2, true, false, 0, lds);   // diagnostic build: --precise-gl 0 only
+        else if (t->errp && lean && p->defer_ok && t->redo_list) {       // --precise-gl 1 on the default tag surface: the deferred build, k_redo also rewrites errp
+            VGL_LAUNCH_SAMPLE(2, false, true, 2, lds);
+            hipLaunchKernelGGL(k_redo, dim3(2048), dim3(64), 0, s, *p, *t);
+        }
         else if (t->errp) { if (lean) VGL_LAUNCH_SAMPLE(2, false, true, 1, lds); else VGL_LAUNCH_SAMPLE(2, false, true, 0, lds); }   // --precise-gl 1, or the deviates were asked for
         else if (lean && p->defer_ok && t->redo_list) {
             VGL_LAUNCH_SAMPLE(2, false, false, 2, lds);
