@@ -52,9 +52,17 @@ WORKLOADS = {
     # (50M / 8): the tile layout keeps G = 15 planes of GL and PL, 120 B per evaluation resident in HBM
     "c5": dict(sites=2_000_000, samples=500, flags=dict(depth=5.0, error_rate=0.01, gl_model=2, do_unobserved=2, add_pl=1), homref=True,
                desc="-explode 1 -doUnobserved 2 -addPL 1 --depth 5 -e 0.01 -GL 2 (simulation part of the gVCF job)"),
+    # c5 with FORMAT/PL in one byte per value (vgl_tile_out.pl_u8, ABI 4: PL <= 255): 80 B per evaluation instead of 125
+    "c5u8": dict(sites=2_000_000, samples=500, flags=dict(depth=5.0, error_rate=0.01, gl_model=2, do_unobserved=2, add_pl=1), homref=True, narrow_pl=True,
+                 desc="-explode 1 -doUnobserved 2 -addPL 1 --depth 5 -e 0.01 -GL 2, PL as uint8 (pl_u8)"),
     # same shape as c3 with one fixed quality score (--error-qs 0, the reference's default)
     "fixedq": dict(sites=1_000_000, samples=1000, flags=dict(depth=20.0, error_rate=0.01, gl_model=2),
                    desc="--depth 20 -e 0.01 --error-qs 0 -GL 2"),
+    # c3's flags with the other GL paths of the reference (gl_methods.cpp:233-302 / :152-231), a quarter of c3's sites
+    "gl1q": dict(sites=262_144, samples=1000, flags=dict(depth=20.0, error_rate=0.01, error_qs=2, beta_variance=1e-5, gl_model=1),
+                 desc="--depth 20 -e 0.01 --error-qs 2 --beta-variance 1e-5 -GL 1"),
+    "precise": dict(sites=262_144, samples=1000, flags=dict(depth=20.0, error_rate=0.01, error_qs=2, beta_variance=1e-5, gl_model=2, precise_gl=1),
+                    desc="--depth 20 -e 0.01 --error-qs 2 --beta-variance 1e-5 -GL 2 --precise-gl 1"),
 }
 KERNELS = ["k_depth", "k_sample", "k_site", "k_gl"]
 
@@ -66,6 +74,8 @@ def log(msg):
 def workload_args(name="c3"):
     from vcfgl_amd import VcfglArgs, _abi
     a = VcfglArgs(seed=42, **WORKLOADS[name]["flags"])
+    if WORKLOADS[name].get("sample_major") or os.environ.get("BENCH_SAMPLE_MAJOR"):
+        a.out_layout = _abi.VGL_LAYOUT_SAMPLE_MAJOR
     a.rng_mode, a.beta_sampler = _abi.VGL_RNG_TILE, _abi.VGL_BETA_RAND48
     a._workload = name
     return a
@@ -140,20 +150,46 @@ def spawn_ranks(opt):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    # poll every rank: the first one that fails ends the run at once (a rank blocked in a rendezvous or a collective would
+    # otherwise hold the launcher until the process group's own timeout, minutes after the real error was printed)
     rc = 0
     try:
-        for p in procs:
-            rc = max(rc, abs(p.wait()))
-            if rc:
-                break
+        live = list(procs)
+        while live and rc == 0:
+            time.sleep(0.2)
+            for p in list(live):
+                r = p.poll()
+                if r is None:
+                    continue
+                live.remove(p)
+                if r != 0:
+                    rc = abs(r) or 1
+                    break
     finally:
         for p in procs:
             if p.poll() is None:
                 p.terminate()
+        t_end = time.time() + 10.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
     sys.exit(rc)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+
+def source_sha():
+    """sha1 over the kernel / host sources of the library: a committed PMC profile carries the value of the build it was taken from"""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "vcfgl_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
 
 def profile_entry(workload):
     """committed PMC profile of this workload's kernels (profiles/pmc_traffic.json, written by tools/pmc_summary.py)"""
@@ -204,7 +240,10 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
         "fmt_dp": torch.empty((S, N), dtype=torch.int32, device=dev),
         "gl": torch.empty((S, G, N), dtype=torch.float32, device=dev),
     }
-    if args.add_pl:
+    narrow_pl = bool(wl.get("narrow_pl"))
+    if args.add_pl and narrow_pl:
+        out["pl_u8"] = torch.empty((S, G, N), dtype=torch.uint8, device=dev)
+    elif args.add_pl:
         out["pl"] = torch.empty((S, G, N), dtype=torch.int32, device=dev)
     structs = []
     for s0 in range(0, S, TS):
@@ -220,6 +259,8 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
     def to_transport(x):
         return x if transport is None else x.to(transport)
 
+    comm = {"gather_s": 0.0, "sample_s": 0.0, "sample_bytes": 0, "sample_packed_bytes": 0}
+
     def step():
         for s0, n, t in structs:
             sim._check(sim.lib.vgl_simulate_tile_device(sim.ctx, site_base + s0, n, gt[s0:s0 + n].data_ptr(), C.byref(t),
@@ -232,9 +273,29 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
                         gathered_bytes[0] += sum(q.nbytes() for q in got)
         if dist is not None:                                      # record-index gather to the writer rank + the summary's counters
             stream.synchronize()
+            t_c = time.perf_counter()
             gather_site_index(to_transport(out["site_status"]), to_transport(out["n_alleles"]), world, rank, S_total if opt.scaling == "strong" else S * world,
                               always_collective=True)
             reduce_site_counters(to_transport(out["site_status"]), world, always_collective=True)
+            torch.cuda.synchronize()
+            comm["gather_s"] += time.perf_counter() - t_c
+            if gather == "sample":
+                # the RECORD gather north_star names, on a sample: the packed records of this rank's last tile travel to the
+                # writer (point to point, one xGMI link per peer), timed on its own so that the link rate is on record without
+                # moving the whole step's 65 GB per GPU through one writer
+                s0, n, _ = structs[-1]
+                with torch.cuda.stream(stream):
+                    p = pack_records({k: v[s0:s0 + n] for k, v in out.items()}, site0=site_base + s0)
+                stream.synchronize()
+                t_c = time.perf_counter()
+                with torch.cuda.stream(stream):
+                    got = gather_records(p, world, rank, transport=transport, always_collective=True)
+                stream.synchronize()
+                torch.cuda.synchronize()
+                comm["sample_s"] += time.perf_counter() - t_c
+                comm["sample_packed_bytes"] += p.nbytes()
+                if got is not None:
+                    comm["sample_bytes"] += sum(q.nbytes() for q in got[1:])      # bytes that crossed a link into the writer
 
     def barrier():
         stream.synchronize()
@@ -250,6 +311,8 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
     sim.timing(True)
     sim.kernel_ms(reset=True)
     gathered_bytes[0] = 0
+    for k in comm:
+        comm[k] = 0
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -266,35 +329,59 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
     res = None
     if rank == 0:
         evals_total = float(S_total) * N * steps
-        b_eval = 1 + 4 + 4 * G + (4 * G if args.add_pl else 0)  # packed GT in + DP out + GL (+ PL) out
+        b_eval = 1 + 4 + 4 * G + ((G if narrow_pl else 4 * G) if args.add_pl else 0)  # packed GT in + DP out + GL (+ PL) out
         dom = int(np.argmax(kms))
         avg_ms = kms[dom] / max(klaunch[dom], 1)
         evals_per_launch = float(S) * N * steps / max(klaunch[dom], 1)     # average over the launches, partial last tile included
         achieved = b_eval * evals_per_launch / (avg_ms * 1e-3) / 1e9
         prof = profile_entry(name)
         kprof = prof.get("kernels", {}).get(KERNELS[dom], {})
+        fresh = bool(prof) and prof.get("src_sha") == source_sha()   # the committed counters describe THIS build
         # wavefronts per launch of the dominant kernel (launch geometry of vgl_sample.hip / vgl_gl.hip)
         sites_per_launch = float(S) * steps / max(klaunch[dom], 1)
         waves = sites_per_launch * N / 1024.0 if KERNELS[dom] == "k_depth" else sites_per_launch * ((N + 63) // 64)
+        scale = sites_per_launch / float(kprof.get("sites_per_launch", sites_per_launch) or sites_per_launch)   # profile launches -> this run's
+        src = f"profiles/{prof.get('source')}_pmc_summary.json (committed counters of {'this build' if fresh else 'an EARLIER build: stale'}, not measured by this run)"
         valu = None
         if kprof.get("valu_insts_per_wave"):
             a = kprof["valu_insts_per_wave"] * waves / (avg_ms * 1e-3)
             valu = {"achieved": a, "peak": VALU_PEAK_WAVE_INST_PER_S, "unit": "wavefront VALU instructions/s", "frac": a / VALU_PEAK_WAVE_INST_PER_S,
                     "valu_insts_per_wave": kprof["valu_insts_per_wave"], "waves_per_launch": waves,
-                    "valu_busy_frac_pmc": kprof.get("valu_busy_frac"), "source": f"profiles/{prof.get('source')}_pmc_summary.json (not measured by this run)",
+                    "valu_busy_frac_pmc": kprof.get("valu_busy_frac"), "source": src, "profile_matches_build": fresh,
                     "peak_note": "1024 SIMDs x 2.4 GHz / 4 cycles per wavefront instruction (float64 / three-operand class)"}
+        traffic = kprof.get("hbm_bytes_per_launch") * scale if kprof.get("hbm_bytes_per_launch") else None
+        traffic_frac = (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None
+        busy = kprof.get("valu_busy_frac")
+        if traffic_frac is not None and busy is not None:
+            bound = "hbm" if traffic_frac >= busy else "valu"
+            basis = f"PMC of the dominant kernel: HBM traffic {traffic_frac:.2f} of peak, VALU pipes {busy:.2f} busy"
+        else:
+            bound, basis = ("valu" if KERNELS[dom] == "k_sample" else "hbm"), "no committed counters for this workload: by the kernel's kind"
+        step_bytes = b_eval * float(S) * N
+        step_gbs = step_bytes / (dt / steps) / 1e9
         res = {
             "value": evals_total / dt, "unit": "site-sample GL evals/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
-            "workload": f"{name}: {S} sites x {N} samples per GPU, {wl['desc']}, tags GL+DP{'+PL' if args.add_pl else ''} (G={G}), rng tile mode, rand48 beta sampler",
-            "roofline": {"bound": "valu", "kernel": KERNELS[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "workload": f"{name}: {S} sites x {N} samples per GPU, {wl['desc']}, tags GL+DP{('+PL(u8)' if narrow_pl else '+PL') if args.add_pl else ''} (G={G}), rng tile mode, rand48 beta sampler",
+            "roofline": {"bound": bound, "bound_basis": basis, "kernel": KERNELS[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "bound_note": "achieved / peak / frac are the ALGORITHMIC-bytes HBM figures the contract asks for; the kernel is bound by VALU issue, "
-                                       "see `valu` (SURVEY H7, DESIGN.md section 4)",
-                         "traffic": kprof.get("hbm_bytes_per_launch"),
-                         "traffic_source": f"profiles/{prof.get('source')}_pmc_summary.json, launches of 65536 sites (not measured by this run)" if kprof else None,
+                         "bound_note": "achieved / peak / frac are the ALGORITHMIC-bytes HBM figures of the dominant kernel the contract asks for; `step` is the same "
+                                       "over the whole step (all kernels); `valu` is the instruction roofline (SURVEY H7, DESIGN.md section 4)",
+                         "traffic": traffic, "traffic_frac_of_peak": traffic_frac,
+                         "traffic_source": src if kprof else None,
+                         "step": {"achieved": step_gbs, "frac": step_gbs / HBM_PEAK_GBS, "unit": "GB/s",
+                                  "note": "algorithmic bytes of one step / wall time of one step on this GPU"},
                          "valu": valu, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_eval": b_eval,
                          "kernel_ms_total": dict(zip(KERNELS, kms)), "launches": dict(zip(KERNELS, klaunch))},
         }
+        if dist is not None:
+            res["comm"] = {"backend": opt.backend, "world": dist.get_world_size(), "gather": gather,
+                           "gather_ms": comm["gather_s"] / steps * 1e3,
+                           "gather_note": "per step on the writer: gather of the per-site record index (status, allele count) + all-reduce of the site counters"}
+            if gather == "sample" and comm["sample_s"] > 0:
+                res["comm"].update({"records_sample_ms": comm["sample_s"] / steps * 1e3, "records_sample_bytes_into_writer": comm["sample_bytes"] / steps,
+                                    "records_sample_GBps": comm["sample_bytes"] / comm["sample_s"] / 1e9,
+                                    "records_sample_note": f"packed records of one {structs[-1][1]}-site tile per rank and step, point to point to rank 0 "
+                                                           f"({comm['sample_packed_bytes'] / steps / 1e9:.2f} GB packed per rank); inside the timed region"})
         if dist is not None and gather == "records":
             res["records_gather"] = {"bytes_per_step_at_writer": gathered_bytes[0] / steps, "GBps_into_writer": gathered_bytes[0] / dt / 1e9}
         if name == opt.workload and not opt.no_pack_rate:
@@ -338,26 +425,33 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
     return res
 
 
-def host_path_rate(opt, env):
+def host_path_rate(opt, env, workload="c3"):
     """PCIe-inclusive rate of the host-buffer entry points (vgl_simulate_tile_async / vgl_tile_wait: page-locked destination
     buffers, two tiles in flight, the copies of one tile beside the kernels of the next): never the bench value, reported
-    beside it.  The synchronous call on ordinary numpy buffers is timed too."""
+    beside it.  The synchronous call on ordinary numpy buffers is timed too.  Tags as a record loop
+    would ask for them: sample-major slabs (VGL_LAYOUT_SAMPLE_MAJOR), GL + DP, and for c5 PL in one byte."""
     import ctypes as C
     import numpy as np
     import synth
     from vcfgl_amd import Simulator, _abi
-    args = workload_args("c3")
-    N, TS, tiles = 1000, 16384, 8
+    args = workload_args(workload)
+    args.out_layout = _abi.VGL_LAYOUT_SAMPLE_MAJOR
+    wl = WORKLOADS[workload]
+    N = wl["samples"]
+    TS, tiles = (16384 * 1000) // N, 8
     sim = Simulator(args, N, device=env["local_dev"], max_sites_per_tile=TS)
     lib = sim.lib
-    gts = [synth.binary_sites(k * TS, TS, N) for k in range(2)]
-    b = 4 + 4 * sim.G
+    gts = [np.zeros((TS, N), dtype=np.uint8) if wl.get("homref") else synth.binary_sites(k * TS, TS, N) for k in range(2)]
+    fields = [("site_status", TS * 4), ("n_alleles", TS * 4), ("alleles2acgt", TS * 5), ("fmt_dp", TS * N * 4), ("gl", TS * sim.G * N * 4)]
+    if args.add_pl:
+        fields.append(("pl_u8", TS * sim.G * N))
+    b = 4 + 4 * sim.G + (sim.G if args.add_pl else 0)
     # ---- page-locked destination buffers, two sets
     sets = []
     for _ in range(2):
         t = _abi.TileOut()
         keep = {}
-        for name, nbytes in (("site_status", TS * 4), ("n_alleles", TS * 4), ("alleles2acgt", TS * 5), ("fmt_dp", TS * N * 4), ("gl", TS * sim.G * N * 4)):
+        for name, nbytes in fields:
             ptr = lib.vgl_host_alloc(nbytes)
             assert ptr, lib.vgl_last_error()
             keep[name] = ptr
@@ -381,7 +475,7 @@ def host_path_rate(opt, env):
         for ptr in keep.values():
             lib.vgl_host_free(ptr)
     # ---- the synchronous call on pageable numpy buffers
-    tile = sim.new_tile(TS, fields=["fmt_dp", "gl"])
+    tile = sim.new_tile(TS, fields=[f for f, _ in fields])
     sim._check(lib.vgl_simulate_tile(sim.ctx, 0, TS, gts[0].ctypes.data, tile.byref()))
     t0 = time.perf_counter()
     for k in range(3):
@@ -392,7 +486,7 @@ def host_path_rate(opt, env):
             "mean_depth_check": dp_sum / (TS * N),
             "sync_pageable": {"value": 3 * TS * N / dts, "GBps_over_pcie": 3 * TS * N * b / dts / 1e9},
             "note": f"vgl_simulate_tile_async + vgl_tile_wait, page-locked host buffers, two tiles in flight, {tiles} tiles of {TS} sites x {N} samples, "
-                    "GL+DP copied back (64 B per evaluation); PCIe-inclusive, never the bench value"}
+                    f"sample-major slabs, {'GL+PL(u8)+DP' if args.add_pl else 'GL+DP'} copied back ({b} B per evaluation); PCIe-inclusive, never the bench value"}
 
 
 def main():
@@ -402,8 +496,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--gather", choices=["index", "records"], default="index",
-                    help="N > 1: what the writer rank receives every step (records: the packed records of every tile as well)")
+    ap.add_argument("--gather", choices=["index", "sample", "records"], default="sample",
+                    help="N > 1: what the writer rank receives every step -- index: the per-site record index and the counters; sample (default): "
+                         "also the packed records of one tile per rank; records: the packed records of every tile")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL over xGMI; gloo stages through host memory (rehearsal)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a box with fewer GPUs than ranks: rank r uses device r %% device_count (needs --backend gloo)")
     ap.add_argument("--sites", type=int, default=None)
@@ -419,7 +514,7 @@ def main():
         cpu_worker(opt.cpu_worker, workload_args(opt.workload), opt.samples or WORKLOADS[opt.workload]["samples"])
         return
     if opt.host_path_worker is not None:
-        print(json.dumps(host_path_rate(opt, {"local_dev": int(opt.host_path_worker)})))
+        print(json.dumps({wl: host_path_rate(opt, {"local_dev": int(opt.host_path_worker)}, wl) for wl in ("c3", "c5")}))
         return
     if opt.gpus < 1:
         sys.exit("--gpus must be >= 1")
@@ -429,6 +524,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("BENCH_TEST_LAUNCHER"):                  # tests/test_bench_launch_cpu.py: rank 1 dies at once, the others hang
+        if rank == 1:
+            sys.exit("bench.py: rank 1 fails (launcher test)")
+        time.sleep(600)
     if world != opt.gpus:
         sys.exit(f"bench.py: --gpus {opt.gpus} but WORLD_SIZE is {world}: launch with --nproc-per-node {opt.gpus} (or plain `python bench.py --gpus {opt.gpus}`)")
     import torch
@@ -472,7 +571,7 @@ def main():
     if world == 1 and not opt.no_extra and opt.sites is None and opt.samples is None:
         # the other BASELINE configurations on this GPU, a few passes each, attached to the same line (parity-test cases, not
         # the headline: VERDICT r1 asked for driver-timed evidence of them)
-        for name in ("c5", "fixedq", "c4", "c2"):
+        for name in ("c5", "c5u8", "fixedq", "c4", "c2", "gl1q", "precise"):
             if name == opt.workload:
                 continue
             try:
@@ -480,7 +579,8 @@ def main():
                 extra[name] = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "workload", "roofline")}
             except Exception as e:                             # an extra must never cost the headline line
                 extra[name] = {"error": repr(e)[:300]}
-        extra["host_path_c3"] = host_first
+        extra["host_path_c3"] = host_first.get("c3", host_first) if isinstance(host_first, dict) else host_first
+        extra["host_path_c5"] = host_first.get("c5") if isinstance(host_first, dict) else None
 
     if rank == 0:
         args = workload_args(opt.workload)
@@ -492,10 +592,12 @@ def main():
             "data": "synthetic",
             "config": {"workload": main_res["workload"], "tile_sites": opt.tile_sites,
                        "parallelism": f"site-sharded x{world}" + (f", {opt.backend}" if world > 1 else ""),
-                       "gather": (opt.gather if world > 1 else None)},
+                       "gather": (opt.gather if world > 1 else None),
+                       "rccl_world": (dist.get_world_size() if dist is not None else None),
+                       "backend": (("rccl (torch.distributed nccl)" if opt.backend == "nccl" else "gloo (host staging, rehearsal)") if dist is not None else None)},
             "roofline": main_res["roofline"],
         }
-        for k in ("cpu_baseline", "records_gather", "record_packing"):
+        for k in ("cpu_baseline", "comm", "records_gather", "record_packing"):
             if k in main_res:
                 line[k] = main_res[k]
         if extra:

@@ -103,6 +103,17 @@ typedef struct vgl_rng_layout {
     uint64_t qs_read_stride;
 } vgl_rng_layout;
 
+/* ---- layout of the per-(site, sample) FORMAT arrays with several values per sample (GL, PL, GP, AD, ADF, ADR, pl_u8) -- ABI 4
+ * VGL_LAYOUT_PLANES (default): x[(site * K + k) * n_samples + sample], K = G or A of the context; entries k >= the site's own
+ *   count hold the missing value.  Best for consumers on the device (one contiguous plane per genotype).
+ * VGL_LAYOUT_SAMPLE_MAJOR: the slab of site i starts at x + i * K * n_samples (same allocation) and holds the record's array
+ *   exactly as simRecord keeps it for bcf_update_format_*() (bcf_utils.h:193-196: gl_arr[sample * nGenotypes + g], nGenotypes
+ *   variable per record): x[i * K * n_samples + sample * nK(i) + k], nK(i) = nGenotypes(site i) (GL, PL, GP, pl_u8) or
+ *   n_alleles[i] (AD, ADF, ADR); what lies behind the record's array in a slab is unspecified (the kernels do not write it).  A record loop hands slab pointers to add_tags()
+ *   unchanged: no per-record transposition on the host.  Skipped sites (site_status < 0) write nothing. */
+#define VGL_LAYOUT_PLANES        0
+#define VGL_LAYOUT_SAMPLE_MAJOR  1
+
 /* ---- parameters = the subset of argStruct (io.h:40-148) the hot path reads ----------- */
 typedef struct vgl_params {
     int32_t  abi_version;        /* VGL_ABI_VERSION */
@@ -137,6 +148,7 @@ typedef struct vgl_params {
     int32_t  add_fmt_adr, add_info_adr;
 
     vgl_rng_layout layout;       /* VGL_RNG_TILE window layout; block==0 => library default  */
+    int32_t  out_layout;         /* VGL_LAYOUT_* of the multi-valued FORMAT arrays (ABI 4)   */
 } vgl_params;
 
 /* ---- one tile of outputs = the simRecord arrays add_tags() reads (bcf_utils.h:157-211) -
@@ -176,6 +188,11 @@ typedef struct vgl_tile_out {
                                 (error_qs 2 only; rows >= the library's staging capacity hold NaN)         */
     double*  site_pick_err;  /* [n_sites]  base_pick_error_prob of the site (error_qs 1 only; written for
                                 sites that reach the read loop, i.e. INFO/DP > 0)                          */
+    /* ABI 4: FORMAT/PL in one byte per value (PL is capped at 255, shared.h:208; htslib narrows the int32 array the
+     * reference hands it when it writes the record, vcfgl.cpp:907-939): a quarter of `pl`'s bytes over HBM and PCIe.
+     * Same layout as `pl` (G planes, or sample-major); a missing PL (sample without reads, g >= nGenotypes(site)) is 255
+     * here -- tell it from a capped value by fmt_dp == 0 / n_alleles.  Independent of `pl`: either, both or neither. */
+    uint8_t* pl_u8;          /* [n_sites][G][n_samples]                                        */
 } vgl_tile_out;
 
 typedef struct vgl_ctx vgl_ctx;

@@ -673,6 +673,9 @@ static int gl1_sample(vgl_oracle* o, int64_t site_abs, int s, int n, const int* 
 }
 
 #define PLANE(ptr, K, site, k, s) (ptr)[((size_t)(site) * (K) + (k)) * N + (s)]
+/* element k of sample s of a multi-valued FORMAT array in the layout the parameters ask for (include/vcfgl_hip.h, VGL_LAYOUT_*);
+ * nK = the site's own count (nGenotypes / nAlleles): sample-major slabs hold exactly nK values per sample */
+#define FMTV(ptr, K, nK, site, k, s) (ptr)[sm ? ((size_t)(site) * (K) * N + (size_t)(s) * (nK) + (k)) : (((size_t)(site) * (K) + (k)) * N + (s))]
 
 /* one site: simulate_record_values, vcfgl.cpp:327-1087 */
 static int simulate_site(vgl_oracle* o, int64_t site_abs, int32_t ls, int32_t n_sites, const uint8_t* gt, vgl_tile_out* out) {
@@ -837,15 +840,17 @@ write_site:
     for (int s = 0; s < N; s++) if (out->fmt_dp) out->fmt_dp[(size_t)ls * N + s] = dp[s];
 
     const int have = (status == VGL_SITE_OK);
+    const int sm = (p->out_layout == VGL_LAYOUT_SAMPLE_MAJOR);
+    const int KA = sm ? nAlleles : A, KG = sm ? nG : G;         /* values per sample that are written */
     /* AD remap (vcfgl.cpp:806-843) */
     for (int a = 0; a < A; a++) {
         int b = (have && a < nAlleles) ? alleles2acgt[a] : -1;
         int tot = 0, totf = 0, totr = 0;
         for (int s = 0; s < N; s++) {
             int v = (b >= 0 && b < 4) ? ad[s * 4 + b] : 0, vf = (b >= 0 && b < 4) ? adf[s * 4 + b] : 0, vr = (b >= 0 && b < 4) ? adr[s * 4 + b] : 0;
-            if (out->fmt_ad) PLANE(out->fmt_ad, A, ls, a, s) = v;
-            if (out->fmt_adf) PLANE(out->fmt_adf, A, ls, a, s) = vf;
-            if (out->fmt_adr) PLANE(out->fmt_adr, A, ls, a, s) = vr;
+            if (out->fmt_ad && a < KA) FMTV(out->fmt_ad, A, nAlleles, ls, a, s) = v;
+            if (out->fmt_adf && a < KA) FMTV(out->fmt_adf, A, nAlleles, ls, a, s) = vf;
+            if (out->fmt_adr && a < KA) FMTV(out->fmt_adr, A, nAlleles, ls, a, s) = vr;
             tot += v; totf += vf; totr += vr;
         }
         if (out->info_ad) out->info_ad[(size_t)ls * A + a] = tot;
@@ -874,13 +879,15 @@ write_site:
         float gpv[15]; float sum_gps = 0.0; int miss = 0;
         for (int i = 0; i < G; i++) {
             float v = (have && i < nG) ? g[i] : MISS;
-            if (out->gl) PLANE(out->gl, G, ls, i, s) = v;
-            if (out->pl) {
+            const int wr = (i < KG);                           /* sample-major: the site's own nG values per sample (none for a skipped site) */
+            if (out->gl && wr) FMTV(out->gl, G, nG, ls, i, s) = v;
+            if ((out->pl || out->pl_u8) && wr) {
                 int32_t x;
                 if (f32_is_missing(v)) x = VGL_INT32_MISSING;
                 else if (v == -INFINITY) x = MAXPL;
                 else { x = (int32_t)lroundf(-10.0 * v); if (x > MAXPL) x = MAXPL; }
-                PLANE(out->pl, G, ls, i, s) = x;
+                if (out->pl) FMTV(out->pl, G, nG, ls, i, s) = x;
+                if (out->pl_u8) FMTV(out->pl_u8, G, nG, ls, i, s) = (uint8_t)(x == VGL_INT32_MISSING ? 255 : x);
             }
             if (i < nG && have) {
                 if (f32_is_missing(v)) { gpv[i] = MISS; miss = 1; }
@@ -889,7 +896,7 @@ write_site:
         }
         if (out->gp) {
             if (have && !miss) { for (int i = 0; i < nG; i++) sum_gps += gpv[i]; for (int i = 0; i < nG; i++) gpv[i] /= sum_gps; }
-            for (int i = 0; i < G; i++) PLANE(out->gp, G, ls, i, s) = (have && i < nG) ? gpv[i] : MISS;
+            for (int i = 0; i < KG; i++) FMTV(out->gp, G, nG, ls, i, s) = (have && i < nG) ? gpv[i] : MISS;
         }
     }
     /* I16 (vcfgl.cpp:982-1074) */

@@ -37,3 +37,14 @@ def test_gpus_n_spawns_n_ranks_which_fail_loudly_without_gpus():
     assert r.returncode != 0
     assert "needs GPU" in r.stderr and "0 device(s)" in r.stderr        # a rank per requested GPU was started and said what it lacks
     assert '"n_gpus"' not in r.stdout                                   # and no result line was fabricated
+
+
+def test_one_failing_rank_ends_the_run_at_once():
+    """a rank that exits early (missing GPU, context or RCCL init failure) while the others are blocked -- in a rendezvous, a
+    collective -- must end the launcher with its error right away, not after the process group's timeout"""
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "3"], env=_env(BENCH_TEST_LAUNCHER="1"), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "rank 1 fails" in r.stderr
+    assert time.time() - t0 < 30
+    assert '"n_gpus"' not in r.stdout

@@ -554,3 +554,71 @@ def test_async_host_path_two_tiles_in_flight(oracle):
     sim._check(lib.vgl_simulate_tile_async(sim.ctx, 0, TS, gts[0].ctypes.data, tile.byref(), C.byref(tk)))
     assert lib.vgl_tile_wait(sim.ctx, tk) == _abi.VGL_E_QSBIN
     sim.close()
+
+
+# ---- ABI 4: sample-major FORMAT arrays (what simRecord::add_tags() hands to bcf_update_format_*) and PL in one byte
+
+def _layout_case(oracle, N, n_sites, kw, site0=5):
+    args = VcfglArgs(seed=42, error_rate=0.02, **kw)
+    args.rng_mode, args.beta_sampler = _abi.VGL_RNG_TILE, _abi.VGL_BETA_RAND48
+    gt = synth.acgt_sites(n_sites, N, seed=N, missing=0.05)
+    out = {}
+    for lay in (_abi.VGL_LAYOUT_PLANES, _abi.VGL_LAYOUT_SAMPLE_MAJOR):
+        args.out_layout = lay
+        sim = Simulator(args, N, device=0, max_sites_per_tile=n_sites)
+        fields = sim.default_fields() + ["pl_u8"]
+        out[lay] = (oracle.Oracle(args, N).simulate(site0, gt, fields=fields), sim.simulate(site0, gt, fields=fields), fields)
+        sim.close()
+    return out
+
+
+@pytest.mark.parametrize("N,n_sites", [(1, 9), (2, 9), (63, 7), (64, 7), (65, 7), (130, 12), (1000, 5), (1027, 3)])
+@pytest.mark.parametrize("kw", [dict(depth=6.0, do_unobserved=1, rm_invar_sites=4, rm_empty_sites=1, **ALLTAGS, **STRAND),
+                                dict(depth=1.0, do_unobserved=0, **ALLTAGS),
+                                dict(depth=14.0, do_unobserved=5, error_qs=2, beta_variance=1e-4, add_pl=1, add_fmt_ad=1),
+                                dict(depth=9.0, do_unobserved=3, gl_model=1, add_pl=1, add_fmt_ad=1)])
+def test_sample_major_layout_and_narrow_pl(oracle, N, n_sites, kw):
+    """VGL_LAYOUT_SAMPLE_MAJOR: the slab of a site holds x[sample * nK + k] with the site's own nK (bcf_utils.h:193-196) -- equal
+    to the oracle's slabs byte for byte (nothing else of a slab is written), and to the planes of the same run read the other
+    way round; pl_u8 = PL in one byte, 255 where PL is missing.  Ragged sample counts: partial last wavefronts, sites of 1 .. 5
+    alleles, skipped and empty sites."""
+    out = _layout_case(oracle, N, n_sites, kw)
+    P, SM = _abi.VGL_LAYOUT_PLANES, _abi.VGL_LAYOUT_SAMPLE_MAJOR
+    MULTI = {"gl": "G", "pl": "G", "gp": "G", "pl_u8": "G", "fmt_ad": "A", "fmt_adf": "A", "fmt_adr": "A"}
+
+    def same(f, a, b, tag):
+        if f == "gp":                                                    # device 10^x: 1e-6 absolute where the value is not missing
+            m = a.view(np.uint32) == _abi.FLOAT_MISSING_BITS
+            assert np.array_equal(m, b.view(np.uint32) == _abi.FLOAT_MISSING_BITS), tag
+            assert np.all(np.abs(a[~m].astype(np.float64) - b[~m].astype(np.float64)) <= TOL), tag
+        else:
+            assert np.array_equal(bits(np.ascontiguousarray(a)), bits(np.ascontiguousarray(b))), tag
+
+    for lay in (P, SM):
+        want, got, fields = out[lay]
+        st, na = want.numpy("site_status"), want.numpy("n_alleles")
+        for f in fields:
+            a, b = want.numpy(f), got.numpy(f)
+            if f == "i16":
+                a, b = a[:, :12], b[:, :12]
+            if lay == SM and f in MULTI:
+                # the record arrays themselves (what lies behind them in a slab is unspecified: the host entry points copy the whole
+                # slab back, the kernels write only the record's n_samples x nK values)
+                for i in range(n_sites):
+                    nA = int(na[i]) if st[i] >= 0 else 0
+                    nk = nA * (nA + 1) // 2 if MULTI[f] == "G" else nA
+                    same(f, want.site_records(f, i, nk), got.site_records(f, i, nk), (lay, f, i))
+            else:
+                same(f, a, b, (lay, f))
+    planes, slabs = out[P][1], out[SM][1]
+    st, na = planes.numpy("site_status"), planes.numpy("n_alleles")
+    for i in range(n_sites):
+        if st[i] < 0:
+            continue
+        nA = int(na[i]); nG = nA * (nA + 1) // 2
+        for f, nk in (("gl", nG), ("pl", nG), ("pl_u8", nG), ("fmt_ad", nA), ("fmt_adf", nA), ("fmt_adr", nA)):
+            if f not in planes.arrays:
+                continue
+            assert np.array_equal(bits(slabs.site_records(f, i, nk)), bits(np.ascontiguousarray(planes.numpy(f)[i, :nk, :].T))), (i, f)
+    pl, u8 = planes.numpy("pl"), planes.numpy("pl_u8")
+    assert np.array_equal(u8, np.where(pl == _abi.INT32_MISSING, 255, pl).astype(np.uint8))

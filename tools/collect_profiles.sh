@@ -1,0 +1,14 @@
+#!/bin/bash
+# usage (development container, after tools/profile_round.sh ran on the GPU box): tools/collect_profiles.sh <tag> [workload ...]
+# copies the kernel-trace summaries into profiles/ and writes profiles/<tag>_<wl>_pmc_summary.json + profiles/pmc_traffic.json
+set -eu
+tag=${1:?tag}; shift
+wls=${*:-c3 c5 c4 fixedq c2 gl1q precise}
+for wl in $wls; do
+    f=$(ls gpurun_out/$tag/$wl/kt/*/*kernel_stats.csv | head -1)
+    cp "$f" profiles/${tag}_${wl}_kernel_stats.csv
+    if [ "$wl" = c2 ]; then n=10000; else n=65536; fi
+    python tools/pmc_summary.py gpurun_out/$tag/$wl/pmc ${tag}_${wl} $wl $n > /dev/null
+    echo "$wl: $(grep -c . profiles/${tag}_${wl}_kernel_stats.csv) kernel rows"
+done
+[ -f gpurun_out/$tag/bench.json ] && tail -1 gpurun_out/$tag/bench.json > profiles/${tag}_bench.json || true

@@ -20,7 +20,7 @@ root, tag = sys.argv[1], sys.argv[2]
 workload = sys.argv[3] if len(sys.argv) > 3 else "c3"
 sites_per_launch = int(sys.argv[4]) if len(sys.argv) > 4 else 65536
 out = collections.defaultdict(dict)
-for f in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")):
+for f in sorted(glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")), key=lambda f: (os.sep + "SQ" + os.sep in f, f)):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
@@ -42,9 +42,14 @@ for k, v in out.items():
     if "SQ_ACTIVE_INST_VALU" in v and v.get("GRBM_GUI_ACTIVE"):
         # VALU pipes busy: SQ_ACTIVE_INST_VALU counts 4-cycle quads summed over the chip's 1024 SIMDs (256 CUs x 4);
         # GRBM_GUI_ACTIVE is summed over the 8 XCDs (value / 8 / duration = 2.39 GHz, the part's clock), so one XCD's
-        # busy cycles are value / 8 and each XCD holds 128 SIMDs
+        # busy cycles are value / 8 and each XCD holds 128 SIMDs.  Both counters come from the SAME pass (GRBM has its own two
+        # slots beside the SQ's eight: tools/profile_round.sh), i.e. the same launches at the same clock -- round 2 divided by
+        # the GRBM count of another pass, and short launches (k_depth, 0.7 ms) then read above 1.
         v["valu_busy_frac"] = 4.0 * v["SQ_ACTIVE_INST_VALU"] / (128.0 * v["GRBM_GUI_ACTIVE"])
         traffic.setdefault(k.split("<")[0], {})["valu_busy_frac"] = v["valu_busy_frac"]
+    if "SQ_ACTIVE_INST_VALU" in v and v.get("SQ_WAVE_CYCLES"):
+        # the kernel's own denominator: share of its wavefronts' resident cycles in which a VALU instruction of theirs was executing
+        v["valu_active_share_of_wave_cycles"] = v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"]
     if "SQ_INSTS_VALU" in v and "SQ_WAVES" in v:
         v["valu_insts_per_wave"] = v["SQ_INSTS_VALU"] / v["SQ_WAVES"]
         v["active_lanes_per_valu_inst"] = v.get("SQ_THREAD_CYCLES_VALU", 0) / v["SQ_INSTS_VALU"]
@@ -59,6 +64,9 @@ except Exception:
     allw = {}
 for e in traffic.values():
     e["sites_per_launch"] = sites_per_launch
-allw[workload] = {"source": tag, "kernels": traffic}
+sys.path.insert(0, here)
+import bench
+# SRC_SHA: the profiled tree's bench.source_sha() when the working tree has moved on since the run
+allw[workload] = {"source": tag, "src_sha": os.environ.get("SRC_SHA") or bench.source_sha(), "kernels": traffic}
 json.dump(allw, open(tpath, "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True))

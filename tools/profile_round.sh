@@ -1,32 +1,31 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): tools/profile_round.sh <tag> [workload ...]      (default workloads: c3 c5)
+# usage (on the GPU box, from the repo root): tools/profile_round.sh <tag> [workload ...]      (default: every bench workload)
 # Collects what DESIGN.md section 5 and profiles/ quote for one round:
-#   gpurun_out/<tag>/bench.json                   default bench.py run (C3 + the other configurations as `extra`)
+#   gpurun_out/<tag>/bench.json                   default bench.py run (C3 + the other configurations as `extra`)  [skipped with NOBENCH=1]
 #   gpurun_out/<tag>/<wl>/kt/.../kernel_stats     rocprofv3 --kernel-trace --stats of the workload's bench command
 #   gpurun_out/<tag>/<wl>/pmc/<GROUP>/            one rocprofv3 --pmc pass per counter group (never mixed with a trace)
-# Afterwards, in the development container:
-#   cp gpurun_out/<tag>/<wl>/kt/*/*kernel_stats.csv profiles/<tag>_<wl>_kernel_stats.csv
-#   cp gpurun_out/<tag>/bench.json profiles/<tag>_bench.json
-#   python tools/pmc_summary.py gpurun_out/<tag>/<wl>/pmc <tag>_<wl> <wl>
+# Afterwards, in the development container: tools/collect_profiles.sh <tag> [workload ...]
 set -u
 tag=${1:?tag}; shift
-wls=${*:-c3 c5}
+wls=${*:-c3 c5 c4 fixedq c2 gl1q precise}
 export TMPDIR=/tmp
 out=gpurun_out/$tag
-rm -rf "$out"; mkdir -p "$out"
-python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
-tail -1 "$out/bench.json" | cut -c1-300
+mkdir -p "$out"
+if [ -z "${NOBENCH:-}" ]; then
+    python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
+    tail -1 "$out/bench.json" | cut -c1-300
+fi
 Q="--no-cpu-baseline --no-extra --no-pack-rate"
 for wl in $wls; do
-    mkdir -p "$out/$wl/pmc"
+    rm -rf "$out/$wl"; mkdir -p "$out/$wl/pmc"
     rocprofv3 --kernel-trace --stats --output-format csv -d "$out/$wl/kt" -- python3 bench.py --workload $wl --steps 3 --warmup 1 $Q > "$out/$wl/kt.log" 2>&1
-    P="--workload $wl --sites 131072 --steps 1 --warmup 0 $Q"
-    for g in FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE; do
+    if [ "$wl" = c2 ]; then P="--workload $wl --steps 2 --warmup 0 $Q"; else P="--workload $wl --sites 131072 --steps 1 --warmup 0 $Q"; fi
+    for g in FETCH_SIZE WRITE_SIZE; do
         rocprofv3 --pmc $g --output-format csv -d "$out/$wl/pmc/$g" -- python3 bench.py $P > "$out/$wl/pmc_$g.log" 2>&1
     done
-    rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d "$out/$wl/pmc/SQ" -- python3 bench.py $P > "$out/$wl/pmc_SQ.log" 2>&1
+    rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d "$out/$wl/pmc/SQ" -- python3 bench.py $P > "$out/$wl/pmc_SQ.log" 2>&1
     echo "$wl profiled"
 done
 find "$out" -name "*kernel_trace.csv" -delete      # large; the stats summary is what is kept
 find "$out" -name "*.db" -delete
-ls "$out" "$out"/*/kt/* | head -30
+ls "$out"

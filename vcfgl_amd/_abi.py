@@ -13,6 +13,7 @@ VGL_E_ARG, VGL_E_NODEVICE, VGL_E_NOMEM, VGL_E_CAPACITY, VGL_E_UNSUPPORTED, VGL_E
 VGL_SITE_OK, VGL_SITE_SKIP_INVAR, VGL_SITE_SKIP_EMPTY, VGL_SITE_NO_READS = 0, -3, -4, 1
 VGL_RNG_TILE, VGL_RNG_SERIAL = 0, 1
 VGL_BETA_RAND48, VGL_BETA_STD = 0, 1
+VGL_LAYOUT_PLANES, VGL_LAYOUT_SAMPLE_MAJOR = 0, 1
 VGL_GT_MISSING = 0xF
 FLOAT_MISSING_BITS = 0x7F800001
 INT32_MISSING = -(2 ** 31)
@@ -39,6 +40,7 @@ class Params(C.Structure):
         ("add_fmt_adf", C.c_int32), ("add_info_adf", C.c_int32),
         ("add_fmt_adr", C.c_int32), ("add_info_adr", C.c_int32),
         ("layout", RngLayout),
+        ("out_layout", C.c_int32),
     ]
 
 
@@ -51,6 +53,7 @@ class TileOut(C.Structure):
         ("fmt_ad", C.c_void_p), ("fmt_adf", C.c_void_p), ("fmt_adr", C.c_void_p),
         ("reads", C.c_void_p), ("read_capacity", C.c_int32),
         ("read_errp", C.c_void_p), ("site_pick_err", C.c_void_p),
+        ("pl_u8", C.c_void_p),
     ]
 
 
@@ -61,7 +64,7 @@ TILE_FIELDS = [
     ("info_adf", "int32", "siteA"), ("info_adr", "int32", "siteA"), ("qs", "float32", "siteA"),
     ("i16", "float32", "site16"), ("fmt_dp", "int32", "eval"), ("gl", "float32", "planeG"),
     ("pl", "int32", "planeG"), ("gp", "float32", "planeG"), ("fmt_ad", "int32", "planeA"),
-    ("fmt_adf", "int32", "planeA"), ("fmt_adr", "int32", "planeA"),
+    ("fmt_adf", "int32", "planeA"), ("fmt_adr", "int32", "planeA"), ("pl_u8", "uint8", "planeG"),
 ]
 
 # every symbol include/vcfgl_hip.h declares

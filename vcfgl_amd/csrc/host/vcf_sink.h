@@ -208,10 +208,20 @@ class Sink {
                 const size_t at = indiv.size();
                 indiv.resize(at + (size_t)4 * d.n * N);
                 uint8_t* o = (uint8_t*)&indiv[at];
-                for (int s = 0; s < N; s++) for (int k = 0; k < d.n; k++, o += 4) memcpy(o, &((const float*)d.base)[s * d.ss + k * d.sk], 4);
+                if (d.sk == 1 && d.ss == (size_t)d.n) memcpy(o, d.base, (size_t)4 * d.n * N);      // sample-major input: the record's array as BCF stores it
+                else for (int s = 0; s < N; s++) for (int k = 0; k < d.n; k++, o += 4) memcpy(o, &((const float*)d.base)[s * d.ss + k * d.sk], 4);
             } else {
                 const int32_t* b = (const int32_t*)d.base;
                 int32_t mx = INT32_MIN, mn = INT32_MAX;
+                const bool linear = (d.sk == 1 && d.ss == (size_t)d.n) || d.n == 1;       // values already in the record's order
+                const size_t total = (size_t)d.n * N;
+                if (linear) {
+                    for (size_t j = 0; j < total; j++) {
+                        const int32_t v = b[j];
+                        if (v == I32_MISSING || v == I32_VEND) continue;
+                        if (v > mx) mx = v; if (v < mn) mn = v;
+                    }
+                } else
                 for (int s = 0; s < N; s++) for (int k = 0; k < d.n; k++) {
                     const int32_t v = b[s * d.ss + k * d.sk];
                     if (v == I32_MISSING || v == I32_VEND) continue;
@@ -219,7 +229,8 @@ class Sink {
                 }
                 const int bt = int_type(mn, mx);
                 enc_size(indiv, d.n, bt);
-                for (int s = 0; s < N; s++) for (int k = 0; k < d.n; k++) put_typed_int(indiv, b[s * d.ss + k * d.sk], bt);
+                if (linear) put_typed_ints(indiv, b, total, bt);
+                else for (int s = 0; s < N; s++) for (int k = 0; k < d.n; k++) put_typed_int(indiv, b[s * d.ss + k * d.sk], bt);
             }
         }
         encode_shared(col, (uint32_t)fmt.size(), shared);
@@ -312,6 +323,22 @@ class Sink {
         if (bt == BT_INT8) s += (char)(v == I32_MISSING ? 0x80 : v == I32_VEND ? 0x81 : v);
         else if (bt == BT_INT16) { const uint16_t x = (uint16_t)(v == I32_MISSING ? 0x8000 : v == I32_VEND ? 0x8001 : v); s += (char)(x & 0xff); s += (char)(x >> 8); }
         else put_u32(s, (uint32_t)v);
+    }
+    // `n` values of one typed vector, written in one resize (the per-value appends of put_typed_int dominate the encoding of a wide record)
+    static void put_typed_ints(std::string& s, const int32_t* v, size_t n, int bt) {
+        const size_t at = s.size();
+        if (bt == BT_INT8) {
+            s.resize(at + n);
+            uint8_t* o = (uint8_t*)&s[at];
+            for (size_t j = 0; j < n; j++) o[j] = (uint8_t)(v[j] == I32_MISSING ? 0x80 : v[j] == I32_VEND ? 0x81 : v[j]);
+        } else if (bt == BT_INT16) {
+            s.resize(at + 2 * n);
+            uint8_t* o = (uint8_t*)&s[at];
+            for (size_t j = 0; j < n; j++) { const uint16_t x = (uint16_t)(v[j] == I32_MISSING ? 0x8000 : v[j] == I32_VEND ? 0x8001 : v[j]); o[2 * j] = (uint8_t)(x & 0xff); o[2 * j + 1] = (uint8_t)(x >> 8); }
+        } else {
+            s.resize(at + 4 * n);
+            memcpy(&s[at], v, 4 * n);                                    // little endian host, like the file
+        }
     }
     static void enc_int1(std::string& s, int32_t v) {
         const int bt = (v == I32_MISSING || v == I32_VEND) ? BT_INT8 : int_type(v, v);

@@ -689,7 +689,7 @@ struct GvcfBlocker {
             dp.assign(sv->dp, sv->dp + sv->N);
             const int nG = sv->n_alleles * (sv->n_alleles + 1) / 2;
             pl.assign((size_t)sv->N * nG, 0);
-            for (int s = 0; s < sv->N; ++s) for (int g = 0; g < nG; ++g) pl[(size_t)s * nG + g] = sv->pl[(size_t)g * sv->N + s];
+            pl.assign(sv->pl, sv->pl + (size_t)sv->N * nG);                 // sample-major, like the block's own array
             qsum.clear(); if (sv->qs) qsum.assign(sv->qs, sv->qs + sv->n_alleles);
             chrom = *sv->chrom; start_pos = sv->pos0; alleles = sv->alleles; min_dp = mdp; current_dpr = dp_range;
         } else {
@@ -697,7 +697,7 @@ struct GvcfBlocker {
             for (int s = 0; s < sv->N; ++s) if (dp[s] > sv->dp[s]) dp[s] = sv->dp[s];
             if (sv->n_alleles != 2 || pl.size() != (size_t)sv->N * 3) die("Unexpected number of PL values: %d", sv->N * sv->n_alleles * (sv->n_alleles + 1) / 2);
             for (int s = 0; s < sv->N; ++s) {
-                const int32_t p1 = sv->pl[(size_t)1 * sv->N + s], p2 = sv->pl[(size_t)2 * sv->N + s];
+                const int32_t p1 = sv->pl[(size_t)3 * s + 1], p2 = sv->pl[(size_t)3 * s + 2];
                 if (pl[3 * s + 1] > p1) { pl[3 * s + 1] = p1; pl[3 * s + 2] = p2; }
                 else if (pl[3 * s + 1] == p1 && pl[3 * s + 2] > p2) pl[3 * s + 2] = p2;
             }
@@ -884,7 +884,7 @@ int main(int argc, char** argv) {
     }
 
     vgl_params p; memset(&p, 0, sizeof p);
-    p.abi_version = VGL_ABI_VERSION; p.seed = a.seed; p.n_samples = N; p.rng_mode = a.rng_mode; p.beta_sampler = a.beta_sampler;
+    p.abi_version = VGL_ABI_VERSION; p.out_layout = VGL_LAYOUT_SAMPLE_MAJOR; p.seed = a.seed; p.n_samples = N; p.rng_mode = a.rng_mode; p.beta_sampler = a.beta_sampler;
     p.depth = a.depth; p.depths = a.depths.empty() ? nullptr : a.depths.data();
     p.error_rate = a.error_rate; p.error_qs = a.error_qs; p.beta_variance = a.beta_variance; p.gl_model = a.gl_model;
     p.gl1_theta = a.gl1_theta; p.precise_gl = a.precise_gl; p.adjust_qs = a.adjust_qs; p.adjust_by = a.adjust_by;
@@ -1057,16 +1057,18 @@ int main(int argc, char** argv) {
         if (a.add_info_adf) { add_key("ADF"); for (int k = 0; k < nA; k++) { if (k) info += ','; put_int(info, B.iadf[(size_t)i * A + k]); } }
         if (a.add_info_adr) { add_key("ADR"); for (int k = 0; k < nA; k++) { if (k) info += ','; put_int(info, B.iadr[(size_t)i * A + k]); } }
         line += info.empty() ? "." : info;
-        // FORMAT keys: DP, GL, PL, GP, AD, ADF, ADR; sample s, element k of a tag at plane[k * N + s]
+        // FORMAT keys: DP, GL, PL, GP, AD, ADF, ADR.  The library writes the multi-valued tags sample-major (VGL_LAYOUT_SAMPLE_MAJOR):
+        // the slab of site i holds the record's array as the reference keeps it for bcf_update_format_*(), element k of sample s
+        // at slab[s * n + k] with the site's own n -- the encoders below read (and for BCF copy) it front to back
         fmt.clear();
-        const size_t sN = (size_t)N;
+        const size_t sN = (size_t)N, sG = (size_t)nG, sA = (size_t)nA;
         if (a.add_fmt_dp) fmt.push_back({"DP", false, 1, &B.dp[(size_t)i * N], 1, sN});
-        if (a.add_gl) fmt.push_back({"GL", true, nG, &B.gl[(size_t)i * G * N], 1, sN});
-        if (a.add_pl) fmt.push_back({"PL", false, nG, &B.pl[(size_t)i * G * N], 1, sN});
-        if (a.add_gp) fmt.push_back({"GP", true, nG, &B.gp[(size_t)i * G * N], 1, sN});
-        if (a.add_fmt_ad) fmt.push_back({"AD", false, nA, &B.ad[(size_t)i * A * N], 1, sN});
-        if (a.add_fmt_adf) fmt.push_back({"ADF", false, nA, &B.adf[(size_t)i * A * N], 1, sN});
-        if (a.add_fmt_adr) fmt.push_back({"ADR", false, nA, &B.adr[(size_t)i * A * N], 1, sN});
+        if (a.add_gl) fmt.push_back({"GL", true, nG, &B.gl[(size_t)i * G * N], sG, 1});
+        if (a.add_pl) fmt.push_back({"PL", false, nG, &B.pl[(size_t)i * G * N], sG, 1});
+        if (a.add_gp) fmt.push_back({"GP", true, nG, &B.gp[(size_t)i * G * N], sG, 1});
+        if (a.add_fmt_ad) fmt.push_back({"AD", false, nA, &B.ad[(size_t)i * A * N], sA, 1});
+        if (a.add_fmt_adf) fmt.push_back({"ADF", false, nA, &B.adf[(size_t)i * A * N], sA, 1});
+        if (a.add_fmt_adr) fmt.push_back({"ADR", false, nA, &B.adr[(size_t)i * A * N], sA, 1});
     };
     // everything the writer does with one finished tile, in site order (TSV lines, pileup, gVCF blocks, records)
     auto write_tile = [&](TileBufs& B) {

@@ -114,6 +114,7 @@ struct VglDevParams {
     uint64_t x0;
     VglAffine off[4];                  // J^(off[k])
     VglAffine site_pow[40];            // J^(block * N * 2^b)  (k_sitebase)
+    int32_t out_layout;                // VGL_LAYOUT_*: k_gl stores the multi-valued FORMAT arrays as planes or sample-major
     int32_t site_hash_bits;            // W of vgl_site_hash(): sites [0, 2^W) are addressable
     uint32_t depth_magic;              // k_depth, 2 <= N < 1024: floor(2^32 / N) + 1, so that t / N = mulhi(t, magic) for t < 2048
     const VglAffine* samp_tab;         // [N] J^(block * s)
@@ -166,7 +167,7 @@ struct VglTilePtrs {
     int32_t* site_status; int32_t* n_alleles; int32_t* n_alleles_obs; int8_t* alleles2acgt;
     int32_t* info_dp; int32_t* info_ad; int32_t* info_adf; int32_t* info_adr;
     float* qs; float* i16;
-    int32_t* fmt_dp; float* gl; int32_t* pl; float* gp;
+    int32_t* fmt_dp; float* gl; int32_t* pl; float* gp; uint8_t* pl_u8;
     int32_t* fmt_ad; int32_t* fmt_adf; int32_t* fmt_adr;
     uint8_t* reads_out; int32_t reads_out_cap;
     double* site_pick_err;    // [n_sites] per-site beta deviate of --error-qs 1 (dump; may be null)

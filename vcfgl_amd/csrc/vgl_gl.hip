@@ -549,16 +549,76 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
             for (int i = 0; i < NG; ++i) acc[i] = __uint_as_float(colx[i * WG]);
         }
     }
-    // VGL_PUT(base, NP, expr of i): the loops are spelled out here (not in a lambda) so that acc[] stays in registers
-#define VGL_PUT(BASE, NP, EXPR)                                                                          \
+    // VGL_PUT(base, KMAX, nK, expr of i): the loops are spelled out here (not in a lambda) so that acc[] stays in registers.
+    // VGL_LAYOUT_PLANES: one store per plane, lanes = consecutive samples.  VGL_LAYOUT_SAMPLE_MAJOR (include/vcfgl_hip.h): the
+    // record's array as simRecord keeps it, x[sample * nK + k] with the site's own nK -- the wavefront's 64 x nK values are one
+    // contiguous run of the slab, so they pass through the wavefront's own columns of s_x (free once every lane has read its
+    // accumulators: columns 64 wv .. 64 wv + 63 of every row belong to this wavefront alone) in linear order and leave as
+    // nK fully coalesced stores of 256 bytes.
+    const bool sm = P.out_layout == 1;                                   // VGL_LAYOUT_SAMPLE_MAJOR
+    const int wv = tid >> 6;
+    const uint32_t wb = 64u * (uint32_t)wv;
+    int ls_w = 0, sb_w = 0;
+    const bool wave_ok = bx * (uint32_t)WPB + (uint32_t)wv < nwaves;
+    if (wave_ok) wave_site(wv, ls_w, sb_w);
+    const uint32_t nv = wave_ok ? (uint32_t)((N - sb_w) < 64 ? (N - sb_w) : 64) : 0u;       // samples of this wavefront's chunk
+    const uint32_t nG0u = (uint32_t)__builtin_amdgcn_readfirstlane(nG0), nA0u = (uint32_t)__builtin_amdgcn_readfirstlane(nA0);
+#define VGL_WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#define VGL_PUT(BASE, KMAX, NK, EXPR)                                                                    \
     do {                                                                                                 \
         uint32_t* const base_ = (uint32_t*)(BASE);                                                       \
-        if (base_ && live0) {                                                                            \
-            _Pragma("unroll") for (int i = 0; i < (NP); ++i) base_[((size_t)ls0 * (NP) + i) * N + s0] = (EXPR); \
+        if (base_ && !sm) {                                                                              \
+            if (live0) { _Pragma("unroll") for (int i = 0; i < (KMAX); ++i) base_[((size_t)ls0 * (KMAX) + i) * N + s0] = (EXPR); } \
+        } else if (base_) {                                                                              \
+            const uint32_t nk_ = (NK);                                                                   \
+            _Pragma("unroll") for (int i = 0; i < (KMAX); ++i)                                           \
+                if ((uint32_t)i < nk_) { const uint32_t L_ = (uint32_t)lane * nk_ + (uint32_t)i; s_x[(L_ >> 6) * WG + wb + (L_ & 63u)] = (EXPR); } \
+            VGL_WAVE_LDS_SYNC();                                                                         \
+            uint32_t* const dst_ = base_ + (size_t)ls_w * (KMAX) * N + (size_t)sb_w * nk_;               \
+            const uint32_t total_ = nv * nk_;                                                            \
+            _Pragma("unroll") for (int k = 0; k < (KMAX); ++k) {                                         \
+                const uint32_t L_ = 64u * (uint32_t)k + (uint32_t)lane;                                  \
+                if (L_ < total_) dst_[L_] = s_x[k * WG + wb + (uint32_t)lane];                           \
+            }                                                                                            \
+            VGL_WAVE_LDS_SYNC();                                                                         \
         }                                                                                                \
     } while (0)
-    VGL_PUT(T.gl, NG, __float_as_uint((sample_ok && i < nG0) ? acc[i] : MISS));
-    VGL_PUT(T.pl, NG, pl_of(acc[i], sample_ok && i < nG0));
+    VGL_PUT(T.gl, NG, nG0u, __float_as_uint((sample_ok && i < nG0) ? acc[i] : MISS));
+    VGL_PUT(T.pl, NG, nG0u, pl_of(acc[i], sample_ok && i < nG0));
+    if (T.pl_u8) {                                                       // PL in one byte (capped at 255; 255 also stands for missing)
+        if (!sm) {
+            if (live0) {
+#pragma unroll
+                for (int i = 0; i < NG; ++i) {
+                    const uint32_t v = pl_of(acc[i], sample_ok && i < nG0);
+                    T.pl_u8[((size_t)ls0 * NG + i) * N + s0] = (uint8_t)(v > 255u ? 255u : v);
+                }
+            }
+        } else {
+            uint8_t* const sb8 = (uint8_t*)s_x;
+#pragma unroll
+            for (int i = 0; i < NG; ++i)
+                if ((uint32_t)i < nG0u) {
+                    const uint32_t v = pl_of(acc[i], sample_ok && i < nG0);
+                    const uint32_t Lb = (uint32_t)lane * nG0u + (uint32_t)i, W = Lb >> 2;
+                    sb8[((((W >> 6) * WG) + wb + (W & 63u)) << 2) | (Lb & 3u)] = (uint8_t)(v > 255u ? 255u : v);
+                }
+            VGL_WAVE_LDS_SYNC();
+            uint8_t* const dst = T.pl_u8 + (size_t)ls_w * NG * N + (size_t)sb_w * nG0u;
+            const uint32_t total = nv * nG0u;                             // bytes of this wavefront's run
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                                 // 64 x 15 bytes = 240 words at most
+                const uint32_t b0 = 4u * (64u * (uint32_t)k + (uint32_t)lane);
+                const uint32_t word = s_x[k * WG + wb + (uint32_t)lane];
+                if (b0 + 4u <= total) __builtin_memcpy(dst + b0, &word, 4);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) if (b0 + (uint32_t)j < total) dst[b0 + j] = (uint8_t)(word >> (8 * j));
+                }
+            }
+            VGL_WAVE_LDS_SYNC();
+        }
+    }
     if (T.gp) {                                                          // GP = 10^GL normalised by its float32 sum in genotype order
         float sum_gps = 0.0f;
 #pragma unroll
@@ -567,14 +627,15 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
             acc[i] = valid ? (float)exp10_nonpos((double)acc[i]) : 0.0f;
             if (valid) sum_gps += acc[i];
         }
-        VGL_PUT(T.gp, NG, __float_as_uint((sample_ok && i < nG0) ? acc[i] / sum_gps : MISS));
+        VGL_PUT(T.gp, NG, nG0u, __float_as_uint((sample_ok && i < nG0) ? acc[i] / sum_gps : MISS));
     }
     if (T.fmt_ad || T.fmt_adf || T.fmt_adr) {
         const uint64_t adf4 = (P.need_adf && live0) ? T.adf4[(size_t)ls0 * N + s0] : a;
-        VGL_PUT(T.fmt_ad, A, (uint32_t)cnt_of(a, (have0 && i < nA0) ? nib(si_n.alleles2acgt, i) : 0xF));
-        VGL_PUT(T.fmt_adf, A, (uint32_t)cnt_of(adf4, (have0 && i < nA0) ? nib(si_n.alleles2acgt, i) : 0xF));
-        VGL_PUT(T.fmt_adr, A, (uint32_t)(cnt_of(a, (have0 && i < nA0) ? nib(si_n.alleles2acgt, i) : 0xF) - cnt_of(adf4, (have0 && i < nA0) ? nib(si_n.alleles2acgt, i) : 0xF)));
+        VGL_PUT(T.fmt_ad, A, nA0u, (uint32_t)cnt_of(a, (have0 && i < nA0) ? nib(si_n.alleles2acgt, i) : 0xF));
+        VGL_PUT(T.fmt_adf, A, nA0u, (uint32_t)cnt_of(adf4, (have0 && i < nA0) ? nib(si_n.alleles2acgt, i) : 0xF));
+        VGL_PUT(T.fmt_adr, A, nA0u, (uint32_t)(cnt_of(a, (have0 && i < nA0) ? nib(si_n.alleles2acgt, i) : 0xF) - cnt_of(adf4, (have0 && i < nA0) ? nib(si_n.alleles2acgt, i) : 0xF)));
     }
+#undef VGL_WAVE_LDS_SYNC
 #undef VGL_PUT
 }
 

@@ -190,7 +190,7 @@ struct vgl_ctx {
     // host (copy stream) run beside the kernels of the next tile (compute stream) -- SURVEY H8
     struct HostSlot {
         uint8_t* d_gt = nullptr; uint8_t* h_gt = nullptr;          // h_gt: pinned staging of the packed genotypes
-        void* d_out[17] = {nullptr}; size_t d_out_bytes[17] = {0};
+        void* d_out[18] = {nullptr}; size_t d_out_bytes[18] = {0};
         uint8_t* d_reads_out = nullptr; size_t d_reads_out_bytes = 0;
         double* d_errp_out = nullptr; size_t d_errp_out_bytes = 0;
         double* d_pick_out = nullptr;
@@ -313,6 +313,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     if (p->n_qs_bins < 0 || p->n_qs_bins > VGL_MAX_QS_BINS) return fail(VGL_E_ARG, "at most %d qs bins are supported", VGL_MAX_QS_BINS);
     if (p->gl_model == 1 && p->precise_gl) return fail(VGL_E_ARG, "Precise genotype likelihood error (--precise-gl 1) is not supported with genotype likelihood model 1 (--gl-model 1).");
     if (p->rng_mode != VGL_RNG_TILE && p->rng_mode != VGL_RNG_SERIAL) return fail(VGL_E_ARG, "rng_mode must be VGL_RNG_TILE or VGL_RNG_SERIAL");
+    if (p->out_layout != VGL_LAYOUT_PLANES && p->out_layout != VGL_LAYOUT_SAMPLE_MAJOR) return fail(VGL_E_ARG, "out_layout must be VGL_LAYOUT_PLANES or VGL_LAYOUT_SAMPLE_MAJOR");
     if (p->rng_mode == VGL_RNG_TILE && p->error_qs != 0 && p->beta_sampler != VGL_BETA_RAND48)
         return fail(VGL_E_UNSUPPORTED, "the mt19937 beta sampler is one global serial stream: use VGL_RNG_SERIAL, or VGL_BETA_RAND48 with VGL_RNG_TILE");
     const double dmax = max_depth(p);
@@ -357,6 +358,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     D.per_sample_depth = p->depths ? 1 : 0;
     D.need_qsum = (p->add_qs || p->add_i16) ? 1 : 0; D.need_qsumsq = p->add_i16 ? 1 : 0; D.need_adf = D.sample_strand;
     D.i16_mapq = p->i16_mapq; D.add_i16 = p->add_i16;
+    D.out_layout = p->out_layout;
     D.adjust_by = p->adjust_by;
     D.serial = (p->rng_mode == VGL_RNG_SERIAL) ? 1 : 0;
     D.gl1_deep = (p->gl_model == 1 && D.read_cap > 255) ? 1 : 0;
@@ -683,7 +685,7 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     T.site_status = o->site_status; T.n_alleles = o->n_alleles; T.n_alleles_obs = o->n_alleles_obs; T.alleles2acgt = o->alleles2acgt;
     T.info_dp = o->info_dp; T.info_ad = o->info_ad; T.info_adf = o->info_adf; T.info_adr = o->info_adr;
     T.qs = o->qs; T.i16 = o->i16; T.fmt_dp = o->fmt_dp; T.gl = o->gl; T.pl = o->pl; T.gp = o->gp;
-    T.fmt_ad = o->fmt_ad; T.fmt_adf = o->fmt_adf; T.fmt_adr = o->fmt_adr;
+    T.fmt_ad = o->fmt_ad; T.fmt_adf = o->fmt_adf; T.fmt_adr = o->fmt_adr; T.pl_u8 = o->pl_u8;
     T.reads_out = o->read_capacity > 0 ? o->reads : nullptr;
     T.reads_out_cap = o->read_capacity > 0 ? (o->read_capacity < D.read_cap ? o->read_capacity : D.read_cap) : 0;
     if (o->read_capacity > D.read_cap && o->reads)
@@ -795,7 +797,8 @@ extern "C" int vgl_ctx_check(vgl_ctx* c, void* stream) {
 // field table of vgl_tile_out in declaration order: element size and per-tile element count
 struct FieldDesc { size_t off; size_t esz; int kind; };
 enum { K_SITE, K_SITE5, K_SITEA, K_SITE16, K_EVAL, K_PLANEG, K_PLANEA };
-static const FieldDesc FIELDS[17] = {
+enum { N_FIELDS = 18 };
+static const FieldDesc FIELDS[N_FIELDS] = {
     {offsetof(vgl_tile_out, site_status), 4, K_SITE}, {offsetof(vgl_tile_out, n_alleles), 4, K_SITE},
     {offsetof(vgl_tile_out, n_alleles_obs), 4, K_SITE}, {offsetof(vgl_tile_out, alleles2acgt), 1, K_SITE5},
     {offsetof(vgl_tile_out, info_dp), 4, K_SITE}, {offsetof(vgl_tile_out, info_ad), 4, K_SITEA},
@@ -804,7 +807,7 @@ static const FieldDesc FIELDS[17] = {
     {offsetof(vgl_tile_out, fmt_dp), 4, K_EVAL}, {offsetof(vgl_tile_out, gl), 4, K_PLANEG},
     {offsetof(vgl_tile_out, pl), 4, K_PLANEG}, {offsetof(vgl_tile_out, gp), 4, K_PLANEG},
     {offsetof(vgl_tile_out, fmt_ad), 4, K_PLANEA}, {offsetof(vgl_tile_out, fmt_adf), 4, K_PLANEA},
-    {offsetof(vgl_tile_out, fmt_adr), 4, K_PLANEA},
+    {offsetof(vgl_tile_out, fmt_adr), 4, K_PLANEA}, {offsetof(vgl_tile_out, pl_u8), 1, K_PLANEG},
 };
 static size_t field_count(const vgl_ctx* c, int kind, size_t n_sites) {
     const size_t N = c->dp.n_samples, A = c->dp.A, G = c->dp.G;
@@ -857,7 +860,7 @@ extern "C" int vgl_simulate_tile_async(vgl_ctx* c, int64_t site0, int32_t n_site
     HIPCHK(hipMemcpyAsync(S.d_gt, S.h_gt, (size_t)n_sites * N, hipMemcpyHostToDevice, c->s_compute));
     vgl_tile_out d;
     memset(&d, 0, sizeof d);
-    for (int f = 0; f < 17; f++) {
+    for (int f = 0; f < N_FIELDS; f++) {
         void* host = *(void**)((char*)o + FIELDS[f].off);
         if (!host) continue;
         const size_t need = field_count(c, FIELDS[f].kind, (size_t)c->max_sites) * FIELDS[f].esz;
@@ -901,7 +904,7 @@ extern "C" int vgl_simulate_tile_async(vgl_ctx* c, int64_t site0, int32_t n_site
     HIPCHK(hipMemsetAsync(c->d_errflag, 0, sizeof(uint32_t), c->s_compute));
     HIPCHK(hipEventRecord(S.ev_kernels, c->s_compute));
     HIPCHK(hipStreamWaitEvent(c->s_copy, S.ev_kernels, 0));
-    for (int f = 0; f < 17; f++) {
+    for (int f = 0; f < N_FIELDS; f++) {
         void* host = *(void**)((char*)o + FIELDS[f].off);
         if (!host) continue;
         HIPCHK(hipMemcpyAsync(host, S.d_out[f], field_count(c, FIELDS[f].kind, (size_t)n_sites) * FIELDS[f].esz, hipMemcpyDeviceToHost, c->s_copy));

@@ -102,6 +102,7 @@ class VcfglArgs:
     add_info_adr: int = 0
     rng_mode: int = _abi.VGL_RNG_TILE
     beta_sampler: int = _abi.VGL_BETA_RAND48
+    out_layout: int = _abi.VGL_LAYOUT_PLANES       # layout of the multi-valued FORMAT arrays (include/vcfgl_hip.h)
     extra: dict = field(default_factory=dict)   # parsed but unused flags (output mode, threads, ...)
 
     # ------------------------------------------------------------------ parsing
@@ -219,6 +220,7 @@ class VcfglArgs:
         for f in ("add_gl", "add_gp", "add_pl", "add_i16", "add_qs", "add_fmt_dp", "add_info_dp", "add_fmt_ad",
                   "add_info_ad", "add_fmt_adf", "add_info_adf", "add_fmt_adr", "add_info_adr"):
             setattr(p, f, int(getattr(self, f)))
+        p.out_layout = int(self.out_layout)
         return p, keep
 
     @property

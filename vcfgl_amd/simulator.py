@@ -50,7 +50,7 @@ class Simulator:
     def default_fields(self):
         """Every output the context can produce: QS / I16 need -addQS / -addI16 (their inputs,
         the per-base quality sums, are only accumulated when asked for)."""
-        skip = set()
+        skip = {"pl_u8"}                                   # the narrow PL plane is produced on request
         if not (self.args.add_qs or self.args.add_i16):
             skip.add("qs")
         if not self.args.add_i16:

@@ -62,5 +62,11 @@ class Tile:
         a = self.arrays[name]
         return a if self.device is None else a.cpu().numpy()
 
+    def site_records(self, name, site, n_values):
+        """VGL_LAYOUT_SAMPLE_MAJOR: the [n_samples][n_values] array of one site of a multi-valued FORMAT field (what the
+        reference keeps in simRecord::gl_arr etc.), n_values = nGenotypes(site) or n_alleles(site)"""
+        a = self.numpy(name)
+        return a[site].reshape(-1)[: self.n_samples * n_values].reshape(self.n_samples, n_values)
+
     def byref(self):
         return C.byref(self.struct)
