@@ -238,6 +238,9 @@ int vgl_simulate_tile(vgl_ctx* ctx, int64_t site0, int32_t n_sites,
 int   vgl_simulate_tile_async(vgl_ctx* ctx, int64_t site0, int32_t n_sites, const uint8_t* gt, vgl_tile_out* out, int32_t* ticket);
 int   vgl_tile_wait(vgl_ctx* ctx, int32_t ticket);
 void* vgl_host_alloc(size_t bytes);            /* page-locked host memory (NULL on failure); needs a HIP device */
+/* the same, placed for DMA from `device` (on a two-socket host page-locked memory lands on the NUMA node next to the device
+ * that is current when it is allocated: 53 against 35 GB/s of copy-back measured): buffers of a multi-device record loop (ABI 4) */
+void* vgl_host_alloc_on(int32_t device, size_t bytes);
 void  vgl_host_free(void* p);
 
 /* Device variant: `gt` and every pointer in `out` are device memory owned by the caller

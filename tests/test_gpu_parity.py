@@ -622,3 +622,34 @@ def test_sample_major_layout_and_narrow_pl(oracle, N, n_sites, kw):
             assert np.array_equal(bits(slabs.site_records(f, i, nk)), bits(np.ascontiguousarray(planes.numpy(f)[i, :nk, :].T))), (i, f)
     pl, u8 = planes.numpy("pl"), planes.numpy("pl_u8")
     assert np.array_equal(u8, np.where(pl == _abi.INT32_MISSING, 255, pl).astype(np.uint8))
+
+
+def test_async_tile_that_fails_after_its_first_enqueue_leaves_the_context_usable(oracle):
+    """vgl_simulate_tile_async commits ticket and slot only when the whole tile is enqueued: a call that fails part-way (here: an
+    INFO/QS buffer without -addQS, refused after the genotypes' copy was enqueued) drains the streams, clears the device error
+    word and frees the slot; the next tiles run, two in flight, with the tickets and the values of an undisturbed context"""
+    import ctypes as C
+    args = VcfglArgs(seed=42, depth=12.0, error_rate=0.01, add_pl=1)
+    args.rng_mode, args.beta_sampler = _abi.VGL_RNG_TILE, _abi.VGL_BETA_RAND48
+    N, S = 70, 16
+    sim = Simulator(args, N, device=0, max_sites_per_tile=S)
+    gts = [synth.binary_sites(k * S, S, N) for k in range(3)]
+    bad = sim.new_tile(S, fields=["fmt_dp", "gl", "qs"])                 # qs needs -addQS in the context parameters
+    t = C.c_int32(-7)
+    rc = sim.lib.vgl_simulate_tile_async(sim.ctx, 0, S, gts[0].ctypes.data, bad.byref(), C.byref(t))
+    assert rc == _abi.VGL_E_ARG and t.value == -7
+    assert sim.lib.vgl_tile_wait(sim.ctx, 0) == _abi.VGL_E_ARG           # nothing is in flight under either ticket
+    tiles, tick = [sim.new_tile(S, fields=["fmt_dp", "gl", "pl"]) for _ in range(3)], [C.c_int32() for _ in range(3)]
+    sim._check(sim.lib.vgl_simulate_tile_async(sim.ctx, 0, S, gts[0].ctypes.data, tiles[0].byref(), C.byref(tick[0])))
+    sim._check(sim.lib.vgl_simulate_tile_async(sim.ctx, S, S, gts[1].ctypes.data, tiles[1].byref(), C.byref(tick[1])))
+    assert (tick[0].value, tick[1].value) == (0, 1)
+    sim._check(sim.lib.vgl_tile_wait(sim.ctx, tick[0]))
+    sim._check(sim.lib.vgl_simulate_tile_async(sim.ctx, 2 * S, S, gts[2].ctypes.data, tiles[2].byref(), C.byref(tick[2])))
+    sim._check(sim.lib.vgl_tile_wait(sim.ctx, tick[1]))
+    sim._check(sim.lib.vgl_tile_wait(sim.ctx, tick[2]))
+    sim.close()
+    orc = oracle.Oracle(args, N)
+    for k in range(3):
+        want = orc.simulate(k * S, gts[k], fields=["fmt_dp", "gl", "pl"])
+        for f in ("fmt_dp", "pl", "gl"):
+            assert np.array_equal(bits(want.numpy(f)), bits(tiles[k].numpy(f))), (k, f)

@@ -72,7 +72,7 @@ EXPORTS = [
     "vgl_max_alleles", "vgl_max_genotypes", "vgl_default_rng_layout", "vgl_abi_version",
     "vgl_last_error", "vgl_ctx_create", "vgl_ctx_destroy", "vgl_simulate_tile",
     "vgl_simulate_tile_device", "vgl_ctx_check", "vgl_ctx_timing", "vgl_ctx_kernel_ms", "vgl_rng_tile_max_sites", "vgl_rng_tile_site_hash",
-    "vgl_simulate_tile_async", "vgl_tile_wait", "vgl_host_alloc", "vgl_host_free",
+    "vgl_simulate_tile_async", "vgl_tile_wait", "vgl_host_alloc", "vgl_host_alloc_on", "vgl_host_free",
 ]
 
 _LIB = None
@@ -113,6 +113,8 @@ def load_library():
     lib.vgl_tile_wait.argtypes = [C.c_void_p, C.c_int32]
     lib.vgl_host_alloc.restype = C.c_void_p
     lib.vgl_host_alloc.argtypes = [C.c_size_t]
+    lib.vgl_host_alloc_on.restype = C.c_void_p
+    lib.vgl_host_alloc_on.argtypes = [C.c_int32, C.c_size_t]
     lib.vgl_host_free.argtypes = [C.c_void_p]
     lib.vgl_simulate_tile_device.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.POINTER(TileOut), C.c_void_p]
     lib.vgl_ctx_check.argtypes = [C.c_void_p, C.c_void_p]

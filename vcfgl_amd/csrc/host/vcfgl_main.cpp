@@ -634,10 +634,11 @@ struct SiteStream {
 // page-locked host array (vgl_host_alloc): grows, never shrinks
 template <class T> struct PBuf {
     T* p = nullptr; size_t n = 0;
+    static int& device() { static thread_local int d = -1; return d; }   // >= 0: place the memory for DMA from that device (vgl_host_alloc_on)
     void resize(size_t m) {
         if (m <= n) return;
         if (p) vgl_host_free(p);
-        p = (T*)vgl_host_alloc(m * sizeof(T));
+        p = (T*)(device() >= 0 ? vgl_host_alloc_on(device(), m * sizeof(T)) : vgl_host_alloc(m * sizeof(T)));
         if (!p) die("%s", vgl_last_error());
         n = m;
     }
@@ -974,9 +975,15 @@ int main(int argc, char** argv) {
     const size_t E = (size_t)TS * N;
     const int R = 2 * D;                                        // tiles in flight: two per device
     std::vector<std::unique_ptr<TileBufs>> ring(R);
-    for (auto& up : ring) {
+    for (size_t ri = 0; ri < ring.size(); ri++) {
+        auto& up = ring[ri];
         up.reset(new TileBufs());
         TileBufs& B = *up;
+        // ring entry ri only ever serves device ri % D (tiles are dealt round robin, two entries per device): its page-locked
+        // buffers are placed next to that device
+        const int dev_of_entry = devices[ri % (size_t)D];
+        PBuf<uint8_t>::device() = dev_of_entry; PBuf<int32_t>::device() = dev_of_entry; PBuf<int8_t>::device() = dev_of_entry;
+        PBuf<float>::device() = dev_of_entry; PBuf<double>::device() = dev_of_entry;
         B.meta.resize(TS); B.gt.resize(E);
         B.st.resize(TS); B.na.resize(TS); B.nobs.resize(TS); B.a2b.resize((size_t)TS * 5);
         memset(&B.o, 0, sizeof B.o);
@@ -1155,6 +1162,7 @@ int main(int argc, char** argv) {
             if (B.ns < TS) eof = true;
             if (B.ns == 0) break;
             n_sites_total += (size_t)B.ns;
+            PBuf<uint8_t>::device() = devices[B.dev]; PBuf<double>::device() = devices[B.dev];      // dump buffers of this entry: next to its device, like the rest
             if (pile_fp) { B.reads.resize((size_t)pile_cap * TS * N); memset(B.reads.data(), 0xFF, (size_t)pile_cap * B.ns * N); B.o.reads = B.reads.data(); B.o.read_capacity = pile_cap; }   // capacity of the per-read dump: the library stages at most read_cap reads; ask generously
             if (want_errp) { B.errp.resize((size_t)pile_cap * TS * N); B.o.read_errp = B.errp.data(); B.o.read_capacity = pile_cap; }
             if (dump_pick) { B.pick.resize(TS); B.o.site_pick_err = B.pick.data(); }

@@ -835,27 +835,21 @@ extern "C" void* vgl_host_alloc(size_t bytes) {
     if (hipHostMalloc(&p, bytes ? bytes : 1, flags) != hipSuccess) { fail(VGL_E_NOMEM, "hipHostMalloc of %zu bytes failed", bytes); return nullptr; }
     return p;
 }
+extern "C" void* vgl_host_alloc_on(int32_t device, size_t bytes) {
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess || hipSetDevice(device) != hipSuccess) { fail(VGL_E_NODEVICE, "device %d is not available", device); return nullptr; }
+    void* p = vgl_host_alloc(bytes);
+    (void)hipSetDevice(cur);
+    return p;
+}
 extern "C" void vgl_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 // Host buffers in, host buffers out, asynchronously: the tile's kernels are enqueued on the context's compute stream, the copies of
 // its tags back to the host on its copy stream behind them; with two tiles in flight the copies of tile t overlap the kernels of
 // tile t + 1.  Destination buffers from vgl_host_alloc() (pinned) are written by DMA directly; pageable ones work, more slowly.
-extern "C" int vgl_simulate_tile_async(vgl_ctx* c, int64_t site0, int32_t n_sites, const uint8_t* gt, vgl_tile_out* o, int32_t* ticket) {
-    if (!c || !o || !ticket) return fail(VGL_E_ARG, "null argument");
-    if (n_sites < 0 || n_sites > c->max_sites) return fail(VGL_E_ARG, "n_sites %d exceeds max_sites_per_tile %d", n_sites, c->max_sites);
-    if (n_sites > 0 && !gt) return fail(VGL_E_ARG, "null gt");
-    HIPCHK(hipSetDevice(c->device));
-    const int k = c->next_slot;
-    vgl_ctx::HostSlot& S = c->slot[k];
-    if (S.busy) return fail(VGL_E_ARG, "two tiles are already in flight: vgl_tile_wait() the older one first");
-    if (!c->s_compute) { HIPCHK(hipStreamCreateWithFlags(&c->s_compute, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking)); }
-    if (!S.ev_kernels) { HIPCHK(hipEventCreateWithFlags(&S.ev_kernels, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&S.ev_copied, hipEventDisableTiming)); }
+// the fallible part of vgl_simulate_tile_async, from the first enqueue on (its caller cleans up after a failure)
+static int enqueue_host_tile(vgl_ctx* c, vgl_ctx::HostSlot& S, int64_t site0, int32_t n_sites, const uint8_t* gt, vgl_tile_out* o) {
     const size_t N = c->dp.n_samples;
-    if (!S.d_gt) { HIPCHK(hipMalloc((void**)&S.d_gt, (size_t)c->max_sites * N)); HIPCHK(hipHostMalloc((void**)&S.h_gt, (size_t)c->max_sites * N, hipHostMallocDefault));
-                   HIPCHK(hipHostMalloc((void**)&S.h_flag, sizeof(uint32_t), hipHostMallocDefault)); }
-    *ticket = k; c->next_slot = k ^ 1;
-    S.rc = VGL_OK; *S.h_flag = 0;
-    if (n_sites == 0) { S.busy = true; HIPCHK(hipEventRecord(S.ev_copied, c->s_copy)); return VGL_OK; }
     memcpy(S.h_gt, gt, (size_t)n_sites * N);
     HIPCHK(hipMemcpyAsync(S.d_gt, S.h_gt, (size_t)n_sites * N, hipMemcpyHostToDevice, c->s_compute));
     vgl_tile_out d;
@@ -913,6 +907,44 @@ extern "C" int vgl_simulate_tile_async(vgl_ctx* c, int64_t site0, int32_t n_site
     if (d.read_errp && c->dp.error_qs == 2) HIPCHK(hipMemcpyAsync(o->read_errp, d.read_errp, (size_t)o->read_capacity * n_sites * N * sizeof(double), hipMemcpyDeviceToHost, c->s_copy));
     if (d.site_pick_err) HIPCHK(hipMemcpyAsync(o->site_pick_err, d.site_pick_err, (size_t)n_sites * sizeof(double), hipMemcpyDeviceToHost, c->s_copy));
     HIPCHK(hipEventRecord(S.ev_copied, c->s_copy));
+    return VGL_OK;
+}
+
+// Host buffers in, host buffers out, asynchronously: the tile's kernels are enqueued on the context's compute stream, the copies of
+// its tags back to the host on its copy stream behind them; with two tiles in flight the copies of tile t overlap the kernels of
+// tile t + 1.  Destination buffers from vgl_host_alloc() (pinned) are written by DMA directly; pageable ones work, more slowly.
+// The ticket and the slot are committed only when everything is enqueued: after a failure part-way the streams are drained, the
+// sticky device error word is cleared and the slot is free again -- no later tile inherits this one's flags or shares its buffers
+// with work still in flight.
+extern "C" int vgl_simulate_tile_async(vgl_ctx* c, int64_t site0, int32_t n_sites, const uint8_t* gt, vgl_tile_out* o, int32_t* ticket) {
+    if (!c || !o || !ticket) return fail(VGL_E_ARG, "null argument");
+    if (n_sites < 0 || n_sites > c->max_sites) return fail(VGL_E_ARG, "n_sites %d exceeds max_sites_per_tile %d", n_sites, c->max_sites);
+    if (n_sites > 0 && !gt) return fail(VGL_E_ARG, "null gt");
+    HIPCHK(hipSetDevice(c->device));
+    const int k = c->next_slot;
+    vgl_ctx::HostSlot& S = c->slot[k];
+    if (S.busy) return fail(VGL_E_ARG, "two tiles are already in flight: vgl_tile_wait() the older one first");
+    if (!c->s_compute) { HIPCHK(hipStreamCreateWithFlags(&c->s_compute, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking)); }
+    if (!S.ev_kernels) { HIPCHK(hipEventCreateWithFlags(&S.ev_kernels, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&S.ev_copied, hipEventDisableTiming)); }
+    const size_t N = c->dp.n_samples;
+    if (!S.d_gt) HIPCHK(hipMalloc((void**)&S.d_gt, (size_t)c->max_sites * N));
+    if (!S.h_gt) HIPCHK(hipHostMalloc((void**)&S.h_gt, (size_t)c->max_sites * N, hipHostMallocDefault));
+    if (!S.h_flag) HIPCHK(hipHostMalloc((void**)&S.h_flag, sizeof(uint32_t), hipHostMallocDefault));
+    S.rc = VGL_OK; *S.h_flag = 0;
+    if (n_sites == 0) HIPCHK(hipEventRecord(S.ev_copied, c->s_copy));
+    else {
+        const int rc = enqueue_host_tile(c, S, site0, n_sites, gt, o);
+        if (rc != VGL_OK) {
+            char keep[sizeof g_err];
+            memcpy(keep, g_err, sizeof keep);                        // the first error is the one to report
+            (void)hipStreamSynchronize(c->s_compute);
+            (void)hipStreamSynchronize(c->s_copy);
+            (void)hipMemset(c->d_errflag, 0, sizeof(uint32_t));
+            memcpy(g_err, keep, sizeof keep);
+            return rc;
+        }
+    }
+    *ticket = k; c->next_slot = k ^ 1;
     S.busy = true;
     return VGL_OK;
 }
