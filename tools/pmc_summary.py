@@ -45,8 +45,13 @@ for k, v in out.items():
         # busy cycles are value / 8 and each XCD holds 128 SIMDs.  Both counters come from the SAME pass (GRBM has its own two
         # slots beside the SQ's eight: tools/profile_round.sh), i.e. the same launches at the same clock -- round 2 divided by
         # the GRBM count of another pass, and short launches (k_depth, 0.7 ms) then read above 1.
-        v["valu_busy_frac"] = 4.0 * v["SQ_ACTIVE_INST_VALU"] / (128.0 * v["GRBM_GUI_ACTIVE"])
-        traffic.setdefault(k.split("<")[0], {})["valu_busy_frac"] = v["valu_busy_frac"]
+        # SQ_ACTIVE_INST_VALU turns out to be one quad per VALU instruction (it tracks SQ_INSTS_VALU within 4 % on every kernel
+        # here): the quotient is "VALU instructions x 4 cycles / SIMD cycles", an ISSUE-SLOT estimate.  The part issues its
+        # two-operand 32-bit forms in about 2.6 cycles (tools/valu_rates.hip), so a kernel made of those (k_depth, the fixed-score
+        # k_sample) reads above 1: the raw value is kept, the fraction is capped at 1.
+        v["valu_issue_slots_at_4_cycles"] = 4.0 * v["SQ_ACTIVE_INST_VALU"] / (128.0 * v["GRBM_GUI_ACTIVE"])
+        v["valu_busy_frac"] = min(1.0, v["valu_issue_slots_at_4_cycles"])
+        traffic.setdefault(k.split("<")[0], {}).update({"valu_busy_frac": v["valu_busy_frac"], "valu_issue_slots_at_4_cycles": v["valu_issue_slots_at_4_cycles"]})
     if "SQ_ACTIVE_INST_VALU" in v and v.get("SQ_WAVE_CYCLES"):
         # the kernel's own denominator: share of its wavefronts' resident cycles in which a VALU instruction of theirs was executing
         v["valu_active_share_of_wave_cycles"] = v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"]
