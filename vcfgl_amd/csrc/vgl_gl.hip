@@ -77,14 +77,15 @@ __device__ __forceinline__ float f32_missing() { return __uint_as_float(F32_MISS
 __device__ __forceinline__ int nib(uint32_t v, int k) { return (int)((v >> (4 * k)) & 0xF); }
 // PL of one likelihood (vcfgl.cpp:907-939)
 // lroundf(-10.0 * gl) capped at MAXPL, MAXPL for gl = -inf.  The double product of a float and -10 is exact, so its conversion to
-// float is the float product x; gl <= 0 (the maximum has been subtracted), so x >= 0 and lroundf(x) = trunc(x) + (x - trunc(x) >= 0.5)
-// (the difference is exact); x = +inf gives NaN in the compare (false) and +inf in the sum, which the cap takes.  Branch-free.
+// float is the float product x; gl <= 0 (the maximum has been subtracted), so x >= 0 and lroundf(x) = floor(x + 0.5).  In float32
+// trunc(x + 0.5f) equals that for EVERY x in [0, 255] except x = 0.5 - 2^-25 (the sum rounds up to 1), which one compare puts right
+// (checked over all 1.1e9 float32 values of the range; x = -10 gl does reach that value, for gl = -0x1.999998p-5); capping x at 255
+// first takes x = +inf (gl = -inf) and keeps the conversion in range.  Branch-free, seven instructions.
 __device__ __forceinline__ uint32_t pl_of(const float v, const bool valid) {
-    const float x = v * -10.0f;
-    const float t = truncf(x);
-    float r = t + (((x - t) >= 0.5f) ? 1.0f : 0.0f);
-    r = __builtin_fminf(r, (float)MAXPL);
-    return valid ? (uint32_t)(int32_t)r : (uint32_t)I32_MISSING;
+    const float x = __builtin_fminf(v * -10.0f, (float)MAXPL);
+    uint32_t r = (uint32_t)(int32_t)(x + 0.5f);
+    r -= (x == 0x1.fffffep-2f) ? 1u : 0u;
+    return valid ? r : (uint32_t)I32_MISSING;
 }
 // log10(x) for 0 < x <= 1 (--precise-gl 1: three per read, gl_methods.cpp:171-220), relative error < 1e-15 -- the mode is held to 1e-6,
 // like the device log10() it replaces: x = m 2^e with m in [sqrt(1/2), sqrt(2)), ln m = 2 atanh((m - 1) / (m + 1)) by its series up to
@@ -169,15 +170,20 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
     // ---- depth of the evaluation this thread would own in natural order
     int dp0 = -1;                                                      // -1: no evaluation (padding lane)
     int k0 = 1;                                                        // GL model 2: distinct bases among its reads
-    int ls0 = 0, s0 = N;
+    // In natural order a wavefront is 64 consecutive samples of ONE site: its site, first sample and site record are wave-uniform
+    // and are kept in scalar registers (the compiler cannot see that tid >> 6 is uniform), so that the natural-order loads and the
+    // epilogue's stores address memory as scalar base + lane offset and the allele table is decoded by scalar instructions
+    int ls0 = 0, sb0 = 0, s0 = N;
     uint64_t a = 0;                                                    // its per-base depths (kept for the epilogue, which runs in natural order)
     {
-        const uint32_t w = bx * (uint32_t)WPB + (uint32_t)(tid >> 6);
+        const int wv_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const uint32_t w = bx * (uint32_t)WPB + (uint32_t)wv_s;
         if (w < nwaves) {
-            int sb; wave_site(tid >> 6, ls0, sb);
-            s0 = sb + (tid & 63);
+            wave_site(wv_s, ls0, sb0);
+            ls0 = __builtin_amdgcn_readfirstlane(ls0); sb0 = __builtin_amdgcn_readfirstlane(sb0);
+            s0 = sb0 + (tid & 63);
             if (s0 < N) {
-                a = T.ad4[(size_t)ls0 * N + s0];
+                a = T.ad4[(size_t)ls0 * N + (size_t)sb0 + (size_t)(tid & 63)];
                 dp0 = (int)((a & 0xFFFF) + ((a >> 16) & 0xFFFF) + ((a >> 32) & 0xFFFF) + ((a >> 48) & 0xFFFF));
                 if (dp0 > 1023) dp0 = 1023;
                 if (GLM == 2) k0 = (int)((a & 0xFFFFULL) != 0) + (int)(((a >> 16) & 0xFFFF) != 0) + (int)(((a >> 32) & 0xFFFF) != 0) + (int)((a >> 48) != 0);
@@ -225,7 +231,9 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
     const int lane = tid & 63;
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t w = bx * (uint32_t)WPB + (uint32_t)(otid >> 6);
-    const VglSiteInfo si_n = T.sinfo[ls0];                             // the natural evaluation's site (epilogue); in flight during the loop
+    VglSiteInfo si_n = T.sinfo[ls0];                                   // the natural evaluation's site (epilogue): wave-uniform
+    si_n.status = __builtin_amdgcn_readfirstlane(si_n.status); si_n.n_alleles = __builtin_amdgcn_readfirstlane(si_n.n_alleles);
+    si_n.alleles2acgt = (uint32_t)__builtin_amdgcn_readfirstlane((int)si_n.alleles2acgt);
     int ls = 0, s = N;
     if (w < nwaves) { int sb; wave_site(otid >> 6, ls, sb); s = sb + (otid & 63); }
     const bool live = s < N;
@@ -558,9 +566,8 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
     const bool sm = P.out_layout == 1;                                   // VGL_LAYOUT_SAMPLE_MAJOR
     const int wv = tid >> 6;
     const uint32_t wb = 64u * (uint32_t)wv;
-    int ls_w = 0, sb_w = 0;
-    const bool wave_ok = bx * (uint32_t)WPB + (uint32_t)wv < nwaves;
-    if (wave_ok) wave_site(wv, ls_w, sb_w);
+    const int ls_w = ls0, sb_w = sb0;                                    // (scalar: the natural-order wavefront's site and first sample)
+    const bool wave_ok = bx * (uint32_t)WPB + (uint32_t)__builtin_amdgcn_readfirstlane(wv) < nwaves;
     const uint32_t nv = wave_ok ? (uint32_t)((N - sb_w) < 64 ? (N - sb_w) : 64) : 0u;       // samples of this wavefront's chunk
     const uint32_t nG0u = (uint32_t)__builtin_amdgcn_readfirstlane(nG0), nA0u = (uint32_t)__builtin_amdgcn_readfirstlane(nA0);
 #define VGL_WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
@@ -568,7 +575,7 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
     do {                                                                                                 \
         uint32_t* const base_ = (uint32_t*)(BASE);                                                       \
         if (base_ && !sm) {                                                                              \
-            if (live0) { _Pragma("unroll") for (int i = 0; i < (KMAX); ++i) base_[((size_t)ls0 * (KMAX) + i) * N + s0] = (EXPR); } \
+            if (live0) { _Pragma("unroll") for (int i = 0; i < (KMAX); ++i) base_[((size_t)ls0 * (KMAX) + i) * N + (size_t)sb0 + (size_t)lane] = (EXPR); } \
         } else if (base_) {                                                                              \
             const uint32_t nk_ = (NK);                                                                   \
             _Pragma("unroll") for (int i = 0; i < (KMAX); ++i)                                           \
@@ -591,7 +598,7 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
 #pragma unroll
                 for (int i = 0; i < NG; ++i) {
                     const uint32_t v = pl_of(acc[i], sample_ok && i < nG0);
-                    T.pl_u8[((size_t)ls0 * NG + i) * N + s0] = (uint8_t)(v > 255u ? 255u : v);
+                    T.pl_u8[((size_t)ls0 * NG + i) * N + (size_t)sb0 + (size_t)lane] = (uint8_t)(v > 255u ? 255u : v);
                 }
             }
         } else {
@@ -630,7 +637,7 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
         VGL_PUT(T.gp, NG, nG0u, __float_as_uint((sample_ok && i < nG0) ? acc[i] / sum_gps : MISS));
     }
     if (T.fmt_ad || T.fmt_adf || T.fmt_adr) {
-        const uint64_t adf4 = (P.need_adf && live0) ? T.adf4[(size_t)ls0 * N + s0] : a;
+        const uint64_t adf4 = (P.need_adf && live0) ? T.adf4[(size_t)ls0 * N + (size_t)sb0 + (size_t)lane] : a;
         VGL_PUT(T.fmt_ad, A, nA0u, (uint32_t)cnt_of(a, (have0 && i < nA0) ? nib(si_n.alleles2acgt, i) : 0xF));
         VGL_PUT(T.fmt_adf, A, nA0u, (uint32_t)cnt_of(adf4, (have0 && i < nA0) ? nib(si_n.alleles2acgt, i) : 0xF));
         VGL_PUT(T.fmt_adr, A, nA0u, (uint32_t)(cnt_of(a, (have0 && i < nA0) ? nib(si_n.alleles2acgt, i) : 0xF) - cnt_of(adf4, (have0 && i < nA0) ? nib(si_n.alleles2acgt, i) : 0xF)));

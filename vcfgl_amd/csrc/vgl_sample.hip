@@ -402,7 +402,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                         // quality scores are taken from it by the dense pass after the loop
                         *(lds_u32*)(uintptr_t)(576u + (uint32_t)k) = __float_as_uint(qs_stage_pf(gx_prev, val));   // l_it[item]
                         if (DEFER) { if (redo) *(lds_u32*)(uintptr_t)(576u + (uint32_t)k) = 0x7FC00000u; }        // NaN: undecided for the dense pass
-                        if (PREC) { T.errp[(size_t)((it_m >> 4) & 0x3FF) * plane + ev0 + (it_m >> 26)] = (DEFER ? div_inrange(gx_prev, gx_prev + val) : gx_prev / (gx_prev + val)); it_m = m_n; }   // DEFER: both shape parameters >= 8, the operands are far from the exponent limits
+                        if (PREC) {
+                            // read index x plane as ONE 32 x 32 -> 64-bit multiply-add (the tile has fewer than 2^32 evaluations: vgl_launch_sample)
+                            const uint64_t ei = (uint64_t)((it_m >> 4) & 0x3FFu) * (uint64_t)(uint32_t)plane + (uint64_t)(ev0 + (it_m >> 26));
+                            T.errp[ei] = (DEFER ? div_inrange(gx_prev, gx_prev + val) : gx_prev / (gx_prev + val));   // DEFER: both shape parameters >= 8, the operands are far from the exponent limits
+                            it_m = m_n;
+                        }
                         // the lane adopts kn and claims the next unclaimed item from the wave's counter (any assignment of
                         // items to lanes gives the same result)
                         st = st_n;
@@ -614,6 +619,7 @@ __global__ __launch_bounds__(64) void k_redo(const VglDevParams P, const VglTile
 extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
     const int64_t waves = (int64_t)t->n_sites * p->chunks;
     if (waves == 0) return 0;
+    if ((int64_t)t->n_sites * p->n_samples >= (1LL << 32)) return (int)hipErrorInvalidValue;     // evaluation indices of a tile are 32-bit in places
     if (p->serial) return vgl_launch_sample_serial(p, t, stream);
     const bool dbg = t->dbg != nullptr;                         // VGL_DEBUG_STAMPS / VGL_DEBUG_PHASE
     // wavefronts never cooperate here, and a workgroup's wave slots and LDS are only handed on when its last
