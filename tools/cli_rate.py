@@ -24,7 +24,10 @@ with open(vcf, "w") as f:
         f.write("chr1\t%d\t.\t0\t1\t.\tPASS\t.\tGT\t" % (i + 1) + "\t".join(tok[idx]) + "\n")
 print(f"input: {S} sites x {N} samples, {os.path.getsize(vcf) / 1e6:.1f} MB of VCF text")
 flags = "--seed 42 --depth 20 -e 0.01 --error-qs 2 --beta-variance 1e-5 -GL 2".split() + os.environ.get("CLI_EXTRA", "").split()   # e.g. CLI_EXTRA="--devices 0,0 --tile-sites 8192"
-for mode, threads in (("v", 0), ("v", 1), ("u", 0), ("u", 1), ("u", 16), ("b", 0), ("b", 1), ("b", 64)):
+runs = (("v", 0), ("v", 1), ("u", 0), ("u", 1), ("u", 16), ("b", 0), ("b", 1), ("b", 64))
+if os.environ.get("CLI_MODES"):                              # e.g. CLI_MODES="u:0,u:16"
+    runs = tuple((m.split(":")[0], int(m.split(":")[1])) for m in os.environ["CLI_MODES"].split(","))
+for mode, threads in runs:
     out = os.path.join(d, f"o_{mode}{threads}")
     t0 = time.perf_counter()
     th = ["--threads", str(threads)] if threads else []          # 0: not given (the program's default: up to 8 internal threads)
