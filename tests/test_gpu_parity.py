@@ -439,6 +439,16 @@ def test_deferred_reads_are_redrawn_by_k_redo(oracle, monkeypatch, every, cap, d
     assert_parity(want, got, check_gp=False)
 
 
+@pytest.mark.parametrize("mean,var,depth", [(0.2, 0.032, 40), (0.05, 0.03, 120), (0.001, 5e-7, 25), (0.3, 0.15, 200), (0.02, 1e-4, 7)])
+def test_gl1_per_read_scores_over_several_quality_windows(oracle, mean, var, depth):
+    """k_gl<.,1> with per-read scores sorts each lane's reads by counting over windows of 16 quality values from the wavefront's
+    top score down: beta shapes whose scores spread over the whole range [4, 63] (several windows per wavefront, bins with many
+    reads, scores below errmod's clamp at 4), deep pileups (counts up to the depth), a narrow high-quality shape (one window)"""
+    args = VcfglArgs(seed=17, depth=depth, error_rate=mean, error_qs=2, beta_variance=var, gl_model=1, add_pl=1, add_fmt_ad=1)
+    want, got = run_both(oracle, args, synth.acgt_sites(8, 150, seed=21, missing=0.03), site0=40)
+    assert_parity(want, got, check_gp=False)
+
+
 @pytest.mark.parametrize("var", [1e-9, 1e-12])
 def test_error_qs2_very_large_shape_parameters(oracle, var):
     """beta shape parameters of 1e4 .. 1e10 (--beta-variance 1e-9 / 1e-12): the gamma sampler's second test compares
