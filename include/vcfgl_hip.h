@@ -23,8 +23,11 @@
  * consecutive samples of one site reads and writes contiguous 256-byte segments):
  *
  *     per (site, sample) scalar      x[site * n_samples + sample]
- *     per (site, k, sample) plane    x[(site * K + k) * n_samples + sample]
+ *     per (site, k, sample) plane    x[(site * K + k) * n_samples + sample]      (VGL_LAYOUT_PLANES, the default)
  *     per site vector                x[site * K + k]
+ *
+ * With vgl_params.out_layout = VGL_LAYOUT_SAMPLE_MAJOR (ABI 4) the multi-valued FORMAT arrays come back as the reference
+ * itself keeps them (simRecord::gl_arr etc., bcf_utils.h:193-196), one slab per site: see VGL_LAYOUT_* below.
  */
 #ifndef VCFGL_HIP_H
 #define VCFGL_HIP_H
