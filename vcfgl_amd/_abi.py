@@ -79,7 +79,8 @@ _LIB = None
 
 
 def library_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libvcfgl_hip.so")
+    # VGL_LIB: another build of the same library (A/B timing of kernel variants: tools/ab_build.sh)
+    return os.environ.get("VGL_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libvcfgl_hip.so")
 
 
 def load_library():

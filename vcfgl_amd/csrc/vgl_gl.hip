@@ -176,11 +176,11 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
     int ls0 = 0, sb0 = 0, s0 = N;
     uint64_t a = 0;                                                    // its per-base depths (kept for the epilogue, which runs in natural order)
     {
-        const int wv_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int wv_s = (GLM == 2) ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
         const uint32_t w = bx * (uint32_t)WPB + (uint32_t)wv_s;
         if (w < nwaves) {
             wave_site(wv_s, ls0, sb0);
-            ls0 = __builtin_amdgcn_readfirstlane(ls0); sb0 = __builtin_amdgcn_readfirstlane(sb0);
+            if (GLM == 2) { ls0 = __builtin_amdgcn_readfirstlane(ls0); sb0 = __builtin_amdgcn_readfirstlane(sb0); }   // (measured: the GL model 1 kernel is 8 % slower with it)
             s0 = sb0 + (tid & 63);
             if (s0 < N) {
                 a = T.ad4[(size_t)ls0 * N + (size_t)sb0 + (size_t)(tid & 63)];
@@ -231,9 +231,7 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
     const int lane = tid & 63;
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t w = bx * (uint32_t)WPB + (uint32_t)(otid >> 6);
-    VglSiteInfo si_n = T.sinfo[ls0];                                   // the natural evaluation's site (epilogue): wave-uniform
-    si_n.status = __builtin_amdgcn_readfirstlane(si_n.status); si_n.n_alleles = __builtin_amdgcn_readfirstlane(si_n.n_alleles);
-    si_n.alleles2acgt = (uint32_t)__builtin_amdgcn_readfirstlane((int)si_n.alleles2acgt);
+    const VglSiteInfo si_nv = T.sinfo[ls0];                            // the natural evaluation's site (epilogue); in flight during the loop
     int ls = 0, s = N;
     if (w < nwaves) { int sb; wave_site(otid >> 6, ls, sb); s = sb + (otid & 63); }
     const bool live = s < N;
@@ -525,6 +523,11 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
     // a plane and no tag needs a transposition of its own.
     __syncthreads();
     const bool live0 = (bx * (uint32_t)WPB + (uint32_t)(tid >> 6) < nwaves) && (s0 < N);
+    VglSiteInfo si_n;                                                    // wave-uniform: to scalar registers, here where it is first needed
+    if (GLM == 2) {
+        si_n.status = __builtin_amdgcn_readfirstlane(si_nv.status); si_n.n_alleles = __builtin_amdgcn_readfirstlane(si_nv.n_alleles);
+        si_n.alleles2acgt = (uint32_t)__builtin_amdgcn_readfirstlane((int)si_nv.alleles2acgt); si_n.acgt2alleles = 0;
+    } else si_n = si_nv;
     const int nA0 = si_n.n_alleles, nG0 = nA0 * (nA0 + 1) / 2;
     const bool have0 = (si_n.status == SITE_OK);
     const int dpn = (int)((a & 0xFFFF) + ((a >> 16) & 0xFFFF) + ((a >> 32) & 0xFFFF) + ((a >> 48) & 0xFFFF));
