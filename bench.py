@@ -279,23 +279,28 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
             reduce_site_counters(to_transport(out["site_status"]), world, always_collective=True)
             torch.cuda.synchronize()
             comm["gather_s"] += time.perf_counter() - t_c
-            if gather == "sample":
-                # the RECORD gather north_star names, on a sample: the packed records of this rank's last tile travel to the
-                # writer (point to point, one xGMI link per peer), timed on its own so that the link rate is on record without
-                # moving the whole step's 65 GB per GPU through one writer
-                s0, n, _ = structs[-1]
-                with torch.cuda.stream(stream):
-                    p = pack_records({k: v[s0:s0 + n] for k, v in out.items()}, site0=site_base + s0)
-                stream.synchronize()
-                t_c = time.perf_counter()
-                with torch.cuda.stream(stream):
-                    got = gather_records(p, world, rank, transport=transport, always_collective=True)
-                stream.synchronize()
-                torch.cuda.synchronize()
-                comm["sample_s"] += time.perf_counter() - t_c
-                comm["sample_packed_bytes"] += p.nbytes()
-                if got is not None:
-                    comm["sample_bytes"] += sum(q.nbytes() for q in got[1:])      # bytes that crossed a link into the writer
+
+    def sampled_record_gather():
+        """the RECORD gather north_star names, on a sample and OUTSIDE the timed steps: the packed records of this rank's last tile
+        travel to the writer (point to point, one xGMI link per peer), so that the link rate is on record without moving the whole
+        step's 65 GB per GPU through one writer.  Twice; the second pass is the one reported."""
+        s0, n, _ = structs[-1]
+        for rep in range(2):
+            with torch.cuda.stream(stream):
+                p = pack_records({k: v[s0:s0 + n] for k, v in out.items()}, site0=site_base + s0)
+            stream.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t_c = time.perf_counter()
+            with torch.cuda.stream(stream):
+                got = gather_records(p, world, rank, transport=transport, always_collective=True)
+            stream.synchronize()
+            torch.cuda.synchronize()
+            dist.barrier()
+            comm["sample_s"] = time.perf_counter() - t_c
+            comm["sample_packed_bytes"] = p.nbytes()
+            comm["sample_bytes"] = sum(q.nbytes() for q in got[1:]) if got is not None else 0      # bytes that crossed a link into the writer
+            del p, got
 
     def barrier():
         stream.synchronize()
@@ -325,6 +330,8 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev if transport is None else transport)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        if gather == "sample":
+            sampled_record_gather()
 
     res = None
     if rank == 0:
@@ -378,10 +385,14 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
                            "gather_ms": comm["gather_s"] / steps * 1e3,
                            "gather_note": "per step on the writer: gather of the per-site record index (status, allele count) + all-reduce of the site counters"}
             if gather == "sample" and comm["sample_s"] > 0:
-                res["comm"].update({"records_sample_ms": comm["sample_s"] / steps * 1e3, "records_sample_bytes_into_writer": comm["sample_bytes"] / steps,
-                                    "records_sample_GBps": comm["sample_bytes"] / comm["sample_s"] / 1e9,
-                                    "records_sample_note": f"packed records of one {structs[-1][1]}-site tile per rank and step, point to point to rank 0 "
-                                                           f"({comm['sample_packed_bytes'] / steps / 1e9:.2f} GB packed per rank); inside the timed region"})
+                gbps = comm["sample_bytes"] / comm["sample_s"] / 1e9
+                full_bytes = b_eval * float(S) * N * (world - 1)            # what a full record gather would move into the writer per step (upper bound: unpacked size)
+                res["comm"].update({"records_sample_ms": comm["sample_s"] * 1e3, "records_sample_bytes_into_writer": comm["sample_bytes"],
+                                    "records_sample_GBps": gbps,
+                                    "full_record_gather_s_per_step_at_that_rate": (full_bytes / 1e9 / gbps) if gbps > 0 else None,
+                                    "records_sample_note": f"packed records of one {structs[-1][1]}-site tile per rank ({comm['sample_packed_bytes'] / 1e9:.2f} GB), point to point "
+                                                           "to rank 0, measured once AFTER the timed steps (not part of `value`; --gather records puts every tile's "
+                                                           "records inside the timed steps)"})
         if dist is not None and gather == "records":
             res["records_gather"] = {"bytes_per_step_at_writer": gathered_bytes[0] / steps, "GBps_into_writer": gathered_bytes[0] / dt / 1e9}
         if name == opt.workload and not opt.no_pack_rate:
