@@ -464,6 +464,16 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(const uint32_t x) {
     return v;
 }
 
+// the four 16-bit per-base depths of the wavefront's 64 evaluations (ad4: A | C << 16 | G << 32 | T << 48, each at most read_cap <= 1023, so
+// that a field's sum over the wavefront, at most 65 472, stays inside its 16 bits) summed by TWO 32-bit DPP scans (wave_incl_scan_u32:
+// seven adds each, the total in lane 63) -- the nine separate ds_bpermute reductions of rounds 1-2 were 160 vector instructions per
+// wavefront, a tenth of the fixed-score k_sample.  Wave-uniform results.
+__device__ __forceinline__ void wave_sum_ad4(const uint64_t ad4, int out[4]) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32((uint32_t)ad4), 63);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32((uint32_t)(ad4 >> 32)), 63);
+    out[0] = (int)(lo & 0xFFFFu); out[1] = (int)(lo >> 16); out[2] = (int)(hi & 0xFFFFu); out[3] = (int)(hi >> 16);
+}
+
 // sample_read_base() on states carried shifted left by 16 bits: 64-bit wraparound is then the generator's mod 2^48 (no masking
 // per step), u < 0.5 is the sign bit, floor(4u) the top two bits.  err_thresh16 = err_thresh << 16, saturated (sample_thresh16).
 __device__ __forceinline__ uint64_t lcg_next16(const uint64_t x) { return x * VGL_LCG_A + (VGL_LCG_C << 16); }

@@ -538,12 +538,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
     }
 
     // ---- per-site sums: wave reduction, one atomic per wave and counter
+    // every read of an evaluation shows one base: INFO/DP is the sum of the four per-base totals; without strand draws every read is "forward"
     int v[9];
-    v[0] = dp;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) { v[1 + b] = (int)((ad4 >> (16 * b)) & 0xFFFF); v[5 + b] = (int)((adf4 >> (16 * b)) & 0xFFFF); }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) v[k] = wave_sum(v[k]);
+    wave_sum_ad4(ad4, &v[1]);
+    if (k_strand) wave_sum_ad4(adf4, &v[5]);
+    else { v[5] = v[1]; v[6] = v[2]; v[7] = v[3]; v[8] = v[4]; }
+    v[0] = v[1] + v[2] + v[3] + v[4];
     if (lane == 0) {
         int32_t* acc = T.acc + (size_t)ls * VGL_ACC_STRIDE;
 #pragma unroll

@@ -403,12 +403,12 @@ __global__ __launch_bounds__(256) void k_sample_serial(const VglDevParams P, con
         }
         if (T.reads_out) for (int r = dp; r < T.reads_out_cap; ++r) T.reads_out[(size_t)r * plane + ev] = 0xFF;
     }
+    // every read of an evaluation shows one base: INFO/DP is the sum of the four per-base totals; without strand draws every read is "forward"
     int v[9];
-    v[0] = dp;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) { v[1 + b] = (int)((ad4 >> (16 * b)) & 0xFFFF); v[5 + b] = (int)((adf4 >> (16 * b)) & 0xFFFF); }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) v[k] = wave_sum(v[k]);
+    wave_sum_ad4(ad4, &v[1]);
+    if ((P.sample_strand != 0)) wave_sum_ad4(adf4, &v[5]);
+    else { v[5] = v[1]; v[6] = v[2]; v[7] = v[3]; v[8] = v[4]; }
+    v[0] = v[1] + v[2] + v[3] + v[4];
     if (lane == 0) {
         int32_t* acc = T.acc + (size_t)ls * VGL_ACC_STRIDE;
 #pragma unroll
