@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     bool fwd;
                     const int r_base = sample_read_base16(st_hap16, st_base16, a0, a1, err_thresh16, k_strand, fwd);
                     rw |= ((q_gl << 2) | (uint32_t)r_base) << (8 * j);
-                    if (T.reads_out && r < T.reads_out_cap) T.reads_out[(size_t)r * plane + ev] = (uint8_t)((q_i << 2) | r_base);
+                    if (!LEAN) { if (T.reads_out && r < T.reads_out_cap) T.reads_out[(size_t)r * plane + ev] = (uint8_t)((q_i << 2) | r_base); }
                     const uint64_t one = 1ULL << (16 * r_base);
                     ad4 += one;
                     if (k_strand) { if (fwd) adf4 += one; }               // without strand draws adf4 = ad4 (set after the loops)
@@ -665,8 +665,10 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
         }
         else { if (lean) VGL_LAUNCH_SAMPLE(2, false, false, 1, lds); else VGL_LAUNCH_SAMPLE(2, false, false, 0, lds); }
     }
-    else if (p->error_qs == 1) VGL_LAUNCH_SAMPLE(1, false, false, 0, 0);
-    else VGL_LAUNCH_SAMPLE(0, false, false, 0, 0);
+    // fixed quality score: the LEAN build (no strand draws, forward-strand depths, quality sums or per-read dump) keeps those
+    // options' per-read instructions out of the read loop
+    else if (p->error_qs == 1) { if (lean) VGL_LAUNCH_SAMPLE(1, false, false, 1, 0); else VGL_LAUNCH_SAMPLE(1, false, false, 0, 0); }
+    else { if (lean) VGL_LAUNCH_SAMPLE(0, false, false, 1, 0); else VGL_LAUNCH_SAMPLE(0, false, false, 0, 0); }
 #undef VGL_LAUNCH_SAMPLE
     return (int)hipGetLastError();
 }
