@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_bound_sweep(const uint32_t lo, const un
             if (!(fabsf(exf) >= 0x1p-126f)) { --n; continue; }
             acc_update(mr, arg, viol, fabs((double)r - ex), fabs(ex) * 0x1p-23, bits);
         } else if (MODE == VGL_BOUND_TANF) {
-            const float yf = tanf(x);
+            const float yf = vgl_tanf_0pi(x);
             const float y2 = yf * yf;
             // half of the second term of tanf_err_bound belongs to the rounding of a to af
             const double bound = (double)(fabsf(yf) * 0x1p-21f) + (double)((1.0f + y2) * x * 0x1p-24f);

@@ -125,6 +125,22 @@ static __device__ int poisson_draw(const VglPois& p, uint64_t& st, const double*
 // Flat loop: one attempt per iteration for every lane that has not accepted yet.
 // The bounds themselves are the helpers below; tests/test_gpu_bounds.py sweeps every float32 argument of each
 // hardware function on the device and asserts them (vgl_bounds.hip), so a toolchain change that moves one fails the suite.
+// tan(a) for a float a in (0, pi] (the rejection sampler's tan(PI u)), in float32: quadrant n = rint(a 2/pi) in {0, 1, 2}, r = a - n pi/2 by a
+// two-constant reduction (a - n hi is exact for these n; the smallest |r| next to the pole is 4.4e-8, kept to 2^-24 relative), tan r =
+// r + r^3 P(r^2) on [-pi/4, pi/4] (the classic degree-6 minimax in r^2), -1 / tan r (v_rcp_f32, 1 ulp) in the odd quadrant.  About 20
+// instructions; the general-argument library tanf spends 80 on its branch-free large-argument reduction, which no argument here needs.
+// Error against tan(a): asserted below 4 ulp + the argument term by tests/test_gpu_bounds.py over EVERY float32 of the range.
+__device__ __forceinline__ float vgl_tanf_0pi(const float a) {
+    const float n = __builtin_rintf(a * 0.63661977f);
+    float r = __builtin_fmaf(n, -1.57079637f, a);                     // (float)(pi/2)
+    r = __builtin_fmaf(n, 4.37113883e-8f, r);                          // pi/2 = 1.57079637 - 4.37113883e-8
+    const float z = r * r;
+    float p = 9.38540185543e-3f;
+    p = __builtin_fmaf(p, z, 3.11992232697e-3f); p = __builtin_fmaf(p, z, 2.44301354525e-2f); p = __builtin_fmaf(p, z, 5.34112807005e-2f);
+    p = __builtin_fmaf(p, z, 1.33387994085e-1f); p = __builtin_fmaf(p, z, 3.33331568548e-1f);
+    const float t = __builtin_fmaf(p * z, r, r);
+    return (n == 1.0f) ? -__builtin_amdgcn_rcpf(t) : t;
+}
 // |tanf(af) - tan(a)| for af = (float)a: 4 ulp of the result + the argument's rounding (half of the second term) through tan' = 1 + y^2
 __device__ __forceinline__ float tanf_err_bound(const float yf, const float y2, const float af) {
     return fabsf(yf) * 0x1p-21f + (1.0f + y2) * af * 0x1p-23f;
@@ -139,7 +155,7 @@ __device__ __forceinline__ void poisson_attempt(const VglPois& p, const uint64_t
                                                 const double* __restrict__ glt, const int glt_n, bool& neg, bool& rej, double& em) {
     const double a = VGL_PI * u01(st1);
     const float af = (float)a;
-    const float yf = tanf(af);
+    const float yf = vgl_tanf_0pi(af);
     const float y2 = yf * yf;
     const float dy = tanf_err_bound(yf, y2, af);                             // |yf - tan(a)|
     const double e0 = p.sq * (double)yf + p.lm;
