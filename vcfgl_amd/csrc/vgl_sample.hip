@@ -146,9 +146,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
             VglPois pc = P.pois0;
             if (P.per_sample_depth) pc = P.pois[s];
             if (DM == 2) {                                               // rng.h:289-299
-                double em = -1.0, t = 1.0;
-                do { ++em; t *= next_u(st_depth); } while (t > pc.g);
-                n = (int)em;
+                // the product method's loop on a state carried shifted by 4 (lcg_next52r / bits_1xxx_52r: no mask and no 64-bit shift
+                // per uniform, the same 48 bits in the mantissa as u01())
+                double t = 1.0;
+                int em = -1;
+                uint64_t s52 = st_depth << 4;
+                uint32_t k3ff = 0x3FF00000u;
+                asm volatile("" : "+v"(k3ff));
+                do { ++em; s52 = lcg_next52r(s52); t *= bits_1xxx_52r(s52, k3ff) - 1.0; } while (t > pc.g);
+                n = em;
             } else n = poisson_draw_fast(pc, st_depth, P.gamma_ln_tab, P.gamma_ln_n);
         }
         const uint32_t g = T.gt[ev];
