@@ -149,9 +149,10 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
     const int N = P.n_samples;
     const int tid = threadIdx.x;
     if (GLM == 2 && !PREC) {
-        if (P.error_qs == 2)
+        if (P.error_qs == 2) {                                          // the per-quality terms of the read loop, in LDS
             for (int i = tid; i < 3 * QL; i += WG) s_q2gl[i] = P.q2gl[(i / QL) * 257 + (i % QL)];
-        __syncthreads();
+            if (!P.gl_sort) __syncthreads();                            // (with the sort, its barriers stand between these stores and the loop)
+        }
     }
     const uint32_t nwaves = (uint32_t)T.n_sites * (uint32_t)P.chunks;                   // < 2^31 (checked by the launcher)
     const uint32_t bx = P.xcd_map ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x;     // logical workgroup (XCD-contiguous)
