@@ -83,3 +83,24 @@ def test_two_ranks_on_one_gpu_gather_the_records_of_the_hip_path(oracle):
         for ref in (whole, want_o):
             want = ref.numpy(f)[kept]
             assert np.array_equal(got.view(np.int32) if got.dtype == np.float32 else got, want.view(np.int32) if want.dtype == np.float32 else want), f
+
+
+@pytest.mark.timeout(600)
+def test_bench_two_ranks_on_one_gpu_prints_a_self_describing_line():
+    """`bench.py --gpus 2 --share-gpu --backend gloo`: the launcher starts two ranks, both simulate their site range on the one GPU,
+    the index gather / counter all-reduce run inside the timed steps and the sampled record gather after them; rank 0 prints ONE
+    line that says what ran (n_gpus, the process group's size and backend, the comm block) -- the rehearsal of the driver's SCALE run"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo", "--sites", "8192", "--tile-sites", "4096",
+                        "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--no-pack-rate"], env=env, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_world"] == 2 and d["config"]["backend"].startswith("gloo") and d["config"]["gather"] == "sample"
+    assert d["scaling"] == "weak" and d["value"] > 0 and d["roofline"]["frac"] > 0
+    c = d["comm"]
+    assert c["world"] == 2 and c["gather_ms"] > 0 and c["records_sample_bytes_into_writer"] > 0 and c["records_sample_GBps"] > 0
+    assert "AFTER the timed steps" in c["records_sample_note"]
