@@ -14,6 +14,7 @@ pools) are reached through volume, not only through debug hooks:
   gl1q     -GL 1 --error-qs 2, 1e7: k_gl<.,1> with per-read scores
   eqs1     --error-qs 1 (one beta deviate per site), 1e7
   fixedq   --error-qs 0 with strand tags, 1e7: k_sample<0> with strand draws, k_depth
+  c3sm     c3's flags + PL, VGL_LAYOUT_SAMPLE_MAJOR slabs and pl_u8 (ABI 4), multi-allelic input, 1e7: k_gl's sample-major stores
 
 The site ranges start far from 0 (absolute site indexing: the same values the full job produces there).  Integer fields, and GL
 wherever its per-read terms come from the qScore LUT or constants, must be EQUAL.  Where the device evaluates a logarithm or a
@@ -57,6 +58,8 @@ CASES = {
                  flags=dict(depth=20.0, gl_model=1, add_pl=1, **EQS2)),
     "eqs1": dict(N=1000, S=10_000, site0=13_000_000, gt="binary", fields=BASE + ["pl", "fmt_ad"], tile=4096,
                  flags=dict(depth=20.0, gl_model=2, error_rate=0.01, error_qs=1, beta_variance=1e-5, add_pl=1, add_fmt_ad=1)),
+    "c3sm": dict(N=1000, S=10_000, site0=17_000_000, gt="acgt", fields=BASE + ["pl", "pl_u8", "fmt_ad"], tile=4096,
+                 flags=dict(depth=20.0, gl_model=2, add_pl=1, add_fmt_ad=1, out_layout=_abi.VGL_LAYOUT_SAMPLE_MAJOR, **EQS2)),
     "fixedq": dict(N=1000, S=10_000, site0=15_000_000, gt="acgt", fields=[f for f in EVERY if f != "gp"], tile=4096,
                    flags=dict(depth=20.0, gl_model=2, error_rate=0.01, add_pl=1, add_qs=1, add_info_dp=1, add_fmt_ad=1, add_info_ad=1, **STRAND)),
 }
@@ -85,6 +88,9 @@ def _gpu_checksums(case):
     out = np.zeros((S, len(case["fields"])), dtype=np.uint64)
     for s0 in range(0, S, tile_sites):
         n = min(tile_sites, S - s0)
+        if case["flags"].get("out_layout"):                     # sample-major slabs: what lies behind a record's array is not written
+            for f in case["fields"]:
+                tile[f].zero_()
         sim.simulate_device(site0 + s0, _gt_torch(case, site0 + s0, n, dev), tile)
         sim.check()
         for k, f in enumerate(case["fields"]):
