@@ -280,15 +280,7 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
                 const uint32_t* colw = (const uint32_t*)T.reads + ev;
                 const int lastw = (dp - 1) >> 2;
                 uint32_t w0 = colw[0], w1 = colw[(size_t)(1 < lastw ? 1 : lastw) * plane], w2 = colw[(size_t)(2 < lastw ? 2 : lastw) * plane];
-                uint32_t cur = 0;
-                for (int r = 0; r < dp; ++r) {
-                    if ((r & 3) == 0) {                                                           // (r is the same in every active lane)
-                        cur = w0; w0 = w1; w1 = w2;
-                        const int nw = (r >> 2) + 3;
-                        w2 = colw[(size_t)(nw < lastw ? nw : lastw) * plane];
-                    }
-                    const uint32_t rb = cur & 0xFFu;
-                    cur >>= 8;
+                auto one_read = [&](const uint32_t rb, const int r) {
                     const int ci = (int)((cmap >> ((rb & 3) * 2)) & 3);                           // the read's base among the present ones
                     if (per_read) {
                         if (!PREC) {
@@ -337,6 +329,16 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
                         }
                         if (NT & 1) tr[NT - 1] -= mx;
                     }
+                };
+                // four reads per trip: one staged word, its bytes taken with constant shifts
+                for (int r0 = 0; r0 < dp; r0 += 4) {                                          // (r0 is the same in every active lane)
+                    const uint32_t cur = w0;
+                    w0 = w1; w1 = w2;
+                    const int nw = (r0 >> 2) + 3;
+                    w2 = colw[(size_t)(nw < lastw ? nw : lastw) * plane];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (r0 + j < dp) one_read((cur >> (8 * j)) & 0xFFu, r0 + j);
                 }
                 // deposit: column otid (= the evaluation's natural position in the workgroup), rows = genotype index over (present
                 // base ranks 0..3, 4 = absent) whatever KK this wavefront ran with, so that the reader needs no KK
