@@ -139,13 +139,21 @@ template <int A, int GLM, bool PREC, int WPB>
 __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const VglTilePtrs T) {
     constexpr int WG = 64 * WPB;                                        // evaluations (threads) per workgroup: 256 or 512
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    __shared__ uint16_t s_perm[WG];
-    constexpr int NG = A * (A + 1) / 2;
-    __shared__ uint32_t s_x[(GLM == 1 ? 16 : 15) * WG];                // the accumulators (up to 15 rows) of the workgroup's evaluations on their way from sorted to natural order; before that, GL model 1
-                                                                        // with per-read scores: a (base, quality) histogram per lane, 64 one-byte rows per wavefront
-    uint32_t* const s_hist = s_x;                                       // [1026] bins of the depth sort (done before s_x is used)
     constexpr int QL = 96;                                              // quality scores below QL take their three terms from LDS
-    __shared__ double s_q2gl[(GLM == 2 && !PREC) ? 3 * QL : 1];
+    constexpr int NG = A * (A + 1) / 2;
+    // one LDS object, so that its members lie in this order: the per-quality terms first -- at LDS offset 0 their three rows are
+    // reached by the immediate offsets of ds_read2_b64 / ds_read_b64 (an add per read otherwise)
+    struct Lds {
+        double q2gl[(GLM == 2 && !PREC) ? 3 * QL : 1];
+        uint32_t x[(GLM == 1 ? 16 : 15) * WG];                          // the accumulators (up to 15 rows) of the workgroup's evaluations on their way from sorted to natural order; before that,
+                                                                        // GL model 1 with per-read scores: a (base, quality) histogram per lane, 64 one-byte rows per wavefront
+        uint16_t perm[WG];
+    };
+    __shared__ Lds s_lds;
+    double* const s_q2gl = s_lds.q2gl;
+    uint32_t* const s_x = s_lds.x;
+    uint16_t* const s_perm = s_lds.perm;
+    uint32_t* const s_hist = s_x;                                       // [1026] bins of the depth sort (done before s_x is used)
     const int N = P.n_samples;
     const int tid = threadIdx.x;
     if (GLM == 2 && !PREC) {
