@@ -7,6 +7,8 @@ wls=${*:-c3 c5 c5u8 c4 fixedq c2 gl1q precise}
 for wl in $wls; do
     f=$(ls gpurun_out/$tag/$wl/kt/*/*kernel_stats.csv | head -1)
     cp "$f" profiles/${tag}_${wl}_kernel_stats.csv
+    [ -f gpurun_out/$tag/$wl/kernel_timed_stats.csv ] && cp gpurun_out/$tag/$wl/kernel_timed_stats.csv profiles/${tag}_${wl}_kernel_timed_stats.csv
+    [ -n "${KTONLY:-}" ] && continue
     if [ "$wl" = c2 ]; then n=10000; else n=65536; fi
     python tools/pmc_summary.py gpurun_out/$tag/$wl/pmc ${tag}_${wl} $wl $n > /dev/null
     echo "$wl: $(grep -c . profiles/${tag}_${wl}_kernel_stats.csv) kernel rows"
