@@ -159,6 +159,8 @@ struct VglTilePtrs {
     uint32_t* qsumsq;        // [n_sites][4][N]
     int32_t*  acc;           // [n_sites][16]
     VglSiteInfo* sinfo;      // [n_sites]
+    uint64_t* rowmap;        // [n_sites][16] GL model 2: for every set of bases an evaluation may show (4 bits), the accumulator row of each of
+                             // the site's genotypes, 4 bits per genotype in bcf_alleles2gt order (k_site writes it, k_gl's epilogue reads one entry per lane)
     uint32_t* errflag;
     int32_t*  dp_pre;        // [n_sites][N] depth draws of k_depth (tile mode)
     uint64_t* site_base;     // [n_sites] tile mode: J^(block N H(site)) (x0), the generator state in front of the site's windows (k_sitebase)

@@ -6,9 +6,12 @@
 #include "vgl_common.hip.h"
 
 // ------------------------------------------------------------------------------------
-// one lane per site: status + allele order (vcfgl.cpp:396-404, 665-766; no-reads :228-315)
+// one lane per site: status + allele order (vcfgl.cpp:396-404, 665-766; no-reads :228-315).  With the row table of k_gl (T.rowmap, GL model 2)
+// SIXTEEN lanes per site: all work out the site (a few hundred instructions), lane `pm` writes table entry `pm`, lane 0 everything else
 __global__ __launch_bounds__(256) void k_site(const VglDevParams P, const VglTilePtrs T) {
-    const int ls = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t gt_ = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ls = (int)(T.rowmap ? (gt_ >> 4) : gt_);                 // (a tile's sites fit an int: vgl_simulate_tile checks)
+    const uint32_t pm = T.rowmap ? (uint32_t)(gt_ & 15) : 0u;
     if (ls >= T.n_sites) return;
     const int32_t* acc = T.acc + (size_t)ls * VGL_ACC_STRIDE;
     const int A = P.A;
@@ -46,6 +49,28 @@ __global__ __launch_bounds__(256) void k_site(const VglDevParams P, const VglTil
             nObs = n_all; nAll = n_all + (add_unobs ? 1 : 0);
         }
     }
+    if (T.rowmap) {
+        // k_gl (GL model 2) leaves an evaluation's accumulators in rows indexed by the RANKS of its present bases (0..3, 4 = an allele it
+        // has no read of): row(ri, rj) = max(tri) + min(rank), tri = rank (rank + 1) / 2.  Which row holds genotype (i, j) of the site's
+        // alleles depends only on the site's allele order and on which of the four bases the evaluation shows -- 16 cases, tabulated here
+        // once per site instead of being worked out by every (site, sample) thread: entry [present mask] = 15 x 4 bits in bcf_alleles2gt order
+        {
+            uint64_t m = 0;
+            int pr[5];
+            for (int i = 0; i < 5; ++i) {
+                const int bb = (i < A) ? (a2b[i] & 0xF) : 0xF;
+                pr[i] = (bb < 4 && ((pm >> bb) & 1u)) ? __popc(pm & ((1u << bb) - 1u)) : 4;
+            }
+            for (int i = 0; i < A; ++i)
+                for (int j = 0; j <= i; ++j) {
+                    const int ti = pr[i] * (pr[i] + 1) / 2, tj = pr[j] * (pr[j] + 1) / 2;
+                    const int row = (ti > tj ? ti : tj) + (pr[i] < pr[j] ? pr[i] : pr[j]);
+                    m |= (uint64_t)row << (4 * (i * (i + 1) / 2 + j));
+                }
+            T.rowmap[(size_t)ls * 16 + pm] = m;
+        }
+        if (pm != 0) return;
+    }
     VglSiteInfo si;
     si.status = status; si.n_alleles = nAll;
     uint32_t pa = 0, pb = 0;
@@ -71,6 +96,7 @@ __global__ __launch_bounds__(256) void k_site(const VglDevParams P, const VglTil
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) uint32_t vgl_gu32;             // a global-memory word (an address the compiler cannot trace keeps its address space)
 
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ float f32_missing() { return __uint_as_float(F32_MISSING_BITS); }
@@ -148,11 +174,13 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
         uint32_t x[(GLM == 1 ? 16 : 15) * WG];                          // the accumulators (up to 15 rows) of the workgroup's evaluations on their way from sorted to natural order; before that,
                                                                         // GL model 1 with per-read scores: a (base, quality) histogram per lane, 64 one-byte rows per wavefront
         uint16_t perm[WG];
+        int32_t ws[2 * WPB];                                            // (site, first sample) of the workgroup's wavefronts in natural order
     };
     __shared__ Lds s_lds;
     double* const s_q2gl = s_lds.q2gl;
     uint32_t* const s_x = s_lds.x;
     uint16_t* const s_perm = s_lds.perm;
+    int32_t* const s_ws = s_lds.ws;
     uint32_t* const s_hist = s_x;                                       // [1026] bins of the depth sort (done before s_x is used)
     const int N = P.n_samples;
     const int tid = threadIdx.x;
@@ -184,18 +212,24 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
     // epilogue's stores address memory as scalar base + lane offset and the allele table is decoded by scalar instructions
     int ls0 = 0, sb0 = 0, s0 = N;
     uint64_t a = 0;                                                    // its per-base depths (kept for the epilogue, which runs in natural order)
+    uint64_t rmap = 0;                                                 // GL model 2: accumulator row of each genotype for this evaluation's set of bases (k_site's table)
     {
         const int wv_s = (GLM == 2) ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
         const uint32_t w = bx * (uint32_t)WPB + (uint32_t)wv_s;
         if (w < nwaves) {
             wave_site(wv_s, ls0, sb0);
             if (GLM == 2) { ls0 = __builtin_amdgcn_readfirstlane(ls0); sb0 = __builtin_amdgcn_readfirstlane(sb0); }   // (measured: the GL model 1 kernel is 8 % slower with it)
+            if (P.gl_sort && (tid & 63) == 0) { s_ws[2 * (tid >> 6)] = ls0; s_ws[2 * (tid >> 6) + 1] = sb0; }       // for the lane the sort hands an evaluation of this wavefront to
             s0 = sb0 + (tid & 63);
             if (s0 < N) {
                 a = T.ad4[(size_t)ls0 * N + (size_t)sb0 + (size_t)(tid & 63)];
                 dp0 = (int)((a & 0xFFFF) + ((a >> 16) & 0xFFFF) + ((a >> 32) & 0xFFFF) + ((a >> 48) & 0xFFFF));
                 if (dp0 > 1023) dp0 = 1023;
-                if (GLM == 2) k0 = (int)((a & 0xFFFFULL) != 0) + (int)(((a >> 16) & 0xFFFF) != 0) + (int)(((a >> 32) & 0xFFFF) != 0) + (int)((a >> 48) != 0);
+                if (GLM == 2) {
+                    const uint32_t q0 = (a & 0xFFFFULL) != 0, q1 = ((a >> 16) & 0xFFFF) != 0, q2 = ((a >> 32) & 0xFFFF) != 0, q3 = (a >> 48) != 0;
+                    k0 = (int)(q0 + q1 + q2 + q3);
+                    rmap = T.rowmap[(size_t)ls0 * 16 + (q0 | (q1 << 1) | (q2 << 2) | (q3 << 3))];      // (in flight during the loop)
+                }
             }
         }
     }
@@ -242,7 +276,12 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
     const uint32_t w = bx * (uint32_t)WPB + (uint32_t)(otid >> 6);
     const VglSiteInfo si_nv = T.sinfo[ls0];                            // the natural evaluation's site (epilogue); in flight during the loop
     int ls = 0, s = N;
-    if (w < nwaves) { int sb; wave_site(otid >> 6, ls, sb); s = sb + (otid & 63); }
+    if (w < nwaves) {
+        int sb;
+        if (P.gl_sort) { ls = s_ws[2 * (otid >> 6)]; sb = s_ws[2 * (otid >> 6) + 1]; }      // (written before the sort's barriers)
+        else wave_site(otid >> 6, ls, sb);
+        s = sb + (otid & 63);
+    }
     const bool live = s < N;
     if (!live) { ls = 0; s = 0; }                                      // padding lane: reads stay in range, nothing is deposited
     const size_t ev = (size_t)ls * N + s;
@@ -543,28 +582,19 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
     const bool have0 = (si_n.status == SITE_OK);
     const int dpn = (int)((a & 0xFFFF) + ((a >> 16) & 0xFFFF) + ((a >> 32) & 0xFFFF) + ((a >> 48) & 0xFFFF));
     const bool sample_ok = have0 && live0 && dpn > 0;
+    if (GLM == 2) {
+#pragma unroll
+        for (int i = 0; i < NG; ++i) acc[i] = MISS;                      // (unused until here with GL model 2; PL / GP look at sample_ok, not at the value)
+    }
     if (sample_ok) {
         const uint32_t* colx = s_x + tid;
         if (GLM == 2) {
-            // genotype (i, j) of the site's alleles -> row of (rank of i's base among this evaluation's present bases or 4, same for j)
-            const uint32_t p0 = (a & 0xFFFFULL) != 0, p1 = ((a >> 16) & 0xFFFF) != 0, p2 = ((a >> 32) & 0xFFFF) != 0, p3 = (a >> 48) != 0;
-            const uint32_t cmap = (p0 << 2) | ((p0 + p1) << 4) | ((p0 + p1 + p2) << 6);
-            const uint32_t pmask = p0 | (p1 << 1) | (p2 << 2) | (p3 << 3);
-            int pr[A], tri[A];
+            // genotype idx (bcf_alleles2gt order) of the site's alleles -> accumulator row: four bits of the table entry loaded at the start
+            const uint32_t rlo = (uint32_t)rmap, rhi = (uint32_t)(rmap >> 32);
 #pragma unroll
-            for (int i = 0; i < A; ++i) {
-                const int bb = nib(si_n.alleles2acgt, i);
-                pr[i] = (bb < 4 && ((pmask >> bb) & 1)) ? (int)((cmap >> (2 * bb)) & 3) : 4;
-                tri[i] = pr[i] * (pr[i] + 1) / 2;
-            }
-#pragma unroll
-            for (int i = 0; i < A; ++i) {
-#pragma unroll
-                for (int j = 0; j <= i; ++j) {
-                    const int idx = i * (i + 1) / 2 + j;                                         // bcf_alleles2gt
-                    const int m = (tri[i] > tri[j] ? tri[i] : tri[j]) + (pr[i] < pr[j] ? pr[i] : pr[j]);
-                    acc[idx] = __uint_as_float(colx[m * WG]);
-                }
+            for (int idx = 0; idx < NG; ++idx) {
+                const uint32_t m = ((idx < 8 ? rlo : rhi) >> (4 * (idx & 7))) & 15u;
+                acc[idx] = __uint_as_float(colx[m * WG]);
             }
         } else {
 #pragma unroll
@@ -585,11 +615,22 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
     const uint32_t nv = wave_ok ? (uint32_t)((N - sb_w) < 64 ? (N - sb_w) : 64) : 0u;       // samples of this wavefront's chunk
     const uint32_t nG0u = (uint32_t)__builtin_amdgcn_readfirstlane(nG0), nA0u = (uint32_t)__builtin_amdgcn_readfirstlane(nA0);
 #define VGL_WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+// the rows of one plane group: the row pointer is wave-uniform and is kept in scalar registers (pinned: left to itself the compiler folds the
+// lane into a 64-bit vector address and pays a 64-bit vector add per row), the lane is the 32-bit offset of the store
+#define VGL_ROWS(BASE_, KMAX, EXPR)                                                                      \
+    do {                                                                                                 \
+        vgl_gu32* rp_ = (vgl_gu32*)((BASE_) + ((size_t)ls0 * (KMAX)) * N + (size_t)sb0);                 \
+        _Pragma("unroll") for (int i = 0; i < (KMAX); ++i) {                                             \
+            if constexpr (GLM == 2) asm volatile("" : "+s"(rp_));                                        \
+            rp_[(uint32_t)lane] = (EXPR);                                                                \
+            rp_ += N;                                                                                    \
+        }                                                                                                \
+    } while (0)
 #define VGL_PUT(BASE, KMAX, NK, EXPR)                                                                    \
     do {                                                                                                 \
         uint32_t* const base_ = (uint32_t*)(BASE);                                                       \
         if (base_ && !sm) {                                                                              \
-            if (live0) { _Pragma("unroll") for (int i = 0; i < (KMAX); ++i) base_[((size_t)ls0 * (KMAX) + i) * N + (size_t)sb0 + (size_t)lane] = (EXPR); } \
+            if (live0) VGL_ROWS(base_, KMAX, EXPR);                                                      \
         } else if (base_) {                                                                              \
             const uint32_t nk_ = (NK);                                                                   \
             _Pragma("unroll") for (int i = 0; i < (KMAX); ++i)                                           \
@@ -604,15 +645,21 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
             VGL_WAVE_LDS_SYNC();                                                                         \
         }                                                                                                \
     } while (0)
-    VGL_PUT(T.gl, NG, nG0u, __float_as_uint((sample_ok && i < nG0) ? acc[i] : MISS));
+    if (GLM == 2 && T.gl && !sm && nG0u == (uint32_t)NG) {                // every genotype of the plane group exists at this site: the registers hold
+        if (live0) VGL_ROWS((uint32_t*)T.gl, NG, __float_as_uint(acc[i]));  // the value or (no reads / site not written) the missing pattern already
+    } else VGL_PUT(T.gl, NG, nG0u, __float_as_uint((sample_ok && i < nG0) ? acc[i] : MISS));
     VGL_PUT(T.pl, NG, nG0u, pl_of(acc[i], sample_ok && i < nG0));
     if (T.pl_u8) {                                                       // PL in one byte (capped at 255; 255 also stands for missing)
         if (!sm) {
             if (live0) {
+                typedef __attribute__((address_space(1))) uint8_t gu8;
+                gu8* rp = (gu8*)(T.pl_u8 + ((size_t)ls0 * NG) * N + (size_t)sb0);         // (scalar row pointer: VGL_ROWS)
 #pragma unroll
                 for (int i = 0; i < NG; ++i) {
                     const uint32_t v = pl_of(acc[i], sample_ok && i < nG0);
-                    T.pl_u8[((size_t)ls0 * NG + i) * N + (size_t)sb0 + (size_t)lane] = (uint8_t)(v > 255u ? 255u : v);
+                    if constexpr (GLM == 2) asm volatile("" : "+s"(rp));
+                    rp[(uint32_t)lane] = (uint8_t)(v > 255u ? 255u : v);
+                    rp += N;
                 }
             }
         } else {
@@ -658,6 +705,7 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
     }
 #undef VGL_WAVE_LDS_SYNC
 #undef VGL_PUT
+#undef VGL_ROWS
 }
 
 // ------------------------------------------------------------------------------------
@@ -774,7 +822,7 @@ extern "C" int vgl_launch_hts_offsets(const VglDevParams* p, const VglTilePtrs* 
 
 extern "C" int vgl_launch_site(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
     if (t->n_sites == 0) return 0;
-    hipLaunchKernelGGL(k_site, dim3((t->n_sites + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p, *t);
+    hipLaunchKernelGGL(k_site, dim3((unsigned)(((size_t)t->n_sites * (t->rowmap ? 16 : 1) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p, *t);
     return (int)hipGetLastError();
 }
 

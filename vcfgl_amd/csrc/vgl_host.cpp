@@ -173,7 +173,7 @@ struct vgl_ctx {
     double* d_q2gl = nullptr; double* d_gamma_ln = nullptr; double* d_gl1_fk = nullptr; double* d_gl1_beta = nullptr; double* d_gl1_bsum = nullptr; double* d_gl1_lhet = nullptr;
     // workspace
     uint8_t* d_reads = nullptr; double* d_errp = nullptr; uint64_t* d_ad4 = nullptr; uint64_t* d_adf4 = nullptr;
-    uint32_t* d_qsum = nullptr; uint32_t* d_qsumsq = nullptr; int32_t* d_acc = nullptr; VglSiteInfo* d_sinfo = nullptr;
+    uint32_t* d_qsum = nullptr; uint32_t* d_qsumsq = nullptr; int32_t* d_acc = nullptr; VglSiteInfo* d_sinfo = nullptr; uint64_t* d_rowmap = nullptr;
     uint32_t* d_errflag = nullptr;
     unsigned long long* d_redo_list = nullptr; uint32_t* d_redo_count = nullptr; uint32_t redo_cap = 0; uint32_t* d_redo_bits = nullptr;   // k_sample<2, deferred> -> k_redo
     // beta chain of VGL_RNG_SERIAL with --error-qs 2 and the std beta sampler (vgl_betachain.hip); grow-only buffers
@@ -278,7 +278,7 @@ extern "C" int vgl_ctx_destroy(vgl_ctx* c) {
     if (!c) return VGL_OK;
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_gl1_fk, c->d_gl1_beta, c->d_gamma_ln, c->d_samp_tab, c->d_qs_read_tab, c->d_pois, c->d_q2gl, c->d_gl1_bsum, c->d_gl1_lhet, c->d_reads, c->d_errp, c->d_ad4,
-                    c->d_adf4, c->d_qsum, c->d_qsumsq, c->d_acc, c->d_sinfo, c->d_errflag, c->d_dbg, c->d_redo_list, c->d_redo_count, c->d_redo_bits,
+                    c->d_adf4, c->d_qsum, c->d_qsumsq, c->d_acc, c->d_sinfo, c->d_rowmap, c->d_errflag, c->d_dbg, c->d_redo_list, c->d_redo_count, c->d_redo_bits,
                     c->d_serial, c->d_sst, c->d_site_thresh, c->d_scout_dp, c->d_site_tail, c->d_sdp, c->d_step_tab,
                     c->d_depth_tab, c->d_site_base, c->d_site_hash, c->d_dp_pre, c->d_hts_off, c->d_hts_base, c->d_roff, c->d_rtotal, c->d_errp_lin, c->d_cw, c->d_ccons, c->d_cexit,
                     c->d_ccnt, c->d_centry, c->d_cbase, c->d_cpos, c->d_csnap, c->d_csnapw, c->d_cctl};
@@ -548,6 +548,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     if (D.need_qsumsq) TRY(dmalloc(&c->d_qsumsq, E * 4));
     TRY(dmalloc(&c->d_acc, (size_t)max_sites * VGL_ACC_STRIDE));
     TRY(dmalloc(&c->d_sinfo, (size_t)max_sites));
+    if (p->gl_model == 2) TRY(dmalloc(&c->d_rowmap, (size_t)max_sites * 16));
     TRY(dmalloc(&c->d_errflag, (size_t)1));
     if (D.defer_ok) {
         // about 6 reads in 10^4 take this path at C3 / C4 (tools/redo_rate.py); the list has room for 1 in 64 of the staging capacity
@@ -672,7 +673,7 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     memset(&T, 0, sizeof T);
     T.site0 = site0; T.n_sites = n_sites; T.gt = gt;
     T.reads = c->d_reads; T.errp = c->d_errp; T.ad4 = c->d_ad4; T.adf4 = c->d_adf4; T.qsum = c->d_qsum; T.qsumsq = c->d_qsumsq;
-    T.acc = c->d_acc; T.sinfo = c->d_sinfo; T.errflag = c->d_errflag; T.dbg = c->d_dbg; T.dp_pre = c->d_dp_pre;
+    T.acc = c->d_acc; T.sinfo = c->d_sinfo; T.rowmap = c->d_rowmap; T.errflag = c->d_errflag; T.dbg = c->d_dbg; T.dp_pre = c->d_dp_pre;
     T.site_base = c->d_site_base; T.site_hash = c->d_site_hash;
     T.redo_list = c->d_redo_list; T.redo_count = c->d_redo_count; T.redo_cap = c->redo_cap; T.redo_bits = c->d_redo_bits;
     if (D.serial) {
