@@ -331,7 +331,10 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
         if gather == "sample":
-            sampled_record_gather()
+            try:                                                   # (after the timed steps: a failure here is reported in `comm`, it must not cost the line)
+                sampled_record_gather()
+            except Exception as e:
+                comm["sample_error"] = repr(e)[:300]
 
     res = None
     if rank == 0:
@@ -384,6 +387,8 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
             res["comm"] = {"backend": opt.backend, "world": dist.get_world_size(), "gather": gather,
                            "gather_ms": comm["gather_s"] / steps * 1e3,
                            "gather_note": "per step on the writer: gather of the per-site record index (status, allele count) + all-reduce of the site counters"}
+            if comm.get("sample_error"):
+                res["comm"]["records_sample_error"] = comm["sample_error"]
             if gather == "sample" and comm["sample_s"] > 0:
                 gbps = comm["sample_bytes"] / comm["sample_s"] / 1e9
                 full_bytes = b_eval * float(S) * N * (world - 1)            # what a full record gather would move into the writer per step (upper bound: unpacked size)
