@@ -1,0 +1,122 @@
+"""The fused build of k_gl (GL model 2, one fixed quality score, default tag surface, every mean depth below 12, 256 < N <= 512): one
+workgroup samples a site's reads, orders its alleles and evaluates the likelihoods without staging anything in HBM.  Same oracle
+parity as the three-kernel path (bit-exact integers and GL), which `VGL_NO_FUSE=1` still runs."""
+import os
+
+import numpy as np
+import pytest
+
+import synth
+from vcfgl_amd import Simulator, VcfglArgs, _abi
+from test_gpu_parity import assert_parity, run_both
+
+pytestmark = pytest.mark.gpu
+
+TAGS = dict(add_gp=1, add_pl=1, add_info_dp=1, add_fmt_ad=1, add_info_ad=1)       # (no QS / I16 / strand tags: those take the three-kernel path)
+
+
+def _is_fused(args, N, gt):
+    """the sample bucket of the context's kernel timing stays empty when the fused kernel runs"""
+    import torch
+    args.rng_mode, args.beta_sampler = _abi.VGL_RNG_TILE, _abi.VGL_BETA_RAND48
+    sim = Simulator(args, N, device=0, max_sites_per_tile=gt.shape[0])
+    sim.timing(True)
+    g = torch.from_numpy(np.ascontiguousarray(gt)).to("cuda:0")
+    tile = sim.new_tile(gt.shape[0], fields=["fmt_dp", "gl"], device="cuda:0")
+    for _ in range(3):
+        sim.simulate_device(0, g, tile); sim.check()
+    ms, n = sim.kernel_ms(reset=True)
+    sim.close()
+    return ms[1] < 0.2 * ms[3]
+
+
+@pytest.mark.parametrize("N", [257, 300, 500, 511, 512])
+@pytest.mark.parametrize("depth", [0.3, 2.0, 5.0, 11.9])
+def test_fused_shapes_and_depths(oracle, N, depth):
+    args = VcfglArgs(seed=11, depth=depth, error_rate=0.01, **TAGS)
+    gt = synth.binary_sites(5, 60, N)
+    want, got = run_both(oracle, args, gt, site0=5)
+    assert_parity(want, got)
+
+
+def test_the_fused_kernel_is_the_one_that_runs():
+    gt = np.zeros((8192, 500), dtype=np.uint8)
+    assert _is_fused(VcfglArgs(seed=11, depth=5.0, error_rate=0.01, **TAGS), 500, gt)
+    assert not _is_fused(VcfglArgs(seed=11, depth=5.0, error_rate=0.01, add_qs=1, **TAGS), 500, gt)          # -addQS needs the per-base quality sums
+    assert not _is_fused(VcfglArgs(seed=11, depth=5.0, error_rate=0.01, **TAGS), 600, np.zeros((8192, 600), dtype=np.uint8))
+
+
+@pytest.mark.parametrize("kw", [dict(do_unobserved=0), dict(do_unobserved=1), dict(do_unobserved=2), dict(do_unobserved=3), dict(do_unobserved=4),
+                                dict(rm_invar_sites=4), dict(rm_empty_sites=1, depth=0.01), dict(error_rate=0.2), dict(error_rate=0.0), dict(error_qs=1, beta_variance=1e-5)])
+def test_fused_site_options(oracle, kw):
+    """allele-order options (4 or 5 alleles per site), skipped sites, many errors (three and four bases per evaluation), no errors;
+    --error-qs 1 (a per-site draw) is NOT fused and must still be right"""
+    a = dict(seed=5, depth=4.0, error_rate=0.01)
+    a.update(TAGS); a.update(kw)
+    want, got = run_both(oracle, VcfglArgs(**a), synth.acgt_range(100, 80, 400, missing=0.03), site0=100)
+    assert_parity(want, got)
+
+
+def test_fused_per_sample_depths_and_missing_genotypes(oracle):
+    N = 333
+    rng = np.random.default_rng(3)
+    depths = list(rng.uniform(0.0, 11.5, N))
+    args = VcfglArgs(seed=9, depths=depths, error_rate=0.02, **TAGS)
+    want, got = run_both(oracle, args, synth.acgt_range(0, 50, N, missing=0.2))
+    assert_parity(want, got)
+
+
+@pytest.mark.parametrize("layout", [_abi.VGL_LAYOUT_PLANES, _abi.VGL_LAYOUT_SAMPLE_MAJOR])
+def test_fused_layouts_and_narrow_pl(oracle, layout):
+    N, S = 500, 70
+    args = VcfglArgs(seed=21, depth=5.0, error_rate=0.01, do_unobserved=2, add_pl=1, add_fmt_ad=1, out_layout=layout)
+    args.rng_mode, args.beta_sampler = _abi.VGL_RNG_TILE, _abi.VGL_BETA_RAND48
+    gt = np.zeros((S, N), dtype=np.uint8)                                  # config C5's hom-ref sites
+    fields = ["site_status", "n_alleles", "alleles2acgt", "fmt_dp", "gl", "pl", "pl_u8", "fmt_ad"]
+    o = oracle.Oracle(args, N)
+    want = o.simulate(0, gt, fields=fields)
+    sim = Simulator(args, N, device=0, max_sites_per_tile=S)
+    got = sim.simulate(0, gt, fields=fields)
+    sim.close()
+    MULTI = {"gl": "G", "pl": "G", "pl_u8": "G", "fmt_ad": "A"}
+    st, na = want.numpy("site_status"), want.numpy("n_alleles")
+    for f in fields:
+        if layout == _abi.VGL_LAYOUT_SAMPLE_MAJOR and f in MULTI:             # the record arrays (what lies behind them in a slab is unspecified)
+            for i in range(S):
+                nA = int(na[i]) if st[i] >= 0 else 0
+                nk = nA * (nA + 1) // 2 if MULTI[f] == "G" else nA
+                assert np.array_equal(np.ascontiguousarray(want.site_records(f, i, nk)).view(np.uint8),
+                                      np.ascontiguousarray(got.site_records(f, i, nk)).view(np.uint8)), (f, i)
+        else:
+            assert np.array_equal(want.numpy(f).view(np.uint8), got.numpy(f).view(np.uint8)), f
+
+
+def test_fused_equals_three_kernel_path_and_tiling(oracle):
+    """3000 sites x 500 samples at config C5's flags: the fused kernel, the three-kernel path (VGL_NO_FUSE=1) and a run in ragged tiles agree bit for bit"""
+    N, S = 500, 3000
+    args = VcfglArgs(seed=42, depth=5.0, error_rate=0.01, do_unobserved=2, add_pl=1, add_fmt_ad=1, add_info_ad=1)
+    args.rng_mode, args.beta_sampler = _abi.VGL_RNG_TILE, _abi.VGL_BETA_RAND48
+    gt = synth.binary_sites(0, S, N)
+    gt[::3] = 0
+    fields = ["site_status", "n_alleles", "n_alleles_obs", "alleles2acgt", "info_dp", "info_ad", "fmt_dp", "gl", "pl", "fmt_ad"]
+    sim = Simulator(args, N, device=0, max_sites_per_tile=S)
+    a = sim.simulate(0, gt, fields=fields)
+    sim.close()
+    os.environ["VGL_NO_FUSE"] = "1"
+    try:
+        sim = Simulator(args, N, device=0, max_sites_per_tile=S)
+        b = sim.simulate(0, gt, fields=fields)
+        sim.close()
+    finally:
+        del os.environ["VGL_NO_FUSE"]
+    for f in fields:
+        assert np.array_equal(a.numpy(f).view(np.uint8), b.numpy(f).view(np.uint8)), f
+    sim = Simulator(args, N, device=0, max_sites_per_tile=1100)
+    s0 = 0
+    for n in (1, 1100, 7, 900, 992):
+        t = sim.simulate(s0, gt[s0:s0 + n], fields=fields)
+        for f in fields:
+            assert np.array_equal(t.numpy(f).view(np.uint8), a.numpy(f)[s0:s0 + n].view(np.uint8)), (f, s0)
+        s0 += n
+    sim.close()
+    assert s0 == S

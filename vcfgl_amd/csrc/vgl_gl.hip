@@ -6,93 +6,118 @@
 #include "vgl_common.hip.h"
 
 // ------------------------------------------------------------------------------------
-// one lane per site: status + allele order (vcfgl.cpp:396-404, 665-766; no-reads :228-315).  With the row table of k_gl (T.rowmap, GL model 2)
-// SIXTEEN lanes per site: all work out the site (a few hundred instructions), lane `pm` writes table entry `pm`, lane 0 everything else
+// status + allele order of one site from its summed depths (vcfgl.cpp:396-404, 665-766; no-reads :228-315)
+// Registers only (no indexed local arrays: in the fused build of k_gl a whole workgroup waits for this): the four bases are ordered by a
+// sorting network on keys (depth << 2 | 3 - base) -- descending depth, ties in the order A < C < G < T, as the reference's stable
+// insertion sort leaves them -- and the two allele tables are built as words of 4-bit entries (0xF = none), the form VglSiteInfo keeps
+struct VglSiteOrder { int status, nAll, nObs; uint32_t a2b, b2a; };      // a2b: allele -> base (4 = unobserved), b2a: base -> allele; entries 0..4
+__device__ __forceinline__ int site_nib(const uint32_t w, const int i) { const int v = (int)((w >> (4 * i)) & 0xFu); return v == 0xF ? -1 : v; }
+__device__ __forceinline__ VglSiteOrder site_order(const VglDevParams& P, const int info_dp, const int ad[4]) {
+    VglSiteOrder o;
+    const bool add_unobs = (P.A == 5);
+    uint32_t a2b = 0xFFFFFu, b2a = 0xFFFFFu;
+    int status = SITE_OK, nAll = 0, nObs = 0;
+    auto set = [](uint32_t w, const int i, const int v) { return (w & ~(0xFu << (4 * i))) | ((uint32_t)v << (4 * i)); };
+    if (0 == info_dp) {
+        if (P.rm_empty_sites) status = SITE_SKIP_EMPTY;
+        else {
+            status = SITE_NO_READS;
+            if (P.do_unobserved == 0) { nAll = 1; nObs = 0; }
+            else if (P.do_unobserved <= 2) { nAll = 1; nObs = 0; a2b = 0xFFFF4u; }
+            else if (P.do_unobserved == 3) { nAll = 4; nObs = 4; a2b = 0xF3210u; }
+            else { nAll = 5; nObs = 4; a2b = 0x43210u; }
+        }
+    } else {
+        const int nObservedBases = (ad[0] > 0) + (ad[1] > 0) + (ad[2] > 0) + (ad[3] > 0);
+        if ((P.rm_invar_sites & 4) && 1 == nObservedBases) status = SITE_SKIP_INVAR;
+        else {
+            uint64_t k0 = ((uint64_t)(uint32_t)ad[0] << 2) | 3u, k1 = ((uint64_t)(uint32_t)ad[1] << 2) | 2u, k2 = ((uint64_t)(uint32_t)ad[2] << 2) | 1u, k3 = ((uint64_t)(uint32_t)ad[3] << 2);
+            auto cx = [](uint64_t& hi, uint64_t& lo) { const uint64_t a = hi > lo ? hi : lo, b = hi > lo ? lo : hi; hi = a; lo = b; };
+            cx(k0, k1); cx(k2, k3); cx(k0, k2); cx(k1, k3); cx(k1, k2);                           // descending
+            const bool explode = P.do_unobserved >= 3;
+            const int n_all = explode ? 4 : nObservedBases;                                       // the bases listed: all four, or those with reads (they sort first)
+            const uint64_t ks[4] = {k0, k1, k2, k3};
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                if (a < n_all) { const int b = 3 - (int)(ks[a] & 3u); a2b = set(a2b, a, b); b2a = set(b2a, b, a); }
+            if (add_unobs) { a2b = set(a2b, n_all, 4); b2a = set(b2a, 4, n_all); }
+            nObs = n_all; nAll = n_all + (add_unobs ? 1 : 0);
+        }
+    }
+    o.status = status; o.nAll = nAll; o.nObs = nObs; o.a2b = a2b; o.b2a = b2a;
+    return o;
+}
+// k_gl (GL model 2) leaves an evaluation's accumulators in rows indexed by the RANKS of its present bases (0..3, 4 = an allele it
+// has no read of): row(ri, rj) = max(tri) + min(rank), tri = rank (rank + 1) / 2.  Which row holds genotype (i, j) of the site's
+// alleles depends only on the site's allele order and on which of the four bases the evaluation shows -- 16 cases, tabulated
+// once per site instead of being worked out by every (site, sample) thread: entry [present mask] = 15 x 4 bits in bcf_alleles2gt order
+template <int A>
+__device__ __forceinline__ uint64_t site_rowmap_entry_t(const uint32_t a2b, const uint32_t pm) {
+    uint64_t m = 0;
+    int pr[A];
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+        const uint32_t bb = (a2b >> (4 * i)) & 0xFu;
+        pr[i] = (bb < 4u && ((pm >> bb) & 1u)) ? __popc(pm & ((1u << bb) - 1u)) : 4;
+    }
+#pragma unroll
+    for (int i = 0; i < A; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            const int ti = pr[i] * (pr[i] + 1) / 2, tj = pr[j] * (pr[j] + 1) / 2;
+            const int row = (ti > tj ? ti : tj) + (pr[i] < pr[j] ? pr[i] : pr[j]);
+            m |= (uint64_t)row << (4 * (i * (i + 1) / 2 + j));
+        }
+    return m;
+}
+__device__ __forceinline__ uint64_t site_rowmap_entry(const int A, const uint32_t a2b, const uint32_t pm) {
+    return A == 5 ? site_rowmap_entry_t<5>(a2b, pm) : site_rowmap_entry_t<4>(a2b, pm);
+}
+__device__ __forceinline__ VglSiteInfo site_info_of(const VglSiteOrder& o) {
+    VglSiteInfo si;
+    si.status = o.status; si.n_alleles = o.nAll;
+    si.acgt2alleles = o.b2a; si.alleles2acgt = o.a2b;
+    return si;
+}
+// the per-site outputs (one thread per site): `acc` = the site's sums, [0] INFO/DP, [1..4] per-base depth, [5..8] forward-strand depth
+__device__ __forceinline__ void site_outputs(const VglDevParams& P, const VglTilePtrs& T, const int ls, const VglSiteOrder& o, const int32_t* acc) {
+    const int A = P.A;
+    T.site_status[ls] = o.status;
+    T.n_alleles[ls] = o.nAll;
+    if (T.n_alleles_obs) T.n_alleles_obs[ls] = o.nObs;
+#pragma unroll
+    for (int k = 0; k < 5; k++) T.alleles2acgt[(size_t)ls * 5 + k] = (int8_t)site_nib(o.a2b, k);
+    if (T.info_dp) T.info_dp[ls] = acc[0];
+    const bool have = (o.status == SITE_OK);
+    if (T.info_ad || T.info_adf || T.info_adr)
+        for (int a = 0; a < A; a++) {
+            const int b = (have && a < o.nAll) ? site_nib(o.a2b, a) : -1;
+            const bool real = (b >= 0 && b < 4);
+            int tot = 0, totf = 0;
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) if (real && b == bb) { tot = acc[1 + bb]; totf = acc[5 + bb]; }
+            if (T.info_ad) T.info_ad[(size_t)ls * A + a] = tot;
+            if (T.info_adf) T.info_adf[(size_t)ls * A + a] = totf;
+            if (T.info_adr) T.info_adr[(size_t)ls * A + a] = tot - totf;
+        }
+}
+
+// one lane per site.  With the row table of k_gl (T.rowmap, GL model 2) SIXTEEN lanes per site: all work out the site (a few hundred
+// instructions), lane `pm` writes table entry `pm`, lane 0 everything else
 __global__ __launch_bounds__(256) void k_site(const VglDevParams P, const VglTilePtrs T) {
     const size_t gt_ = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int ls = (int)(T.rowmap ? (gt_ >> 4) : gt_);                 // (a tile's sites fit an int: vgl_simulate_tile checks)
     const uint32_t pm = T.rowmap ? (uint32_t)(gt_ & 15) : 0u;
     if (ls >= T.n_sites) return;
     const int32_t* acc = T.acc + (size_t)ls * VGL_ACC_STRIDE;
-    const int A = P.A;
-    const int info_dp = acc[0];
-    int ad[4] = {acc[1], acc[2], acc[3], acc[4]};
-    int a2b[5] = {-1, -1, -1, -1, -1}, b2a[5] = {-1, -1, -1, -1, -1};
-    int status = SITE_OK, nAll = 0, nObs = 0;
-
-    if (0 == info_dp) {
-        if (P.rm_empty_sites) status = SITE_SKIP_EMPTY;
-        else {
-            status = SITE_NO_READS;
-            switch (P.do_unobserved) {
-                case 0: nAll = 1; nObs = 0; break;
-                case 1: case 2: nAll = 1; nObs = 0; a2b[0] = 4; break;
-                case 3: nAll = 4; nObs = 4; for (int a = 0; a < 4; a++) a2b[a] = a; break;
-                default: nAll = 5; nObs = 4; for (int a = 0; a < 4; a++) a2b[a] = a; a2b[4] = 4; break;
-            }
-        }
-    } else {
-        int nObservedBases = 0;
-        for (int b = 0; b < 4; b++) if (ad[b] > 0) nObservedBases++;
-        if ((P.rm_invar_sites & 4) && 1 == nObservedBases) status = SITE_SKIP_INVAR;
-        else {
-            int sorted[4] = {0, 1, 2, 3};
-            for (int i = 1; i < 4; i++)
-                for (int j = i; j > 0 && ad[sorted[j]] > ad[sorted[j - 1]]; j--) { int t = sorted[j]; sorted[j] = sorted[j - 1]; sorted[j - 1] = t; }
-            for (int a = 0; a < 4; a++) { a2b[a] = sorted[a]; b2a[sorted[a]] = a; }
-            const bool explode = P.do_unobserved >= 3, add_unobs = (A == 5);
-            for (int b = 0; b < 4; b++)
-                if (!(ad[b] > 0) && !explode) { a2b[b2a[b]] = -1; b2a[b] = -1; }
-            int unobs = -1, n_all = 0;
-            for (int a = 0; a < 5; a++) { if (-1 == a2b[a]) { if (add_unobs) unobs = a; break; } ++n_all; }
-            if (add_unobs) { a2b[unobs] = 4; b2a[4] = unobs; }
-            nObs = n_all; nAll = n_all + (add_unobs ? 1 : 0);
-        }
-    }
+    const int ad[4] = {acc[1], acc[2], acc[3], acc[4]};
+    const VglSiteOrder o = site_order(P, acc[0], ad);
     if (T.rowmap) {
-        // k_gl (GL model 2) leaves an evaluation's accumulators in rows indexed by the RANKS of its present bases (0..3, 4 = an allele it
-        // has no read of): row(ri, rj) = max(tri) + min(rank), tri = rank (rank + 1) / 2.  Which row holds genotype (i, j) of the site's
-        // alleles depends only on the site's allele order and on which of the four bases the evaluation shows -- 16 cases, tabulated here
-        // once per site instead of being worked out by every (site, sample) thread: entry [present mask] = 15 x 4 bits in bcf_alleles2gt order
-        {
-            uint64_t m = 0;
-            int pr[5];
-            for (int i = 0; i < 5; ++i) {
-                const int bb = (i < A) ? (a2b[i] & 0xF) : 0xF;
-                pr[i] = (bb < 4 && ((pm >> bb) & 1u)) ? __popc(pm & ((1u << bb) - 1u)) : 4;
-            }
-            for (int i = 0; i < A; ++i)
-                for (int j = 0; j <= i; ++j) {
-                    const int ti = pr[i] * (pr[i] + 1) / 2, tj = pr[j] * (pr[j] + 1) / 2;
-                    const int row = (ti > tj ? ti : tj) + (pr[i] < pr[j] ? pr[i] : pr[j]);
-                    m |= (uint64_t)row << (4 * (i * (i + 1) / 2 + j));
-                }
-            T.rowmap[(size_t)ls * 16 + pm] = m;
-        }
+        T.rowmap[(size_t)ls * 16 + pm] = site_rowmap_entry(P.A, o.a2b, pm);
         if (pm != 0) return;
     }
-    VglSiteInfo si;
-    si.status = status; si.n_alleles = nAll;
-    uint32_t pa = 0, pb = 0;
-    for (int k = 0; k < 5; k++) { pa |= (uint32_t)(b2a[k] & 0xF) << (4 * k); pb |= (uint32_t)(a2b[k] & 0xF) << (4 * k); }
-    si.acgt2alleles = pa; si.alleles2acgt = pb;
-    T.sinfo[ls] = si;
-
-    T.site_status[ls] = status;
-    T.n_alleles[ls] = nAll;
-    if (T.n_alleles_obs) T.n_alleles_obs[ls] = nObs;
-    for (int k = 0; k < 5; k++) T.alleles2acgt[(size_t)ls * 5 + k] = (int8_t)a2b[k];
-    if (T.info_dp) T.info_dp[ls] = info_dp;
-    const bool have = (status == SITE_OK);
-    for (int a = 0; a < A; a++) {
-        const int b = (have && a < nAll) ? a2b[a] : -1;
-        const bool real = (b >= 0 && b < 4);
-        const int tot = real ? acc[1 + b] : 0;
-        const int totf = real ? acc[5 + b] : 0;
-        if (T.info_ad) T.info_ad[(size_t)ls * A + a] = tot;
-        if (T.info_adf) T.info_adf[(size_t)ls * A + a] = totf;
-        if (T.info_adr) T.info_adr[(size_t)ls * A + a] = tot - totf;
-    }
+    T.sinfo[ls] = site_info_of(o);
+    site_outputs(P, T, ls, o, acc);
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -161,8 +186,14 @@ __device__ __forceinline__ int cnt_of(uint64_t ad4, int b) { return b < 4 ? (int
 // Which wavefront of a workgroup takes the heaviest 64 evaluations rotates with the workgroup index.
 // GLM, PREC: the GL model (1 / 2) and --precise-gl as template parameters -- the paths share no code, and the
 // model-1 tables and the double log10 of --precise-gl 1 would cost the plain model-2 loop registers (occupancy)
-template <int A, int GLM, bool PREC, int WPB>
+// FUSED (GL model 2, one fixed quality score, the default tag surface, every mean depth below 12, 256 < N <= 512): the workgroup IS one
+// site, and what k_sample, k_site and the loads of this kernel would pass through HBM stays in the workgroup -- each thread first draws
+// its own evaluation's depth and reads (k_sample's fixed-score path), the per-base depths are summed over the site in LDS, sixteen
+// threads work out the allele order and the row table (k_site's code), and the likelihood pass below takes per-base depths, site
+// record, row table and the staged reads (two bits each: the score is the same for all) from LDS.  One launch per tile instead of three.
+template <int A, int GLM, bool PREC, int WPB, bool FUSED = false>
 __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const VglTilePtrs T) {
+    static_assert(!FUSED || (GLM == 2 && !PREC && WPB == 8), "the fused build exists for GL model 2, 512 threads");
     constexpr int WG = 64 * WPB;                                        // evaluations (threads) per workgroup: 256 or 512
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     constexpr int QL = 96;                                              // quality scores below QL take their three terms from LDS
@@ -170,11 +201,16 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
     // one LDS object, so that its members lie in this order: the per-quality terms first -- at LDS offset 0 their three rows are
     // reached by the immediate offsets of ds_read2_b64 / ds_read_b64 (an add per read otherwise)
     struct Lds {
-        double q2gl[(GLM == 2 && !PREC) ? 3 * QL : 1];
+        double q2gl[(GLM == 2 && !PREC && !FUSED) ? 3 * QL : 1];
         uint32_t x[(GLM == 1 ? 16 : 15) * WG];                          // the accumulators (up to 15 rows) of the workgroup's evaluations on their way from sorted to natural order; before that,
                                                                         // GL model 1 with per-read scores: a (base, quality) histogram per lane, 64 one-byte rows per wavefront
         uint16_t perm[WG];
         int32_t ws[2 * WPB];                                            // (site, first sample) of the workgroup's wavefronts in natural order
+        // FUSED: per-base depths of the site's evaluations, the site's row table, its summed depths and its record
+        uint64_t f_ad4[FUSED ? WG : 1];
+        uint64_t f_rowmap[FUSED ? 16 : 1];
+        int32_t f_acc[FUSED ? 16 : 1];
+        VglSiteInfo f_si;
     };
     __shared__ Lds s_lds;
     double* const s_q2gl = s_lds.q2gl;
@@ -182,22 +218,87 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
     uint16_t* const s_perm = s_lds.perm;
     int32_t* const s_ws = s_lds.ws;
     uint32_t* const s_hist = s_x;                                       // [1026] bins of the depth sort (done before s_x is used)
+    uint32_t* const s_fw = s_x + 1536;                                  // FUSED: [4][WG] staged reads, sixteen per word (behind the sort's bins; free before the deposits)
     const int N = P.n_samples;
     const int tid = threadIdx.x;
-    if (GLM == 2 && !PREC) {
+    if (GLM == 2 && !PREC && !FUSED) {
         if (P.error_qs == 2) {                                          // the per-quality terms of the read loop, in LDS
             for (int i = tid; i < 3 * QL; i += WG) s_q2gl[i] = P.q2gl[(i / QL) * 257 + (i % QL)];
             if (!P.gl_sort) __syncthreads();                            // (with the sort, its barriers stand between these stores and the loop)
         }
     }
-    const uint32_t nwaves = (uint32_t)T.n_sites * (uint32_t)P.chunks;                   // < 2^31 (checked by the launcher)
+    const uint32_t chunks_k = FUSED ? (uint32_t)WPB : (uint32_t)P.chunks;              // FUSED: a site takes the whole workgroup (wavefronts beyond its samples idle)
+    const uint32_t nwaves = (uint32_t)T.n_sites * chunks_k;                             // < 2^31 (checked by the launcher)
     const uint32_t bx = P.xcd_map ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x;     // logical workgroup (XCD-contiguous)
+    uint64_t f_a = 0;                                                   // FUSED: this thread's per-base depths
+    if constexpr (FUSED) {
+        // ---- k_sample<0, LEAN> for the evaluation (site bx, sample tid): vcfgl.cpp:364-389, 469-613 (vgl_sample.hip)
+        const int site = (int)bx;
+        if (tid < 16) s_lds.f_acc[tid] = 0;
+        __syncthreads();
+        uint64_t ad4s = 0;
+        if (tid < N) {
+            const size_t ev = (size_t)site * N + (size_t)tid;
+            const uint64_t xe = aff(P.samp_tab[tid], T.site_base[site]);
+            const uint64_t st_depth = aff(P.off[0], xe);
+            uint64_t st_hap16 = aff(P.off[1], xe) << 16, st_base16 = aff(P.off[2], xe) << 16;      // sample_read_base16: states carried shifted by 16
+            VglPois pc = P.pois0;
+            if (P.per_sample_depth) pc = P.pois[tid];
+            double t = 1.0;                                             // the product method (rng.h:289-299), state carried shifted by 4
+            int em = -1;
+            uint64_t s52 = st_depth << 4;
+            uint32_t k3ff = 0x3FF00000u;
+            asm volatile("" : "+v"(k3ff));
+            do { ++em; s52 = lcg_next52r(s52); t *= bits_1xxx_52r(s52, k3ff) - 1.0; } while (t > pc.g);
+            const uint32_t g = T.gt[ev];
+            const int a0 = (int)(g & 0xF), a1 = (int)((g >> 4) & 0xF);
+            int dps = (a0 == 0xF || a1 == 0xF) ? 0 : em;
+            if (dps > P.read_cap) { atomicOr(T.errflag, VGL_DEVERR_CAPACITY); dps = P.read_cap; }
+            const uint64_t err_thresh16 = sample_thresh16(P.err_thresh);
+            uint32_t wcur = 0;
+            for (int r0 = 0; r0 < dps; r0 += 4) {
+                uint32_t rw = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (r0 + j < dps) {
+                        bool fwd;
+                        const int r_base = sample_read_base16(st_hap16, st_base16, a0, a1, err_thresh16, false, fwd);
+                        rw |= (uint32_t)r_base << (2 * j);
+                        ad4s += 1ULL << (16 * r_base);
+                    }
+                wcur |= rw << (8 * ((r0 >> 2) & 3));
+                if (((r0 >> 2) & 3) == 3 || r0 + 4 >= dps) { s_fw[(r0 >> 4) * WG + tid] = wcur; wcur = 0; }
+            }
+            if (T.fmt_dp) T.fmt_dp[ev] = dps;
+        }
+        f_a = ad4s;
+        s_lds.f_ad4[tid] = ad4s;
+        // ---- the site's summed depths (every read shows one base; without strand draws every read counts as forward)
+        int v[5];
+        wave_sum_ad4(ad4s, &v[1]);
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int k = 1; k < 5; ++k) if (v[k]) atomicAdd(&s_lds.f_acc[k], v[k]);
+        }
+        __syncthreads();
+        // ---- k_site: sixteen threads work out the allele order, thread m writes row-table entry m, thread 0 the site's outputs
+        if (tid < 16) {
+            int32_t acc9[9];
+#pragma unroll
+            for (int k = 1; k < 5; ++k) { acc9[k] = s_lds.f_acc[k]; acc9[4 + k] = acc9[k]; }
+            acc9[0] = acc9[1] + acc9[2] + acc9[3] + acc9[4];
+            const VglSiteOrder o = site_order(P, acc9[0], &acc9[1]);
+            s_lds.f_rowmap[tid] = site_rowmap_entry(P.A, o.a2b, (uint32_t)tid);
+            if (tid == 0) { s_lds.f_si = site_info_of(o); site_outputs(P, T, site, o, acc9); }
+        }
+        __syncthreads();
+    }
     // wave k of this workgroup is wave 4 bx + k of the tile = (site, 64-sample chunk).  One scalar division per workgroup; a lane
     // then finds the site of ANY of the four waves with three compares (a per-lane 64-bit division was 60+ vector instructions,
     // three times per lane)
-    const uint32_t wg_ls = (bx * (uint32_t)WPB) / (uint32_t)P.chunks, wg_rem = (bx * (uint32_t)WPB) - wg_ls * (uint32_t)P.chunks;
+    const uint32_t wg_ls = (bx * (uint32_t)WPB) / chunks_k, wg_rem = (bx * (uint32_t)WPB) - wg_ls * chunks_k;
     auto wave_site = [&](const int k, int& ls_, int& s_base) {
-        const int t = (int)wg_rem + k, c = P.chunks;
+        const int t = (int)wg_rem + k, c = (int)chunks_k;
         int add = 0;
 #pragma unroll
         for (int j = 1; j < WPB; ++j) add += (t >= j * c) ? 1 : 0;
@@ -222,13 +323,15 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
             if (P.gl_sort && (tid & 63) == 0) { s_ws[2 * (tid >> 6)] = ls0; s_ws[2 * (tid >> 6) + 1] = sb0; }       // for the lane the sort hands an evaluation of this wavefront to
             s0 = sb0 + (tid & 63);
             if (s0 < N) {
-                a = T.ad4[(size_t)ls0 * N + (size_t)sb0 + (size_t)(tid & 63)];
+                if constexpr (FUSED) a = f_a;
+                else a = T.ad4[(size_t)ls0 * N + (size_t)sb0 + (size_t)(tid & 63)];
                 dp0 = (int)((a & 0xFFFF) + ((a >> 16) & 0xFFFF) + ((a >> 32) & 0xFFFF) + ((a >> 48) & 0xFFFF));
                 if (dp0 > 1023) dp0 = 1023;
                 if (GLM == 2) {
                     const uint32_t q0 = (a & 0xFFFFULL) != 0, q1 = ((a >> 16) & 0xFFFF) != 0, q2 = ((a >> 32) & 0xFFFF) != 0, q3 = (a >> 48) != 0;
                     k0 = (int)(q0 + q1 + q2 + q3);
-                    rmap = T.rowmap[(size_t)ls0 * 16 + (q0 | (q1 << 1) | (q2 << 2) | (q3 << 3))];      // (in flight during the loop)
+                    if constexpr (FUSED) rmap = s_lds.f_rowmap[q0 | (q1 << 1) | (q2 << 2) | (q3 << 3)];
+                    else rmap = T.rowmap[(size_t)ls0 * 16 + (q0 | (q1 << 1) | (q2 << 2) | (q3 << 3))];   // (in flight during the loop)
                 }
             }
         }
@@ -274,7 +377,8 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
     const int lane = tid & 63;
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t w = bx * (uint32_t)WPB + (uint32_t)(otid >> 6);
-    const VglSiteInfo si_nv = T.sinfo[ls0];                            // the natural evaluation's site (epilogue); in flight during the loop
+    VglSiteInfo si_nv;                                                 // the natural evaluation's site (epilogue); in flight during the loop
+    if constexpr (FUSED) si_nv = s_lds.f_si; else si_nv = T.sinfo[ls0];
     int ls = 0, s = N;
     if (w < nwaves) {
         int sb;
@@ -286,13 +390,24 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
     if (!live) { ls = 0; s = 0; }                                      // padding lane: reads stay in range, nothing is deposited
     const size_t ev = (size_t)ls * N + s;
     const size_t plane = (size_t)T.n_sites * N;
-    const VglSiteInfo si = T.sinfo[ls];
+    VglSiteInfo si;
+    uint64_t ad4;
+    if constexpr (FUSED) { si = s_lds.f_si; ad4 = s_lds.f_ad4[otid]; }
+    else { si = T.sinfo[ls]; ad4 = T.ad4[ev]; }
     const int nA = si.n_alleles;
     const bool have = (si.status == SITE_OK);
     const float MISS = f32_missing();
-
-    const uint64_t ad4 = T.ad4[ev];
     const int dp = (have && live) ? (int)((ad4 & 0xFFFF) + ((ad4 >> 16) & 0xFFFF) + ((ad4 >> 32) & 0xFFFF) + ((ad4 >> 48) & 0xFFFF)) : 0;
+    // FUSED: the staged reads of the evaluation (at most 64, sixteen per word) from LDS into registers; behind the barrier the words'
+    // place belongs to the deposits
+    uint32_t fw0 = 0, fw1 = 0, fw2 = 0, fw3 = 0;
+    if constexpr (FUSED) {
+        if (dp > 0) fw0 = s_fw[otid];
+        if (dp > 16) fw1 = s_fw[WG + otid];
+        if (dp > 32) fw2 = s_fw[2 * WG + otid];
+        if (dp > 48) fw3 = s_fw[3 * WG + otid];
+        __syncthreads();
+    }
 
     float acc[NG];
 #pragma unroll
@@ -308,7 +423,7 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
             // accumulators for k = 1 .. 4 instead of A (A + 1) / 2 = 15, each updated by exactly the reference's operations.  A
             // wavefront runs the loop built for the largest k among its lanes (a lane with fewer present bases leaves the higher
             // slots to duplicates of its absent-allele sequences); the genotype-ordered values are read back through LDS.
-            const bool per_read = (P.error_qs == 2);
+            const bool per_read = !FUSED && (P.error_qs == 2);
             const uint32_t p0 = (ad4 & 0xFFFFULL) != 0, p1 = ((ad4 >> 16) & 0xFFFF) != 0, p2 = ((ad4 >> 32) & 0xFFFF) != 0, p3 = (ad4 >> 48) != 0;
             const int k_pres = (int)(p0 + p1 + p2 + p3);
             const uint32_t cmap = (p0 << 2) | ((p0 + p1) << 4) | ((p0 + p1 + p2) << 6);          // 2 bits per base: its rank among the present bases
@@ -326,7 +441,8 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
                 // (vgl_read_byte); three words = 12 reads are kept in flight
                 const uint32_t* colw = (const uint32_t*)T.reads + ev;
                 const int lastw = (dp - 1) >> 2;
-                uint32_t w0 = colw[0], w1 = colw[(size_t)(1 < lastw ? 1 : lastw) * plane], w2 = colw[(size_t)(2 < lastw ? 2 : lastw) * plane];
+                uint32_t w0 = 0, w1 = 0, w2 = 0;
+                if constexpr (!FUSED) { w0 = colw[0]; w1 = colw[(size_t)(1 < lastw ? 1 : lastw) * plane]; w2 = colw[(size_t)(2 < lastw ? 2 : lastw) * plane]; }
                 auto one_read = [&](const uint32_t rb, const int r) {
                     const int ci = (int)((cmap >> ((rb & 3) * 2)) & 3);                           // the read's base among the present ones
                     if (per_read) {
@@ -378,6 +494,15 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
                     }
                 };
                 // four reads per trip: one staged word, its bytes taken with constant shifts
+                if constexpr (FUSED) {
+                    for (int r0 = 0; r0 < dp; r0 += 4) {                                      // sixteen reads per word, two bits each (the base; the score is fixed)
+                        const int wi = r0 >> 4;
+                        const uint32_t cur = (wi == 0 ? fw0 : wi == 1 ? fw1 : wi == 2 ? fw2 : fw3) >> ((r0 & 15) * 2);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (r0 + j < dp) one_read((cur >> (2 * j)) & 3u, r0 + j);
+                    }
+                } else
                 for (int r0 = 0; r0 < dp; r0 += 4) {                                          // (r0 is the same in every active lane)
                     const uint32_t cur = w0;
                     w0 = w1; w1 = w2;
@@ -844,6 +969,16 @@ extern "C" int vgl_launch_gl(const VglDevParams* p, const VglTilePtrs* t, void* 
     else if (p->gl_model == 2) { if (wpb == 8) VGL_LAUNCH_GL(2, false, 8); else VGL_LAUNCH_GL(2, false, 4); }
     else VGL_LAUNCH_GL(1, false, 4);
 #undef VGL_LAUNCH_GL
+    return (int)hipGetLastError();
+}
+
+// the fused build (see k_gl): one workgroup per site.  The caller (vgl_host.cpp) checks the conditions
+extern "C" int vgl_launch_fused(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
+    if (t->n_sites == 0) return 0;
+    if (p->n_samples > 512 || p->read_cap > 64 || p->gl_model != 2 || p->precise_gl || p->error_qs != 0) return (int)hipErrorInvalidValue;
+    const dim3 g((unsigned)t->n_sites), b(512);
+    if (p->A == 5) hipLaunchKernelGGL((k_gl<5, 2, false, 8, true>), g, b, 0, (hipStream_t)stream, *p, *t);
+    else hipLaunchKernelGGL((k_gl<4, 2, false, 8, true>), g, b, 0, (hipStream_t)stream, *p, *t);
     return (int)hipGetLastError();
 }
 

@@ -424,6 +424,10 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     D.dbg_redo_every = getenv("VGL_DEBUG_REDO_EVERY") ? atoi(getenv("VGL_DEBUG_REDO_EVERY")) : 0;
     D.defer_ok = (!D.serial && p->error_qs == 2 && !D.need_qsum && !D.sample_strand && !D.need_adf && p->adjust_qs == 0 &&
                   !D.gx.changed && !D.gy.changed && D.gx.alpha0 >= 8.0 && D.gy.alpha0 >= 8.0 && !getenv("VGL_NO_DEFER") && !getenv("VGL_DEBUG_QS_EXACT") && !getenv("VGL_NO_LEAN")) ? 1 : 0;
+    // one workgroup per site does everything (k_gl<.., FUSED>, vgl_gl.hip): sampling with one fixed score, the site's allele order and the
+    // likelihoods, with nothing staged in HBM between them
+    D.fused = (!D.serial && p->error_qs == 0 && p->gl_model == 2 && !p->precise_gl && D.depth_pre == 2 && !D.need_qsum && !D.sample_strand &&
+               !D.need_adf && p->adjust_qs == 0 && N > 256 && N <= 512 && D.read_cap <= 64 && !getenv("VGL_NO_FUSE") && !getenv("VGL_NO_LEAN")) ? 1 : 0;
     if (D.defer_ok && D.pool_cap > 1472) {      // 20 wavefronts' pools in a CU's 160 KB of LDS: 576 + 5 x 1472 + 8 B each
         D.pool_cap = 1472;
         D.pool_lds_bytes = (576 + 4 * (D.pool_cap + 2) + D.pool_cap + 7) & ~7;
@@ -719,16 +723,18 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
         if (vgl_launch_sitebase(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_sitebase launch failed");
         if (D.depth_pre == 1 && vgl_launch_depth(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_depth launch failed");
     }
+    const bool fused = D.fused && !T.reads_out && !o->qs && !o->i16 && !dump_errp;
     if (c->timing) HIPCHK(hipEventRecord(e[1], st));
-    if (vgl_launch_sample(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_sample launch failed: %s", hipGetErrorString(hipGetLastError()));
+    if (!fused && vgl_launch_sample(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_sample launch failed: %s", hipGetErrorString(hipGetLastError()));
     if (c->timing) HIPCHK(hipEventRecord(e[2], st));
-    if (vgl_launch_site(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_site launch failed");
+    if (!fused && vgl_launch_site(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_site launch failed");
     if (c->timing) HIPCHK(hipEventRecord(e[3], st));
     if (D.serial && D.gl1_deep) {                            // where each deep evaluation's shuffle starts in htslib's stream
         if (vgl_launch_hts_offsets(&D, &T, c->d_serial, c->d_hts_off, c->d_hts_base, st)) return fail(VGL_E_NODEVICE, "k_hts_offsets launch failed");
         T.hts_off = c->d_hts_off; T.hts_base = c->d_hts_base;
     }
-    if (vgl_launch_gl(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_gl launch failed");
+    if (fused) { if (vgl_launch_fused(&D, &T, st)) return fail(VGL_E_NODEVICE, "fused k_gl launch failed"); }
+    else if (vgl_launch_gl(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_gl launch failed");
     if (c->timing) HIPCHK(hipEventRecord(e[4], st));
     if (o->qs || o->i16) if (vgl_launch_siteagg(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_siteagg launch failed");
     if (dump_errp) {
