@@ -1,5 +1,5 @@
-"""The fused build of k_gl (GL model 2, one fixed quality score, default tag surface, every mean depth below 12, 256 < N <= 512): one
-workgroup samples a site's reads, orders its alleles and evaluates the likelihoods without staging anything in HBM.  Same oracle
+"""The fused build of k_gl (GL model 2, one fixed quality score, default tag surface, every mean depth below 12, 128 < N <= 512): one
+workgroup (256 or 512 threads) samples a site's reads, orders its alleles and evaluates the likelihoods without staging anything in HBM.  Same oracle
 parity as the three-kernel path (bit-exact integers and GL), which `VGL_NO_FUSE=1` still runs."""
 import os
 
@@ -30,8 +30,8 @@ def _is_fused(args, N, gt):
     return ms[1] < 0.2 * ms[3]
 
 
-@pytest.mark.parametrize("N", [257, 300, 500, 511, 512])
-@pytest.mark.parametrize("depth", [0.3, 2.0, 5.0, 11.9])
+@pytest.mark.parametrize("N", [128, 129, 200, 256, 257, 300, 500, 511, 512, 513, 777, 1000, 1024, 1025])
+@pytest.mark.parametrize("depth", [0.3, 5.0, 11.9])
 def test_fused_shapes_and_depths(oracle, N, depth):
     args = VcfglArgs(seed=11, depth=depth, error_rate=0.01, **TAGS)
     gt = synth.binary_sites(5, 60, N)
@@ -43,7 +43,9 @@ def test_the_fused_kernel_is_the_one_that_runs():
     gt = np.zeros((8192, 500), dtype=np.uint8)
     assert _is_fused(VcfglArgs(seed=11, depth=5.0, error_rate=0.01, **TAGS), 500, gt)
     assert not _is_fused(VcfglArgs(seed=11, depth=5.0, error_rate=0.01, add_qs=1, **TAGS), 500, gt)          # -addQS needs the per-base quality sums
-    assert not _is_fused(VcfglArgs(seed=11, depth=5.0, error_rate=0.01, **TAGS), 600, np.zeros((8192, 600), dtype=np.uint8))
+    assert _is_fused(VcfglArgs(seed=11, depth=5.0, error_rate=0.01, **TAGS), 200, np.zeros((8192, 200), dtype=np.uint8))             # 256 threads per site
+    assert not _is_fused(VcfglArgs(seed=11, depth=5.0, error_rate=0.01, **TAGS), 600, np.zeros((8192, 600), dtype=np.uint8))          # (1024 threads per site were slower than three kernels)
+    assert not _is_fused(VcfglArgs(seed=11, depth=12.0, error_rate=0.01, **TAGS), 500, np.zeros((8192, 500), dtype=np.uint8))        # k_depth's rejection sampler, deeper staging
 
 
 @pytest.mark.parametrize("kw", [dict(do_unobserved=0), dict(do_unobserved=1), dict(do_unobserved=2), dict(do_unobserved=3), dict(do_unobserved=4),

@@ -97,7 +97,7 @@ struct VglDevParams {
     int32_t gl_sort;         // k_gl: re-deal the lanes of a workgroup in depth order (pays at depth >= 8; below, natural
                              // order keeps every store of a wavefront one contiguous segment and the kernel is HBM bound)
     int32_t gl_flip2;        // k_gl sort: the two-base group in ascending depth order (VGL_GL_FLIP2, default 1)
-    int32_t fused;           // tile mode, GL model 2, one fixed quality score, default tag surface, every mean depth < 12, 256 < N <= 512: sampling, site order and
+    int32_t fused;           // tile mode, GL model 2, one fixed quality score, default tag surface, every mean depth < 12, 128 < N <= 512: sampling, site order and
                              // likelihoods of a site in ONE workgroup (k_gl<.., FUSED>; VGL_NO_FUSE=1 turns it off)
     int32_t gl_wpb;          // k_gl, GL model 2: wavefronts per workgroup, 4 or 8 (VGL_GL_WPB)
     int32_t slow_period;     // k_sample<2>: the bounded-log test of the gamma sampler runs every slow_period-th pool iteration,

@@ -186,14 +186,15 @@ __device__ __forceinline__ int cnt_of(uint64_t ad4, int b) { return b < 4 ? (int
 // Which wavefront of a workgroup takes the heaviest 64 evaluations rotates with the workgroup index.
 // GLM, PREC: the GL model (1 / 2) and --precise-gl as template parameters -- the paths share no code, and the
 // model-1 tables and the double log10 of --precise-gl 1 would cost the plain model-2 loop registers (occupancy)
-// FUSED (GL model 2, one fixed quality score, the default tag surface, every mean depth below 12, 256 < N <= 512): the workgroup IS one
+// FUSED (GL model 2, one fixed quality score, the default tag surface, every mean depth below 12, 128 < N <= 512: 256 or 512 threads): the workgroup IS one
 // site, and what k_sample, k_site and the loads of this kernel would pass through HBM stays in the workgroup -- each thread first draws
 // its own evaluation's depth and reads (k_sample's fixed-score path), the per-base depths are summed over the site in LDS, sixteen
 // threads work out the allele order and the row table (k_site's code), and the likelihood pass below takes per-base depths, site
 // record, row table and the staged reads (two bits each: the score is the same for all) from LDS.  One launch per tile instead of three.
 template <int A, int GLM, bool PREC, int WPB, bool FUSED = false>
 __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const VglTilePtrs T) {
-    static_assert(!FUSED || (GLM == 2 && !PREC && WPB == 8), "the fused build exists for GL model 2, 512 threads");
+    static_assert(!FUSED || (GLM == 2 && !PREC), "the fused build exists for GL model 2 with the score table");
+    static_assert(WPB == 4 || WPB == 8, "workgroups of 256 or 512 threads");
     constexpr int WG = 64 * WPB;                                        // evaluations (threads) per workgroup: 256 or 512
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     constexpr int QL = 96;                                              // quality scores below QL take their three terms from LDS
@@ -972,13 +973,20 @@ extern "C" int vgl_launch_gl(const VglDevParams* p, const VglTilePtrs* t, void* 
     return (int)hipGetLastError();
 }
 
-// the fused build (see k_gl): one workgroup per site.  The caller (vgl_host.cpp) checks the conditions
+// the fused build (see k_gl): one workgroup of 256 / 512 threads per site (1024 threads for up to 1024 samples were measured: 2.07e10 against
+// 2.34e10 evaluations/s for the three kernels at N = 1000 and C5's flags -- two workgroups per CU, sixteen wavefronts behind every barrier).
+// The caller (vgl_host.cpp) checks the other conditions
 extern "C" int vgl_launch_fused(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
     if (t->n_sites == 0) return 0;
     if (p->n_samples > 512 || p->read_cap > 64 || p->gl_model != 2 || p->precise_gl || p->error_qs != 0) return (int)hipErrorInvalidValue;
-    const dim3 g((unsigned)t->n_sites), b(512);
-    if (p->A == 5) hipLaunchKernelGGL((k_gl<5, 2, false, 8, true>), g, b, 0, (hipStream_t)stream, *p, *t);
-    else hipLaunchKernelGGL((k_gl<4, 2, false, 8, true>), g, b, 0, (hipStream_t)stream, *p, *t);
+    const dim3 g((unsigned)t->n_sites);
+    hipStream_t s = (hipStream_t)stream;
+#define VGL_LAUNCH_FUSED(WPB) \
+    do { if (p->A == 5) hipLaunchKernelGGL((k_gl<5, 2, false, WPB, true>), g, dim3(64 * WPB), 0, s, *p, *t); \
+         else hipLaunchKernelGGL((k_gl<4, 2, false, WPB, true>), g, dim3(64 * WPB), 0, s, *p, *t); } while (0)
+    if (p->n_samples <= 256) VGL_LAUNCH_FUSED(4);
+    else VGL_LAUNCH_FUSED(8);
+#undef VGL_LAUNCH_FUSED
     return (int)hipGetLastError();
 }
 

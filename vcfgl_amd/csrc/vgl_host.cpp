@@ -427,7 +427,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     // one workgroup per site does everything (k_gl<.., FUSED>, vgl_gl.hip): sampling with one fixed score, the site's allele order and the
     // likelihoods, with nothing staged in HBM between them
     D.fused = (!D.serial && p->error_qs == 0 && p->gl_model == 2 && !p->precise_gl && D.depth_pre == 2 && !D.need_qsum && !D.sample_strand &&
-               !D.need_adf && p->adjust_qs == 0 && N > 256 && N <= 512 && D.read_cap <= 64 && !getenv("VGL_NO_FUSE") && !getenv("VGL_NO_LEAN")) ? 1 : 0;
+               !D.need_adf && p->adjust_qs == 0 && N > 128 && N <= 512 && D.read_cap <= 64 && !getenv("VGL_NO_FUSE") && !getenv("VGL_NO_LEAN")) ? 1 : 0;
     if (D.defer_ok && D.pool_cap > 1472) {      // 20 wavefronts' pools in a CU's 160 KB of LDS: 576 + 5 x 1472 + 8 B each
         D.pool_cap = 1472;
         D.pool_lds_bytes = (576 + 4 * (D.pool_cap + 2) + D.pool_cap + 7) & ~7;
