@@ -68,9 +68,10 @@ def test_fused_per_sample_depths_and_missing_genotypes(oracle):
     assert_parity(want, got)
 
 
+@pytest.mark.parametrize("N", [500, 300, 130])                             # 300, 130: wavefronts of the site's workgroup beyond its samples
 @pytest.mark.parametrize("layout", [_abi.VGL_LAYOUT_PLANES, _abi.VGL_LAYOUT_SAMPLE_MAJOR])
-def test_fused_layouts_and_narrow_pl(oracle, layout):
-    N, S = 500, 70
+def test_fused_layouts_and_narrow_pl(oracle, layout, N):
+    S = 70
     args = VcfglArgs(seed=21, depth=5.0, error_rate=0.01, do_unobserved=2, add_pl=1, add_fmt_ad=1, out_layout=layout)
     args.rng_mode, args.beta_sampler = _abi.VGL_RNG_TILE, _abi.VGL_BETA_RAND48
     gt = np.zeros((S, N), dtype=np.uint8)                                  # config C5's hom-ref sites
@@ -122,3 +123,38 @@ def test_fused_equals_three_kernel_path_and_tiling(oracle):
         s0 += n
     sim.close()
     assert s0 == S
+
+
+def test_fused_through_the_host_program(tmp_path):
+    """config C5's shape through vcfgl_hip (vgl_simulate_tile_async, sample-major slabs, pl_u8, gVCF blocks): 300 samples, an exploded
+    contig, --tile-sites below the site count -- the files written with the fused kernel and with VGL_NO_FUSE=1 are the same bytes"""
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    BIN = os.path.join(ROOT, "vcfgl_amd", "bin", "vcfgl_hip")
+    N, L = 300, 3000
+    rng = np.random.default_rng(4)
+    inp = str(tmp_path / "in.vcf")
+    with open(inp, "w") as fh:
+        fh.write("##fileformat=VCFv4.2\n##FILTER=<ID=PASS,Description=\"All filters passed\">\n")
+        fh.write(f"##contig=<ID=chr1,length={L}>\n##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n")
+        fh.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(f"s{i}" for i in range(N)) + "\n")
+        for p in sorted(rng.choice(np.arange(1, L), size=40, replace=False)):
+            g = rng.integers(0, 2, size=(N, 2))
+            fh.write(f"chr1\t{p}\t.\t0\t1\t.\tPASS\t.\tGT\t" + "\t".join(f"{a}|{b}" for a, b in g) + "\n")
+    outs = []
+    for nofuse in (False, True):
+        env = dict(os.environ)
+        if nofuse:
+            env["VGL_NO_FUSE"] = "1"
+        for flags, tag in ((["-explode", "1", "-doGVCF", "1", "--gvcf-dps", "5,10,20", "-doUnobserved", "2", "-addPL", "1"], "g"),
+                           (["-explode", "1", "-doUnobserved", "2", "-addPL", "1", "-addGP", "1", "-addFormatAD", "1", "-addInfoAD", "1"], "p")):
+            out = str(tmp_path / f"o_{tag}_{int(nofuse)}")
+            r = subprocess.run([BIN, "-i", inp, "-o", out, "-O", "v", "--seed", "42", "--depth", "5", "--error-rate", "0.01", "--tile-sites", "700"] + flags,
+                               capture_output=True, text=True, timeout=600, env=env)
+            assert r.returncode == 0, r.stderr[-800:]
+            body = [l for l in open(out + ".vcf") if not l.startswith("##")]
+            outs.append((tag, nofuse, body))
+    by = {(t, n): b for t, n, b in outs}
+    for t in ("g", "p"):
+        assert len(by[(t, False)]) > 100
+        assert by[(t, False)] == by[(t, True)], t

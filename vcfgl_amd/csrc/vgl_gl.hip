@@ -738,7 +738,7 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
     const uint32_t wb = 64u * (uint32_t)wv;
     const int ls_w = ls0, sb_w = sb0;                                    // (scalar: the natural-order wavefront's site and first sample)
     const bool wave_ok = bx * (uint32_t)WPB + (uint32_t)__builtin_amdgcn_readfirstlane(wv) < nwaves;
-    const uint32_t nv = wave_ok ? (uint32_t)((N - sb_w) < 64 ? (N - sb_w) : 64) : 0u;       // samples of this wavefront's chunk
+    const uint32_t nv = (wave_ok && sb_w < N) ? (uint32_t)((N - sb_w) < 64 ? (N - sb_w) : 64) : 0u;   // samples of this wavefront's chunk (FUSED: a site's workgroup may have wavefronts beyond its samples)
     const uint32_t nG0u = (uint32_t)__builtin_amdgcn_readfirstlane(nG0), nA0u = (uint32_t)__builtin_amdgcn_readfirstlane(nA0);
 #define VGL_WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 // the rows of one plane group: the row pointer is wave-uniform and is kept in scalar registers (pinned: left to itself the compiler folds the
