@@ -63,8 +63,29 @@ WORKLOADS = {
                  desc="--depth 20 -e 0.01 --error-qs 2 --beta-variance 1e-5 -GL 1"),
     "precise": dict(sites=262_144, samples=1000, flags=dict(depth=20.0, error_rate=0.01, error_qs=2, beta_variance=1e-5, gl_model=2, precise_gl=1),
                     desc="--depth 20 -e 0.01 --error-qs 2 --beta-variance 1e-5 -GL 2 --precise-gl 1"),
+    # c3's flags with the reference's whole optional tag surface (test/runTests.sh:287-314, test1: -addGP -addPL -addI16 -addQS -addInfoDP
+    # -addFormatAD/ADF/ADR -addInfoAD/ADF/ADR): strand draws, per-base quality sums, k_siteagg, GP; a quarter of c3's sites (244 B of tags per evaluation)
+    "alltags": dict(sites=262_144, samples=1000,
+                    flags=dict(depth=20.0, error_rate=0.01, error_qs=2, beta_variance=1e-5, gl_model=2, add_gp=1, add_pl=1, add_i16=1, add_qs=1, add_info_dp=1,
+                               add_fmt_ad=1, add_info_ad=1, add_fmt_adf=1, add_info_adf=1, add_fmt_adr=1, add_info_adr=1),
+                    fields=["fmt_dp", "gl", "pl", "gp", "fmt_ad", "fmt_adf", "fmt_adr", "info_dp", "info_ad", "info_adf", "info_adr", "qs", "i16"],
+                    desc="--depth 20 -e 0.01 --error-qs 2 --beta-variance 1e-5 -GL 2 -addGP 1 -addPL 1 -addI16 1 -addQS 1 -addInfoDP 1 -addFormatAD/ADF/ADR 1 -addInfoAD/ADF/ADR 1"),
+    # c3's flags + -addQS -addI16 only (what a bcftools-style caller turns on): the per-base quality sums and the strand draws
+    "qsi16": dict(sites=262_144, samples=1000,
+                  flags=dict(depth=20.0, error_rate=0.01, error_qs=2, beta_variance=1e-5, gl_model=2, add_i16=1, add_qs=1),
+                  fields=["fmt_dp", "gl", "qs", "i16"],
+                  desc="--depth 20 -e 0.01 --error-qs 2 --beta-variance 1e-5 -GL 2 -addQS 1 -addI16 1"),
 }
-KERNELS = ["k_depth", "k_sample", "k_site", "k_gl"]
+KERNELS = ["k_depth", "k_sample", "k_redo", "k_site", "k_gl", "k_siteagg"]      # vgl_ctx_kernel_ms buckets (ABI 5: VGL_T_*)
+
+
+def algorithmic_bytes_per_eval(fields, G):
+    """SURVEY 8d: B_eval = 1 (packed GT in) + 4 (DP out) + 4 G (GL) [+ 4 G (PL), or G as pl_u8] [+ 4 G (GP)] [+ 16 per AD-type FORMAT tag];
+    per-site outputs (INFO tags, QS, I16) are not per-evaluation bytes"""
+    b = 1
+    for f in fields:
+        b += {"fmt_dp": 4, "gl": 4 * G, "pl": 4 * G, "gp": 4 * G, "pl_u8": G, "fmt_ad": 16, "fmt_adf": 16, "fmt_adr": 16}.get(f, 0)
+    return b
 
 
 def log(msg):
@@ -222,6 +243,7 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
     TS = max(1, min(opt.tile_sites, S))
     sim = Simulator(args, N, device=local_dev, max_sites_per_tile=TS)
     G = sim.G
+    info = sim.info()
     log(f"{name}: rank {rank}/{world} sites [{site_base}, {site_base + S}) x {N} samples, tiles of {TS}")
 
     # ---- inputs resident in HBM before the timed region
@@ -233,18 +255,12 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
             n = min(65536, S - s0)
             gt[s0:s0 + n] = synth.binary_sites_torch(site_base + s0, n, N, dev)
     # ---- outputs: the whole job's tag arrays stay in HBM (65 B per evaluation at C3)
-    out = {
-        "site_status": torch.empty((S,), dtype=torch.int32, device=dev),
-        "n_alleles": torch.empty((S,), dtype=torch.int32, device=dev),
-        "alleles2acgt": torch.empty((S, 5), dtype=torch.int8, device=dev),
-        "fmt_dp": torch.empty((S, N), dtype=torch.int32, device=dev),
-        "gl": torch.empty((S, G, N), dtype=torch.float32, device=dev),
-    }
     narrow_pl = bool(wl.get("narrow_pl"))
-    if args.add_pl and narrow_pl:
-        out["pl_u8"] = torch.empty((S, G, N), dtype=torch.uint8, device=dev)
-    elif args.add_pl:
-        out["pl"] = torch.empty((S, G, N), dtype=torch.int32, device=dev)
+    fields = list(wl.get("fields") or (["fmt_dp", "gl"] + ((["pl_u8"] if narrow_pl else ["pl"]) if args.add_pl else [])))
+    A = sim.A
+    shapes = {"site": (S,), "site5": (S, 5), "siteA": (S, A), "site16": (S, 16), "eval": (S, N), "planeG": (S, G, N), "planeA": (S, A, N)}
+    kinds = {f: (dt, kind) for f, dt, kind in _abi.TILE_FIELDS}
+    out = {f: torch.empty(shapes[kinds[f][1]], dtype=getattr(torch, kinds[f][0]), device=dev) for f in ["site_status", "n_alleles", "alleles2acgt"] + fields}
     structs = []
     for s0 in range(0, S, TS):
         n = min(TS, S - s0)
@@ -286,9 +302,20 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
         step's 65 GB per GPU through one writer.  Twice; the second pass is the one reported."""
         s0, n, _ = structs[-1]
         for rep in range(2):
-            with torch.cuda.stream(stream):
-                p = pack_records({k: v[s0:s0 + n] for k, v in out.items()}, site0=site_base + s0)
-            stream.synchronize()
+            # every rank first says whether its packing worked: a rank that failed (out of memory in pack_records, say) must not
+            # leave its peers waiting in the barriers and transfers below until the process group times out
+            p, err = None, None
+            try:
+                with torch.cuda.stream(stream):
+                    p = pack_records({k: v[s0:s0 + n] for k, v in out.items()}, site0=site_base + s0)
+                stream.synchronize()
+            except Exception as e:
+                err = repr(e)[:300]
+            ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev if transport is None else transport)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                comm["sample_error"] = err or "another rank failed to pack its records: sampled gather skipped on every rank"
+                return
             dist.barrier()
             torch.cuda.synchronize()
             t_c = time.perf_counter()
@@ -301,6 +328,19 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
             comm["sample_packed_bytes"] = p.nbytes()
             comm["sample_bytes"] = sum(q.nbytes() for q in got[1:]) if got is not None else 0      # bytes that crossed a link into the writer
             del p, got
+
+    if dist is not None and gather == "records":
+        # the writer receives one packed tile from every peer at a time: refuse up front when that cannot fit beside its own arrays
+        need = (world - 1) * algorithmic_bytes_per_eval(fields, G) * TS * N * 2           # receive buffers + their unpacked view
+        free = torch.cuda.mem_get_info(dev)[0] if rank == 0 else 0
+        okt = torch.tensor([1 if (rank != 0 or free > need) else 0], dtype=torch.int32, device=dev if transport is None else transport)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if int(okt.item()) == 0:
+            if rank == 0:
+                log(f"--gather records: the writer needs about {need / 1e9:.1f} GB for the peers' packed tiles but has {free / 1e9:.1f} GB free: "
+                    f"use a smaller --tile-sites, fewer --sites, or --gather sample")
+            dist.barrier()
+            sys.exit(3)
 
     def barrier():
         stream.synchronize()
@@ -326,10 +366,14 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
     sim.check(stream.cuda_stream)
     kms, klaunch = sim.kernel_ms(reset=True)
     sim.timing(False)
+    per_rank = None
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if transport is None else transport)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        # every rank's own clock and kernel buckets to rank 0 (the first multi-GPU run must show a load imbalance at once), then the max
+        mine = torch.tensor([dt] + [float(x) for x in kms] + [float(x) for x in klaunch], dtype=torch.float64, device=dev if transport is None else transport)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [t.cpu().tolist() for t in allr]
+        dt = max(r[0] for r in per_rank)
         if gather == "sample":
             try:                                                   # (after the timed steps: a failure here is reported in `comm`, it must not cost the line)
                 sampled_record_gather()
@@ -339,7 +383,7 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
     res = None
     if rank == 0:
         evals_total = float(S_total) * N * steps
-        b_eval = 1 + 4 + 4 * G + ((G if narrow_pl else 4 * G) if args.add_pl else 0)  # packed GT in + DP out + GL (+ PL) out
+        b_eval = algorithmic_bytes_per_eval(fields, G)
         dom = int(np.argmax(kms))
         avg_ms = kms[dom] / max(klaunch[dom], 1)
         evals_per_launch = float(S) * N * steps / max(klaunch[dom], 1)     # average over the launches, partial last tile included
@@ -371,7 +415,8 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
         step_gbs = step_bytes / (dt / steps) / 1e9
         res = {
             "value": evals_total / dt, "unit": "site-sample GL evals/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
-            "workload": f"{name}: {S} sites x {N} samples per GPU, {wl['desc']}, tags GL+DP{('+PL(u8)' if narrow_pl else '+PL') if args.add_pl else ''} (G={G}), rng tile mode, rand48 beta sampler",
+            "workload": f"{name}: {S} sites x {N} samples per GPU, {wl['desc']}, outputs {'+'.join(fields)} (G={G}), rng tile mode, rand48 beta sampler",
+            "ctx": {k: info[k] for k in ("fused", "fused_split", "sample_lean", "depth_mode", "gl_sort", "gl_wpb", "read_cap", "pool_cap", "workspace_bytes")},
             "roofline": {"bound": bound, "bound_basis": basis, "kernel": KERNELS[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "bound_note": "achieved / peak / frac are the ALGORITHMIC-bytes HBM figures of the dominant kernel the contract asks for; `step` is the same "
@@ -383,6 +428,15 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
                          "valu": valu, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_eval": b_eval,
                          "kernel_ms_total": dict(zip(KERNELS, kms)), "launches": dict(zip(KERNELS, klaunch))},
         }
+        if per_rank is not None:
+            nb = len(KERNELS)
+            evals_rank = float(S) * N * steps
+            res["ranks"] = {
+                "evals_per_s": {"min": evals_rank / max(r[0] for r in per_rank), "max": evals_rank / min(r[0] for r in per_rank),
+                                "per_rank": [evals_rank / r[0] for r in per_rank]},
+                "ms_per_step": {"min": min(r[0] for r in per_rank) / steps * 1e3, "max": max(r[0] for r in per_rank) / steps * 1e3},
+                "kernel_ms_per_launch": [{k: (r[1 + i] / r[1 + nb + i] if r[1 + nb + i] else 0.0) for i, k in enumerate(KERNELS)} for r in per_rank],
+                "note": "each rank's own wall clock over the timed steps (value uses the slowest) and its kernel buckets: equal work per rank, so a spread here is the machine, not the sharding"}
         if dist is not None:
             res["comm"] = {"backend": opt.backend, "world": dist.get_world_size(), "gather": gather,
                            "gather_ms": comm["gather_s"] / steps * 1e3,
@@ -587,12 +641,12 @@ def main():
     if world == 1 and not opt.no_extra and opt.sites is None and opt.samples is None:
         # the other BASELINE configurations on this GPU, a few passes each, attached to the same line (parity-test cases, not
         # the headline: VERDICT r1 asked for driver-timed evidence of them)
-        for name in ("c5", "c5u8", "fixedq", "c4", "c2", "gl1q", "precise"):
+        for name in ("c5", "c5u8", "fixedq", "c4", "c2", "gl1q", "precise", "alltags", "qsi16"):
             if name == opt.workload:
                 continue
             try:
                 r = run_workload(name, opt, env, steps=(20 if name == "c2" else 3), warmup=1, gather="index")
-                extra[name] = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "workload", "roofline")}
+                extra[name] = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "workload", "ctx", "roofline")}
             except Exception as e:                             # an extra must never cost the headline line
                 extra[name] = {"error": repr(e)[:300]}
         extra["host_path_c3"] = host_first.get("c3", host_first) if isinstance(host_first, dict) else host_first
@@ -613,7 +667,7 @@ def main():
                        "backend": (("rccl (torch.distributed nccl)" if opt.backend == "nccl" else "gloo (host staging, rehearsal)") if dist is not None else None)},
             "roofline": main_res["roofline"],
         }
-        for k in ("cpu_baseline", "comm", "records_gather", "record_packing"):
+        for k in ("ctx", "cpu_baseline", "comm", "records_gather", "record_packing", "ranks"):
             if k in main_res:
                 line[k] = main_res[k]
         if extra:

@@ -39,7 +39,9 @@
 extern "C" {
 #endif
 
-#define VGL_ABI_VERSION 4
+#define VGL_ABI_VERSION 5
+/* the library is built with -fvisibility=hidden: these entry points are its whole dynamic symbol table */
+#define VGL_API __attribute__((visibility("default")))
 
 /* ---- error codes (returned by every entry point; 0 = success) ----------------------- */
 #define VGL_OK              0
@@ -201,26 +203,26 @@ typedef struct vgl_tile_out {
 typedef struct vgl_ctx vgl_ctx;
 
 /* Layout helpers (pure host arithmetic, usable without a GPU). */
-int32_t vgl_max_alleles(const vgl_params* p);      /* 4 or 5:  shared.h:148-152              */
-int32_t vgl_max_genotypes(const vgl_params* p);    /* 10 or 15: lut_nAlleles_to_nGenotypes    */
-int     vgl_default_rng_layout(const vgl_params* p, vgl_rng_layout* out);
+VGL_API int32_t vgl_max_alleles(const vgl_params* p);      /* 4 or 5:  shared.h:148-152              */
+VGL_API int32_t vgl_max_genotypes(const vgl_params* p);    /* 10 or 15: lut_nAlleles_to_nGenotypes    */
+VGL_API int     vgl_default_rng_layout(const vgl_params* p, vgl_rng_layout* out);
 /* VGL_RNG_TILE addresses one rand48 sequence of period 2^48: a job may use sites [0, *max_sites) before its windows
  * would repeat; *max_sites = 2^W, the largest power of two with 2^W * n_samples * block <= 2^48 (BASELINE config C4, 1e7
  * sites x 2000 samples at depth 30: 2^24 = 1.68e7).  vgl_simulate_tile* return VGL_E_ARG beyond that.  The reference's
  * serial streams have no such limit (rng.h:8-10) -- VGL_RNG_SERIAL neither. */
-int     vgl_rng_tile_max_sites(const vgl_params* p, int64_t* max_sites);
+VGL_API int     vgl_rng_tile_max_sites(const vgl_params* p, int64_t* max_sites);
 /* H(site) of the window layout above (pure host arithmetic; VGL_E_ARG outside [0, max_sites)). */
-int     vgl_rng_tile_site_hash(const vgl_params* p, int64_t site, int64_t* hashed);
-int     vgl_abi_version(void);
-const char* vgl_last_error(void);
+VGL_API int     vgl_rng_tile_site_hash(const vgl_params* p, int64_t site, int64_t* hashed);
+VGL_API int     vgl_abi_version(void);
+VGL_API const char* vgl_last_error(void);
 
 /* Replaces args_get()'s sampler/LUT construction (io.cpp:1036-1074,1276) and main()'s
  * preCalc block (vcfgl.cpp:1661-1767): validates flags, builds the Poisson constants,
  * beta shape parameters, fixed-qscore terms, GL1 error-model tables and rand48 jump
  * tables, uploads them, and sizes the staging workspace for `max_sites_per_tile`.
  * `device` is the HIP device ordinal.  Fails with VGL_E_NODEVICE when no GPU is present. */
-int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_sites_per_tile, vgl_ctx** out);
-int vgl_ctx_destroy(vgl_ctx* ctx);
+VGL_API int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_sites_per_tile, vgl_ctx** out);
+VGL_API int vgl_ctx_destroy(vgl_ctx* ctx);
 
 /* Replaces the call of simulate_record_values() (vcfgl.cpp:1522,1552,1611) for `n_sites`
  * consecutive records whose absolute indices (in simulation order) start at `site0`.
@@ -228,7 +230,7 @@ int vgl_ctx_destroy(vgl_ctx* ctx);
  *        space 0..3 exactly as check_rec_alleles() leaves them in true_gts_acgt_int
  *        (vcfgl.cpp:132-147); VGL_GT_MISSING (0xF) in either nibble = missing genotype.
  * Host variant: `gt` and every pointer in `out` are host memory; the call is synchronous. */
-int vgl_simulate_tile(vgl_ctx* ctx, int64_t site0, int32_t n_sites,
+VGL_API int vgl_simulate_tile(vgl_ctx* ctx, int64_t site0, int32_t n_sites,
                       const uint8_t* gt, vgl_tile_out* out);
 
 /* Asynchronous host variant (the tags of a tile are 65 B per evaluation and must stream over PCIe while the next
@@ -238,13 +240,13 @@ int vgl_simulate_tile(vgl_ctx* ctx, int64_t site0, int32_t n_sites,
  * tiles may be in flight per context, submitted in site order; the buffers of an in-flight tile must not be touched.
  * Buffers obtained from vgl_host_alloc() are page-locked and are written by DMA at the link's rate; ordinary (pageable)
  * buffers work too, more slowly.  vgl_simulate_tile() is the two calls back to back. */
-int   vgl_simulate_tile_async(vgl_ctx* ctx, int64_t site0, int32_t n_sites, const uint8_t* gt, vgl_tile_out* out, int32_t* ticket);
-int   vgl_tile_wait(vgl_ctx* ctx, int32_t ticket);
-void* vgl_host_alloc(size_t bytes);            /* page-locked host memory (NULL on failure); needs a HIP device */
+VGL_API int   vgl_simulate_tile_async(vgl_ctx* ctx, int64_t site0, int32_t n_sites, const uint8_t* gt, vgl_tile_out* out, int32_t* ticket);
+VGL_API int   vgl_tile_wait(vgl_ctx* ctx, int32_t ticket);
+VGL_API void* vgl_host_alloc(size_t bytes);            /* page-locked host memory (NULL on failure); needs a HIP device */
 /* the same, placed for DMA from `device` (on a two-socket host page-locked memory lands on the NUMA node next to the device
  * that is current when it is allocated: 53 against 35 GB/s of copy-back measured): buffers of a multi-device record loop (ABI 4) */
-void* vgl_host_alloc_on(int32_t device, size_t bytes);
-void  vgl_host_free(void* p);
+VGL_API void* vgl_host_alloc_on(int32_t device, size_t bytes);
+VGL_API void  vgl_host_free(void* p);
 
 /* Device variant: `gt` and every pointer in `out` are device memory owned by the caller
  * (hipMalloc / a torch tensor's data_ptr); work is enqueued on `hip_stream` (a hipStream_t
@@ -253,20 +255,64 @@ void  vgl_host_free(void* p);
  * use one context per stream / per GPU for concurrent tiles.
  * (VGL_RNG_SERIAL with error_qs 2 and VGL_BETA_STD synchronises the stream inside the call: the number of
  * reads of the tile and the progress of the beta chain come back to the host.) */
-int vgl_simulate_tile_device(vgl_ctx* ctx, int64_t site0, int32_t n_sites,
+VGL_API int vgl_simulate_tile_device(vgl_ctx* ctx, int64_t site0, int32_t n_sites,
                              const uint8_t* gt, vgl_tile_out* out, void* hip_stream);
 
 /* Sticky device-side error flags of the last tiles (capacity overflow, qs-bin miss):
  * synchronises the stream, returns VGL_OK or the first VGL_E_* raised, and clears them. */
-int vgl_ctx_check(vgl_ctx* ctx, void* hip_stream);
+VGL_API int vgl_ctx_check(vgl_ctx* ctx, void* hip_stream);
 
 /* Kernel timing hook for bench.py: brackets the device work of every following
  * vgl_simulate_tile_device call with hipEvents on its stream.  vgl_ctx_kernel_ms returns
- * accumulated milliseconds and launch counts since the last reset, in four buckets:
- * [0] depth draws ahead of the sampling kernel (k_depth; the stream scouts in VGL_RNG_SERIAL), [1] k_sample,
- * [2] k_site, [3] k_gl.  (ABI version 3: four buckets; version 2 had three and left the depth kernel untimed.) */
-int vgl_ctx_timing(vgl_ctx* ctx, int32_t enable);
-int vgl_ctx_kernel_ms(vgl_ctx* ctx, double ms[4], int64_t launches[4], int32_t reset);
+ * accumulated milliseconds and launch counts since the last reset, one entry per bucket (ABI 5: six buckets,
+ * the caller passes the length of its arrays; entries beyond VGL_N_TIMING_BUCKETS are zeroed):
+ *   [VGL_T_DEPTH]   what runs ahead of the sampling kernel: k_sitebase + k_depth (the stream scouts in VGL_RNG_SERIAL)
+ *   [VGL_T_SAMPLE]  k_sample
+ *   [VGL_T_REDO]    k_redo (the reads the deferred build of k_sample<2> leaves to a double-precision second look)
+ *   [VGL_T_SITE]    k_site
+ *   [VGL_T_GL]      k_gl (the fused kernel, when it runs, is all of the tile and is counted here)
+ *   [VGL_T_SITEAGG] what runs behind k_gl: k_siteagg (INFO/QS, INFO/I16) and the device copies of the per-read dumps
+ * (ABI 3 had four buckets and left k_siteagg untimed; k_redo was part of k_sample's.) */
+#define VGL_N_TIMING_BUCKETS 6
+#define VGL_T_DEPTH   0
+#define VGL_T_SAMPLE  1
+#define VGL_T_REDO    2
+#define VGL_T_SITE    3
+#define VGL_T_GL      4
+#define VGL_T_SITEAGG 5
+VGL_API int vgl_ctx_timing(vgl_ctx* ctx, int32_t enable);
+VGL_API int vgl_ctx_kernel_ms(vgl_ctx* ctx, double* ms, int64_t* launches, int32_t n_buckets, int32_t reset);
+
+/* ---- what a context will launch (ABI 5) ------------------------------------------------------------------------------
+ * The library picks one of several builds of its kernels from the flags (vgl_ctx_create); a record loop sizes its tiles
+ * and a test asserts "the fused kernel runs here" from this record instead of inferring either from timings.
+ * `size` is set by the caller to sizeof(vgl_ctx_info_t) (fields beyond it are not written; new fields are appended). */
+#define VGL_DEPTH_INPLACE_MIXED   0  /* mixed per-sample means: rng.h:284-351's general sampler inside k_sample          */
+#define VGL_DEPTH_KDEPTH          1  /* every mean >= 12: k_depth (rejection method, rng.h:300-312) ahead of k_sample    */
+#define VGL_DEPTH_INPLACE_PRODUCT 2  /* every mean < 12: the product method's loop (rng.h:289-299) inside k_sample        */
+#define VGL_DEPTH_SERIAL_SCOUT    3  /* VGL_RNG_SERIAL: the scout kernels walk the reference's stream                     */
+typedef struct vgl_ctx_info_t {
+    int32_t size;                /* in: sizeof(vgl_ctx_info_t) of the caller                                              */
+    int32_t abi_version;
+    int32_t device;
+    int32_t n_samples, max_sites_per_tile;
+    int32_t max_alleles, max_genotypes;
+    int32_t rng_mode;            /* VGL_RNG_*                                                                             */
+    int32_t depth_mode;          /* VGL_DEPTH_*                                                                           */
+    int32_t fused;               /* 1: a tile that asks for no QS / I16 / per-read dump runs as ONE kernel (k_gl<.., FUSED>) */
+    int32_t fused_split;         /* workgroups per site of that kernel (1, or several with the site sums exchanged in HBM)   */
+    int32_t sample_lean;         /* build of k_sample a tile without per-read dump gets: 0 every option's state carried,
+                                    1 default tag surface, 2 = 1 with the double-precision fallbacks deferred to k_redo     */
+    int32_t gl_sort;             /* k_gl re-deals a workgroup's evaluations in (distinct bases, depth) order                */
+    int32_t gl_wpb;              /* wavefronts per k_gl workgroup (4 or 8)                                                  */
+    int32_t read_cap;            /* staged reads per (site, sample): a deeper draw is VGL_E_CAPACITY                        */
+    int32_t pool_cap;            /* quality-score work items per wavefront and LDS segment (--error-qs 2)                   */
+    int32_t pool_lds_bytes;      /* LDS bytes per wavefront of k_sample<2>                                                  */
+    int32_t test_hooks;          /* 1: this library was built with -DVGL_TEST_HOOKS (environment overrides, vgl_dbg_*)      */
+    int64_t workspace_bytes;     /* device memory the context owns for max_sites_per_tile (tables + staging)                */
+    int64_t rng_tile_max_sites;  /* VGL_RNG_TILE: sites [0, this) are addressable (vgl_rng_tile_max_sites); 0 in serial mode */
+} vgl_ctx_info_t;
+VGL_API int vgl_ctx_info(const vgl_ctx* ctx, vgl_ctx_info_t* out);
 
 #ifdef __cplusplus
 }

@@ -18,7 +18,8 @@ def oracle():
     """The CPU oracle (test infrastructure): built on demand from oracle/vgl_oracle.c."""
     so = os.path.join(ROOT, "oracle", "libvgl_oracle.so")
     src = os.path.join(ROOT, "oracle", "vgl_oracle.c")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    hdr = os.path.join(ROOT, "include", "vcfgl_hip.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libvgl_oracle.so"])
     import oracle_lib
     return oracle_lib

@@ -31,15 +31,39 @@ def test_header_symbols_exported():
     assert lib.vgl_abi_version() == _abi.ABI_VERSION
 
 
+def _dynamic_functions(path):
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    return {ln.split()[-1] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in "TW" and ln.split()[-1].startswith("vgl_")}
+
+
+def test_shipped_library_exports_the_header_and_nothing_else():
+    """-fvisibility=hidden: the dynamic symbol table of libvcfgl_hip.so is include/vcfgl_hip.h; the vgl_dbg_* entry points and the
+    environment overrides live in the -DVGL_TEST_HOOKS build (libvcfgl_hip_hooks.so), which the product path never loads"""
+    lib_dir = os.path.join(ROOT, "vcfgl_amd", "lib")
+    shipped = _dynamic_functions(os.path.join(lib_dir, "libvcfgl_hip.so"))
+    assert shipped == set(_abi.EXPORTS), shipped ^ set(_abi.EXPORTS)
+    assert not [s for s in shipped if s.startswith("vgl_dbg")]
+    hooks = _dynamic_functions(os.path.join(lib_dir, "libvcfgl_hip_hooks.so"))
+    assert hooks == set(_abi.EXPORTS) | set(_abi.HOOK_EXPORTS), hooks ^ (set(_abi.EXPORTS) | set(_abi.HOOK_EXPORTS))
+    blob = open(os.path.join(lib_dir, "libvcfgl_hip.so"), "rb").read()
+    for name in (b"VGL_NO_FUSE", b"VGL_DEBUG_READ_CAP", b"VGL_GL_SORT", b"VGL_DEBUG_STAMPS"):
+        assert name not in blob, name                          # the shipped library reads no environment variable
+    assert b"VGL_NO_FUSE" in open(os.path.join(lib_dir, "libvcfgl_hip_hooks.so"), "rb").read()
+    hl = _abi.load_library(hooks=True)
+    assert hl is not _abi.load_library() and hl.vgl_abi_version() == _abi.ABI_VERSION
+
+
 def test_struct_sizes_match_header():
     """The ctypes mirror must lay out vgl_params / vgl_tile_out like the C compiler does."""
     import subprocess, tempfile
-    src = '#include "vcfgl_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu\\n",sizeof(vgl_params),sizeof(vgl_tile_out),sizeof(vgl_rng_layout));return 0;}\n'
+    src = ('#include "vcfgl_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu\\n",sizeof(vgl_params),sizeof(vgl_tile_out),'
+           'sizeof(vgl_rng_layout),sizeof(vgl_ctx_info_t));return 0;}\n')
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(d, "t"), os.path.join(d, "t.c")])
-        a, b, c = map(int, subprocess.check_output([os.path.join(d, "t")]).split())
-    assert (a, b, c) == (C.sizeof(_abi.Params), C.sizeof(_abi.TileOut), C.sizeof(_abi.RngLayout))
+        a, b, c, e = map(int, subprocess.check_output([os.path.join(d, "t")]).split())
+    assert (a, b, c, e) == (C.sizeof(_abi.Params), C.sizeof(_abi.TileOut), C.sizeof(_abi.RngLayout), C.sizeof(_abi.CtxInfo))
 
 
 @pytest.mark.parametrize("du,A,G", [(0, 4, 10), (1, 5, 15), (2, 5, 15), (3, 4, 10), (4, 5, 15), (5, 5, 15)])
@@ -105,3 +129,16 @@ def test_rng_period_limit_of_tile_mode():
     a3 = VcfglArgs(seed=42, depth=20.0, error_rate=0.01, error_qs=2, beta_variance=1e-5)
     p3, _ = a3.to_struct(1000)
     assert lib.vgl_rng_tile_max_sites(C.byref(p3), C.byref(mx)) == 0 and mx.value > 8 * 1_000_000      # C3 on 8 GPUs, weak scaling
+
+
+def test_layout_whose_single_site_exceeds_the_period_is_refused():
+    """block * n_samples > 2^48: not even site 0's windows fit the generator's period -- VGL_E_ARG, not a silent wrap"""
+    lib = _abi.load_library()
+    a = VcfglArgs(seed=42, depth=20.0, error_rate=0.01)
+    p, _ = a.to_struct(1000)
+    p.layout.block = (1 << 40) + 1
+    p.layout.qs_read_stride = 32
+    mx, h = C.c_int64(-7), C.c_int64(-7)
+    assert lib.vgl_rng_tile_max_sites(C.byref(p), C.byref(mx)) == _abi.VGL_E_ARG and mx.value == -7
+    assert lib.vgl_rng_tile_site_hash(C.byref(p), 0, C.byref(h)) == _abi.VGL_E_ARG
+    assert b"period" in lib.vgl_last_error()

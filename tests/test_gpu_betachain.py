@@ -89,7 +89,7 @@ def test_every_deviate_matches_the_cpu_generator(err, var, max_words, monkeypatc
     args.rng_mode, args.beta_sampler = _abi.VGL_RNG_SERIAL, _abi.VGL_BETA_STD
     k = err * (1 - err) / var - 1.0
     a, b = err * k, (1 - err) * k
-    sim = Simulator(args, N, max_sites_per_tile=S)
+    sim = Simulator(args, N, max_sites_per_tile=S, hooks=True)      # vgl_dbg_chain / VGL_CHAIN_MAX_WORDS: the -DVGL_TEST_HOOKS build
     cpu = StdBeta(seed, 1_500_000)
     total = 0
     for tile in range(3):                                           # consecutive tiles continue the generator

@@ -24,7 +24,7 @@ def f2b(x):
 
 
 def sweep(mode, lo_bits, hi_bits, param=0.0, count=None):
-    lib = _abi.load_library()
+    lib = _abi.load_library(hooks=True)                   # vgl_bounds.hip is part of the -DVGL_TEST_HOOKS build only
     lib.vgl_dbg_bound_sweep.argtypes = [C.c_int, C.c_uint32, C.c_ulonglong, C.c_double, C.POINTER(C.c_double)]
     out = (C.c_double * 4)()
     n = count if count is not None else hi_bits - lo_bits + 1

@@ -32,11 +32,12 @@ def bits(a):
     return a.view(np.uint32) if a.dtype == np.float32 else a
 
 
-def run_both(oracle, args, gt, site0=0, read_capacity=0, max_sites=None):
+def run_both(oracle, args, gt, site0=0, read_capacity=0, max_sites=None, hooks=False):
+    """hooks=True: through the -DVGL_TEST_HOOKS build of the library (the VGL_DEBUG_* / VGL_NO_* environment overrides only exist there)"""
     args.rng_mode, args.beta_sampler = _abi.VGL_RNG_TILE, _abi.VGL_BETA_RAND48
     n_sites, N = gt.shape
     o = oracle.Oracle(args, N)
-    sim = Simulator(args, N, device=0, max_sites_per_tile=max_sites or max(n_sites, 1))
+    sim = Simulator(args, N, device=0, max_sites_per_tile=max_sites or max(n_sites, 1), hooks=hooks)
     want = o.simulate(site0, gt, fields=sim.default_fields(), read_capacity=read_capacity)
     got = sim.simulate(site0, gt, read_capacity=read_capacity)
     sim.close()
@@ -361,7 +362,8 @@ def test_capacity_overflow_is_reported(oracle, eqs, monkeypatch):
     from vcfgl_amd import VglError
     monkeypatch.setenv("VGL_DEBUG_READ_CAP", "8")
     args = VcfglArgs(seed=42, depth=20, error_rate=0.01, error_qs=eqs, beta_variance=1e-5 if eqs else -1.0)
-    sim = Simulator(args, 100, max_sites_per_tile=8)
+    sim = Simulator(args, 100, max_sites_per_tile=8, hooks=True)
+    assert sim.info()["read_cap"] == 8 and sim.info()["test_hooks"] == 1
     with pytest.raises(VglError) as ei:
         sim.simulate(0, synth.binary_sites(0, 8, 100))
     assert ei.value.code == _abi.VGL_E_CAPACITY
@@ -415,7 +417,7 @@ def test_undecided_quality_scores_are_redrawn_exactly(oracle, monkeypatch, depth
     wavefront): results must not change."""
     monkeypatch.setenv("VGL_DEBUG_QS_EXACT", "1")
     args = VcfglArgs(seed=5, depth=depth, error_rate=0.01, error_qs=2, beta_variance=1e-5, adjust_qs=3, **ALLTAGS)
-    want, got = run_both(oracle, args, synth.binary_sites(0, 12, N), read_capacity=128)
+    want, got = run_both(oracle, args, synth.binary_sites(0, 12, N), read_capacity=128, hooks=True)
     assert np.array_equal(want.numpy("reads"), got.numpy("reads"))
     assert_parity(want, got)
 
@@ -435,7 +437,7 @@ def test_deferred_reads_are_redrawn_by_k_redo(oracle, monkeypatch, every, cap, d
         monkeypatch.setenv("VGL_DEBUG_REDO_CAP", str(cap))
     kw = dict(qs_bins=[(0, 2, 2), (3, 14, 12), (15, 30, 23), (31, 40, 37)]) if bins else {}          # the rta3 bins (doc/error_qs.MD)
     args = VcfglArgs(seed=77, depth=depth, error_rate=0.01, error_qs=2, beta_variance=1e-5, add_pl=1, **kw)
-    want, got = run_both(oracle, args, synth.binary_sites(0, 10, N))
+    want, got = run_both(oracle, args, synth.binary_sites(0, 10, N), hooks=True)
     assert_parity(want, got, check_gp=False)
 
 

@@ -27,7 +27,7 @@ def test_device_site_states_follow_the_specification_and_carry_no_lattice(oracle
     ol = oracle.lib()
     jump, x0 = ol.vgl_oracle_rand48_jump, ol.vgl_oracle_rand48_seed(42)
     N = 1000
-    sim = Simulator(c3_args(), N, device=0, max_sites_per_tile=4)
+    sim = Simulator(c3_args(), N, device=0, max_sites_per_tile=4, hooks=True)
     mx = C.c_int64()
     sim.lib.vgl_rng_tile_max_sites(C.byref(sim.params), C.byref(mx))
     W, block = mx.value.bit_length() - 1, sim.params.layout.block

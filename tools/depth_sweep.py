@@ -8,7 +8,7 @@ import torch, synth
 from vcfgl_amd import Simulator, VcfglArgs
 N, S, B = 1000, 32768, 65.0
 gt = synth.binary_sites_torch(0, S, N, "cuda:0")
-print("error-qs depth  ms/tile (depth, sample, site, gl)            evals/s   algorithmic GB/s  of 8 TB/s")
+print("error-qs depth  ms/tile (depth, sample, redo, site, gl, siteagg)            evals/s   algorithmic GB/s  of 8 TB/s")
 for eqs in (0, 2):
     for depth in (1.0, 2.0, 5.0, 10.0, 20.0, 30.0, 60.0):
         kw = dict(error_qs=2, beta_variance=1e-5) if eqs == 2 else {}

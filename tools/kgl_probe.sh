@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage (GPU box): tools/kgl_probe.sh  -> k_gl at the C5 and C3 flags: time per launch for each VGL_GL_SORT, and SQ counters
 export TMPDIR=/tmp
+export VGL_LIB=$PWD/vcfgl_amd/lib/libvcfgl_hip_hooks.so   # VGL_GL_SORT is an override of the -DVGL_TEST_HOOKS build
 out=gpurun_out/kglprobe; rm -rf $out; mkdir -p $out
 Q="--no-cpu-baseline --no-extra --no-pack-rate"
 for wl in c5 c3; do

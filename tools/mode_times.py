@@ -16,5 +16,5 @@ for name, kw in (("plain", {}), ("precise-gl 1", dict(precise_gl=1)), ("addGP ad
     for _ in range(3):
         sim.simulate_device(0, gt, tile); sim.check()
     ms, n = sim.kernel_ms(reset=True)
-    print(name, [round(x / max(k, 1), 3) for x, k in zip(ms, n)], "ms per 16384-site tile (depth, sample, site, gl)")
+    print(name, [round(x / max(k, 1), 3) for x, k in zip(ms, n)], "ms per 16384-site tile (depth, sample, redo, site, gl, siteagg)")
     sim.close()

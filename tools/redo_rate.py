@@ -9,7 +9,7 @@ from vcfgl_amd import Simulator, VcfglArgs
 for name, kw, N, S in (("c3", dict(depth=20.0, beta_variance=1e-5), 1000, 16384), ("c4", dict(depth=30.0, beta_variance=1e-5), 2000, 8192),
                        ("var 1e-4", dict(depth=20.0, beta_variance=1e-4), 1000, 16384), ("e 0.05 var 2e-4", dict(depth=20.0, error_rate=0.05, beta_variance=2e-4), 1000, 16384)):
     a = VcfglArgs(seed=42, error_qs=2, **({"error_rate": 0.01} | kw))
-    sim = Simulator(a, N, max_sites_per_tile=S)
+    sim = Simulator(a, N, max_sites_per_tile=S, hooks=True)
     gt = synth.binary_sites_torch(0, S, N, "cuda:0")
     tile = sim.new_tile(S, fields=["fmt_dp", "gl"], device="cuda:0")
     sim.simulate_device(0, gt, tile); sim.check()

@@ -5,7 +5,7 @@ import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 from vcfgl_amd import _abi
-lib = _abi.load_library()
+lib = _abi.load_library(hooks=True)
 lib.vgl_dbg_vlog.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
 rng = np.random.default_rng(3)
 u = np.concatenate([rng.random(8_000_000), 0.5 + (rng.random(2_000_000) - 0.5) * 1e-2, rng.random(1_000_000) * 1e-3, 1 - rng.random(1_000_000) * 1e-3,

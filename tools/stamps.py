@@ -9,7 +9,7 @@ import torch, synth
 from vcfgl_amd import Simulator, VcfglArgs, _abi
 N, S = 1000, 8192
 a = VcfglArgs(seed=42, depth=20.0, error_rate=0.01, error_qs=2, beta_variance=1e-5)
-sim = Simulator(a, N, max_sites_per_tile=S)
+sim = Simulator(a, N, max_sites_per_tile=S, hooks=True)
 gt = synth.binary_sites_torch(0, S, N, "cuda:0")
 tile = sim.new_tile(S, fields=["fmt_dp", "gl"], device="cuda:0")
 sim.simulate_device(0, gt, tile); sim.check()

@@ -1,7 +1,7 @@
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np, ctypes as C
 from vcfgl_amd import _abi
-lib=_abi.load_library()
+lib=_abi.load_library(hooks=True)
 lib.vgl_dbg_vlog.argtypes=[C.c_void_p,C.c_void_p,C.c_int,C.c_int]
 rng=np.random.default_rng(1)
 parts=[rng.random(4_000_000).astype(np.float32), (1-rng.random(2_000_000)*1e-3).astype(np.float32), (1+ (rng.random(2_000_000)-0.5)*0.2).astype(np.float32),

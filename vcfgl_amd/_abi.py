@@ -6,7 +6,7 @@ not been built -- the product path never falls back to a CPU implementation.
 import ctypes as C
 import os
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 VGL_OK = 0
 VGL_E_ARG, VGL_E_NODEVICE, VGL_E_NOMEM, VGL_E_CAPACITY, VGL_E_UNSUPPORTED, VGL_E_QSBIN, VGL_E_ADJQ = -1, -2, -3, -4, -5, -6, -7
@@ -57,6 +57,22 @@ class TileOut(C.Structure):
     ]
 
 
+class CtxInfo(C.Structure):
+    """vgl_ctx_info_t (ABI 5): what a context will launch"""
+    _fields_ = [
+        ("size", C.c_int32), ("abi_version", C.c_int32), ("device", C.c_int32),
+        ("n_samples", C.c_int32), ("max_sites_per_tile", C.c_int32), ("max_alleles", C.c_int32), ("max_genotypes", C.c_int32),
+        ("rng_mode", C.c_int32), ("depth_mode", C.c_int32), ("fused", C.c_int32), ("fused_split", C.c_int32), ("sample_lean", C.c_int32),
+        ("gl_sort", C.c_int32), ("gl_wpb", C.c_int32), ("read_cap", C.c_int32), ("pool_cap", C.c_int32), ("pool_lds_bytes", C.c_int32),
+        ("test_hooks", C.c_int32), ("workspace_bytes", C.c_int64), ("rng_tile_max_sites", C.c_int64),
+    ]
+
+
+VGL_DEPTH_INPLACE_MIXED, VGL_DEPTH_KDEPTH, VGL_DEPTH_INPLACE_PRODUCT, VGL_DEPTH_SERIAL_SCOUT = 0, 1, 2, 3
+# vgl_ctx_kernel_ms buckets (VGL_T_*)
+TIMING_BUCKETS = ["k_depth", "k_sample", "k_redo", "k_site", "k_gl", "k_siteagg"]
+T_DEPTH, T_SAMPLE, T_REDO, T_SITE, T_GL, T_SITEAGG = range(6)
+
 # (field, dtype, shape-kind): shape kinds resolved by tile.py
 TILE_FIELDS = [
     ("site_status", "int32", "site"), ("n_alleles", "int32", "site"), ("n_alleles_obs", "int32", "site"),
@@ -72,23 +88,29 @@ EXPORTS = [
     "vgl_max_alleles", "vgl_max_genotypes", "vgl_default_rng_layout", "vgl_abi_version",
     "vgl_last_error", "vgl_ctx_create", "vgl_ctx_destroy", "vgl_simulate_tile",
     "vgl_simulate_tile_device", "vgl_ctx_check", "vgl_ctx_timing", "vgl_ctx_kernel_ms", "vgl_rng_tile_max_sites", "vgl_rng_tile_site_hash",
-    "vgl_simulate_tile_async", "vgl_tile_wait", "vgl_host_alloc", "vgl_host_alloc_on", "vgl_host_free",
+    "vgl_simulate_tile_async", "vgl_tile_wait", "vgl_host_alloc", "vgl_host_alloc_on", "vgl_host_free", "vgl_ctx_info",
 ]
+# entry points of the -DVGL_TEST_HOOKS build only (lib/libvcfgl_hip_hooks.so): never in the shipped library
+HOOK_EXPORTS = ["vgl_dbg_bound_sweep", "vgl_dbg_chain", "vgl_dbg_redo_count", "vgl_dbg_site_base", "vgl_dbg_stamps", "vgl_dbg_vlog"]
 
-_LIB = None
+_LIB = {}
 
 
-def library_path():
+def library_path(hooks=False):
     # VGL_LIB: another build of the same library (A/B timing of kernel variants: tools/ab_build.sh)
-    return os.environ.get("VGL_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libvcfgl_hip.so")
+    if os.environ.get("VGL_LIB"):
+        return os.environ["VGL_LIB"]
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libvcfgl_hip_hooks.so" if hooks else "libvcfgl_hip.so")
 
 
-def load_library():
-    """dlopen libvcfgl_hip.so and set prototypes.  Raises RuntimeError when it is not built."""
-    global _LIB
-    if _LIB is not None:
-        return _LIB
-    path = library_path()
+def load_library(hooks=False):
+    """dlopen libvcfgl_hip.so and set prototypes.  Raises RuntimeError when it is not built.
+    hooks=True: the -DVGL_TEST_HOOKS build of the same sources (environment overrides such as VGL_NO_FUSE / VGL_DEBUG_READ_CAP and
+    the vgl_dbg_* entry points) -- what the hook cases of the test-suite and tools/ load; the product path never does."""
+    hooks = bool(hooks)
+    if hooks in _LIB:
+        return _LIB[hooks]
+    path = library_path(hooks)
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -120,8 +142,9 @@ def load_library():
     lib.vgl_simulate_tile_device.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.POINTER(TileOut), C.c_void_p]
     lib.vgl_ctx_check.argtypes = [C.c_void_p, C.c_void_p]
     lib.vgl_ctx_timing.argtypes = [C.c_void_p, C.c_int32]
-    lib.vgl_ctx_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]
+    lib.vgl_ctx_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32, C.c_int32]
+    lib.vgl_ctx_info.argtypes = [C.c_void_p, C.POINTER(CtxInfo)]
     if lib.vgl_abi_version() != ABI_VERSION:
         raise RuntimeError("libvcfgl_hip.so ABI version mismatch")
-    _LIB = lib
+    _LIB[hooks] = lib
     return lib

@@ -17,6 +17,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <errno.h>
 #include <string.h>
 #include <time.h>
 #include <zlib.h>
@@ -790,7 +791,10 @@ int main(int argc, char** argv) {
     if (a.enc_threads <= 0 && !a.threads_given) { const unsigned hc = std::thread::hardware_concurrency(); enc_threads = (int)std::max(1u, std::min(8u, hc)); }
     // the HIP runtime initialises (about 0.07 s) while the input is read and parsed
     std::thread hip_warm;
-    if (!a.depth_inf) hip_warm = std::thread([] { vgl_host_free(vgl_host_alloc(4096)); });
+    // (on the first device the run selected: a primary context on GPU 0 would otherwise be created for a run that never uses it;
+    //  a failure here is not swallowed for good -- vgl_ctx_create on the same device reports it below)
+    const int warm_dev = a.devices.empty() ? a.device : a.devices[0];
+    if (!a.depth_inf) hip_warm = std::thread([warm_dev] { vgl_host_free(vgl_host_alloc_on(warm_dev, 4096)); });
     Vcf vcf = read_vcf(a.in_fn, a.print_truth != 0, enc_threads);
     if (hip_warm.joinable()) hip_warm.join();
     lap(0);
@@ -1214,6 +1218,10 @@ int main(int argc, char** argv) {
     if (a.print_qscores) files.push_back("-> Qscores output: stdout");
     fflush(stdout);
     runlog.finish(sb, files);
-    fflush(NULL);
+    // a flush that fails here (ENOSPC, EPIPE on stdout's TSV listings) is a failed run; VCFGL_HIP_NORMAL_EXIT=1 leaves through
+    // exit() instead of _exit(), so that atexit handlers (profilers, sanitizers) run -- at the price of the piecewise teardown
+    const int flush_rc = fflush(NULL);
+    if (flush_rc != 0) { fprintf(stderr, "\n[ERROR] could not flush the output streams: %s\n", strerror(errno)); _exit(1); }
+    if (getenv("VCFGL_HIP_NORMAL_EXIT")) exit(0);
     _exit(0);
 }

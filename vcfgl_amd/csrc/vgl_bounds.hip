@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_bound_div(const unsigned long long coun
     if (viol) { atomicAdd(&out->viol, viol); out->arg_bits = arg; }
 }
 
-extern "C" int vgl_dbg_bound_sweep(int mode, uint32_t lo_bits, unsigned long long count, double param, double out[4]) {
+extern "C" __attribute__((visibility("default"))) int vgl_dbg_bound_sweep(int mode, uint32_t lo_bits, unsigned long long count, double param, double out[4]) {
     BoundAcc* d = nullptr;
     if (hipMalloc((void**)&d, sizeof(BoundAcc)) != hipSuccess) return -1;
     if (hipMemset(d, 0, sizeof(BoundAcc)) != hipSuccess) { (void)hipFree(d); return -1; }

@@ -99,6 +99,9 @@ struct VglDevParams {
     int32_t gl_flip2;        // k_gl sort: the two-base group in ascending depth order (VGL_GL_FLIP2, default 1)
     int32_t fused;           // tile mode, GL model 2, one fixed quality score, default tag surface, every mean depth < 12, 128 < N <= 512: sampling, site order and
                              // likelihoods of a site in ONE workgroup (k_gl<.., FUSED>; VGL_NO_FUSE=1 turns it off)
+    int32_t fused_split;     // fused build: workgroups per site (1: the workgroup is the site)
+    int32_t lean_ok;         // the tag surface needs none of the optional per-read state of k_sample's owners (quality sums, strand draws, --adjust-qs):
+                             // the LEAN builds serve every tile that asks for no per-read dump
     int32_t gl_wpb;          // k_gl, GL model 2: wavefronts per workgroup, 4 or 8 (VGL_GL_WPB)
     int32_t slow_period;     // k_sample<2>: the bounded-log test of the gamma sampler runs every slow_period-th pool iteration,
     int32_t slow_period_n;   //              that of the normal sampler every slow_period_n-th
@@ -220,6 +223,7 @@ extern "C" {
 int vgl_launch_sitebase(const VglDevParams* p, const VglTilePtrs* t, void* stream);
 int vgl_launch_depth(const VglDevParams* p, const VglTilePtrs* t, void* stream);
 int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, void* stream);
+int vgl_launch_redo(const VglDevParams* p, const VglTilePtrs* t, void* stream);      // k_redo, when vgl_launch_sample ran the deferred build (else nothing)
 int vgl_launch_site(const VglDevParams* p, const VglTilePtrs* t, void* stream);
 int vgl_launch_gl(const VglDevParams* p, const VglTilePtrs* t, void* stream);
 int vgl_launch_siteagg(const VglDevParams* p, const VglTilePtrs* t, void* stream);

@@ -23,6 +23,15 @@ static int fail(int code, const char* fmt, ...) {
 }
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? VGL_E_NOMEM : VGL_E_NODEVICE, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
 
+// Environment overrides (tuning switches and test hooks) exist only in the -DVGL_TEST_HOOKS build of the library
+// (lib/libvcfgl_hip_hooks.so, what the test-suite's hook cases and tools/ load): the shipped library reads no environment variable.
+#ifdef VGL_TEST_HOOKS
+static const char* hook_env(const char* name) { return getenv(name); }
+#else
+static const char* hook_env(const char*) { return nullptr; }
+#endif
+static int hook_int(const char* name, int dflt) { const char* v = hook_env(name); return v ? atoi(v) : dflt; }
+
 extern "C" const char* vgl_last_error(void) { return g_err; }
 extern "C" int vgl_abi_version(void) { return VGL_ABI_VERSION; }
 
@@ -55,10 +64,12 @@ extern "C" int vgl_default_rng_layout(const vgl_params* p, vgl_rng_layout* out) 
 }
 
 // W of vgl_site_hash(): the largest W with 2^W * n_samples * block <= 2^48, the period of rand48
+// (-1: not even one site's windows fit the period -- block * n_samples > 2^48)
 static int site_hash_bits(const vgl_params* p) {
     vgl_rng_layout lay;
     if (p->layout.block) lay = p->layout; else vgl_default_rng_layout(p, &lay);
     const uint64_t raw = (uint64_t)((((unsigned __int128)1 << 48) / lay.block) / (uint64_t)p->n_samples);
+    if (raw < 1) return -1;
     int W = 0;
     while (W < 40 && (2ULL << W) <= raw) ++W;
     return W;
@@ -68,13 +79,16 @@ static int site_hash_bits(const vgl_params* p) {
 // e = H(site) * n_samples + sample, and H (vgl_site_hash, vgl_device.h) permutes [0, 2^W) with 2^W * n_samples * block <= 2^48.
 extern "C" int vgl_rng_tile_max_sites(const vgl_params* p, int64_t* max_sites) {
     if (!p || !max_sites || p->n_samples <= 0) return fail(VGL_E_ARG, "null argument");
-    *max_sites = (int64_t)1 << site_hash_bits(p);
+    const int W = site_hash_bits(p);
+    if (W < 0) return fail(VGL_E_ARG, "VGL_RNG_TILE: layout.block x n_samples exceeds the 2^48 period of rand48: not even one site is addressable");
+    *max_sites = (int64_t)1 << W;
     return VGL_OK;
 }
 
 extern "C" int vgl_rng_tile_site_hash(const vgl_params* p, int64_t site, int64_t* hashed) {
     if (!p || !hashed || p->n_samples <= 0) return fail(VGL_E_ARG, "null argument");
     const int W = site_hash_bits(p);
+    if (W < 0) return fail(VGL_E_ARG, "VGL_RNG_TILE: layout.block x n_samples exceeds the 2^48 period of rand48: not even one site is addressable");
     if (site < 0 || site >= ((int64_t)1 << W)) return fail(VGL_E_ARG, "site %lld outside [0, 2^%d)", (long long)site, W);
     *hashed = (int64_t)vgl_site_hash((uint64_t)site, W);
     return VGL_OK;
@@ -202,9 +216,11 @@ struct vgl_ctx {
     int next_slot = 0;
     // timing
     bool timing = false;
-    std::vector<hipEvent_t> ev;     // groups of 5
-    double ms[4] = {0, 0, 0, 0}; int64_t launches[4] = {0, 0, 0, 0};    // k_depth, k_sample, k_site, k_gl
+    std::vector<hipEvent_t> ev;     // groups of VGL_N_TIMING_BUCKETS + 1
+    double ms[VGL_N_TIMING_BUCKETS] = {0}; int64_t launches[VGL_N_TIMING_BUCKETS] = {0};    // VGL_T_*
+    size_t ws_bytes = 0;            // device memory owned (vgl_ctx_info)
 };
+#define VGL_NEV (VGL_N_TIMING_BUCKETS + 1)
 
 static int errprob_to_qs_fixed(const vgl_params* p, double ep, int* qs, int* adjqs) {
     // vcfgl.cpp:1668-1694
@@ -268,9 +284,12 @@ static void gamma1_init(VglGamma1* g, double shape) {         // Gamma1Sampler_i
     g->a2 = 1.0 / sqrt(9. * g->a1);
 }
 
+static thread_local size_t* g_acct = nullptr;      // where dmalloc tallies the bytes it hands out (the context being built / grown)
+struct AcctScope { explicit AcctScope(vgl_ctx* c) { g_acct = &c->ws_bytes; } ~AcctScope() { g_acct = nullptr; } };
 template <typename T> static int dmalloc(T** p, size_t n) {
     if (n == 0) n = 1;
     HIPCHK(hipMalloc((void**)p, n * sizeof(T)));
+    if (g_acct) *g_acct += n * sizeof(T);
     return VGL_OK;
 }
 
@@ -326,6 +345,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     HIPCHK(hipSetDevice(device));
 
     vgl_ctx* c = new vgl_ctx();
+    AcctScope acct(c);
     c->p = *p; c->p.depths = nullptr; c->p.qs_bins = nullptr;
     c->device = device; c->max_sites = max_sites;
     VglDevParams& D = c->dp;
@@ -335,7 +355,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     D.A = vgl_max_alleles(p); D.G = vgl_max_genotypes(p);
     int cap = (int)ceil(dmax + 8.0 * sqrt(dmax) + 16.0);
     D.read_cap = (cap + 3) & ~3;
-    if (getenv("VGL_DEBUG_READ_CAP")) D.read_cap = (atoi(getenv("VGL_DEBUG_READ_CAP")) + 3) & ~3;   // test hook: force the overflow path (a multiple of 4: staged reads are packed four per word)
+    if (hook_env("VGL_DEBUG_READ_CAP")) D.read_cap = (atoi(hook_env("VGL_DEBUG_READ_CAP")) + 3) & ~3;   // test hook: force the overflow path (a multiple of 4: staged reads are packed four per word)
     if (D.read_cap > 1023) { delete c; return fail(VGL_E_ARG, "mean depth too large for the staging layout"); }
     {   // quality-score pool of one wavefront: the summed depth of its (up to) 64 samples
         double lmax = 0.0;
@@ -364,7 +384,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     D.gl1_deep = (p->gl_model == 1 && D.read_cap > 255) ? 1 : 0;
     D.scout_lds_bytes = ((size_t)p->n_samples * 9 <= 144 * 1024) ? (int32_t)(((size_t)p->n_samples * 9 + 15) & ~(size_t)15) : 0;
     D.beta_std = (p->beta_sampler == VGL_BETA_STD) ? 1 : 0;
-    D.beta_chain = (D.serial && D.beta_std && p->error_qs == 2 && !getenv("VGL_NO_BETA_CHAIN")) ? 1 : 0;
+    D.beta_chain = (D.serial && D.beta_std && p->error_qs == 2 && !hook_env("VGL_NO_BETA_CHAIN")) ? 1 : 0;
     {   // depth mode: k_depth pays for the rejection sampler (lambda >= 12, rng.h:300); the product method's short loop
         // stays inside k_sample, which is specialised for "all product" (2) and "mixed" (0)
         double dmin = p->depth, dmx = p->depth;
@@ -373,16 +393,16 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     }
     // k_gl lane order: 0 natural, 1 depth-sorted lanes storing their own evaluations (4-byte pieces), 2 depth-sorted lanes and
     // natural-order stores through LDS -- the last is at least as fast as the others from depth 5 (config C5) to depth 30
-    D.gl_sort = getenv("VGL_GL_SORT") ? atoi(getenv("VGL_GL_SORT")) : (dmax >= 1.0 ? 2 : 0);
-    D.gl_flip2 = getenv("VGL_GL_FLIP2") ? atoi(getenv("VGL_GL_FLIP2")) : 1;
-    D.gl_wpb = getenv("VGL_GL_WPB") ? atoi(getenv("VGL_GL_WPB")) : (D.gl_sort ? 8 : 4);
-    D.slow_period = getenv("VGL_SLOW_PERIOD") ? atoi(getenv("VGL_SLOW_PERIOD")) : 4;
+    D.gl_sort = hook_int("VGL_GL_SORT", dmax >= 1.0 ? 2 : 0);
+    D.gl_flip2 = hook_int("VGL_GL_FLIP2", 1);
+    D.gl_wpb = hook_int("VGL_GL_WPB", D.gl_sort ? 8 : 4);
+    D.slow_period = hook_int("VGL_SLOW_PERIOD", 4);
     if (D.slow_period < 1) D.slow_period = 1;
-    D.slow_period_n = getenv("VGL_SLOW_PERIOD_N") ? atoi(getenv("VGL_SLOW_PERIOD_N")) : 4;
+    D.slow_period_n = hook_int("VGL_SLOW_PERIOD_N", 4);
     if (D.slow_period_n < 1) D.slow_period_n = 1;
-    D.xcd_map = getenv("VGL_XCD_MAP") ? atoi(getenv("VGL_XCD_MAP")) : 1;
-    D.dbg_phase = getenv("VGL_DEBUG_PHASE") ? atoi(getenv("VGL_DEBUG_PHASE")) : 0;
-    D.dbg_qs_exact = getenv("VGL_DEBUG_QS_EXACT") ? atoi(getenv("VGL_DEBUG_QS_EXACT")) : 0;
+    D.xcd_map = hook_int("VGL_XCD_MAP", 1);
+    D.dbg_phase = hook_int("VGL_DEBUG_PHASE", 0);
+    D.dbg_qs_exact = hook_int("VGL_DEBUG_QS_EXACT", 0);
     for (int i = 0; i < p->n_qs_bins * 3; i++) D.qs_bins[i] = p->qs_bins[i];
     D.err_thresh = (uint64_t)ceil(ldexp(p->error_rate, 48));
 
@@ -421,13 +441,15 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     // (k_redo then also rewrites the read's staged error probability); everything else
     // (-addQS / -addI16, strand tags, --adjust-qs, a per-read dump, a beta shape parameter below 8 -- the gamma sampler's
     // bounded test then leaves its series' range |a2 x| <= 1/3 too often) runs the build with the fallbacks inline.
-    D.dbg_redo_every = getenv("VGL_DEBUG_REDO_EVERY") ? atoi(getenv("VGL_DEBUG_REDO_EVERY")) : 0;
+    D.dbg_redo_every = hook_int("VGL_DEBUG_REDO_EVERY", 0);
+    // the tag surface needs none of the owners' optional per-read state (quality sums, strand draws, --adjust-qs): the LEAN builds of k_sample
+    D.lean_ok = (!D.need_qsum && !D.sample_strand && !D.need_adf && p->adjust_qs == 0 && !hook_env("VGL_NO_LEAN")) ? 1 : 0;
     D.defer_ok = (!D.serial && p->error_qs == 2 && !D.need_qsum && !D.sample_strand && !D.need_adf && p->adjust_qs == 0 &&
-                  !D.gx.changed && !D.gy.changed && D.gx.alpha0 >= 8.0 && D.gy.alpha0 >= 8.0 && !getenv("VGL_NO_DEFER") && !getenv("VGL_DEBUG_QS_EXACT") && !getenv("VGL_NO_LEAN")) ? 1 : 0;
+                  !D.gx.changed && !D.gy.changed && D.gx.alpha0 >= 8.0 && D.gy.alpha0 >= 8.0 && !hook_env("VGL_NO_DEFER") && !hook_env("VGL_DEBUG_QS_EXACT") && !hook_env("VGL_NO_LEAN")) ? 1 : 0;
     // one workgroup per site does everything (k_gl<.., FUSED>, vgl_gl.hip): sampling with one fixed score, the site's allele order and the
     // likelihoods, with nothing staged in HBM between them
     D.fused = (!D.serial && p->error_qs == 0 && p->gl_model == 2 && !p->precise_gl && D.depth_pre == 2 && !D.need_qsum && !D.sample_strand &&
-               !D.need_adf && p->adjust_qs == 0 && N > 128 && N <= 512 && D.read_cap <= 64 && !getenv("VGL_NO_FUSE") && !getenv("VGL_NO_LEAN")) ? 1 : 0;
+               !D.need_adf && p->adjust_qs == 0 && N > 128 && N <= 512 && D.read_cap <= 64 && !hook_env("VGL_NO_FUSE") && !hook_env("VGL_NO_LEAN")) ? 1 : 0;
     if (D.defer_ok && D.pool_cap > 1472) {      // 20 wavefronts' pools in a CU's 160 KB of LDS: 576 + 5 x 1472 + 8 B each
         D.pool_cap = 1472;
         D.pool_lds_bytes = (576 + 4 * (D.pool_cap + 2) + D.pool_cap + 7) & ~7;
@@ -450,6 +472,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
 #define TRYHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { vgl_ctx_destroy(c); return fail(e_ == hipErrorOutOfMemory ? VGL_E_NOMEM : VGL_E_NODEVICE, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
     if (!D.serial) {                                               // k_sitebase's outputs; k_depth: J^(off0 + block*s)
         D.site_hash_bits = site_hash_bits(&c->p);
+        if (D.site_hash_bits < 0) { vgl_ctx_destroy(c); return fail(VGL_E_ARG, "VGL_RNG_TILE: layout.block x n_samples exceeds the 2^48 period of rand48: not even one site is addressable"); }
         D.depth_magic = (uint32_t)((1ULL << 32) / (uint64_t)N + 1ULL);
         std::vector<VglAffine> dt(N);
         for (int s = 0; s < N; s++) dt[s] = aff_compose(D.off[0], samp[s]);
@@ -558,7 +581,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
         // about 6 reads in 10^4 take this path at C3 / C4 (tools/redo_rate.py); the list has room for 1 in 64 of the staging capacity
         // (VGL_DEBUG_REDO_CAP: test hook), what does not fit is marked in a bitmap over the staged reads (all zero between tiles)
         const size_t reads = E * (size_t)D.read_cap;
-        c->redo_cap = (uint32_t)std::min<size_t>(0xFFFFFFF0u, getenv("VGL_DEBUG_REDO_CAP") ? (size_t)atol(getenv("VGL_DEBUG_REDO_CAP")) : std::max<size_t>(65536, reads / 64));
+        c->redo_cap = (uint32_t)std::min<size_t>(0xFFFFFFF0u, hook_env("VGL_DEBUG_REDO_CAP") ? (size_t)atol(hook_env("VGL_DEBUG_REDO_CAP")) : std::max<size_t>(65536, reads / 64));
         TRY(dmalloc(&c->d_redo_bits, (reads + 31) / 32));
         TRYHIP(hipMemset(c->d_redo_bits, 0, sizeof(uint32_t) * ((reads + 31) / 32)));
         TRY(dmalloc(&c->d_redo_list, (size_t)c->redo_cap));
@@ -566,16 +589,16 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
         TRYHIP(hipMemset(c->d_redo_count, 0, sizeof(uint32_t)));
     }
     TRYHIP(hipMemset(c->d_errflag, 0, sizeof(uint32_t)));
-    if (getenv("VGL_DEBUG_STAMPS") || getenv("VGL_DEBUG_PHASE")) { TRY(dmalloc(&c->d_dbg, (size_t)16)); TRYHIP(hipMemset(c->d_dbg, 0, 128)); }
+    if (hook_env("VGL_DEBUG_STAMPS") || hook_env("VGL_DEBUG_PHASE")) { TRY(dmalloc(&c->d_dbg, (size_t)16)); TRYHIP(hipMemset(c->d_dbg, 0, 128)); }
     TRYHIP(hipDeviceSynchronize());          // tables and cleared words are in place before any (non-blocking) stream uses them
     *out = c;
     return VGL_OK;
 }
 
 static int resolve_timing(vgl_ctx* c) {
-    for (size_t i = 0; i + 4 < c->ev.size(); i += 5) {
-        HIPCHK(hipEventSynchronize(c->ev[i + 4]));
-        for (int k = 0; k < 4; k++) {
+    for (size_t i = 0; i + VGL_NEV - 1 < c->ev.size(); i += VGL_NEV) {
+        HIPCHK(hipEventSynchronize(c->ev[i + VGL_NEV - 1]));
+        for (int k = 0; k < VGL_N_TIMING_BUCKETS; k++) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, c->ev[i + k], c->ev[i + k + 1]));
             c->ms[k] += ms; c->launches[k] += 1;
@@ -592,13 +615,38 @@ extern "C" int vgl_ctx_timing(vgl_ctx* c, int32_t enable) {
     return VGL_OK;
 }
 
-extern "C" int vgl_ctx_kernel_ms(vgl_ctx* c, double ms[4], int64_t launches[4], int32_t reset) {
-    if (!c) return fail(VGL_E_ARG, "null ctx");
+extern "C" int vgl_ctx_kernel_ms(vgl_ctx* c, double* ms, int64_t* launches, int32_t n_buckets, int32_t reset) {
+    if (!c || !ms || !launches || n_buckets < 0) return fail(VGL_E_ARG, "null ctx / arrays");
     HIPCHK(hipSetDevice(c->device));
     int rc = resolve_timing(c);
     if (rc) return rc;
-    for (int k = 0; k < 4; k++) { ms[k] = c->ms[k]; launches[k] = c->launches[k]; }
-    if (reset) for (int k = 0; k < 4; k++) { c->ms[k] = 0; c->launches[k] = 0; }
+    for (int k = 0; k < n_buckets; k++) { ms[k] = k < VGL_N_TIMING_BUCKETS ? c->ms[k] : 0.0; launches[k] = k < VGL_N_TIMING_BUCKETS ? c->launches[k] : 0; }
+    if (reset) for (int k = 0; k < VGL_N_TIMING_BUCKETS; k++) { c->ms[k] = 0; c->launches[k] = 0; }
+    return VGL_OK;
+}
+
+// what this context launches (include/vcfgl_hip.h: vgl_ctx_info_t)
+extern "C" int vgl_ctx_info(const vgl_ctx* c, vgl_ctx_info_t* out) {
+    if (!c || !out) return fail(VGL_E_ARG, "null argument");
+    if (out->size < (int32_t)sizeof(int32_t) * 2) return fail(VGL_E_ARG, "vgl_ctx_info_t.size must be set by the caller");
+    vgl_ctx_info_t r;
+    memset(&r, 0, sizeof r);
+    const VglDevParams& D = c->dp;
+    r.size = out->size < (int32_t)sizeof r ? out->size : (int32_t)sizeof r;
+    r.abi_version = VGL_ABI_VERSION; r.device = c->device;
+    r.n_samples = D.n_samples; r.max_sites_per_tile = c->max_sites; r.max_alleles = D.A; r.max_genotypes = D.G;
+    r.rng_mode = c->p.rng_mode;
+    r.depth_mode = D.serial ? VGL_DEPTH_SERIAL_SCOUT : D.depth_pre;
+    r.fused = D.fused; r.fused_split = D.fused ? (D.fused_split > 0 ? D.fused_split : 1) : 0;
+    r.sample_lean = D.serial ? 0 : (D.lean_ok ? ((D.error_qs == 2 && D.defer_ok) ? 2 : 1) : 0);
+    r.gl_sort = D.gl_sort; r.gl_wpb = (D.gl_model == 2 && D.gl_wpb == 8) ? 8 : 4;
+    r.read_cap = D.read_cap; r.pool_cap = D.error_qs == 2 ? D.pool_cap : 0; r.pool_lds_bytes = D.error_qs == 2 ? D.pool_lds_bytes : 0;
+#ifdef VGL_TEST_HOOKS
+    r.test_hooks = 1;
+#endif
+    r.workspace_bytes = (int64_t)c->ws_bytes;
+    r.rng_tile_max_sites = D.serial ? 0 : ((int64_t)1 << D.site_hash_bits);
+    memcpy(out, &r, (size_t)r.size);
     return VGL_OK;
 }
 
@@ -623,7 +671,7 @@ static int run_beta_chain(vgl_ctx* c, const VglDevParams& D, int n_sites, hipStr
         // a deviate takes ~15-19 words on average; the chunk is sized for the rest of the tile, at most 2^28 words
         long long n_words = remaining * 24 + 4096 + margin;
         long long cap_words = 1LL << 28;
-        if (getenv("VGL_CHAIN_MAX_WORDS")) cap_words = atoll(getenv("VGL_CHAIN_MAX_WORDS"));      // test hook: many small chunks
+        if (hook_env("VGL_CHAIN_MAX_WORDS")) cap_words = atoll(hook_env("VGL_CHAIN_MAX_WORDS"));      // test hook: many small chunks
         if (n_words > cap_words) n_words = cap_words;
         n_words &= ~1LL;
         if (n_words > c->chain_words_cap) {
@@ -700,17 +748,19 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
         return fail(VGL_E_ARG, "qs / i16 outputs need -addQS / -addI16 in the context parameters");
     // dumps of the deviates (ABI 2): the per-read error probabilities go through the --precise-gl staging planes
     const bool dump_errp = o->read_errp && o->read_capacity > 0 && D.error_qs == 2;
+    AcctScope acct(c);
     if (dump_errp && !c->d_errp && dmalloc(&c->d_errp, (size_t)c->max_sites * D.n_samples * D.read_cap))
         return fail(VGL_E_NOMEM, "out of device memory (read_errp staging)");
     const bool errp_always = (c->p.precise_gl || (D.serial && !D.beta_chain)) && D.error_qs == 2;    // as sized by vgl_ctx_create
     T.errp = (errp_always || dump_errp) ? c->d_errp : nullptr;
     T.site_pick_err = (D.error_qs == 1) ? o->site_pick_err : nullptr;
 
-    hipEvent_t e[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    if (c->timing) for (int k = 0; k < 5; k++) HIPCHK(hipEventCreate(&e[k]));
+    hipEvent_t e[VGL_NEV];
+    for (int k = 0; k < VGL_NEV; k++) e[k] = nullptr;
+    if (c->timing) for (int k = 0; k < VGL_NEV; k++) HIPCHK(hipEventCreate(&e[k]));
     HIPCHK(hipMemsetAsync(c->d_acc, 0, sizeof(int32_t) * VGL_ACC_STRIDE * (size_t)n_sites, st));
     if (c->d_redo_count) HIPCHK(hipMemsetAsync(c->d_redo_count, 0, sizeof(uint32_t), st));
-    if (c->timing) HIPCHK(hipEventRecord(e[0], st));        // bucket 0: depth draws ahead of k_sample (k_depth; the scouts in serial mode)
+    if (c->timing) HIPCHK(hipEventRecord(e[VGL_T_DEPTH], st));        // depth draws ahead of k_sample (k_sitebase + k_depth; the scouts in serial mode)
     if (D.serial) {
         if (vgl_launch_scout(&D, &T, c->d_serial, st)) return fail(VGL_E_NODEVICE, "k_scout launch failed");
         c->serial_next_site = site0 + n_sites;
@@ -724,18 +774,20 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
         if (D.depth_pre == 1 && vgl_launch_depth(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_depth launch failed");
     }
     const bool fused = D.fused && !T.reads_out && !o->qs && !o->i16 && !dump_errp;
-    if (c->timing) HIPCHK(hipEventRecord(e[1], st));
+    if (c->timing) HIPCHK(hipEventRecord(e[VGL_T_SAMPLE], st));
     if (!fused && vgl_launch_sample(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_sample launch failed: %s", hipGetErrorString(hipGetLastError()));
-    if (c->timing) HIPCHK(hipEventRecord(e[2], st));
+    if (c->timing) HIPCHK(hipEventRecord(e[VGL_T_REDO], st));
+    if (!fused && vgl_launch_redo(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_redo launch failed");
+    if (c->timing) HIPCHK(hipEventRecord(e[VGL_T_SITE], st));
     if (!fused && vgl_launch_site(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_site launch failed");
-    if (c->timing) HIPCHK(hipEventRecord(e[3], st));
+    if (c->timing) HIPCHK(hipEventRecord(e[VGL_T_GL], st));
     if (D.serial && D.gl1_deep) {                            // where each deep evaluation's shuffle starts in htslib's stream
         if (vgl_launch_hts_offsets(&D, &T, c->d_serial, c->d_hts_off, c->d_hts_base, st)) return fail(VGL_E_NODEVICE, "k_hts_offsets launch failed");
         T.hts_off = c->d_hts_off; T.hts_base = c->d_hts_base;
     }
     if (fused) { if (vgl_launch_fused(&D, &T, st)) return fail(VGL_E_NODEVICE, "fused k_gl launch failed"); }
     else if (vgl_launch_gl(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_gl launch failed");
-    if (c->timing) HIPCHK(hipEventRecord(e[4], st));
+    if (c->timing) HIPCHK(hipEventRecord(e[VGL_T_SITEAGG], st));
     if (o->qs || o->i16) if (vgl_launch_siteagg(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_siteagg launch failed");
     if (dump_errp) {
         const size_t row = (size_t)n_sites * D.n_samples;
@@ -744,12 +796,14 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
         if ((size_t)o->read_capacity > rows)
             HIPCHK(hipMemsetAsync(o->read_errp + rows * row, 0xFF, ((size_t)o->read_capacity - rows) * row * sizeof(double), st));
     }
-    if (c->timing) for (int k = 0; k < 5; k++) c->ev.push_back(e[k]);
+    if (c->timing) HIPCHK(hipEventRecord(e[VGL_NEV - 1], st));
+    if (c->timing) for (int k = 0; k < VGL_NEV; k++) c->ev.push_back(e[k]);
     return VGL_OK;
 }
 
+#ifdef VGL_TEST_HOOKS
 // diagnostic (not in the public header): the beta deviates of the last serial tile in draw order
-extern "C" long long vgl_dbg_chain(vgl_ctx* c, double* out, long long n) {
+extern "C" __attribute__((visibility("default"))) long long vgl_dbg_chain(vgl_ctx* c, double* out, long long n) {
     if (!c || !c->d_errp_lin) return -1;
     long long R = 0;
     if (hipMemcpy(&R, c->d_rtotal, sizeof R, hipMemcpyDeviceToHost) != hipSuccess) return -1;
@@ -759,7 +813,7 @@ extern "C" long long vgl_dbg_chain(vgl_ctx* c, double* out, long long n) {
 }
 
 // diagnostic (not in the public header): the generator states in front of the windows of the last tile's sites (k_sitebase)
-extern "C" int vgl_dbg_site_base(vgl_ctx* c, uint64_t* out, int n) {
+extern "C" __attribute__((visibility("default"))) int vgl_dbg_site_base(vgl_ctx* c, uint64_t* out, int n) {
     if (!c || !c->d_site_base || n > c->max_sites) return VGL_E_ARG;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipDeviceSynchronize());
@@ -768,7 +822,7 @@ extern "C" int vgl_dbg_site_base(vgl_ctx* c, uint64_t* out, int n) {
 }
 
 // diagnostic (not in the public header): read and clear the VGL_DEBUG_STAMPS counters
-extern "C" int vgl_dbg_stamps(vgl_ctx* c, unsigned long long out[16]) {
+extern "C" __attribute__((visibility("default"))) int vgl_dbg_stamps(vgl_ctx* c, unsigned long long out[16]) {
     if (!c || !c->d_dbg) return fail(VGL_E_ARG, "context was not created with VGL_DEBUG_STAMPS=1");
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, c->d_dbg, 128, hipMemcpyDeviceToHost));
@@ -777,7 +831,7 @@ extern "C" int vgl_dbg_stamps(vgl_ctx* c, unsigned long long out[16]) {
 }
 
 // diagnostic (not part of the C ABI): entries of the last tile's redo list (k_sample<2, deferred> -> k_redo)
-extern "C" int vgl_dbg_redo_count(vgl_ctx* c, unsigned* n) {
+extern "C" __attribute__((visibility("default"))) int vgl_dbg_redo_count(vgl_ctx* c, unsigned* n) {
     if (!c || !n) return VGL_E_ARG;
     *n = 0;
     if (!c->d_redo_count) return VGL_OK;
@@ -786,6 +840,7 @@ extern "C" int vgl_dbg_redo_count(vgl_ctx* c, unsigned* n) {
     HIPCHK(hipMemcpy(n, c->d_redo_count, sizeof(unsigned), hipMemcpyDeviceToHost));
     return VGL_OK;
 }
+#endif
 
 extern "C" int vgl_ctx_check(vgl_ctx* c, void* stream) {
     if (!c) return fail(VGL_E_ARG, "null ctx");
@@ -838,7 +893,7 @@ extern "C" void* vgl_host_alloc(size_t bytes) {
     // default flags: page-locked, placed on the host NUMA node nearest to the calling thread's current device (measured: 53 GB/s
     // of DMA into it against 35 GB/s into hipHostMallocPortable memory on the two-socket box); every device of the process can
     // still write it.  VGL_HOST_ALLOC_FLAGS overrides (diagnostic).
-    const unsigned flags = getenv("VGL_HOST_ALLOC_FLAGS") ? (unsigned)strtoul(getenv("VGL_HOST_ALLOC_FLAGS"), nullptr, 0) : hipHostMallocDefault;
+    const unsigned flags = hook_env("VGL_HOST_ALLOC_FLAGS") ? (unsigned)strtoul(hook_env("VGL_HOST_ALLOC_FLAGS"), nullptr, 0) : hipHostMallocDefault;
     if (hipHostMalloc(&p, bytes ? bytes : 1, flags) != hipSuccess) { fail(VGL_E_NOMEM, "hipHostMalloc of %zu bytes failed", bytes); return nullptr; }
     return p;
 }
@@ -869,6 +924,9 @@ static int enqueue_host_tile(vgl_ctx* c, vgl_ctx::HostSlot& S, int64_t site0, in
             if (S.d_out[f]) (void)hipFree(S.d_out[f]);
             S.d_out[f] = nullptr; S.d_out_bytes[f] = 0;
             HIPCHK(hipMalloc(&S.d_out[f], need));
+            // VGL_LAYOUT_SAMPLE_MAJOR: the kernels write n_samples x nK(site) values of a slab, the copy below takes the slab whole --
+            // what lies behind a record's array is then zeros from here, not another job's memory (once per buffer, not per tile)
+            HIPCHK(hipMemsetAsync(S.d_out[f], 0, need, c->s_compute));
             S.d_out_bytes[f] = need;
         }
         *(void**)((char*)&d + FIELDS[f].off) = S.d_out[f];

@@ -622,12 +622,23 @@ __global__ __launch_bounds__(64) void k_redo(const VglDevParams P, const VglTile
     }
 }
 
+// the deferred build of k_sample<2> (LEAN 2) serves this tile: vgl_launch_sample runs it, vgl_launch_redo runs k_redo behind it
+static bool sample_deferred(const VglDevParams* p, const VglTilePtrs* t) {
+    return !p->serial && p->error_qs == 2 && p->lean_ok && !t->reads_out && p->defer_ok && t->redo_list && !(t->dbg != nullptr && !t->errp);
+}
+extern "C" int vgl_launch_redo(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
+    if ((int64_t)t->n_sites * p->chunks == 0 || !sample_deferred(p, t)) return 0;
+    hipLaunchKernelGGL(k_redo, dim3(2048), dim3(64), 0, (hipStream_t)stream, *p, *t);
+    return (int)hipGetLastError();
+}
+
 extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
     const int64_t waves = (int64_t)t->n_sites * p->chunks;
     if (waves == 0) return 0;
     if ((int64_t)t->n_sites * p->n_samples >= (1LL << 32)) return (int)hipErrorInvalidValue;     // evaluation indices of a tile are 32-bit in places
     if (p->serial) return vgl_launch_sample_serial(p, t, stream);
-    const bool dbg = t->dbg != nullptr;                         // VGL_DEBUG_STAMPS / VGL_DEBUG_PHASE
+    const bool dbg = t->dbg != nullptr;                         // VGL_DEBUG_STAMPS / VGL_DEBUG_PHASE (a -DVGL_TEST_HOOKS library only)
+    (void)dbg;
     // wavefronts never cooperate here, and a workgroup's wave slots and LDS are only handed on when its last
     // wavefront retires: one wavefront per workgroup keeps every SIMD at its full complement of waves
     const int wpb = 1;
@@ -639,7 +650,7 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
     do { if (dm == 1) hipLaunchKernelGGL((k_sample<EQS, DBG, 1, PREC, LEAN>), g, b, LDS, s, *p, *t); \
          else if (dm == 2) hipLaunchKernelGGL((k_sample<EQS, DBG, 2, PREC, LEAN>), g, b, LDS, s, *p, *t); \
          else hipLaunchKernelGGL((k_sample<EQS, DBG, 0, PREC, LEAN>), g, b, LDS, s, *p, *t); } while (0)
-    const bool lean = !p->need_qsum && !p->sample_strand && !p->need_adf && !t->reads_out && p->adjust_qs == 0 && !getenv("VGL_NO_LEAN");
+    const bool lean = p->lean_ok && !t->reads_out;
     if (p->error_qs == 2) {
         // the pool loop addresses LDS by integer offsets from 0: none of its instantiations may own static LDS
         static const bool static_lds_free = [] {
@@ -648,7 +659,9 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
 #define VGL_STATIC_LDS(DBG, DM, PREC, LEAN) \
             if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_sample<2, DBG, DM, PREC, LEAN>)) != hipSuccess) return false; \
             worst = a.sharedSizeBytes > worst ? a.sharedSizeBytes : worst;
+#ifdef VGL_TEST_HOOKS
             VGL_STATIC_LDS(true, 0, false, 0) VGL_STATIC_LDS(true, 1, false, 0) VGL_STATIC_LDS(true, 2, false, 0)
+#endif
             VGL_STATIC_LDS(false, 0, true, 1) VGL_STATIC_LDS(false, 1, true, 1) VGL_STATIC_LDS(false, 2, true, 1)
             VGL_STATIC_LDS(false, 0, true, 0) VGL_STATIC_LDS(false, 1, true, 0) VGL_STATIC_LDS(false, 2, true, 0)
             VGL_STATIC_LDS(false, 0, false, 1) VGL_STATIC_LDS(false, 1, false, 1) VGL_STATIC_LDS(false, 2, false, 1)
@@ -659,16 +672,12 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
             return worst == 0;
         }();
         if (!static_lds_free) return (int)hipErrorInvalidConfiguration;
-        if (dbg && !t->errp) VGL_LAUNCH_SAMPLE(2, true, false, 0, lds);   // diagnostic build: --precise-gl 0 only
-        else if (t->errp && lean && p->defer_ok && t->redo_list) {       // --precise-gl 1 on the default tag surface: the deferred build, k_redo also rewrites errp
-            VGL_LAUNCH_SAMPLE(2, false, true, 2, lds);
-            hipLaunchKernelGGL(k_redo, dim3(2048), dim3(64), 0, s, *p, *t);
-        }
+#ifdef VGL_TEST_HOOKS
+        if (dbg && !t->errp) { VGL_LAUNCH_SAMPLE(2, true, false, 0, lds); } else   // diagnostic build (VGL_DEBUG_STAMPS / VGL_DEBUG_PHASE): --precise-gl 0 only
+#endif
+        if (t->errp && sample_deferred(p, t)) VGL_LAUNCH_SAMPLE(2, false, true, 2, lds);   // --precise-gl 1 on the default tag surface: the deferred build, k_redo (vgl_launch_redo) also rewrites errp
         else if (t->errp) { if (lean) VGL_LAUNCH_SAMPLE(2, false, true, 1, lds); else VGL_LAUNCH_SAMPLE(2, false, true, 0, lds); }   // --precise-gl 1, or the deviates were asked for
-        else if (lean && p->defer_ok && t->redo_list) {
-            VGL_LAUNCH_SAMPLE(2, false, false, 2, lds);
-            hipLaunchKernelGGL(k_redo, dim3(2048), dim3(64), 0, s, *p, *t);
-        }
+        else if (sample_deferred(p, t)) VGL_LAUNCH_SAMPLE(2, false, false, 2, lds);
         else { if (lean) VGL_LAUNCH_SAMPLE(2, false, false, 1, lds); else VGL_LAUNCH_SAMPLE(2, false, false, 0, lds); }
     }
     // fixed quality score: the LEAN build (no strand draws, forward-strand depths, quality sums or per-read dump) keeps those
@@ -679,6 +688,7 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
     return (int)hipGetLastError();
 }
 
+#ifdef VGL_TEST_HOOKS
 // ------------------------------------------------------------------------------------
 // debug hook (not part of the C ABI): the raw hardware / ocml float32 functions over a buffer, for the exploratory scripts
 // tools/vlogcheck.py and tools/sincos_check.py.  The bounds the kernels rely on are asserted by tests/test_gpu_bounds.py
@@ -692,8 +702,8 @@ __global__ void k_dbg_vlog(const float* in, float* out, int n, int mode) {
     else if (mode == 3) out[i] = __builtin_amdgcn_sinf(in[i]);     // v_sin_f32: sin(2 pi x)
     else out[i] = __builtin_amdgcn_cosf(in[i]);                    // v_cos_f32: cos(2 pi x)
 }
-extern "C" int vgl_dbg_vlog(const float* d_in, float* d_out, int n, int mode) {
+extern "C" __attribute__((visibility("default"))) int vgl_dbg_vlog(const float* d_in, float* d_out, int n, int mode) {
     hipLaunchKernelGGL(k_dbg_vlog, dim3((n + 255) / 256), dim3(256), 0, 0, d_in, d_out, n, mode);
     return (int)hipDeviceSynchronize();
 }
-
+#endif

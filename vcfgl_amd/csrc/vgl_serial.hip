@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void k_sample_serial(const VglDevParams P, con
         const uint32_t g = T.gt[ev];
         const int a0 = g & 0xF, a1 = (g >> 4) & 0xF;
         dp = T.sdp[ev];                                            // the scout's depth draw (0 for a missing genotype)
-        if (dp >= P.read_cap) atomicOr(T.errflag, (dp > P.read_cap) ? VGL_DEVERR_CAPACITY : 0u);
+        if (dp > P.read_cap) { atomicOr(T.errflag, VGL_DEVERR_CAPACITY); dp = P.read_cap; }   // (the scouts clamp their draws already; wave_sum_ad4's 16-bit fields rely on dp <= read_cap <= 1023)
         const uint64_t err_thresh = (P.error_qs == 1) ? T.site_thresh[ls] : P.err_thresh;
         for (int r = 0; r < dp; ++r) {
             bool fwd;

@@ -29,10 +29,10 @@ class Simulator:
     """One vgl_ctx.  `simulate(site0, gt)` takes host numpy GT bytes [n_sites][n_samples];
     `simulate_device(site0, gt_tensor, tile, stream)` takes torch device tensors."""
 
-    def __init__(self, args: VcfglArgs, n_samples: int, device: int = 0, max_sites_per_tile: int = 4096):
+    def __init__(self, args: VcfglArgs, n_samples: int, device: int = 0, max_sites_per_tile: int = 4096, hooks: bool = False):
         self.args = args
         self.n_samples = n_samples
-        self.lib = _abi.load_library()
+        self.lib = _abi.load_library(hooks=hooks)         # hooks: the -DVGL_TEST_HOOKS build (tests / tools only)
         self.params, self._keep = args.to_struct(n_samples)
         self.ctx = C.c_void_p()
         rc = self.lib.vgl_ctx_create(C.byref(self.params), device, max_sites_per_tile, C.byref(self.ctx))
@@ -83,10 +83,19 @@ class Simulator:
         self._check(self.lib.vgl_ctx_timing(self.ctx, 1 if enable else 0))
 
     def kernel_ms(self, reset=True):
-        ms = (C.c_double * 4)()               # k_depth, k_sample, k_site, k_gl
-        n = (C.c_int64 * 4)()
-        self._check(self.lib.vgl_ctx_kernel_ms(self.ctx, ms, n, 1 if reset else 0))
+        """accumulated milliseconds and launch counts per bucket (_abi.TIMING_BUCKETS: k_depth, k_sample, k_redo, k_site, k_gl, k_siteagg)"""
+        nb = len(_abi.TIMING_BUCKETS)
+        ms = (C.c_double * nb)()
+        n = (C.c_int64 * nb)()
+        self._check(self.lib.vgl_ctx_kernel_ms(self.ctx, ms, n, nb, 1 if reset else 0))
         return list(ms), list(n)
+
+    def info(self):
+        """vgl_ctx_info(): the builds this context launches, its capacities and workspace (a dict)"""
+        ci = _abi.CtxInfo()
+        ci.size = C.sizeof(_abi.CtxInfo)
+        self._check(self.lib.vgl_ctx_info(self.ctx, C.byref(ci)))
+        return {f: getattr(ci, f) for f, _ in _abi.CtxInfo._fields_}
 
     def close(self):
         if getattr(self, "ctx", None):
