@@ -150,6 +150,35 @@ def test_strand_i16_adf_adr(oracle):
     assert_parity(want, got, i16=True)
 
 
+@pytest.mark.parametrize("N,n_sites", [(1, 40), (63, 17), (64, 16), (65, 15), (130, 1), (130, 33), (1000, 18), (1027, 5)])
+@pytest.mark.parametrize("eqs", [0, 2])
+def test_siteagg_sixteen_sites_per_wavefront(oracle, N, n_sites, eqs):
+    """k_siteagg (INFO/QS, INFO/I16): a wavefront takes sixteen sites, walks the samples in chunks of 64 and keeps every order-dependent
+    float32 sum in sample order -- ragged site counts, sample counts around the chunk size, skipped and empty sites, missing calls"""
+    kw = dict(error_qs=2, beta_variance=1e-4, adjust_qs=2) if eqs else {}
+    args = VcfglArgs(seed=9, depth=3.0, error_rate=0.02, rm_invar_sites=4, **kw, **ALLTAGS, **STRAND)
+    want, got = run_both(oracle, args, synth.acgt_sites(n_sites, N, seed=N + n_sites, missing=0.04), site0=11)
+    assert_parity(want, got, i16=True)
+
+
+@pytest.mark.parametrize("kw,N,depth", [(dict(error_rate=1e-7), 300, 20), (dict(error_rate=0.01, i16_mapq=37), 700, 20), (dict(error_rate=0.01, i16_mapq=59), 400, 60),
+                                        (dict(error_rate=0.01, i16_mapq=0), 100, 5), (dict(error_rate=0.01, i16_mapq=60), 2000, 30)])
+def test_siteagg_beyond_the_exact_range_of_float32(oracle, kw, N, depth):
+    """INFO/I16 fields 5-12 are float32 running sums of integers; k_siteagg takes them from integer totals while every partial sum is
+    exact (<= 2^24, or the multiples of 2^tz(c) up to 2^(24 + tz(c)) for the repeated addition of the mapping quality c) and walks the
+    rest in the reference's order: q = 63 (sum of squares 3969 per read: 6000 reads cross 2^24), odd mapping qualities (37^2 = 1369:
+    14000 reads; 59^2 x 24000), mapping quality 0, and a deep wide site (60^2 x 60000 = 2^27.7, still exact: 3600 = 2^4 x 225)"""
+    args = VcfglArgs(seed=3, depth=depth, add_qs=1, **kw, **STRAND)
+    gt = synth.binary_sites(0, 5, N)
+    gt[1] = 0                                                   # a hom-ref site: every read on one base
+    want, got = run_both(oracle, args, gt)
+    assert float(want.numpy("i16")[:, 4:12].max()) > 2 ** 24 or kw.get("i16_mapq") == 0
+    for f in ("site_status", "fmt_dp", "info_dp", "info_adf"):
+        assert np.array_equal(want.numpy(f), got.numpy(f)), f
+    assert np.array_equal(want.numpy("qs").view(np.uint32), got.numpy("qs").view(np.uint32)), "QS"
+    assert np.array_equal(want.numpy("i16")[:, :12].view(np.uint32), got.numpy("i16")[:, :12].view(np.uint32)), "I16[0..11]"
+
+
 @pytest.mark.parametrize("precise", [0, 1])
 @pytest.mark.parametrize("adj", [0, 3])
 def test_error_qs2_beta_quality_scores(oracle, precise, adj):

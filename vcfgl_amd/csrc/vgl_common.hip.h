@@ -494,6 +494,24 @@ __device__ __forceinline__ void wave_sum_ad4(const uint64_t ad4, int out[4]) {
     out[0] = (int)(lo & 0xFFFFu); out[1] = (int)(lo >> 16); out[2] = (int)(hi & 0xFFFFu); out[3] = (int)(hi >> 16);
 }
 
+// per-site integer totals of the per-base quality sums (-addQS / -addI16): the wavefront's eight sums by DPP scans, one atomic each into
+// acc[VGL_ACC_QSUM ..] (k_siteagg: INFO/I16 fields 5-8 are the reference's float32 running sums of these integers over the samples,
+// vcfgl.cpp:997-1000,1052-1056 -- exact, hence order-free, while they stay below 2^24).  Lanes without an evaluation pass zeros.
+__device__ __forceinline__ void wave_add_qsum_totals(int32_t* acc, const int lane, const uint32_t q[4], const uint32_t qq[4], const bool with_sq) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(q[b]), 63);
+        if (lane == 0 && t) atomicAdd((unsigned int*)&acc[VGL_ACC_QSUM + b], t);
+    }
+    if (with_sq) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(qq[b]), 63);
+            if (lane == 0 && t) atomicAdd((unsigned int*)&acc[VGL_ACC_QSUMSQ + b], t);
+        }
+    }
+}
+
 // sample_read_base() on states carried shifted left by 16 bits: 64-bit wraparound is then the generator's mod 2^48 (no masking
 // per step), u < 0.5 is the sign bit, floor(4u) the top two bits.  err_thresh16 = err_thresh << 16, saturated (sample_thresh16).
 __device__ __forceinline__ uint64_t lcg_next16(const uint64_t x) { return x * VGL_LCG_A + (VGL_LCG_C << 16); }

@@ -60,9 +60,13 @@ __device__ __forceinline__ size_t vgl_read_byte(const int r, const size_t plane,
 #define VGL_DEVERR_ADJQ     8u
 #define VGL_DEVERR_INTERNAL 16u   /* a layout assumption of a kernel does not hold (k_sample<2>: dynamic LDS must start at offset 0) */
 
-// per-site accumulator layout (int32 x 16): [0] INFO/DP, [1..4] ACGT depth,
-// [5..8] forward-strand ACGT depth, [9..12] reverse-strand ACGT depth
-#define VGL_ACC_STRIDE 16
+// per-site accumulator layout (int32 x 24): [0] INFO/DP, [1..4] ACGT depth, [5..8] forward-strand ACGT depth;
+// with -addQS / -addI16 (uint32 bit patterns, modulo 2^32): [16..19] per-base sum over the samples of the quality sums (acgt_fmt_qsum_arr),
+// [20..23] of the squared-quality sums -- the integer totals k_siteagg turns into INFO/I16 fields 5-8 where the reference's float32
+// running sums stay exact (below 2^24)
+#define VGL_ACC_STRIDE 24
+#define VGL_ACC_QSUM 16
+#define VGL_ACC_QSUMSQ 20
 
 // per-site record produced by k_site for k_gl (one 16-byte row)
 struct VglSiteInfo {

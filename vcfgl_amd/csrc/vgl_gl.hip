@@ -835,62 +835,134 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
 }
 
 // ------------------------------------------------------------------------------------
-// one lane per site, samples in order: the reference accumulates these in float32 in sample
-// order (vcfgl.cpp:875-897, 997-1066), which a tree reduction would not reproduce bit for bit.
+// INFO/QS and INFO/I16 (vcfgl.cpp:845-898, 982-1074): float32 sums over a site's samples IN SAMPLE ORDER, which a tree reduction would not
+// reproduce bit for bit.  One wavefront takes SIXTEEN sites:
+//   * QS: qs[allele of b] += (float)qsum[s][b] / sum_s is an order-dependent chain per (site, base) -- 64 chains per wavefront.  The
+//     wavefront walks the samples in chunks of 64: for each of its sites the lanes (lane = sample) load the chunk's four quality sums
+//     (coalesced, 256 bytes per row), form the four correctly rounded quotients and leave them in LDS; then lane (site j, base b) adds
+//     the 64 values of ITS chain in sample order.  A sample without reads, or a base without an allele, contributes +0 where the
+//     reference skips it: x + 0 = x for these non-negative sums.  (Round 3: one lane per site walking N samples with 16 KB between the
+//     lanes' addresses: 7.1 ms per 65536 x 1000 tile.)
+//   * I16 fields 5-8 are float32 running sums of INTEGERS (per-sample quality sums): while the total stays at or below 2^24 every partial
+//     sum is an integer the format holds exactly, so the result is the integer total whatever the order -- k_sample leaves those totals
+//     in acc[16..23].  Fields 9-12 add the constant mapping quality once per read: K additions of c are exact while K c <= 2^24 2^tz(c)
+//     (every partial sum is a multiple of 2^tz(c)); beyond that the remaining additions are performed one by one (no memory traffic).
+//     A site whose integer totals leave the exact range is walked sample by sample by one lane, as the reference does (rare: more than
+//     2^24 / q^2 reads of one base at a site).
+// fields 1-4: per-base strand depths of the site (acc); fields 13-16: tail distances, drawn from libc rand() in serial mode, 0 in tile mode.
+#define VGL_AGG_SITES 16
+#define VGL_AGG_ROW 65                                                 // 64 samples + 1 word of padding: the chain lanes' reads fall on distinct banks
+// the reference's K-fold `acc += c` (acc starts at 0; c a positive integer-valued float): jump over the exact range, walk the rest
+__device__ __forceinline__ float repeated_add(const float c, const long long K) {
+    if (K <= 0 || c == 0.0f) return 0.0f;
+    const unsigned long long ci = (unsigned long long)c;
+    if ((float)ci != c || ci == 0ULL || ci >= (1ULL << 24)) { float v = 0.0f; for (long long k = 0; k < K; ++k) v += c; return v; }
+    const int tz = __builtin_ctzll(ci);
+    const unsigned long long lim = 1ULL << (24 + tz);                  // multiples of 2^tz up to here are float32 values
+    const unsigned long long k0 = lim / ci;                            // k c <= lim for k <= k0
+    if ((unsigned long long)K <= k0) return (float)((unsigned long long)K * ci);
+    float v = (float)(k0 * ci);
+    for (unsigned long long k = k0; k < (unsigned long long)K; ++k) v += c;
+    return v;
+}
 __global__ __launch_bounds__(64) void k_siteagg(const VglDevParams P, const VglTilePtrs T) {
-    const int ls = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ls >= T.n_sites) return;
+    __shared__ float s_x[VGL_AGG_SITES * 4 * VGL_AGG_ROW];
+    const int lane = threadIdx.x;
     const int N = P.n_samples, A = P.A;
-    const VglSiteInfo si = T.sinfo[ls];
-    const bool have = (si.status == SITE_OK);
-    const int nA = si.n_alleles;
-    const uint32_t* qsum = T.qsum + (size_t)ls * 4 * N;
+    const int ls_w = blockIdx.x * VGL_AGG_SITES;                        // first site of this wavefront
+    const int n_w = (T.n_sites - ls_w) < VGL_AGG_SITES ? (T.n_sites - ls_w) : VGL_AGG_SITES;
+    // ---- INFO/QS
     if (T.qs) {
-        float qsv[5] = {0, 0, 0, 0, 0};
-        if (have && P.need_qsum)
-            for (int s = 0; s < N; ++s) {
-                float sum = 0.0f;
-                uint32_t q[4];
-                for (int b = 0; b < 4; ++b) { q[b] = qsum[(size_t)b * N + s]; sum += (float)(int)q[b]; }
-                if (0.0f != sum)
-                    for (int b = 0; b < 4; ++b) {
-                        const int a = nib(si.acgt2alleles, b);
-                        if (a == 0xF) continue;
-                        const float add = (float)((float)(int)q[b] / sum);
-                        qsv[0] += (a == 0) ? add : 0.0f; qsv[1] += (a == 1) ? add : 0.0f; qsv[2] += (a == 2) ? add : 0.0f;
-                        qsv[3] += (a == 3) ? add : 0.0f; qsv[4] += (a == 4) ? add : 0.0f;
+        const int j_c = lane >> 2;                                      // this lane's chain: (site, base)
+        float chain = 0.0f;
+        uint64_t have_m = 0;                                            // sites of the wavefront that are written and carry quality sums
+        {
+            const bool hv = lane < n_w && P.need_qsum && T.sinfo[ls_w + lane].status == SITE_OK;
+            have_m = __ballot(hv);
+        }
+        if (have_m) {
+            for (int c0 = 0; c0 < N; c0 += 64) {
+                const int sidx = c0 + lane;
+                for (int j = 0; j < n_w; ++j) {
+                    float x0 = 0.0f, x1 = 0.0f, x2 = 0.0f, x3 = 0.0f;
+                    if ((have_m >> j) & 1) {                            // wave-uniform
+                        if (sidx < N) {
+                            const uint32_t* q = T.qsum + (size_t)(ls_w + j) * 4 * N + sidx;
+                            const float f0 = (float)(int)q[0], f1 = (float)(int)q[(size_t)N], f2 = (float)(int)q[(size_t)2 * N], f3 = (float)(int)q[(size_t)3 * N];
+                            const float sum = ((0.0f + f0) + f1) + f2 + f3;                 // vcfgl.cpp:879-881, in base order
+                            if (0.0f != sum) { x0 = f0 / sum; x1 = f1 / sum; x2 = f2 / sum; x3 = f3 / sum; }
+                        }
                     }
+                    float* row = s_x + (size_t)(j * 4) * VGL_AGG_ROW + lane;
+                    row[0] = x0; row[VGL_AGG_ROW] = x1; row[2 * VGL_AGG_ROW] = x2; row[3 * VGL_AGG_ROW] = x3;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (j_c < n_w) {
+                    const float* mine = s_x + (size_t)lane * VGL_AGG_ROW;
+#pragma unroll 16
+                    for (int k = 0; k < 64; ++k) chain += mine[k];      // samples c0 .. c0 + 63 of chain (j_c, b_c), in order
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
-        for (int a = 0; a < A; ++a) T.qs[(size_t)ls * A + a] = qsv[a];
+        }
+        // qs[a] of site j = the chain of base alleles2acgt[a]: the chain values go back through LDS, lane (j, a) picks its base's
+        s_x[lane] = chain;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int t = lane; t < n_w * A; t += 64) {
+            const int j = t / A, a = t - j * A;
+            const VglSiteInfo si = T.sinfo[ls_w + j];
+            float v = 0.0f;
+            if (si.status == SITE_OK && P.need_qsum) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) if (nib(si.acgt2alleles, b) == a) v = s_x[j * 4 + b];
+            }
+            T.qs[(size_t)(ls_w + j) * A + a] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    if (T.i16) {
+    // ---- INFO/I16: lane j < 16 takes site j
+    if (T.i16 && lane < n_w) {
+        const int ls = ls_w + lane;
+        const VglSiteInfo si = T.sinfo[ls];
+        const bool have = (si.status == SITE_OK);
+        const int nA = si.n_alleles;
         float v[16];
+#pragma unroll
         for (int k = 0; k < 16; ++k) v[k] = 0.0f;
         if (have && P.add_i16 && nA > 1) {
             const int32_t* acc = T.acc + (size_t)ls * VGL_ACC_STRIDE;
+            const uint32_t* qsum = T.qsum + (size_t)ls * 4 * N;
             const uint32_t* qsq = T.qsumsq + (size_t)ls * 4 * N;
             const int refb = nib(si.alleles2acgt, 0);
             const int nObs = (A == 5) ? nA - 1 : nA;
             v[0] = (float)acc[5 + refb]; v[1] = (float)(acc[1 + refb] - acc[5 + refb]);
             const float mq = (float)P.i16_mapq, mq2 = (float)(P.i16_mapq * P.i16_mapq);
-            for (int s = 0; s < N; ++s) {
-                v[4] += (float)(int)qsum[(size_t)refb * N + s];
-                v[5] += (float)(int)qsq[(size_t)refb * N + s];
-                const uint64_t ad4 = T.ad4[(size_t)ls * N + s];
-                for (int a = 0; a < nA; ++a) {
-                    if (a == nObs) continue;
-                    const int cnt = cnt_of(ad4, nib(si.alleles2acgt, a));
-                    for (int i = 0; i < cnt; ++i) {
-                        if (0 == a) { v[8] += mq; v[9] += mq2; } else { v[10] += mq; v[11] += mq2; }
-                    }
-                }
-            }
+            // integer totals (modulo 2^32: trusted while the site's reads cannot have wrapped them -- 3969 = 63^2 per read at most)
+            const bool tot_ok = (unsigned long long)(uint32_t)acc[0] * 3969ULL < (1ULL << 32);
+            unsigned long long t4 = (uint32_t)acc[VGL_ACC_QSUM + refb], t5 = (uint32_t)acc[VGL_ACC_QSUMSQ + refb], t6 = 0, t7 = 0;
+            long long k_ref = acc[1 + refb], k_non = 0;
             for (int a = 1; a < nA; ++a) {
                 if (a == nObs) continue;
                 const int b = nib(si.alleles2acgt, a);
+                t6 += (uint32_t)acc[VGL_ACC_QSUM + b]; t7 += (uint32_t)acc[VGL_ACC_QSUMSQ + b];
+                k_non += acc[1 + b];
                 v[2] += (float)acc[5 + b]; v[3] += (float)(acc[1 + b] - acc[5 + b]);
-                for (int s = 0; s < N; ++s) { v[6] += (float)(int)qsum[(size_t)b * N + s]; v[7] += (float)(int)qsq[(size_t)b * N + s]; }
             }
+            const unsigned long long lim = 1ULL << 24;
+            if (tot_ok && t4 <= lim && t5 <= lim && t6 <= lim && t7 <= lim) {
+                v[4] = (float)t4; v[5] = (float)t5; v[6] = (float)t6; v[7] = (float)t7;
+            } else {
+                // the running sums leave the exact range: the reference's own walk (vcfgl.cpp:997-1000, 1052-1056)
+                for (int s = 0; s < N; ++s) { v[4] += (float)(int)qsum[(size_t)refb * N + s]; v[5] += (float)(int)qsq[(size_t)refb * N + s]; }
+                for (int a = 1; a < nA; ++a) {
+                    if (a == nObs) continue;
+                    const int b = nib(si.alleles2acgt, a);
+                    for (int s = 0; s < N; ++s) { v[6] += (float)(int)qsum[(size_t)b * N + s]; v[7] += (float)(int)qsq[(size_t)b * N + s]; }
+                }
+            }
+            // one addition of the mapping quality (and of its square) per read, reference allele / the others (vcfgl.cpp:1003-1024)
+            v[8] = repeated_add(mq, k_ref); v[9] = repeated_add(mq2, k_ref);
+            v[10] = repeated_add(mq, k_non); v[11] = repeated_add(mq2, k_non);
             // tail distance (vcfgl.cpp:1029-1071): drawn from libc rand() by the serial-mode scout; zero in tile mode
             if (T.site_tail) {
                 const VglSiteTail tl = T.site_tail[ls];
@@ -901,6 +973,7 @@ __global__ __launch_bounds__(64) void k_siteagg(const VglDevParams P, const VglT
                 }
             }
         }
+#pragma unroll
         for (int k = 0; k < 16; ++k) T.i16[(size_t)ls * 16 + k] = v[k];
     }
 }
@@ -992,6 +1065,6 @@ extern "C" int vgl_launch_fused(const VglDevParams* p, const VglTilePtrs* t, voi
 
 extern "C" int vgl_launch_siteagg(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
     if (t->n_sites == 0) return 0;
-    hipLaunchKernelGGL(k_siteagg, dim3((t->n_sites + 63) / 64), dim3(64), 0, (hipStream_t)stream, *p, *t);
+    hipLaunchKernelGGL(k_siteagg, dim3((t->n_sites + VGL_AGG_SITES - 1) / VGL_AGG_SITES), dim3(64), 0, (hipStream_t)stream, *p, *t);
     return (int)hipGetLastError();
 }

@@ -550,6 +550,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
     if (k_strand) wave_sum_ad4(adf4, &v[5]);
     else { v[5] = v[1]; v[6] = v[2]; v[7] = v[3]; v[8] = v[4]; }
     v[0] = v[1] + v[2] + v[3] + v[4];
+    if (!LEAN) {
+        if (P.need_qsum) {                                   // the site's integer totals of the quality sums, for k_siteagg
+            const uint32_t q4[4] = {qs0, qs1, qs2, qs3}, qq4[4] = {qq0, qq1, qq2, qq3};
+            wave_add_qsum_totals(T.acc + (size_t)ls * VGL_ACC_STRIDE, lane, q4, qq4, P.need_qsumsq != 0);
+        }
+    }
     if (lane == 0) {
         int32_t* acc = T.acc + (size_t)ls * VGL_ACC_STRIDE;
 #pragma unroll

@@ -414,6 +414,7 @@ __global__ __launch_bounds__(256) void k_sample_serial(const VglDevParams P, con
 #pragma unroll
         for (int k = 0; k < 9; ++k) if (v[k]) atomicAdd(&acc[k], v[k]);
     }
+    if (P.need_qsum) wave_add_qsum_totals(T.acc + (size_t)ls * VGL_ACC_STRIDE, lane, qs, qq, P.need_qsumsq != 0);
 }
 
 // ------------------------------------------------------------------------------------
