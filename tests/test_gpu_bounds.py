@@ -16,7 +16,7 @@ from vcfgl_amd import _abi
 
 pytestmark = pytest.mark.gpu
 
-FAST_LN, GAMMA_LU, GAMMA_SERIES, GAMMA_REFEXPR, QS_TF, RCP, TANF, EXP2, DIV = range(9)
+FAST_LN, GAMMA_LU, GAMMA_SERIES, GAMMA_REFEXPR, QS_TF, RCP, TANF, EXP2, DIV, QUOT = range(10)
 
 
 def f2b(x):
@@ -86,3 +86,10 @@ def test_div_inrange_equals_ieee_division():
     operands of the ratio-of-uniforms normal sampler (u = X 2^-48 incl. the smallest, v = 1.7156 (u' - 0.5))"""
     r = sweep(DIV, 0, 0, count=4_000_000_000)
     check("div_inrange", r, 4e9)
+
+
+def test_quot_int24_equals_ieee_float_division():
+    """k_siteagg (INFO/QS): (float)q / sum for integers q <= sum <= 2^24 from one double reciprocal per sum is the IEEE float32 quotient --
+    every pair up to 4096, then 4e9 pseudo-random pairs up to 2^24 incl. sums at and next to powers of two"""
+    r = sweep(QUOT, 0, 0, count=(1 << 24) + 4_000_000_000)
+    check("quot_int24", r, 4e9)

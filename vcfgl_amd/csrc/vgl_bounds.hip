@@ -20,6 +20,7 @@ enum {
     VGL_BOUND_TANF = 6,         // tanf / tanf_err_bound on (0, VGL_PI]                   (poisson_attempt)
     VGL_BOUND_EXP2 = 7,         // v_exp_f32 on [-126, 8]                                 (poisson_attempt)
     VGL_BOUND_DIV = 8,          // div_inrange == IEEE quotient, operands shaped like the pool loop's (count = pairs)
+    VGL_BOUND_QUOT = 9,         // quot_int24 == IEEE float32 quotient of integers q <= sum <= 2^24 (k_siteagg; count = pairs)
     VGL_BOUND_N
 };
 
@@ -135,6 +136,29 @@ __global__ __launch_bounds__(256) void k_bound_div(const unsigned long long coun
     if (viol) { atomicAdd(&out->viol, viol); out->arg_bits = arg; }
 }
 
+// quot_int24(q, recip_int24(sum)) against the compiler's IEEE float32 division: pairs 0 .. 2^24 - 1 are EVERY (sum, q) with sum, q in
+// [1, 4096] x [0, 4095] (q <= sum kept), the rest pseudo-random sums up to 2^24 (every 4th one a power of two or one off it) with q <= sum
+__global__ __launch_bounds__(256) void k_bound_quot(const unsigned long long count, BoundAcc* out) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long viol = 0, n = 0; uint32_t arg = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        uint32_t sum, q;
+        if (i < (1ULL << 24)) { sum = 1u + (uint32_t)(i >> 12); q = (uint32_t)(i & 4095u); if (q > sum) continue; }
+        else {
+            const uint64_t h = mix64(i);
+            sum = 1u + (uint32_t)(h & 0xFFFFFFu);
+            if ((i & 3) == 3) { sum = 1u << (1 + (uint32_t)((h >> 50) % 24)); sum += (uint32_t)((h >> 60) % 3) - 1u; }
+            q = (uint32_t)((h >> 24) % ((uint64_t)sum + 1u));
+        }
+        const float fs = (float)sum, fq = (float)q;
+        const float a = quot_int24(fq, recip_int24(fs)), b = fq / fs;
+        ++n;
+        if (__float_as_uint(a) != __float_as_uint(b)) { ++viol; arg = (uint32_t)i; }
+    }
+    atomicAdd(&out->n, n);
+    if (viol) { atomicAdd(&out->viol, viol); out->arg_bits = arg; }
+}
+
 extern "C" __attribute__((visibility("default"))) int vgl_dbg_bound_sweep(int mode, uint32_t lo_bits, unsigned long long count, double param, double out[4]) {
     BoundAcc* d = nullptr;
     if (hipMalloc((void**)&d, sizeof(BoundAcc)) != hipSuccess) return -1;
@@ -150,6 +174,7 @@ extern "C" __attribute__((visibility("default"))) int vgl_dbg_bound_sweep(int mo
         case VGL_BOUND_TANF: hipLaunchKernelGGL((k_bound_sweep<VGL_BOUND_TANF>), g, b, 0, 0, lo_bits, count, param, d); break;
         case VGL_BOUND_EXP2: hipLaunchKernelGGL((k_bound_sweep<VGL_BOUND_EXP2>), g, b, 0, 0, lo_bits, count, param, d); break;
         case VGL_BOUND_DIV: hipLaunchKernelGGL(k_bound_div, g, b, 0, 0, count, d); break;
+        case VGL_BOUND_QUOT: hipLaunchKernelGGL(k_bound_quot, g, b, 0, 0, count, d); break;
         default: (void)hipFree(d); return -2;
     }
     BoundAcc h;

@@ -269,6 +269,21 @@ __device__ __forceinline__ double div_inrange(const double n, const double d) {
     return __builtin_fma(r, y, q);
 }
 
+// (float)(q / sum) for integer-valued floats 0 <= q <= sum <= 2^24 (INFO/QS: a base's share of a sample's quality sum, vcfgl.cpp:893)
+// through ONE double reciprocal per sum: the exact quotient of two such integers is never a rounding tie of float32 (a dyadic q / sum
+// has at most 24 significant bits, i.e. is itself a float32) and lies at least 2^-49 (relative) from the nearest one, while
+// q * (1 / sum) in double -- v_rcp_f64 and two Newton steps, then one multiplication -- is within 2^-51 of it: rounding that double
+// to float32 gives the correctly rounded quotient, what the IEEE division sequence (ten instructions per quotient) returns.
+// tests/test_gpu_bounds.py compares the two over every pair up to 4096 and 4e9 pseudo-random larger pairs (vgl_bounds.hip).
+__device__ __forceinline__ double recip_int24(const float sum) {
+    const double ds = (double)sum;
+    double r = __builtin_amdgcn_rcp(ds);
+    r = __builtin_fma(__builtin_fma(-ds, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-ds, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ float quot_int24(const float q, const double recip_sum) { return (float)((double)q * recip_sum); }
+
 // error probability -> qScore / adjusted qScore, vcfgl.cpp:500-523
 static __device__ void errprob_to_qs(const VglDevParams& P, double ep, int& q, int& aq, uint32_t* errflag) {
     q = -1; aq = -1;

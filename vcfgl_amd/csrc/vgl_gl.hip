@@ -883,18 +883,32 @@ __global__ __launch_bounds__(64) void k_siteagg(const VglDevParams P, const VglT
         if (have_m) {
             for (int c0 = 0; c0 < N; c0 += 64) {
                 const int sidx = c0 + lane;
-                for (int j = 0; j < n_w; ++j) {
-                    float x0 = 0.0f, x1 = 0.0f, x2 = 0.0f, x3 = 0.0f;
-                    if ((have_m >> j) & 1) {                            // wave-uniform
-                        if (sidx < N) {
-                            const uint32_t* q = T.qsum + (size_t)(ls_w + j) * 4 * N + sidx;
-                            const float f0 = (float)(int)q[0], f1 = (float)(int)q[(size_t)N], f2 = (float)(int)q[(size_t)2 * N], f3 = (float)(int)q[(size_t)3 * N];
-                            const float sum = ((0.0f + f0) + f1) + f2 + f3;                 // vcfgl.cpp:879-881, in base order
-                            if (0.0f != sum) { x0 = f0 / sum; x1 = f1 / sum; x2 = f2 / sum; x3 = f3 / sum; }
+                const bool in_n = sidx < N;
+                const size_t s_ld = in_n ? (size_t)sidx : 0;             // (a valid address for every lane: the value is dropped below)
+                // four sites per trip: their sixteen row loads are issued together (the kernel waits on memory, not on arithmetic)
+                for (int j0 = 0; j0 < n_w; j0 += 4) {
+                    uint32_t qv[4][4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int j = (j0 + u < n_w) ? j0 + u : n_w - 1;
+                        const uint32_t* q = T.qsum + (size_t)(ls_w + j) * 4 * N + s_ld;
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) qv[u][b] = q[(size_t)b * N];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int j = j0 + u;
+                        if (j < n_w) {                                   // wave-uniform
+                            const bool on = in_n && ((have_m >> j) & 1);
+                            const float f0 = (float)(int)qv[u][0], f1 = (float)(int)qv[u][1], f2 = (float)(int)qv[u][2], f3 = (float)(int)qv[u][3];
+                            const float sum = (((0.0f + f0) + f1) + f2) + f3;                 // vcfgl.cpp:879-881, in base order
+                            const double r = recip_int24(sum);                              // (float)((float)q / sum), vcfgl.cpp:893: quot_int24
+                            const bool nz = on && (0.0f != sum);
+                            float* row = s_x + (size_t)(j * 4) * VGL_AGG_ROW + lane;
+                            row[0] = nz ? quot_int24(f0, r) : 0.0f; row[VGL_AGG_ROW] = nz ? quot_int24(f1, r) : 0.0f;
+                            row[2 * VGL_AGG_ROW] = nz ? quot_int24(f2, r) : 0.0f; row[3 * VGL_AGG_ROW] = nz ? quot_int24(f3, r) : 0.0f;
                         }
                     }
-                    float* row = s_x + (size_t)(j * 4) * VGL_AGG_ROW + lane;
-                    row[0] = x0; row[VGL_AGG_ROW] = x1; row[2 * VGL_AGG_ROW] = x2; row[3 * VGL_AGG_ROW] = x3;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 if (j_c < n_w) {
