@@ -301,8 +301,9 @@ typedef struct vgl_ctx_info_t {
     int32_t depth_mode;          /* VGL_DEPTH_*                                                                           */
     int32_t fused;               /* 1: a tile that asks for no QS / I16 / per-read dump runs as ONE kernel (k_gl<.., FUSED>) */
     int32_t fused_split;         /* workgroups per site of that kernel (1, or several with the site sums exchanged in HBM)   */
-    int32_t sample_lean;         /* build of k_sample a tile without per-read dump gets: 0 every option's state carried,
-                                    1 default tag surface, 2 = 1 with the double-precision fallbacks deferred to k_redo     */
+    int32_t sample_lean;         /* build of k_sample a tile without per-read dump gets: 0 every option's state carried, double-precision
+                                    fallbacks inline; 1 default tag surface; 2 = 1 with the fallbacks deferred to k_redo; 3 = 0 with the
+                                    fallbacks deferred (optional tags: -addQS / -addI16 / strand tags / --adjust-qs)               */
     int32_t gl_sort;             /* k_gl re-deals a workgroup's evaluations in (distinct bases, depth) order                */
     int32_t gl_wpb;              /* wavefronts per k_gl workgroup (4 or 8)                                                  */
     int32_t read_cap;            /* staged reads per (site, sample): a deeper draw is VGL_E_CAPACITY                        */

@@ -436,15 +436,15 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
         D.sure_margin = 1e-9 + 1e-14 * std::max(D.gx.a1, D.gy.a1);
         D.beta_a = a; D.beta_b = b;
     }
-    // The deferred build of k_sample<2> (5 wavefronts per SIMD, no double-precision fallback code in the kernel: the reads a float32
-    // bound cannot settle go to k_redo) serves the default tag surface of the benchmark configurations, with or without --precise-gl 1
-    // (k_redo then also rewrites the read's staged error probability); everything else
-    // (-addQS / -addI16, strand tags, --adjust-qs, a per-read dump, a beta shape parameter below 8 -- the gamma sampler's
-    // bounded test then leaves its series' range |a2 x| <= 1/3 too often) runs the build with the fallbacks inline.
+    // The deferred builds of k_sample<2> (5 wavefronts per SIMD, no double-precision fallback code in the kernel: the reads a float32
+    // bound cannot settle go to k_redo) serve every tag surface -- LEAN 2 the default one, LEAN 3 (round 4) -addQS / -addI16, strand tags
+    // and --adjust-qs, with or without --precise-gl 1 (k_redo then also rewrites the read's staged error probability).  The build with
+    // the fallbacks inline (LEAN 0 / 1) remains for a per-read dump and for a beta shape parameter below 8 (the gamma sampler's bounded
+    // test then leaves its series' range |a2 x| <= 1/3 too often).
     D.dbg_redo_every = hook_int("VGL_DEBUG_REDO_EVERY", 0);
     // the tag surface needs none of the owners' optional per-read state (quality sums, strand draws, --adjust-qs): the LEAN builds of k_sample
     D.lean_ok = (!D.need_qsum && !D.sample_strand && !D.need_adf && p->adjust_qs == 0 && !hook_env("VGL_NO_LEAN")) ? 1 : 0;
-    D.defer_ok = (!D.serial && p->error_qs == 2 && !D.need_qsum && !D.sample_strand && !D.need_adf && p->adjust_qs == 0 &&
+    D.defer_ok = (!D.serial && p->error_qs == 2 &&
                   !D.gx.changed && !D.gy.changed && D.gx.alpha0 >= 8.0 && D.gy.alpha0 >= 8.0 && !hook_env("VGL_NO_DEFER") && !hook_env("VGL_DEBUG_QS_EXACT") && !hook_env("VGL_NO_LEAN")) ? 1 : 0;
     // one workgroup per site does everything (k_gl<.., FUSED>, vgl_gl.hip): sampling with one fixed score, the site's allele order and the
     // likelihoods, with nothing staged in HBM between them
@@ -638,7 +638,7 @@ extern "C" int vgl_ctx_info(const vgl_ctx* c, vgl_ctx_info_t* out) {
     r.rng_mode = c->p.rng_mode;
     r.depth_mode = D.serial ? VGL_DEPTH_SERIAL_SCOUT : D.depth_pre;
     r.fused = D.fused; r.fused_split = D.fused ? (D.fused_split > 0 ? D.fused_split : 1) : 0;
-    r.sample_lean = D.serial ? 0 : (D.lean_ok ? ((D.error_qs == 2 && D.defer_ok) ? 2 : 1) : 0);
+    r.sample_lean = D.serial ? 0 : (D.lean_ok ? ((D.error_qs == 2 && D.defer_ok) ? 2 : 1) : ((D.error_qs == 2 && D.defer_ok) ? 3 : 0));
     r.gl_sort = D.gl_sort; r.gl_wpb = (D.gl_model == 2 && D.gl_wpb == 8) ? 8 : 4;
     r.read_cap = D.read_cap; r.pool_cap = D.error_qs == 2 ? D.pool_cap : 0; r.pool_lds_bytes = D.error_qs == 2 ? D.pool_lds_bytes : 0;
 #ifdef VGL_TEST_HOOKS

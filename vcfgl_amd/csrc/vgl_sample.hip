@@ -100,9 +100,16 @@ __global__ __launch_bounds__(256) void k_depth(const VglDevParams P, const VglTi
 // pool loop's two bounded tests or in the dense pass; about one read in 10^4) is appended to T.redo_list and drawn again in double
 // by k_redo.  Without log() / pow() / the double gamma sampler the kernel needs 92 VGPRs and no scratch, and is built for 5
 // wavefronts per SIMD (+6.5 % on C3).
+// LEAN 3 (round 4) = the deferred build for the OPTIONAL tag surface (-addQS / -addI16, strand tags, --adjust-qs; no per-read dump): the
+// owners' options are run-time flags as in LEAN 0, the fallbacks are k_redo's as in LEAN 2 -- k_redo then also adds the redrawn read's
+// score to the evaluation's quality sums and to the site totals, which took a placeholder of 0.  The eight quality sums of an owner
+// live only inside a segment's flush (stored, or added to what earlier segments stored, at its end) instead of across the pool loop.
+// LEAN 0 keeps the inline fallbacks: per-read dumps, beta shapes below 8, VGL_NO_DEFER.
 template <int EQS, bool DBG, int DM, bool PREC, int LEAN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? (LEAN == 2 ? 5 : 4) : 1, EQS == 2 ? (LEAN == 2 ? 5 : 4) : 8))) void k_sample(const VglDevParams P, const VglTilePtrs T) {
-    constexpr bool DEFER = (LEAN == 2);
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? (LEAN >= 2 ? 5 : 4) : 1, EQS == 2 ? (LEAN >= 2 ? 5 : 4) : 8))) void k_sample(const VglDevParams P, const VglTilePtrs T) {
+    constexpr bool DEFER = (LEAN >= 2);
+    constexpr bool SLIM = (LEAN == 1 || LEAN == 2);                  // default tag surface: none of the optional per-read state
+    constexpr bool DUMP = (LEAN == 0);                               // a per-read dump (reads_out) may be asked for
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const WavePos wp = wave_pos(P, T);
     if (!wp.valid) return;
@@ -116,6 +123,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
     const size_t plane = (size_t)T.n_sites * N;
 
     int dp = 0, a0 = 0, a1 = 0;
+    int wave_total_reads = 0;                                        // EQS 2: reads of the wavefront's evaluations (wave-uniform)
     uint64_t ad4 = 0, adf4 = 0;
     uint32_t qs0 = 0, qs1 = 0, qs2 = 0, qs3 = 0, qq0 = 0, qq1 = 0, qq2 = 0, qq3 = 0;
     uint64_t st_hap = 0, st_base = 0, st_qs = 0;
@@ -123,9 +131,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
     unsigned long long c_t0 = 0, c_pois = 0, c_owner = 0, c_pool = 0, c_flush = 0, c_iter = 0, c_items = 0, c_tmp = 0;
     if (DBG) c_t0 = clock64();
     uint64_t err_thresh = P.err_thresh;
-    const bool k_strand = LEAN ? false : (P.sample_strand != 0);
-    const bool k_qsum = LEAN ? false : (P.need_qsum != 0);
-    const int k_adj = LEAN ? 0 : P.adjust_qs;
+    const bool k_strand = SLIM ? false : (P.sample_strand != 0);
+    const bool k_qsum = SLIM ? false : (P.need_qsum != 0);
+    const int k_adj = SLIM ? 0 : P.adjust_qs;
 
     // ---- stream states of this evaluation: J^(off_k) . J^(block*s) . J^(block*N*H(site)) (x0); the site factor comes from k_sitebase
     const uint64_t xb = T.site_base[ls];
@@ -200,7 +208,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     bool fwd;
                     const int r_base = sample_read_base16(st_hap16, st_base16, a0, a1, err_thresh16, k_strand, fwd);
                     rw |= ((q_gl << 2) | (uint32_t)r_base) << (8 * j);
-                    if (!LEAN) { if (T.reads_out && r < T.reads_out_cap) T.reads_out[(size_t)r * plane + ev] = (uint8_t)((q_i << 2) | r_base); }
+                    if (DUMP) { if (T.reads_out && r < T.reads_out_cap) T.reads_out[(size_t)r * plane + ev] = (uint8_t)((q_i << 2) | r_base); }
                     const uint64_t one = 1ULL << (16 * r_base);
                     ad4 += one;
                     if (k_strand) { if (fwd) adf4 += one; }               // without strand draws adf4 = ad4 (set after the loops)
@@ -239,6 +247,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
         const int incl = (int)wave_incl_scan_u32((uint32_t)dp);
         const int offs = incl - dp;
         const int total = __builtin_amdgcn_readlane(incl, 63);          // wave-uniform, and known to the compiler as such
+        wave_total_reads = total;
         l_stq[lane] = st_qs << 4;                      // the pool loop works on states scaled by 16 (lcg_next52)
         if (lane == 0) {
             l_it[cap] = 0u;
@@ -253,9 +262,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
         // reloads as a whole (v_readlane, VALU work) inside the loops below; the three values the flush
         // loop needs are therefore pinned to vector registers.
         uint8_t* reads_v = T.reads;
-        uint8_t* reads_out_v = LEAN ? nullptr : T.reads_out;
-        int reads_out_cap_v = (!LEAN && T.reads_out) ? T.reads_out_cap : 0;
-        if (LEAN) asm volatile("" : "+v"(reads_v));
+        uint8_t* reads_out_v = DUMP ? T.reads_out : nullptr;
+        int reads_out_cap_v = (DUMP && T.reads_out) ? T.reads_out_cap : 0;
+        if (!DUMP) asm volatile("" : "+v"(reads_v));
         else asm volatile("" : "+v"(reads_v), "+v"(reads_out_v), "+v"(reads_out_cap_v));
 
         // the pool holds `cap` items; a wavefront with more reads works through segments of equal length
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     const int r_base = sample_read_base16(st_hap16, st_base16, a0, a1, err_thresh16, k_strand, fwd);
                     const uint64_t one = 1ULL << (16 * r_base);
                     ad4 += one;
-                    if (!LEAN) { if (fwd) adf4 += one; }
+                    if (!SLIM) { if (fwd) adf4 += one; }
                     *(lds_u32o*)(uintptr_t)ka = sv;
                     *(lds_u8o*)(uintptr_t)pa = (uint8_t)r_base;
                     sv += 16u; ka += 4u; pa += 1u;
@@ -467,10 +476,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                         __builtin_amdgcn_wave_barrier();
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                         if (inb && !ok) { const uint32_t e = l_it[kk]; q_i = (int)(int16_t)(e & 0xFFFF); aq_i = (int)(int16_t)(e >> 16); }
-                    } else if (inb && !ok) { q_i = 0; aq_i = -1; }      // placeholder: k_redo writes the read's score
+                    } else if (inb && !ok) { q_i = 0; aq_i = SLIM ? -1 : 0; }   // placeholder: k_redo writes the read's score (and adds it to the quality sums, which take 0 here)
                 }
                 qs_finish(P, q_i, aq_i, T.errflag, DEFER ? (inb && ok) : inb);
-                if (LEAN) { if (inb) l_pb[kk] = (uint8_t)((q_i << 2) | l_pb[kk]); }        // the staged byte itself: score << 2 | base
+                if (SLIM) { if (inb) l_pb[kk] = (uint8_t)((q_i << 2) | l_pb[kk]); }        // the staged byte itself: score << 2 | base
                 else if (inb) l_it[kk] = (uint32_t)(q_i & 0xFF) | ((uint32_t)(aq_i & 0xFF) << 8);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -480,7 +489,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
             // -- owners: combine base + quality score, stage the read, quality sums (vcfgl.cpp:525-564)
             // four reads per trip, one 32-bit store of the staged word (vgl_read_byte); a word cut by a segment boundary is
             // stored again, complete, by the next segment (carry_w)
-            if (LEAN) {
+            uint32_t sq0 = 0, sq1 = 0, sq2 = 0, sq3 = 0, sqq0 = 0, sqq1 = 0, sqq2 = 0, sqq3 = 0;   // this segment's share of the owner's quality sums
+            if (SLIM) {
                 // the dense pass has left the staged bytes in l_pb: one (unaligned) 32-bit LDS read per word, masked to the reads of
                 // this segment
                 for (int r0 = rdone & ~3; r0 < r_end; r0 += 4) {
@@ -506,14 +516,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                         const int aq_i = k_adj ? (int)((qe >> 8) & 0xFF) : -1;
                         const int q_gl = (k_adj & 1) ? aq_i : q_i;
                         rw |= (uint32_t)((q_gl << 2) | r_base) << (8 * j);
-                        if (!LEAN) { if (r < reads_out_cap_v) reads_out_v[(size_t)r * plane + ev] = (uint8_t)((q_i << 2) | r_base); }
+                        if (DUMP) { if (r < reads_out_cap_v) reads_out_v[(size_t)r * plane + ev] = (uint8_t)((q_i << 2) | r_base); }
                         if (k_qsum) {
                             const uint32_t qq = (uint32_t)((k_adj & 2) ? aq_i : q_i);
                             const uint32_t q2 = (uint32_t)qs_to_qssq((int)qq);
-                            qs0 += (r_base == 0) ? qq : 0u; qs1 += (r_base == 1) ? qq : 0u;
-                            qs2 += (r_base == 2) ? qq : 0u; qs3 += (r_base == 3) ? qq : 0u;
-                            qq0 += (r_base == 0) ? q2 : 0u; qq1 += (r_base == 1) ? q2 : 0u;
-                            qq2 += (r_base == 2) ? q2 : 0u; qq3 += (r_base == 3) ? q2 : 0u;
+                            sq0 += (r_base == 0) ? qq : 0u; sq1 += (r_base == 1) ? qq : 0u;
+                            sq2 += (r_base == 2) ? qq : 0u; sq3 += (r_base == 3) ? qq : 0u;
+                            sqq0 += (r_base == 0) ? q2 : 0u; sqq1 += (r_base == 1) ? q2 : 0u;
+                            sqq2 += (r_base == 2) ? q2 : 0u; sqq3 += (r_base == 3) ? q2 : 0u;
                         }
                     }
                 }
@@ -521,6 +531,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 carry_w = rw;
             }
             rdone = r_end;
+            if (!SLIM) {
+                if (k_qsum) {
+                    // the owner's quality sums of this segment: stored by the first segment (every evaluation's slots, zeros included), added by
+                    // later ones; the site's integer totals for k_siteagg.  Nothing of them is carried across the pool loop.
+                    if (active) {
+                        uint32_t* q = T.qsum + (size_t)ls * 4 * N + s;
+                        if (seg0 == 0) { q[0] = sq0; q[(size_t)N] = sq1; q[(size_t)2 * N] = sq2; q[(size_t)3 * N] = sq3; }
+                        else { q[0] += sq0; q[(size_t)N] += sq1; q[(size_t)2 * N] += sq2; q[(size_t)3 * N] += sq3; }
+                        if (P.need_qsumsq) {
+                            uint32_t* qq = T.qsumsq + (size_t)ls * 4 * N + s;
+                            if (seg0 == 0) { qq[0] = sqq0; qq[(size_t)N] = sqq1; qq[(size_t)2 * N] = sqq2; qq[(size_t)3 * N] = sqq3; }
+                            else { qq[0] += sqq0; qq[(size_t)N] += sqq1; qq[(size_t)2 * N] += sqq2; qq[(size_t)3 * N] += sqq3; }
+                        }
+                    }
+                    const uint32_t q4[4] = {sq0, sq1, sq2, sq3}, qq4[4] = {sqq0, sqq1, sqq2, sqq3};
+                    wave_add_qsum_totals(T.acc + (size_t)ls * VGL_ACC_STRIDE, lane, q4, qq4, P.need_qsumsq != 0);
+                }
+            }
             __builtin_amdgcn_wave_barrier();
             if (DBG) c_flush += clock64() - c_tmp;
             if (DBG && P.dbg_phase == 4) return;
@@ -531,8 +559,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
         if (!k_strand) adf4 = ad4;
         if (T.fmt_dp) T.fmt_dp[ev] = dp;
         T.ad4[ev] = ad4;
-        if (!LEAN && P.need_adf) T.adf4[ev] = adf4;
-        if (!LEAN && P.need_qsum) {
+        if (!SLIM && P.need_adf) T.adf4[ev] = adf4;
+        if (!SLIM && P.need_qsum && (EQS != 2 || wave_total_reads == 0)) {       // (EQS 2: the segments have stored theirs -- unless the wavefront has no read at all)
             uint32_t* q = T.qsum + (size_t)ls * 4 * N + s;
             q[0] = qs0; q[(size_t)N] = qs1; q[(size_t)2 * N] = qs2; q[(size_t)3 * N] = qs3;
             if (P.need_qsumsq) {
@@ -540,7 +568,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 qq[0] = qq0; qq[(size_t)N] = qq1; qq[(size_t)2 * N] = qq2; qq[(size_t)3 * N] = qq3;
             }
         }
-        if (!LEAN && T.reads_out) for (int r = dp; r < T.reads_out_cap; ++r) T.reads_out[(size_t)r * plane + ev] = 0xFF;
+        if (DUMP && T.reads_out) for (int r = dp; r < T.reads_out_cap; ++r) T.reads_out[(size_t)r * plane + ev] = 0xFF;
     }
 
     // ---- per-site sums: wave reduction, one atomic per wave and counter
@@ -550,8 +578,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
     if (k_strand) wave_sum_ad4(adf4, &v[5]);
     else { v[5] = v[1]; v[6] = v[2]; v[7] = v[3]; v[8] = v[4]; }
     v[0] = v[1] + v[2] + v[3] + v[4];
-    if (!LEAN) {
-        if (P.need_qsum) {                                   // the site's integer totals of the quality sums, for k_siteagg
+    if (!SLIM && EQS != 2) {
+        if (P.need_qsum) {                                   // the site's integer totals of the quality sums, for k_siteagg (EQS 2: added per segment)
             const uint32_t q4[4] = {qs0, qs1, qs2, qs3}, qq4[4] = {qq0, qq1, qq2, qq3};
             wave_add_qsum_totals(T.acc + (size_t)ls * VGL_ACC_STRIDE, lane, q4, qq4, P.need_qsumsq != 0);
         }
@@ -586,8 +614,9 @@ extern "C" int vgl_launch_depth(const VglDevParams* p, const VglTilePtrs* t, voi
 // ------------------------------------------------------------------------------------
 // The reads k_sample<2, ., ., ., 2> could not settle in float32: one lane per list entry draws the read's error probability again
 // in double from the read's own stream (rng.h:433-444: the stream of a read does not depend on who works on it), takes the
-// quality score the exact way (vcfgl.cpp:500-523) and writes it into the staged read (the base bits stay).  Default tag surface
-// only (no quality sums, no --adjust-qs, no per-read dump): nothing else depends on the score.
+// quality score the exact way (vcfgl.cpp:500-523) and writes it into the staged read (the base bits stay); with -addQS / -addI16 it also
+// adds the score to the evaluation's per-base quality sums and the site totals (the kernel counted 0 for the read).  No per-read dump
+// (reads_out) with the deferred builds: nothing else depends on the score.
 __device__ __forceinline__ void redo_read(const VglDevParams& P, const VglTilePtrs& T, const size_t ev, const int r) {
     const size_t N = (size_t)P.n_samples, plane = (size_t)T.n_sites * N;
     const size_t ls = ev / N, s = ev - ls * N;
@@ -598,10 +627,21 @@ __device__ __forceinline__ void redo_read(const VglDevParams& P, const VglTilePt
     const double ep = beta_draw(P, st_x);
     int q, aq;
     errprob_raw(P, ep, q, aq);
+    if (aq < 0 && (P.adjust_qs & 3)) atomicOr(T.errflag, VGL_DEVERR_ADJQ);   // vcfgl.cpp:558, gl_methods.cpp:101
     qs_finish(P, q, aq, T.errflag, true);
     if (T.errp) T.errp[(size_t)r * plane + ev] = ep;                     // --precise-gl 1 / the deviate dump: the read's exact error probability
     uint8_t* const p = T.reads + vgl_read_byte(r, plane, ev);
-    *p = (uint8_t)(((uint32_t)q << 2) | (*p & 3u));
+    const uint32_t base = *p & 3u;
+    const int q_gl = (P.adjust_qs & 1) ? aq : q;                         // vcfgl.cpp:525-531
+    *p = (uint8_t)(((uint32_t)q_gl << 2) | base);
+    if (P.need_qsum) {
+        // LEAN 3: the evaluation's quality sums and the site totals took 0 for this read (several reads of one evaluation may be here: atomics)
+        const uint32_t qq = (uint32_t)((P.adjust_qs & 2) ? aq : q), q2 = (uint32_t)qs_to_qssq((int)qq);
+        int32_t* acc = T.acc + ls * VGL_ACC_STRIDE;
+        atomicAdd(&T.qsum[(ls * 4 + base) * N + s], qq);
+        atomicAdd((unsigned int*)&acc[VGL_ACC_QSUM + base], qq);
+        if (P.need_qsumsq) { atomicAdd(&T.qsumsq[(ls * 4 + base) * N + s], q2); atomicAdd((unsigned int*)&acc[VGL_ACC_QSUMSQ + base], q2); }
+    }
 }
 __global__ __launch_bounds__(64) void k_redo(const VglDevParams P, const VglTilePtrs T) {
     const uint32_t cnt = *T.redo_count;
@@ -628,9 +668,10 @@ __global__ __launch_bounds__(64) void k_redo(const VglDevParams P, const VglTile
     }
 }
 
-// the deferred build of k_sample<2> (LEAN 2) serves this tile: vgl_launch_sample runs it, vgl_launch_redo runs k_redo behind it
+// a deferred build of k_sample<2> (LEAN 2: default tag surface, LEAN 3: optional tags) serves this tile: vgl_launch_sample runs it,
+// vgl_launch_redo runs k_redo behind it
 static bool sample_deferred(const VglDevParams* p, const VglTilePtrs* t) {
-    return !p->serial && p->error_qs == 2 && p->lean_ok && !t->reads_out && p->defer_ok && t->redo_list && !(t->dbg != nullptr && !t->errp);
+    return !p->serial && p->error_qs == 2 && !t->reads_out && p->defer_ok && t->redo_list && !(t->dbg != nullptr && !t->errp);
 }
 extern "C" int vgl_launch_redo(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
     if ((int64_t)t->n_sites * p->chunks == 0 || !sample_deferred(p, t)) return 0;
@@ -674,6 +715,8 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
             VGL_STATIC_LDS(false, 0, false, 2) VGL_STATIC_LDS(false, 1, false, 2) VGL_STATIC_LDS(false, 2, false, 2)
             VGL_STATIC_LDS(false, 0, true, 2) VGL_STATIC_LDS(false, 1, true, 2) VGL_STATIC_LDS(false, 2, true, 2)
             VGL_STATIC_LDS(false, 0, false, 0) VGL_STATIC_LDS(false, 1, false, 0) VGL_STATIC_LDS(false, 2, false, 0)
+            VGL_STATIC_LDS(false, 0, false, 3) VGL_STATIC_LDS(false, 1, false, 3) VGL_STATIC_LDS(false, 2, false, 3)
+            VGL_STATIC_LDS(false, 0, true, 3) VGL_STATIC_LDS(false, 1, true, 3) VGL_STATIC_LDS(false, 2, true, 3)
 #undef VGL_STATIC_LDS
             return worst == 0;
         }();
@@ -681,9 +724,9 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
 #ifdef VGL_TEST_HOOKS
         if (dbg && !t->errp) { VGL_LAUNCH_SAMPLE(2, true, false, 0, lds); } else   // diagnostic build (VGL_DEBUG_STAMPS / VGL_DEBUG_PHASE): --precise-gl 0 only
 #endif
-        if (t->errp && sample_deferred(p, t)) VGL_LAUNCH_SAMPLE(2, false, true, 2, lds);   // --precise-gl 1 on the default tag surface: the deferred build, k_redo (vgl_launch_redo) also rewrites errp
+        if (t->errp && sample_deferred(p, t)) { if (lean) VGL_LAUNCH_SAMPLE(2, false, true, 2, lds); else VGL_LAUNCH_SAMPLE(2, false, true, 3, lds); }   // --precise-gl 1: the deferred builds, k_redo (vgl_launch_redo) also rewrites errp
         else if (t->errp) { if (lean) VGL_LAUNCH_SAMPLE(2, false, true, 1, lds); else VGL_LAUNCH_SAMPLE(2, false, true, 0, lds); }   // --precise-gl 1, or the deviates were asked for
-        else if (sample_deferred(p, t)) VGL_LAUNCH_SAMPLE(2, false, false, 2, lds);
+        else if (sample_deferred(p, t)) { if (lean) VGL_LAUNCH_SAMPLE(2, false, false, 2, lds); else VGL_LAUNCH_SAMPLE(2, false, false, 3, lds); }
         else { if (lean) VGL_LAUNCH_SAMPLE(2, false, false, 1, lds); else VGL_LAUNCH_SAMPLE(2, false, false, 0, lds); }
     }
     // fixed quality score: the LEAN build (no strand draws, forward-strand depths, quality sums or per-read dump) keeps those
