@@ -470,6 +470,47 @@ def test_deferred_reads_are_redrawn_by_k_redo(oracle, monkeypatch, every, cap, d
     assert_parity(want, got, check_gp=False)
 
 
+@pytest.mark.parametrize("every,cap", [(0, None), (3, None), (5, 16)])
+@pytest.mark.parametrize("depth,N,adj,bins", [(20, 300, 0, False), (20, 130, 3, True), (70, 64, 0, False), (70, 64, 3, False), (12, 200, 1, False),
+                                              (12, 200, 2, True), (100, 64, 0, False), (100, 70, 2, False)])
+def test_deferred_build_with_the_optional_tags(oracle, monkeypatch, every, cap, depth, N, adj, bins):
+    """k_sample<2, LEAN 3> (round 4): -addQS / -addI16 / strand tags / --adjust-qs run the deferred build too.  The dense pass gathers the
+    owners' per-base quality sums with LDS atomics (--adjust-qs 0 / 3, at most 132 staged reads: cases 1-4, depth 70 = several pool
+    segments, the sum words sharing LDS with the stream bases of the next segment), the owners' flush loop does otherwise (--adjust-qs 1 /
+    2; depth 100: 196 staged reads); a read k_redo draws again is ADDED to the evaluation's quality sums and the site totals, which took
+    0 for it (VGL_DEBUG_REDO_EVERY sends every k-th candidate there; cap 16: the list overflows into the bitmap)."""
+    if every:
+        monkeypatch.setenv("VGL_DEBUG_REDO_EVERY", str(every))
+    if cap is not None:
+        monkeypatch.setenv("VGL_DEBUG_REDO_CAP", str(cap))
+    kw = dict(qs_bins=[(0, 2, 2), (3, 14, 12), (15, 30, 23), (31, 40, 37)]) if bins else {}
+    args = VcfglArgs(seed=31, depth=depth, error_rate=0.01, error_qs=2, beta_variance=1e-5, adjust_qs=adj, **kw, **ALLTAGS, **STRAND)
+    args.rng_mode, args.beta_sampler = _abi.VGL_RNG_TILE, _abi.VGL_BETA_RAND48
+    gt = synth.acgt_sites(9, N, seed=depth + adj, missing=0.03)
+    sim = Simulator(args, N, device=0, max_sites_per_tile=9, hooks=True)
+    info = sim.info()
+    assert info["sample_lean"] == 3
+    got = sim.simulate(0, gt)
+    sim.close()
+    want = oracle.Oracle(args, N).simulate(0, gt, fields=sim.default_fields())
+    assert_parity(want, got, i16=True)
+
+
+def test_optional_tags_keep_the_inline_build_for_dumps_and_small_shapes(oracle):
+    """a per-read dump, or a beta shape parameter below 8, still runs k_sample<2, LEAN 0> (double-precision fallbacks inline)"""
+    args = VcfglArgs(seed=31, depth=9, error_rate=0.2, error_qs=2, beta_variance=0.032, add_qs=1, add_i16=1)      # alpha = 0.8
+    args.rng_mode, args.beta_sampler = _abi.VGL_RNG_TILE, _abi.VGL_BETA_RAND48
+    sim = Simulator(args, 70, device=0, max_sites_per_tile=8)
+    assert sim.info()["sample_lean"] == 0
+    sim.close()
+    want, got = run_both(oracle, args, synth.acgt_sites(8, 70, seed=2, missing=0.03))
+    assert_parity(want, got, i16=True, check_gp=False)
+    args = VcfglArgs(seed=31, depth=9, error_rate=0.01, error_qs=2, beta_variance=1e-5, add_qs=1, add_i16=1)
+    want, got = run_both(oracle, args, synth.acgt_sites(8, 70, seed=2, missing=0.03), read_capacity=48)          # the dump: inline build
+    assert np.array_equal(want.numpy("reads"), got.numpy("reads"))
+    assert_parity(want, got, i16=True, check_gp=False)
+
+
 @pytest.mark.parametrize("mean,var,depth", [(0.2, 0.032, 40), (0.05, 0.03, 120), (0.001, 5e-7, 25), (0.3, 0.15, 200), (0.02, 1e-4, 7)])
 def test_gl1_per_read_scores_over_several_quality_windows(oracle, mean, var, depth):
     """k_gl<.,1> with per-read scores sorts each lane's reads by counting over windows of 16 quality values from the wavefront's

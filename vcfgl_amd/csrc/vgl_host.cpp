@@ -450,9 +450,14 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     // likelihoods, with nothing staged in HBM between them
     D.fused = (!D.serial && p->error_qs == 0 && p->gl_model == 2 && !p->precise_gl && D.depth_pre == 2 && !D.need_qsum && !D.sample_strand &&
                !D.need_adf && p->adjust_qs == 0 && N > 128 && N <= 512 && D.read_cap <= 64 && !hook_env("VGL_NO_FUSE") && !hook_env("VGL_NO_LEAN")) ? 1 : 0;
+    D.qsum_lds = (D.defer_ok && !D.lean_ok && ((p->adjust_qs & 3) == 0 || (p->adjust_qs & 3) == 3) && D.read_cap <= 132) ? 1 : 0;
     if (D.defer_ok && D.pool_cap > 1472) {      // 20 wavefronts' pools in a CU's 160 KB of LDS: 576 + 5 x 1472 + 8 B each
         D.pool_cap = 1472;
         D.pool_lds_bytes = (576 + 4 * (D.pool_cap + 2) + D.pool_cap + 7) & ~7;
+    }
+    if (D.qsum_lds) {                           // + 512 B of quality-sum words behind the pool (vgl_sample.hip): 576 + 5 x 1416 + 8 + 512 <= 8192
+        if (D.pool_cap > 1416) D.pool_cap = 1416;
+        D.pool_lds_bytes = ((576 + 4 * (D.pool_cap + 2) + D.pool_cap + 7) & ~7) + 512;
     }
     pois_init(&D.pois0, p->depths ? 0.0 : p->depth);
 

@@ -236,6 +236,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
         uint32_t* l_it = (uint32_t*)(wl + 576);
         uint8_t* l_pb = wl + 576 + 4 * ((size_t)cap + 2);
         uint32_t* l_ctr = l_it + cap + 1;             // pool loop: first unclaimed item
+        // LEAN 3, P.qsum_lds: the owners' per-base quality sums are gathered by the dense pass with one LDS atomic per read, into 32-bit
+        // words (sum of squares << 13 | sum: at most 132 reads of a score <= 63 each) -- bases A, C of owner o at l_stq[o] (free between
+        // the pool loop and the next segment), bases G, T in 512 bytes behind the pool
+        const bool qfast = (LEAN == 3) && (P.qsum_lds != 0);
+        uint32_t* l_accB = (uint32_t*)(wl + ((576 + 4 * ((size_t)cap + 2) + (size_t)cap + 7) & ~(size_t)7));
         // the pool loop reads l_stq by LDS byte offsets taken from the item slots: the dynamic LDS block must start at 0
         // (this kernel has no static LDS)
         if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds_raw != 0u) {      // (vgl_launch_sample checks the same on the host)
@@ -279,6 +284,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 // slot value (owner << 26 | read << 4), slot address and base address advance by constants per read
                 typedef __attribute__((address_space(3))) uint32_t lds_u32o;
                 typedef __attribute__((address_space(3))) uint8_t lds_u8o;
+                const uint32_t lane4 = (uint32_t)lane << 2;
                 uint32_t sv = ((uint32_t)lane << 26) | ((uint32_t)rdone << 4);
                 const uint32_t sv_end = ((uint32_t)lane << 26) | ((uint32_t)r_end << 4);
                 uint32_t ka = 576u + 4u * (uint32_t)(offs + rdone - seg0);                     // l_it[k]  (the dynamic LDS block starts at 0)
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     ad4 += one;
                     if (!SLIM) { if (fwd) adf4 += one; }
                     *(lds_u32o*)(uintptr_t)ka = sv;
-                    *(lds_u8o*)(uintptr_t)pa = (uint8_t)r_base;
+                    *(lds_u8o*)(uintptr_t)pa = (uint8_t)((LEAN == 3) ? (lane4 | (uint32_t)r_base) : (uint32_t)r_base);   // (LEAN 3: the dense pass finds the item's owner here)
                     sv += 16u; ka += 4u; pa += 1u;
                 }
             }
@@ -439,6 +445,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
 
             if (DBG) { const unsigned long long c = clock64(); c_pool += c - c_tmp; c_tmp = c; }
             if (DBG && P.dbg_phase == 3) return;
+            if (qfast && k_qsum) {                                      // the pool loop is done with l_stq: zero the 64 x 4 sum words
+                l_stq[lane] = 0ULL;
+                ((uint64_t*)l_accB)[lane] = 0ULL;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
             // -- quality scores of the segment's reads (vcfgl.cpp:500-523), item kb + lane per lane
             for (int kb = 0; kb < segT; kb += 64) {
                 const int kk = kb + lane;
@@ -480,6 +493,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 }
                 qs_finish(P, q_i, aq_i, T.errflag, DEFER ? (inb && ok) : inb);
                 if (SLIM) { if (inb) l_pb[kk] = (uint8_t)((q_i << 2) | l_pb[kk]); }        // the staged byte itself: score << 2 | base
+                else if (qfast) {
+                    // --adjust-qs 0 or 3: one score serves the likelihoods and the quality sums (vcfgl.cpp:525-531, 557-564)
+                    if (inb) {
+                        const uint32_t pb = l_pb[kk];                   // owner << 2 | base
+                        const uint32_t q_s = (uint32_t)((k_adj & 1) ? aq_i : q_i);
+                        l_pb[kk] = (uint8_t)((q_s << 2) | (pb & 3u));
+                        if (k_qsum) {
+                            uint32_t* const slot = ((pb & 2u) ? l_accB : (uint32_t*)l_stq) + ((pb >> 2) * 2u + (pb & 1u));
+                            __hip_atomic_fetch_add(slot, q_s + ((q_s * q_s) << 13), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        }
+                    }
+                }
                 else if (inb) l_it[kk] = (uint32_t)(q_i & 0xFF) | ((uint32_t)(aq_i & 0xFF) << 8);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -490,7 +515,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
             // four reads per trip, one 32-bit store of the staged word (vgl_read_byte); a word cut by a segment boundary is
             // stored again, complete, by the next segment (carry_w)
             uint32_t sq0 = 0, sq1 = 0, sq2 = 0, sq3 = 0, sqq0 = 0, sqq1 = 0, sqq2 = 0, sqq3 = 0;   // this segment's share of the owner's quality sums
-            if (SLIM) {
+            if (SLIM || qfast) {
                 // the dense pass has left the staged bytes in l_pb: one (unaligned) 32-bit LDS read per word, masked to the reads of
                 // this segment
                 for (int r0 = rdone & ~3; r0 < r_end; r0 += 4) {
@@ -510,7 +535,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     const int r = r0 + j;
                     if (r >= rdone && r < r_end) {
                         const int k = offs + r - seg0;
-                        const int r_base = l_pb[k];
+                        const int r_base = l_pb[k] & 3;                 // (LEAN 3 keeps the owner above the base)
                         const uint32_t qe = l_it[k];
                         const int q_i = (int)(qe & 0xFF);
                         const int aq_i = k_adj ? (int)((qe >> 8) & 0xFF) : -1;
@@ -532,6 +557,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
             }
             rdone = r_end;
             if (!SLIM) {
+                if (qfast && k_qsum) {                                  // this owner's sums of the segment, from the dense pass's LDS words
+                    const uint64_t v01 = l_stq[lane], v23 = ((const uint64_t*)l_accB)[lane];
+                    sq0 = (uint32_t)v01 & 0x1FFFu; sqq0 = (uint32_t)v01 >> 13; sq1 = (uint32_t)(v01 >> 32) & 0x1FFFu; sqq1 = (uint32_t)(v01 >> 32) >> 13;
+                    sq2 = (uint32_t)v23 & 0x1FFFu; sqq2 = (uint32_t)v23 >> 13; sq3 = (uint32_t)(v23 >> 32) & 0x1FFFu; sqq3 = (uint32_t)(v23 >> 32) >> 13;
+                    if (seg0 + seglen < total) {                        // another segment follows: its pool loop needs the stream bases back
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                        if (active) l_stq[lane] = aff(P.off[3], aff(P.samp_tab[s], xb)) << 4;
+                        else l_stq[lane] = 0ULL;
+                    }
+                }
                 if (k_qsum) {
                     // the owner's quality sums of this segment: stored by the first segment (every evaluation's slots, zeros included), added by
                     // later ones; the site's integer totals for k_siteagg.  Nothing of them is carried across the pool loop.
