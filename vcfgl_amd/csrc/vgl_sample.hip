@@ -110,6 +110,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
     constexpr bool DEFER = (LEAN >= 2);
     constexpr bool SLIM = (LEAN == 1 || LEAN == 2);                  // default tag surface: none of the optional per-read state
     constexpr bool DUMP = (LEAN == 0);                               // a per-read dump (reads_out) may be asked for
+#ifdef VGL_TEST_HOOKS
+    const int dbg_redo_every = P.dbg_redo_every, dbg_qs_exact = P.dbg_qs_exact;      // test hooks (VGL_DEBUG_REDO_EVERY / VGL_DEBUG_QS_EXACT)
+#else
+    constexpr int dbg_redo_every = 0, dbg_qs_exact = 0;              // (the shipped library carries neither)
+#endif
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const WavePos wp = wave_pos(P, T);
     if (!wp.valid) return;
@@ -224,7 +229,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
         }
     } else {
         // ---- LDS of this wave: [64] u64 qscore-stream bases | [2][4] f64 gamma constants | [cap + 2] u32 item slot | [cap] u8 base.
-        //      An item's slot holds owner << 26 | read << 4 until the item is finished, then the float32 error
+        //      An item's slot holds (8 owner) << 16 | 16 read -- the LDS address of the owner's stream base and the byte offset of the read's
+        //      jump in qs_read_tab, each one 16-bit LDS read away (round 3: owner << 26 | read << 4, a shift and a mask per iteration) --
+        //      until the item is finished, then the float32 error
         //      probability of its read, then (dense pass) qScore | adjusted qScore << 8.  Slot [segT] of a segment is 0: the
         //      prefetch of a lane that has no next item reads it.  Slot [cap + 1]: the pool loop's item counter.
         const int cap = P.pool_cap;
@@ -281,12 +288,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
             if (DBG) c_tmp = clock64();
             int r_end = seg0 + segT - offs; r_end = r_end > dp ? dp : r_end; r_end = r_end < rdone ? rdone : r_end;
             {
-                // slot value (owner << 26 | read << 4), slot address and base address advance by constants per read
+                // slot value ((8 owner) << 16 | 16 read), slot address and base address advance by constants per read
                 typedef __attribute__((address_space(3))) uint32_t lds_u32o;
                 typedef __attribute__((address_space(3))) uint8_t lds_u8o;
                 const uint32_t lane4 = (uint32_t)lane << 2;
-                uint32_t sv = ((uint32_t)lane << 26) | ((uint32_t)rdone << 4);
-                const uint32_t sv_end = ((uint32_t)lane << 26) | ((uint32_t)r_end << 4);
+                uint32_t sv = ((uint32_t)lane << 19) | ((uint32_t)rdone << 4);
+                const uint32_t sv_end = ((uint32_t)lane << 19) | ((uint32_t)r_end << 4);
                 uint32_t ka = 576u + 4u * (uint32_t)(offs + rdone - seg0);                     // l_it[k]  (the dynamic LDS block starts at 0)
                 uint32_t pa = 576u + 4u * ((uint32_t)cap + 2u) + (uint32_t)(offs + rdone - seg0);   // l_pb[k]
                 while (sv < sv_end) {
@@ -320,21 +327,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 // k, kn: the lane's item and the one claimed ahead, as BYTE offsets of their slots (4 x item index: the counter is
                 // bumped by 4, so a claim is an LDS address without a shift)
                 typedef __attribute__((address_space(3))) uint32_t lds_u32;
+                typedef __attribute__((address_space(3))) uint16_t lds_u16;
                 const int segT4 = segT * 4;
                 int k = lane * 4, kn = (lane + 64) * 4;
                 bool have = k < segT4;                       // == (k < segT4) throughout: the loop tests that compare
                 bool stage1 = false;                         // false: first gamma deviate (x), true: second (y)
                 uint64_t st = 0; double gx = 0.0; uint32_t it_m = 0;
-                if (have) { it_m = l_it[lane]; st = aff52(P.qs_read_tab[(it_m >> 4) & 0x3FF], l_stq[it_m >> 26]); }
+                if (have) { it_m = l_it[lane]; st = aff52(P.qs_read_tab[(it_m & 0xFFFFu) >> 4], l_stq[it_m >> 19]); }
                 const bool any_changed = (P.gx.changed | P.gy.changed) != 0;
                 // The bounded-log tests are needed by a few lanes per iteration but cost every lane of the
                 // wave; they run only every P.slow_period-th iteration.  In between, a lane that needs one
                 // holds: its state is left untouched, so the later iteration recomputes the same attempt.
                 int slow_cnt = P.slow_period, slow_cnt_n = P.slow_period_n;
                 uint32_t k3ff = 0x3FF00000u;                 // the exponent word of 1.xxx, in a vector register for v_and_or_b32
-                // a lane that finishes an item claims the next one with an LDS atomic whose result (`claimed`) is first looked at in
-                // the next iteration (kn = fin_prev ? claimed : kn), so no wait stands behind the atomic
-                uint32_t claimed = 0; bool fin_prev = false;
+                // a lane that finishes an item claims the next one with an LDS atomic whose result is first looked at in the next
+                // iteration, so no wait stands behind the atomic; the atomic (issued with only the finishing lanes enabled) returns into
+                // kn's own register -- the other lanes keep theirs without a select
                 // address of the counter and the increment live in vector registers across the loop (the compiler would otherwise
                 // rebuild both with two moves in front of every atomic)
                 __attribute__((address_space(3))) uint32_t* ctr_p = (__attribute__((address_space(3))) uint32_t*)l_ctr;
@@ -368,15 +376,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     if (full_n && __builtin_amdgcn_ballot_w64(n_amb)) {
                         bool und;
                         slow_n = normal_slow_test_t<DEFER>(v, u, n_amb, und);
-                        if (DEFER) redo = und || (n_amb && P.dbg_redo_every && ((uint32_t)(st1 >> 8) % (uint32_t)P.dbg_redo_every) == 0u);
+                        if (DEFER) redo = und || (n_amb && dbg_redo_every && ((uint32_t)(st1 >> 8) % (uint32_t)(dbg_redo_every | (dbg_redo_every == 0))) == 0u);
                     }
                     const bool acc_n = !(q_lo && (q_hi || slow_n));
                     // operands of this lane's next item, fetched here -- far enough behind the claim of the previous iteration and
                     // ahead of their use at the bottom (unconditional, clamped index: no divergent control flow in the loop)
-                    kn = fin_prev ? (int)claimed : kn;
-                    const uint32_t m_n = *(const lds_u32*)(uintptr_t)(576u + (uint32_t)(kn < segT4 ? kn : segT4));   // l_it[...]; l_it[segT] = 0 (a valid slot) stands for "none"
-                    const VglAffine tab_n = *(const VglAffine*)((const uint8_t*)P.qs_read_tab + (m_n & 0x3FFFu << 4));
-                    const uint64_t base_n = *(__attribute__((address_space(3))) const uint64_t*)(uintptr_t)(m_n >> 23);   // l_stq[owner]
+                    // the claim a finishing lane made at the end of the previous iteration lands in kn itself (below): wait for it here
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kn));
+                    const uint32_t kc = (uint32_t)(kn < segT4 ? kn : segT4);                                     // l_it[segT] = 0 (a valid slot) stands for "none"
+                    uint32_t rd16 = *(const lds_u16*)(uintptr_t)(576u + kc);                                     // 16 x read: byte offset of its jump
+                    uint32_t ow8 = *(const lds_u16*)(uintptr_t)(578u + kc);                                      // 8 x owner: LDS address of l_stq[owner]
+                    asm volatile("" : "+v"(rd16), "+v"(ow8));                                                    // (plain 32-bit values: ds_read_u16 has zero-extended them)
+                    const uint32_t m_n = PREC ? (rd16 | (ow8 << 16)) : 0u;
+                    const VglAffine tab_n = *(const VglAffine*)((const uint8_t*)P.qs_read_tab + rd16);
+                    const uint64_t base_n = *(__attribute__((address_space(3))) const uint64_t*)(uintptr_t)ow8;   // l_stq[owner]
                     // gamma step on the accepted deviate
                     const double xn = div_inrange(v, u);
                     const double w = 1.0 + ga2 * xn;
@@ -392,7 +405,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     // 1 - u >= 0.15 a2^2 x^4 (+ P.sure_margin, far above the rounding of either side) is a sure accept: it settles 97 %
                     // of these cases (the sampler's rejection rate is 0.3 % for alpha ~ 10 and 0.003 % for alpha ~ 1000), and the
                     // bounded test below is left with ~0.2 % of the lanes of an iteration.
-                    const bool sure = (1.0 - u2 >= ga2sq015 * x4 + sure_margin) && (w >= 0.5);
+                    const bool sure = (1.0 - u2 >= __builtin_fma(ga2sq015, x4, sure_margin)) && (w >= 0.5);   // (the bound is this kernel's own: one fused step)
                     const bool g_try = have && acc_n && w_pos && !hold;
                     const bool g_amb = g_try && sq_fail && !sure;
                     hold = hold || (g_amb && !full);
@@ -400,7 +413,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     if (full && __builtin_amdgcn_ballot_w64(g_amb)) {
                         bool und;
                         slow_g = gamma_slow_test_t<DEFER>(u2, xsq, ga1, vv, ga2 * xn, g_amb, und);
-                        if (DEFER) redo = redo || und || (g_amb && P.dbg_redo_every && ((uint32_t)(st3 >> 8) % (uint32_t)P.dbg_redo_every) == 1u);
+                        if (DEFER) redo = redo || und || (g_amb && dbg_redo_every && ((uint32_t)(st3 >> 8) % (uint32_t)(dbg_redo_every | (dbg_redo_every == 0))) == 1u);
                     }
                     const bool acc_g = g_try && !(g_amb && slow_g) && !hold;     // slow_g is meaningful on the lanes that asked for it
                     st = hold ? st : (g_try ? st3 : st2);    // u2 is drawn only when w > 0 (rng.h:140-142)
@@ -425,7 +438,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                         if (DEFER) { if (redo) *(lds_u32*)(uintptr_t)(576u + (uint32_t)k) = 0x7FC00000u; }        // NaN: undecided for the dense pass
                         if (PREC) {
                             // read index x plane as ONE 32 x 32 -> 64-bit multiply-add (the tile has fewer than 2^32 evaluations: vgl_launch_sample)
-                            const uint64_t ei = (uint64_t)((it_m >> 4) & 0x3FFu) * (uint64_t)(uint32_t)plane + (uint64_t)(ev0 + (it_m >> 26));
+                            const uint64_t ei = (uint64_t)((it_m & 0xFFFFu) >> 4) * (uint64_t)(uint32_t)plane + (uint64_t)(ev0 + (it_m >> 19));
                             T.errp[ei] = (DEFER ? div_inrange(gx_prev, gx_prev + val) : gx_prev / (gx_prev + val));   // DEFER: both shape parameters >= 8, the operands are far from the exponent limits
                             it_m = m_n;
                         }
@@ -433,11 +446,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                         // items to lanes gives the same result)
                         st = st_n;
                         k = kn;
-                        claimed = __hip_atomic_fetch_add(ctr_p, four_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        asm volatile("" : "+v"(k));                                  // (the copy first: the atomic overwrites kn's register)
+                        asm volatile("ds_add_rtn_u32 %0, %1, %2" : "+v"(kn) : "v"(ctr_p), "v"(four_v) : "memory");
                     }
-                    fin_prev = fin;
                     have = k < segT4;
                 } while (__builtin_amdgcn_ballot_w64(have));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kn) : : "memory");       // the last claims have landed before kn's register is anyone else's
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -458,8 +472,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 const bool inb = kk < segT;
                 const float pf = __uint_as_float(l_it[inb ? kk : cap]);
                 int q_i, aq_i;
-                bool ok = qs_decide_pf(P, pf, q_i, aq_i, k_adj) && !P.dbg_qs_exact;
-                if (DEFER) { if (P.dbg_redo_every) ok = ok && ((uint32_t)(seg0 + kk) % (uint32_t)P.dbg_redo_every) != 2u; }    // test hook
+                bool ok = qs_decide_pf(P, pf, q_i, aq_i, k_adj) && !dbg_qs_exact;
+                if (DEFER) { if (dbg_redo_every) ok = ok && ((uint32_t)(seg0 + kk) % (uint32_t)(dbg_redo_every | (dbg_redo_every == 0))) != 2u; }    // test hook
                 uint64_t amb = __ballot(inb && !ok);
                 if (__builtin_expect(amb != 0, 0)) {
                     // undecided in float32: the owner of the read draws its deviate again in double (rng.h:433-444) -- here, or (DEFER)
