@@ -150,6 +150,28 @@ def test_strand_i16_adf_adr(oracle):
     assert_parity(want, got, i16=True)
 
 
+@pytest.mark.parametrize("kw", [dict(depth=20.0, error_rate=0.01), dict(depth=3.0, error_rate=0.0), dict(depth=60.0, error_rate=0.9), dict(depth=150.0, error_rate=0.2),
+                                dict(depth=8.0, error_rate=0.01, do_unobserved=0), dict(depth=8.0, error_rate=0.01, do_unobserved=3), dict(depth=20.0, error_rate=0.01, precise_gl=1),
+                                dict(depth=20.0, error_rate=0.01, error_qs=1, beta_variance=1e-5), dict(depth=6.0, error_rate=0.002, adjust_qs=1)])
+def test_gl2_one_base_run_table(oracle, kw, monkeypatch):
+    """GL model 2 with one fixed score: a wavefront whose evaluations all show ONE base takes their accumulators from a table indexed by
+    the depth (VglDevParams::gl2_run, built on the host by the reference's own update / maximum / subtract steps) instead of running
+    the read loop.  Equal to the oracle, and to the library with the table switched off (VGL_NO_GL2_RUN, hooks build), for hom-ref
+    tiles (every wavefront takes the table), mixed tiles, score 63 (e = 0), score 0 (e = 0.9: homT = -inf), depth 150, 4 / 5 alleles,
+    sites whose only allele is the evaluation's (no absent allele: variant 1), --precise-gl 1 constants, --error-qs 1"""
+    N = 200
+    args = VcfglArgs(seed=17, **kw, **ALLTAGS)
+    gt = synth.binary_sites(0, 24, N)
+    gt[::2] = 0                                                      # hom-ref sites
+    gt[1] = 0x11                                                     # hom-alt
+    want, got = run_both(oracle, args, gt)
+    assert_parity(want, got, exact_gl=not kw.get("precise_gl"), check_gp=(kw["error_rate"] != 0.9))
+    monkeypatch.setenv("VGL_NO_GL2_RUN", "1")
+    _, plain = run_both(oracle, args, gt, hooks=True)
+    for f in ("gl", "pl", "fmt_ad"):
+        assert np.array_equal(plain.numpy(f).view(np.uint32), got.numpy(f).view(np.uint32)), f
+
+
 @pytest.mark.parametrize("N,n_sites", [(1, 40), (63, 17), (64, 16), (65, 15), (130, 1), (130, 33), (1000, 18), (1027, 5)])
 @pytest.mark.parametrize("eqs", [0, 2])
 def test_siteagg_sixteen_sites_per_wavefront(oracle, N, n_sites, eqs):

@@ -142,6 +142,10 @@ struct VglDevParams {
     const double* q2gl;                // [3][257]
     const double* gamma_ln_tab;        // [gamma_ln_n] gamma_ln(k), k >= 1 (entry 0 unused)
     int32_t gamma_ln_n;
+    const float* gl2_run;              // [2][read_cap + 1][3] GL model 2 with ONE fixed score: the accumulators (hom present, present / absent, absent / absent) of an
+                                       // evaluation whose n reads all show the same base -- the reference's n update / subtract-the-maximum steps
+                                       // (gl_methods.cpp:22-59) run once on the host per n instead of once per evaluation; [0] the site has an allele the
+                                       // evaluation lacks, [1] it has not (only the first accumulator then enters the maximum).  Null with per-read scores.
     const double* gl1_bsum;            // [256][256]  sum_{i<c} fk[i]*beta[q][n][i]   (fixed qScore)
     const double* gl1_lhet;            // [256][256]
     const double* gl1_fkbeta;          // [60][gl1_nc][gl1_nc] fk[i] * beta[q][n][i] at [q - 4][n][i]  (per-read qScores only)

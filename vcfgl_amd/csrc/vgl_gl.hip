@@ -525,6 +525,15 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
                 }
             };
             const bool all_full = __ballot(!has_abs) == 0;
+            if (K == 1 && !per_read && P.gl2_run != nullptr) {
+                // one fixed score and every evaluation of this wavefront shows ONE base: the accumulators after dp identical updates are a
+                // function of dp alone, tabulated on the host by the same operations (VglDevParams::gl2_run) -- no read loop, no staged reads
+                const float* const row = P.gl2_run + ((size_t)(has_abs ? 0 : (P.read_cap + 1)) + (size_t)(dp < P.read_cap ? dp : P.read_cap)) * 3;
+                const float t0 = row[0], t1 = row[1], t2 = row[2];
+                s_x[0 * WG + otid] = __float_as_uint(t0);                 // rows as read_loop<1> deposits them: hom present, present / absent, absent / absent
+                s_x[10 * WG + otid] = __float_as_uint(t1);
+                s_x[14 * WG + otid] = __float_as_uint(t2);
+            } else
             if (all_full) {
                 if (K == 1) read_loop(std::integral_constant<int, 1>{}, std::true_type{});
                 else if (K == 2) read_loop(std::integral_constant<int, 2>{}, std::true_type{});

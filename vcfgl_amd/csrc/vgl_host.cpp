@@ -184,6 +184,7 @@ struct vgl_ctx {
     // device tables
     VglAffine* d_depth_tab = nullptr; int32_t* d_dp_pre = nullptr; uint64_t* d_site_base = nullptr; uint64_t* d_site_hash = nullptr;
     VglAffine* d_samp_tab = nullptr; VglAffine* d_qs_read_tab = nullptr; VglPois* d_pois = nullptr;
+    float* d_gl2_run = nullptr;
     double* d_q2gl = nullptr; double* d_gamma_ln = nullptr; double* d_gl1_fk = nullptr; double* d_gl1_beta = nullptr; double* d_gl1_bsum = nullptr; double* d_gl1_lhet = nullptr;
     // workspace
     uint8_t* d_reads = nullptr; double* d_errp = nullptr; uint64_t* d_ad4 = nullptr; uint64_t* d_adf4 = nullptr;
@@ -296,7 +297,7 @@ template <typename T> static int dmalloc(T** p, size_t n) {
 extern "C" int vgl_ctx_destroy(vgl_ctx* c) {
     if (!c) return VGL_OK;
     (void)hipSetDevice(c->device);
-    void* ptrs[] = {c->d_gl1_fk, c->d_gl1_beta, c->d_gamma_ln, c->d_samp_tab, c->d_qs_read_tab, c->d_pois, c->d_q2gl, c->d_gl1_bsum, c->d_gl1_lhet, c->d_reads, c->d_errp, c->d_ad4,
+    void* ptrs[] = {c->d_gl2_run, c->d_gl1_fk, c->d_gl1_beta, c->d_gamma_ln, c->d_samp_tab, c->d_qs_read_tab, c->d_pois, c->d_q2gl, c->d_gl1_bsum, c->d_gl1_lhet, c->d_reads, c->d_errp, c->d_ad4,
                     c->d_adf4, c->d_qsum, c->d_qsumsq, c->d_acc, c->d_sinfo, c->d_rowmap, c->d_errflag, c->d_dbg, c->d_redo_list, c->d_redo_count, c->d_redo_bits,
                     c->d_serial, c->d_sst, c->d_site_thresh, c->d_scout_dp, c->d_site_tail, c->d_sdp, c->d_step_tab,
                     c->d_depth_tab, c->d_site_base, c->d_site_hash, c->d_dp_pre, c->d_hts_off, c->d_hts_base, c->d_roff, c->d_rtotal, c->d_errp_lin, c->d_cw, c->d_ccons, c->d_cexit,
@@ -517,6 +518,33 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     TRY(dmalloc(&c->d_q2gl, (size_t)3 * 257));
     TRYHIP(hipMemcpy(c->d_q2gl, q2gl.data(), sizeof(double) * 3 * 257, hipMemcpyHostToDevice));
     D.q2gl = c->d_q2gl;
+    if (p->gl_model == 2 && p->error_qs != 2 && !hook_env("VGL_NO_GL2_RUN")) {
+        // GL model 2 with one fixed score: an evaluation whose n reads all show one base ends in accumulators that depend on n alone.
+        // The reference's loop (gl_methods.cpp:22-59: per read one double add rounded to float per genotype, float maximum over the
+        // genotypes that exist, float subtraction) is run here once per n and variant; k_gl looks the three values up instead of
+        // running the loop for every such evaluation (most of them: all reads of a homozygous sample without a base-call error).
+        // Same operations in the same order and precision as k_gl's read loop (-ffp-contract=off; float / double are IEEE on this host).
+        const int rows = D.read_cap + 1;
+        std::vector<float> run((size_t)2 * rows * 3);
+        const double term[3] = {D.pre_homT, D.pre_het, D.pre_homF};
+        for (int variant = 0; variant < 2; ++variant) {
+            volatile float tr[3] = {-0.0f, -0.0f, -0.0f};                   // bcf_utils.h:310 (volatile: every step rounds to float32 in memory)
+            for (int i = 0; i < 3; ++i) run[((size_t)variant * rows) * 3 + i] = tr[i];
+            for (int n = 1; n < rows; ++n) {
+                float mx = -INFINITY;
+                for (int i = 0; i < 3; ++i) {
+                    const float v = (float)((double)tr[i] + term[i]);
+                    tr[i] = v;
+                    if (variant == 0 || i == 0) mx = (v > mx) ? v : mx;
+                }
+                for (int i = 0; i < 3; ++i) { const float d = tr[i] - mx; tr[i] = d; }
+                for (int i = 0; i < 3; ++i) run[((size_t)variant * rows + n) * 3 + i] = tr[i];
+            }
+        }
+        TRY(dmalloc(&c->d_gl2_run, run.size()));
+        TRYHIP(hipMemcpy(c->d_gl2_run, run.data(), sizeof(float) * run.size(), hipMemcpyHostToDevice));
+        D.gl2_run = c->d_gl2_run;
+    }
     if (p->gl_model == 1) {
         std::vector<double> bsum, lhet, fkv, betav;
         if (p->error_qs == 2) {                                    // gl_methods.cpp:233-302: per-read qScores
