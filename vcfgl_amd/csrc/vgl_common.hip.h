@@ -545,6 +545,61 @@ __device__ __forceinline__ int sample_read_base16(uint64_t& st_hap, uint64_t& st
     return r_base;
 }
 
+// The reads of ONE evaluation with one fixed quality score and no strand draws (vcfgl.cpp:469-613 without :494-531, :581-605), four per
+// trip, on states carried shifted by 16 (sample_read_base16).  Per read the common path is the two generator steps, the error compare
+// and one bit: the haplotype picks of a trip are collected as four bits and turned into the trip's bases at once (read j shows
+// a0 or a1), a base-call error (1 % of the reads) patches its read inside the rare branch, and the per-base depths come from the
+// number of a1 picks plus the errors' corrections instead of a 64-bit shift-and-add per read.  HOM (wave-uniform: every evaluation of
+// the wavefront is homozygous): the haplotype stream is not even stepped -- both alleles are the same base, and in VGL_RNG_TILE the
+// stream is the evaluation's own window, read by nobody else.
+// emit(trip, bases): bases = the trip's reads, two bits each (read 4 trip + j at bits 2j); entries beyond dp are a0's bits.
+// Returns the per-base depths (A | C << 16 | G << 32 | T << 48).
+template <bool HOM, class Emit>
+__device__ __forceinline__ uint64_t sample_reads_fixed(uint64_t st_hap16, uint64_t st_base16, const int a0, const int a1, const int dp,
+                                                       const uint64_t err_thresh16, Emit&& emit) {
+    const uint32_t dx = (uint32_t)(a0 ^ a1);
+    const uint32_t rep0 = (uint32_t)a0 * 0x55u;                       // a0 in four 2-bit fields
+    uint32_t n1 = 0;                                                  // reads that picked the second haplotype
+    uint64_t adfix = 0;                                               // the errors' corrections to the per-base depths (modulo 2^64)
+    for (int r0 = 0; r0 < dp; r0 += 4) {
+        uint32_t hb = 0, fix = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (r0 + j < dp) {
+                uint32_t h = 0;
+                if (!HOM) {
+                    st_hap16 = lcg_next16(st_hap16);
+                    h = (uint32_t)(st_hap16 >> 63);                   // u >= 0.5: the second allele (vcfgl.cpp:473)
+                    hb |= h << j;
+                }
+                st_base16 = lcg_next16(st_base16);
+                if (st_base16 < err_thresh16) {                       // vcfgl.cpp:486-488
+                    const uint32_t tb = HOM ? (uint32_t)a0 : (h ? (uint32_t)a1 : (uint32_t)a0);
+                    uint32_t rb;
+                    do { st_base16 = lcg_next16(st_base16); rb = (uint32_t)(st_base16 >> 62); } while (rb == tb);
+                    fix |= (tb ^ rb) << (2 * j);
+                    adfix += (1ULL << (16 * rb)) - (1ULL << (16 * tb));
+                }
+            }
+        }
+        uint32_t bases = rep0 ^ fix;
+        if (!HOM) {
+            uint32_t sp = (hb | (hb << 2)) & 0x33u;                   // bit j -> bit 2j
+            sp = (sp | (sp << 1)) & 0x55u;
+            bases ^= sp * dx;                                         // dx <= 3: no carries between the fields
+            n1 += (uint32_t)__builtin_popcount(hb);
+        }
+        emit(r0 >> 2, bases);
+    }
+    return (((uint64_t)((uint32_t)dp - n1)) << (16 * (a0 & 3))) + (((uint64_t)n1) << (16 * (a1 & 3))) + adfix;   // (dp = 0 for a missing genotype, alleles 0xF)
+}
+// the trip's staged word, one byte per read (score << 2 | base), from its 2-bit bases; qrep = (score << 2) in every byte
+__device__ __forceinline__ uint32_t staged_word_of(const uint32_t bases, const uint32_t qrep) {
+    uint32_t w = (bases | (bases << 12)) & 0x000F000Fu;               // fields 0,1 | fields 2,3
+    w = (w | (w << 6)) & 0x03030303u;                                 // field j at byte j
+    return w | qrep;
+}
+
 // one read: haplotype pick, base-call error, strand (vcfgl.cpp:473,486-488,581-586); all compares
 // are exact integer restatements on the 48-bit state: u<0.5 <=> X<2^47, u<e <=> X<ceil(e 2^48),
 // floor(4u) = X>>46

@@ -256,20 +256,14 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
             int dps = (a0 == 0xF || a1 == 0xF) ? 0 : em;
             if (dps > P.read_cap) { atomicOr(T.errflag, VGL_DEVERR_CAPACITY); dps = P.read_cap; }
             const uint64_t err_thresh16 = sample_thresh16(P.err_thresh);
+            // sample_reads_fixed (vgl_common.hip.h): four reads per trip as eight bits; sixteen reads per LDS word
             uint32_t wcur = 0;
-            for (int r0 = 0; r0 < dps; r0 += 4) {
-                uint32_t rw = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (r0 + j < dps) {
-                        bool fwd;
-                        const int r_base = sample_read_base16(st_hap16, st_base16, a0, a1, err_thresh16, false, fwd);
-                        rw |= (uint32_t)r_base << (2 * j);
-                        ad4s += 1ULL << (16 * r_base);
-                    }
-                wcur |= rw << (8 * ((r0 >> 2) & 3));
-                if (((r0 >> 2) & 3) == 3 || r0 + 4 >= dps) { s_fw[(r0 >> 4) * WG + tid] = wcur; wcur = 0; }
-            }
+            auto emit = [&](const int trip, const uint32_t bases) {
+                wcur |= bases << (8 * (trip & 3));
+                if ((trip & 3) == 3 || 4 * trip + 4 >= dps) { s_fw[(trip >> 2) * WG + tid] = wcur; wcur = 0; }
+            };
+            if (__ballot(dps > 0 && a0 != a1) == 0) ad4s = sample_reads_fixed<true>(st_hap16, st_base16, a0, a1, dps, err_thresh16, emit);
+            else ad4s = sample_reads_fixed<false>(st_hap16, st_base16, a0, a1, dps, err_thresh16, emit);
             if (T.fmt_dp) T.fmt_dp[ev] = dps;
         }
         f_a = ad4s;

@@ -204,6 +204,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
         const uint64_t err_thresh16 = sample_thresh16(err_thresh);
         // four reads per trip: one 32-bit store of the staged word (vgl_read_byte) instead of four byte stores
         uint32_t* const reads_w = (uint32_t*)T.reads;
+        if (SLIM) {
+            // default tag surface (round 4): sample_reads_fixed -- the trip's haplotype picks as four bits, errors patched in the rare branch,
+            // per-base depths from the pick count; a wavefront of homozygous evaluations does not step the haplotype stream at all
+            const uint32_t qrep = (q_gl << 2) * 0x01010101u;
+            uint32_t* const col = reads_w + ev;
+            auto emit = [&](const int trip, const uint32_t bases) { if (stage) col[(size_t)trip * plane] = staged_word_of(bases, qrep); };
+            if (__ballot(active && dp > 0 && a0 != a1) == 0) ad4 = sample_reads_fixed<true>(st_hap16, st_base16, a0, a1, dp, err_thresh16, emit);
+            else ad4 = sample_reads_fixed<false>(st_hap16, st_base16, a0, a1, dp, err_thresh16, emit);
+        } else
         for (int r0 = 0; r0 < dp; r0 += 4) {
             uint32_t rw = 0;
 #pragma unroll
