@@ -35,12 +35,18 @@ def _is_fused(args, N, gt, hooks=False):
     return bool(info["fused"])
 
 
-@pytest.mark.parametrize("N", [128, 129, 200, 256, 257, 300, 500, 511, 512, 513, 777, 1000, 1024, 1025])
-@pytest.mark.parametrize("depth", [0.3, 5.0, 11.9])
-def test_fused_shapes_and_depths(oracle, N, depth):
+@pytest.mark.parametrize("N", [128, 129, 200, 256, 257, 300, 500, 511, 512, 513, 777, 1000, 1024, 1025, 1537, 2000, 4096, 4097])
+@pytest.mark.parametrize("depth", [0.3, 5.0, 11.9, 12.0, 20.0, 45.0, 70.0])
+def test_fused_shapes_and_depths(oracle, N, depth, monkeypatch):
+    """(round 4) sites of more than 512 samples are split over consecutive workgroups (513 ... 4096: 2 ... 8 of them; 4097 runs the three
+    kernels), depths of 12 and more come from k_depth, up to 128 staged reads (depth 45: 115; depth 70 runs the three kernels)"""
+    if N > 1100 and depth not in (5.0, 20.0):
+        pytest.skip("wide sites: two depths are enough")
     args = VcfglArgs(seed=11, depth=depth, error_rate=0.01, **TAGS)
-    gt = synth.binary_sites(5, 60, N)
-    want, got = run_both(oracle, args, gt, site0=5)
+    gt = synth.binary_sites(5, 24 if N > 1100 else 60, N)
+    if depth >= 12.0:
+        monkeypatch.setenv("VGL_FUSE_DEEP", "1")                  # depth 12 and more runs fused only behind this hook (three kernels are faster there)
+    want, got = run_both(oracle, args, gt, site0=5, hooks=depth >= 12.0)
     assert_parity(want, got)
 
 
@@ -49,8 +55,28 @@ def test_the_fused_kernel_is_the_one_that_runs():
     assert _is_fused(VcfglArgs(seed=11, depth=5.0, error_rate=0.01, **TAGS), 500, gt)
     assert not _is_fused(VcfglArgs(seed=11, depth=5.0, error_rate=0.01, add_qs=1, **TAGS), 500, gt)          # -addQS needs the per-base quality sums
     assert _is_fused(VcfglArgs(seed=11, depth=5.0, error_rate=0.01, **TAGS), 200, np.zeros((8192, 200), dtype=np.uint8))             # 256 threads per site
-    assert not _is_fused(VcfglArgs(seed=11, depth=5.0, error_rate=0.01, **TAGS), 600, np.zeros((8192, 600), dtype=np.uint8))          # (1024 threads per site were slower than three kernels)
-    assert not _is_fused(VcfglArgs(seed=11, depth=12.0, error_rate=0.01, **TAGS), 500, np.zeros((8192, 500), dtype=np.uint8))        # k_depth's rejection sampler, deeper staging
+    assert _is_fused(VcfglArgs(seed=11, depth=5.0, error_rate=0.01, **TAGS), 600, np.zeros((2048, 600), dtype=np.uint8))             # (round 4) two workgroups per site
+    assert not _is_fused(VcfglArgs(seed=11, depth=20.0, error_rate=0.01, **TAGS), 1000, np.zeros((2048, 1000), dtype=np.uint8))      # depth 12 and more: the three kernels measured faster (tools/fuse_ab.sh)
+    os.environ["VGL_FUSE_DEEP"] = "1"                             # (the deep fused build stays, behind a hook of the -DVGL_TEST_HOOKS library)
+    try:
+        assert _is_fused(VcfglArgs(seed=11, depth=20.0, error_rate=0.01, **TAGS), 1000, np.zeros((2048, 1000), dtype=np.uint8), hooks=True)    # k_depth's draws, 72 staged reads
+        assert not _is_fused(VcfglArgs(seed=11, depth=70.0, error_rate=0.01, **TAGS), 500, np.zeros((512, 500), dtype=np.uint8), hooks=True)   # 153 staged reads: three kernels
+    finally:
+        del os.environ["VGL_FUSE_DEEP"]
+    assert not _is_fused(VcfglArgs(seed=11, depth=5.0, error_rate=0.01, **TAGS), 4100, np.zeros((256, 4100), dtype=np.uint8))        # nine workgroups per site: three kernels
+    assert not _is_fused(VcfglArgs(seed=11, depth=5.0, error_rate=0.01, error_qs=1, beta_variance=1e-5, **TAGS), 500, gt)            # a per-site draw: three kernels
+
+
+@pytest.mark.parametrize("N,depth", [(600, 5.0), (1000, 20.0), (1500, 14.0), (4000, 3.0)])
+def test_split_fused_workgroup_that_does_not_wait(oracle, N, depth, monkeypatch):
+    """A site split over several fused workgroups: each adds its per-base depth sums to the site's record and waits, bounded, for the
+    others; one that gives up samples the others' depths itself (nothing may depend on two workgroups being resident together).
+    VGL_DEBUG_FUSE_ALONE=1 (hooks build) makes every workgroup take that path: same bits."""
+    monkeypatch.setenv("VGL_DEBUG_FUSE_ALONE", "1")
+    monkeypatch.setenv("VGL_FUSE_DEEP", "1")
+    args = VcfglArgs(seed=23, depth=depth, error_rate=0.02, **TAGS)
+    want, got = run_both(oracle, args, synth.acgt_sites(30, N, seed=N, missing=0.02), hooks=True)
+    assert_parity(want, got)
 
 
 @pytest.mark.parametrize("kw", [dict(do_unobserved=0), dict(do_unobserved=1), dict(do_unobserved=2), dict(do_unobserved=3), dict(do_unobserved=4),

@@ -111,6 +111,7 @@ struct VglDevParams {
     int32_t slow_period_n;   //              that of the normal sampler every slow_period_n-th
     int32_t xcd_map;         // k_gl: workgroup index -> XCD-contiguous logical index (VGL_XCD_MAP=0 turns it off; k_sample, which is
                              // bound by its arithmetic, measured 1-3 % slower with it and keeps the hardware order)
+    int32_t dbg_fuse_alone;  // test hook (VGL_DEBUG_FUSE_ALONE=1): a split fused workgroup does not wait for its neighbours and samples their depths itself
     int32_t dbg_phase;       // diagnostic (VGL_DEBUG_PHASE=n): k_sample returns after phase n; 0 = off
     int32_t dbg_qs_exact;    // test hook (VGL_DEBUG_QS_EXACT=1): k_sample<2> treats every read as undecided in float32
     int32_t dbg_redo_every;  // test hook (VGL_DEBUG_REDO_EVERY=k): the deferred build sends every k-th read and slow-test lane to k_redo

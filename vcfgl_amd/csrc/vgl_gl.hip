@@ -191,9 +191,49 @@ __device__ __forceinline__ int cnt_of(uint64_t ad4, int b) { return b < 4 ? (int
 // its own evaluation's depth and reads (k_sample's fixed-score path), the per-base depths are summed over the site in LDS, sixteen
 // threads work out the allele order and the row table (k_site's code), and the likelihood pass below takes per-base depths, site
 // record, row table and the staged reads (two bits each: the score is the same for all) from LDS.  One launch per tile instead of three.
-template <int A, int GLM, bool PREC, int WPB, bool FUSED = false>
+// FUSEDW (round 4): 0 = not fused; else the staged words per evaluation of the fused build, 4 (at most 64 reads) or 8 (at most 128: depth 20
+// has a staging capacity of 72).  A site with more samples than the workgroup has threads is SPLIT over P.fused_split consecutive
+// workgroups; each adds its per-base depth sums to the site's global record and waits, bounded, for the others (they are neighbours in
+// dispatch order); a workgroup that runs out of patience computes the others' sums itself -- nothing depends on two workgroups being
+// resident at the same time.  Mean depths of 12 and more take the depth draws from k_depth (T.dp_pre).
+template <bool STORE, class Emit>
+__device__ __forceinline__ uint64_t fused_sample_eval(const VglDevParams& P, const VglTilePtrs& T, const int site, const int samp, const int N, int& dps_out, Emit&& emit) {
+    // k_sample<0, LEAN> for the evaluation (site, samp): vcfgl.cpp:364-389, 469-613 (vgl_sample.hip)
+    const size_t ev = (size_t)site * N + (size_t)samp;
+    const uint64_t xe = aff(P.samp_tab[samp], T.site_base[site]);
+    uint64_t st_hap16 = aff(P.off[1], xe) << 16, st_base16 = aff(P.off[2], xe) << 16;      // sample_read_base16: states carried shifted by 16
+    int em;
+    if (P.depth_pre == 1) em = T.dp_pre[ev];                            // the rejection method's draws: k_depth ahead of this kernel
+    else {
+        const uint64_t st_depth = aff(P.off[0], xe);
+        VglPois pc = P.pois0;
+        if (P.per_sample_depth) pc = P.pois[samp];
+        double t = 1.0;                                                 // the product method (rng.h:289-299), state carried shifted by 4
+        em = -1;
+        uint64_t s52 = st_depth << 4;
+        uint32_t k3ff = 0x3FF00000u;
+        asm volatile("" : "+v"(k3ff));
+        do { ++em; s52 = lcg_next52r(s52); t *= bits_1xxx_52r(s52, k3ff) - 1.0; } while (t > pc.g);
+    }
+    const uint32_t g = T.gt[ev];
+    const int a0 = (int)(g & 0xF), a1 = (int)((g >> 4) & 0xF);
+    int dps = (a0 == 0xF || a1 == 0xF) ? 0 : em;
+    if (dps > P.read_cap) { if (STORE) atomicOr(T.errflag, VGL_DEVERR_CAPACITY); dps = P.read_cap; }
+    const uint64_t err_thresh16 = sample_thresh16(P.err_thresh);
+    dps_out = dps;                                                      // (before the reads: emit looks at it)
+    uint64_t ad4s;
+    if (__ballot(dps > 0 && a0 != a1) == 0) ad4s = sample_reads_fixed<true>(st_hap16, st_base16, a0, a1, dps, err_thresh16, emit);
+    else ad4s = sample_reads_fixed<false>(st_hap16, st_base16, a0, a1, dps, err_thresh16, emit);
+    if (STORE && T.fmt_dp) T.fmt_dp[ev] = dps;
+    return ad4s;
+}
+#define VGL_FUSED_SPIN_LIMIT 200000                                     // polls (with s_sleep) before a split workgroup stops waiting for its neighbours
+
+template <int A, int GLM, bool PREC, int WPB, int FUSEDW = 0>
 __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const VglTilePtrs T) {
+    constexpr bool FUSED = FUSEDW != 0;
     static_assert(!FUSED || (GLM == 2 && !PREC), "the fused build exists for GL model 2 with the score table");
+    static_assert(FUSEDW == 0 || FUSEDW == 4 || FUSEDW == 8, "staged words per evaluation of the fused build");
     static_assert(WPB == 4 || WPB == 8, "workgroups of 256 or 512 threads");
     constexpr int WG = 64 * WPB;                                        // evaluations (threads) per workgroup: 256 or 512
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
@@ -219,7 +259,8 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
     uint16_t* const s_perm = s_lds.perm;
     int32_t* const s_ws = s_lds.ws;
     uint32_t* const s_hist = s_x;                                       // [1026] bins of the depth sort (done before s_x is used)
-    uint32_t* const s_fw = s_x + 1536;                                  // FUSED: [4][WG] staged reads, sixteen per word (behind the sort's bins; free before the deposits)
+    uint32_t* const s_fw = s_x + 1536;                                  // FUSED: [FUSEDW][WG] staged reads, sixteen per word (behind the sort's bins; free before the deposits)
+    static_assert(!FUSED || 1536 + FUSEDW * WG <= 15 * WG, "the staged words of the fused build lie inside the accumulator array");
     const int N = P.n_samples;
     const int tid = threadIdx.x;
     if (GLM == 2 && !PREC && !FUSED) {
@@ -228,43 +269,26 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
             if (!P.gl_sort) __syncthreads();                            // (with the sort, its barriers stand between these stores and the loop)
         }
     }
-    const uint32_t chunks_k = FUSED ? (uint32_t)WPB : (uint32_t)P.chunks;              // FUSED: a site takes the whole workgroup (wavefronts beyond its samples idle)
+    const uint32_t chunks_k = FUSED ? (uint32_t)(WPB * P.fused_split) : (uint32_t)P.chunks;   // FUSED: a site takes fused_split whole workgroups (wavefronts beyond its samples idle)
     const uint32_t nwaves = (uint32_t)T.n_sites * chunks_k;                             // < 2^31 (checked by the launcher)
     const uint32_t bx = P.xcd_map ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x;     // logical workgroup (XCD-contiguous)
     uint64_t f_a = 0;                                                   // FUSED: this thread's per-base depths
     if constexpr (FUSED) {
-        // ---- k_sample<0, LEAN> for the evaluation (site bx, sample tid): vcfgl.cpp:364-389, 469-613 (vgl_sample.hip)
-        const int site = (int)bx;
+        const int S = P.fused_split;                                    // workgroups of this site
+        const int site = (int)(bx / (uint32_t)S), part = (int)bx - site * S;
+        const int samp = part * WG + tid;
         if (tid < 16) s_lds.f_acc[tid] = 0;
         __syncthreads();
         uint64_t ad4s = 0;
-        if (tid < N) {
-            const size_t ev = (size_t)site * N + (size_t)tid;
-            const uint64_t xe = aff(P.samp_tab[tid], T.site_base[site]);
-            const uint64_t st_depth = aff(P.off[0], xe);
-            uint64_t st_hap16 = aff(P.off[1], xe) << 16, st_base16 = aff(P.off[2], xe) << 16;      // sample_read_base16: states carried shifted by 16
-            VglPois pc = P.pois0;
-            if (P.per_sample_depth) pc = P.pois[tid];
-            double t = 1.0;                                             // the product method (rng.h:289-299), state carried shifted by 4
-            int em = -1;
-            uint64_t s52 = st_depth << 4;
-            uint32_t k3ff = 0x3FF00000u;
-            asm volatile("" : "+v"(k3ff));
-            do { ++em; s52 = lcg_next52r(s52); t *= bits_1xxx_52r(s52, k3ff) - 1.0; } while (t > pc.g);
-            const uint32_t g = T.gt[ev];
-            const int a0 = (int)(g & 0xF), a1 = (int)((g >> 4) & 0xF);
-            int dps = (a0 == 0xF || a1 == 0xF) ? 0 : em;
-            if (dps > P.read_cap) { atomicOr(T.errflag, VGL_DEVERR_CAPACITY); dps = P.read_cap; }
-            const uint64_t err_thresh16 = sample_thresh16(P.err_thresh);
-            // sample_reads_fixed (vgl_common.hip.h): four reads per trip as eight bits; sixteen reads per LDS word
+        if (samp < N) {
             uint32_t wcur = 0;
+            int dps;
+            int* const dps_p = &dps;
             auto emit = [&](const int trip, const uint32_t bases) {
                 wcur |= bases << (8 * (trip & 3));
-                if ((trip & 3) == 3 || 4 * trip + 4 >= dps) { s_fw[(trip >> 2) * WG + tid] = wcur; wcur = 0; }
+                if ((trip & 3) == 3 || 4 * trip + 4 >= *dps_p) { s_fw[(trip >> 2) * WG + tid] = wcur; wcur = 0; }
             };
-            if (__ballot(dps > 0 && a0 != a1) == 0) ad4s = sample_reads_fixed<true>(st_hap16, st_base16, a0, a1, dps, err_thresh16, emit);
-            else ad4s = sample_reads_fixed<false>(st_hap16, st_base16, a0, a1, dps, err_thresh16, emit);
-            if (T.fmt_dp) T.fmt_dp[ev] = dps;
+            ad4s = fused_sample_eval<true>(P, T, site, samp, N, dps, emit);
         }
         f_a = ad4s;
         s_lds.f_ad4[tid] = ad4s;
@@ -275,6 +299,45 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
 #pragma unroll
             for (int k = 1; k < 5; ++k) if (v[k]) atomicAdd(&s_lds.f_acc[k], v[k]);
         }
+        if (S > 1) {
+            // ---- the other workgroups' shares: agent-scope atomics on the site's record (T.acc, zero at the start of the tile), [9] counts arrivals
+            __syncthreads();
+            int32_t* const acc = T.acc + (size_t)site * VGL_ACC_STRIDE;
+            __shared__ int s_alone;
+            if (tid == 0) {
+                int got = 0;
+#pragma unroll
+                for (int k = 1; k < 5; ++k) got += __hip_atomic_fetch_add(&acc[k], s_lds.f_acc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0;   // (returning: performed before the counter moves)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                int seen = __hip_atomic_fetch_add(&acc[9], 1 + got, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+                for (int spin = 0; seen < S && spin < VGL_FUSED_SPIN_LIMIT && !P.dbg_fuse_alone; ++spin) {
+                    __builtin_amdgcn_s_sleep(8);
+                    seen = __hip_atomic_fetch_add(&acc[9], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                s_alone = seen < S || P.dbg_fuse_alone;
+                if (!s_alone) {
+#pragma unroll
+                    for (int k = 1; k < 5; ++k) s_lds.f_acc[k] = __hip_atomic_fetch_add(&acc[k], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            __syncthreads();
+            if (s_alone) {
+                // the neighbours did not show up in time (nothing promises that they run beside this workgroup): their evaluations' depths are
+                // sampled here as well, counts only -- same streams, same sums
+                for (int p2 = 0; p2 < S; ++p2) {
+                    if (p2 == part) continue;
+                    const int s2 = p2 * WG + tid;
+                    uint64_t ad2 = 0;
+                    if (s2 < N) { int d2; ad2 = fused_sample_eval<false>(P, T, site, s2, N, d2, [](const int, const uint32_t) {}); }
+                    int v2[4];
+                    wave_sum_ad4(ad2, v2);
+                    if ((tid & 63) == 0) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (v2[k]) atomicAdd(&s_lds.f_acc[1 + k], v2[k]);
+                    }
+                }
+            }
+        }
         __syncthreads();
         // ---- k_site: sixteen threads work out the allele order, thread m writes row-table entry m, thread 0 the site's outputs
         if (tid < 16) {
@@ -284,7 +347,7 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
             acc9[0] = acc9[1] + acc9[2] + acc9[3] + acc9[4];
             const VglSiteOrder o = site_order(P, acc9[0], &acc9[1]);
             s_lds.f_rowmap[tid] = site_rowmap_entry(P.A, o.a2b, (uint32_t)tid);
-            if (tid == 0) { s_lds.f_si = site_info_of(o); site_outputs(P, T, site, o, acc9); }
+            if (tid == 0) { s_lds.f_si = site_info_of(o); if (part == 0) site_outputs(P, T, site, o, acc9); }
         }
         __syncthreads();
     }
@@ -395,14 +458,12 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
     const int dp = (have && live) ? (int)((ad4 & 0xFFFF) + ((ad4 >> 16) & 0xFFFF) + ((ad4 >> 32) & 0xFFFF) + ((ad4 >> 48) & 0xFFFF)) : 0;
     // FUSED: the staged reads of the evaluation (at most 64, sixteen per word) from LDS into registers; behind the barrier the words'
     // place belongs to the deposits
-    uint32_t fw0 = 0, fw1 = 0, fw2 = 0, fw3 = 0;
+    uint32_t fw[FUSED ? FUSEDW : 1];
     if constexpr (FUSED) {
-        if (dp > 0) fw0 = s_fw[otid];
-        if (dp > 16) fw1 = s_fw[WG + otid];
-        if (dp > 32) fw2 = s_fw[2 * WG + otid];
-        if (dp > 48) fw3 = s_fw[3 * WG + otid];
+#pragma unroll
+        for (int k = 0; k < FUSEDW; ++k) { fw[k] = 0; if (dp > 16 * k) fw[k] = s_fw[k * WG + otid]; }
         __syncthreads();
-    }
+    } else fw[0] = 0;
 
     float acc[NG];
 #pragma unroll
@@ -492,7 +553,10 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
                 if constexpr (FUSED) {
                     for (int r0 = 0; r0 < dp; r0 += 4) {                                      // sixteen reads per word, two bits each (the base; the score is fixed)
                         const int wi = r0 >> 4;
-                        const uint32_t cur = (wi == 0 ? fw0 : wi == 1 ? fw1 : wi == 2 ? fw2 : fw3) >> ((r0 & 15) * 2);
+                        uint32_t curw = fw[0];
+#pragma unroll
+                        for (int k = 1; k < (FUSED ? FUSEDW : 1); ++k) curw = (wi == k) ? fw[k] : curw;
+                        const uint32_t cur = curw >> ((r0 & 15) * 2);
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             if (r0 + j < dp) one_read((cur >> (2 * j)) & 3u, r0 + j);
@@ -1049,6 +1113,8 @@ extern "C" int vgl_launch_gl(const VglDevParams* p, const VglTilePtrs* t, void* 
     // 8 wavefronts (512 evaluations) per workgroup for GL model 2 at depth: the evaluations with three or four distinct bases, whose
     // loop is the expensive one, then fill one wavefront in 512 rather than one in 256 (P.gl_wpb: vgl_ctx_create, VGL_GL_WPB; measured
     // at C3 / fixed-q / C4: 4 -> 8 wavefronts -7 / -6 / -10 % of the kernel's time, 16 is slower again; equal at depth 5)
+    // (GL model 1 with per-read scores, round 4: 8 wavefronts per workgroup measured 5.80 against 5.29 ms per C3-shaped launch -- its per-lane
+    //  histograms take 4 KB of LDS per wavefront either way and the larger workgroup only adds barrier waiting; it keeps 4)
     const int wpb = (p->gl_model == 2 && p->gl_wpb == 8) ? 8 : 4;
     const unsigned blocks = (unsigned)((waves + wpb - 1) / wpb);
     const size_t lds = 0;
@@ -1068,14 +1134,18 @@ extern "C" int vgl_launch_gl(const VglDevParams* p, const VglTilePtrs* t, void* 
 // The caller (vgl_host.cpp) checks the other conditions
 extern "C" int vgl_launch_fused(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
     if (t->n_sites == 0) return 0;
-    if (p->n_samples > 512 || p->read_cap > 64 || p->gl_model != 2 || p->precise_gl || p->error_qs != 0) return (int)hipErrorInvalidValue;
-    const dim3 g((unsigned)t->n_sites);
+    const int S = p->fused_split;
+    const int wg = p->n_samples <= 256 ? 256 : 512;
+    if (S < 1 || (int64_t)S * wg < p->n_samples || p->read_cap > 128 || p->gl_model != 2 || p->precise_gl || p->error_qs != 0 || (p->depth_pre != 1 && p->depth_pre != 2))
+        return (int)hipErrorInvalidValue;
+    if ((int64_t)t->n_sites * S * 8 + 8 >= (1LL << 31)) return (int)hipErrorInvalidValue;
+    const dim3 g((unsigned)((int64_t)t->n_sites * S));
     hipStream_t s = (hipStream_t)stream;
-#define VGL_LAUNCH_FUSED(WPB) \
-    do { if (p->A == 5) hipLaunchKernelGGL((k_gl<5, 2, false, WPB, true>), g, dim3(64 * WPB), 0, s, *p, *t); \
-         else hipLaunchKernelGGL((k_gl<4, 2, false, WPB, true>), g, dim3(64 * WPB), 0, s, *p, *t); } while (0)
-    if (p->n_samples <= 256) VGL_LAUNCH_FUSED(4);
-    else VGL_LAUNCH_FUSED(8);
+#define VGL_LAUNCH_FUSED(WPB, FW) \
+    do { if (p->A == 5) hipLaunchKernelGGL((k_gl<5, 2, false, WPB, FW>), g, dim3(64 * WPB), 0, s, *p, *t); \
+         else hipLaunchKernelGGL((k_gl<4, 2, false, WPB, FW>), g, dim3(64 * WPB), 0, s, *p, *t); } while (0)
+    if (p->read_cap <= 64) { if (wg == 256) VGL_LAUNCH_FUSED(4, 4); else VGL_LAUNCH_FUSED(8, 4); }
+    else { if (wg == 256) VGL_LAUNCH_FUSED(4, 8); else VGL_LAUNCH_FUSED(8, 8); }
 #undef VGL_LAUNCH_FUSED
     return (int)hipGetLastError();
 }

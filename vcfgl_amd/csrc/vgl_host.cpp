@@ -403,6 +403,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     if (D.slow_period_n < 1) D.slow_period_n = 1;
     D.xcd_map = hook_int("VGL_XCD_MAP", 1);
     D.dbg_phase = hook_int("VGL_DEBUG_PHASE", 0);
+    D.dbg_fuse_alone = hook_int("VGL_DEBUG_FUSE_ALONE", 0);
     D.dbg_qs_exact = hook_int("VGL_DEBUG_QS_EXACT", 0);
     for (int i = 0; i < p->n_qs_bins * 3; i++) D.qs_bins[i] = p->qs_bins[i];
     D.err_thresh = (uint64_t)ceil(ldexp(p->error_rate, 48));
@@ -449,8 +450,14 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
                   !D.gx.changed && !D.gy.changed && D.gx.alpha0 >= 8.0 && D.gy.alpha0 >= 8.0 && !hook_env("VGL_NO_DEFER") && !hook_env("VGL_DEBUG_QS_EXACT") && !hook_env("VGL_NO_LEAN")) ? 1 : 0;
     // one workgroup per site does everything (k_gl<.., FUSED>, vgl_gl.hip): sampling with one fixed score, the site's allele order and the
     // likelihoods, with nothing staged in HBM between them
-    D.fused = (!D.serial && p->error_qs == 0 && p->gl_model == 2 && !p->precise_gl && D.depth_pre == 2 && !D.need_qsum && !D.sample_strand &&
-               !D.need_adf && p->adjust_qs == 0 && N > 128 && N <= 512 && D.read_cap <= 64 && !hook_env("VGL_NO_FUSE") && !hook_env("VGL_NO_LEAN")) ? 1 : 0;
+    // (round 4: sites of more than 512 samples split over consecutive workgroups, up to 128 staged reads, depths from k_depth where the
+    // rejection method draws them -- the reference's default error model at depth 20 runs fused too; VGL_FUSE_MAX_SPLIT: tuning hook)
+    D.fused_split = N <= 512 ? 1 : (N + 511) / 512;
+    D.fused = (!D.serial && p->error_qs == 0 && p->gl_model == 2 && !p->precise_gl && (D.depth_pre == 2 || D.depth_pre == 1) && !D.need_qsum && !D.sample_strand &&
+               (D.depth_pre == 2 || hook_int("VGL_FUSE_DEEP", 0)) &&      // measured (tools/fuse_ab.sh): at depth 20 the three kernels are faster (1.50e10 against 1.40e10 at N = 500, 1.55e10 against 1.36e10 at N = 1000)
+               !D.need_adf && p->adjust_qs == 0 && N > 128 && D.fused_split <= hook_int("VGL_FUSE_MAX_SPLIT", 8) && D.read_cap <= 128 &&
+               !hook_env("VGL_NO_FUSE") && !hook_env("VGL_NO_LEAN")) ? 1 : 0;
+    if (!D.fused) D.fused_split = 0;
     D.qsum_lds = (D.defer_ok && !D.lean_ok && ((p->adjust_qs & 3) == 0 || (p->adjust_qs & 3) == 3) && D.read_cap <= 132) ? 1 : 0;
     if (D.defer_ok && D.pool_cap > 1472) {      // 20 wavefronts' pools in a CU's 160 KB of LDS: 576 + 5 x 1472 + 8 B each
         D.pool_cap = 1472;
