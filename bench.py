@@ -403,6 +403,19 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
                     "valu_insts_per_wave": kprof["valu_insts_per_wave"], "waves_per_launch": waves,
                     "valu_busy_frac_pmc": kprof.get("valu_busy_frac"), "source": src, "profile_matches_build": fresh,
                     "peak_note": "1024 SIMDs x 2.4 GHz / 4 cycles per wavefront instruction (float64 / three-operand class)"}
+            # cost-weighted: the instruction mix of the kernel's hot loop priced with the issue costs measured on this part (tools/loop_cost.py
+            # over the compiler's ISA, tools/valu_rates.hip), instead of a flat 4 cycles per instruction
+            try:
+                lc = json.load(open(os.path.join(ROOT, "profiles", "r04_loop_cost.json")))
+                if KERNELS[dom] == "k_sample" and args.error_qs == 2:
+                    cyc = kprof["valu_insts_per_wave"] * lc["avg_cycles_per_valu_inst"] * waves          # SIMD cycles of vector issue per launch
+                    valu["cost_weighted"] = {"avg_cycles_per_valu_inst": lc["avg_cycles_per_valu_inst"], "valu_per_pool_iteration": lc["valu_per_iteration_weighted"],
+                                             "simd_cycles_per_pool_iteration": lc["simd_cycles_per_iteration_weighted"],
+                                             "frac": cyc / (1024 * 2.4e9 * avg_ms * 1e-3),
+                                             "note": "wavefront VALU instructions x the pool loop's average issue cost / (1024 SIMDs x 2.4 GHz x launch time): share of the chip's vector issue time the kernel uses",
+                                             "source": "profiles/r04_loop_cost.json (tools/loop_cost.py)"}
+            except Exception:
+                pass
         traffic = kprof.get("hbm_bytes_per_launch") * scale if kprof.get("hbm_bytes_per_launch") else None
         traffic_frac = (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None
         busy = kprof.get("valu_busy_frac")

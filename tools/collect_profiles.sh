@@ -3,7 +3,7 @@
 # copies the kernel-trace summaries into profiles/ and writes profiles/<tag>_<wl>_pmc_summary.json + profiles/pmc_traffic.json
 set -eu
 tag=${1:?tag}; shift
-wls=${*:-c3 c5 c5u8 c4 fixedq c2 gl1q precise}
+wls=${*:-c3 c5 c5u8 c4 fixedq c2 gl1q precise alltags qsi16}
 for wl in $wls; do
     f=$(ls gpurun_out/$tag/$wl/kt/*/*kernel_stats.csv | head -1)
     cp "$f" profiles/${tag}_${wl}_kernel_stats.csv

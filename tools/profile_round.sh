@@ -8,7 +8,7 @@
 # Afterwards, in the development container: tools/collect_profiles.sh <tag> [workload ...]
 set -u
 tag=${1:?tag}; shift
-wls=${*:-c3 c5 c5u8 c4 fixedq c2 gl1q precise}
+wls=${*:-c3 c5 c5u8 c4 fixedq c2 gl1q precise alltags qsi16}
 export TMPDIR=/tmp
 out=gpurun_out/$tag
 mkdir -p "$out"

@@ -1002,20 +1002,21 @@ __global__ __launch_bounds__(64) void k_siteagg(const VglDevParams P, const VglT
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     // ---- INFO/I16: lane j < 16 takes site j
-    if (T.i16 && lane < n_w) {
-        const int ls = ls_w + lane;
+    if (T.i16) {
+        const bool mine = lane < n_w;
+        const int ls = ls_w + (mine ? lane : 0);
         const VglSiteInfo si = T.sinfo[ls];
-        const bool have = (si.status == SITE_OK);
+        const bool have = mine && (si.status == SITE_OK);
         const int nA = si.n_alleles;
+        const int nObs = (A == 5) ? nA - 1 : nA;
         float v[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) v[k] = 0.0f;
-        if (have && P.add_i16 && nA > 1) {
+        const bool on = have && P.add_i16 && nA > 1;
+        bool walk = false;                                              // this site's running sums leave the exact range of float32
+        if (on) {
             const int32_t* acc = T.acc + (size_t)ls * VGL_ACC_STRIDE;
-            const uint32_t* qsum = T.qsum + (size_t)ls * 4 * N;
-            const uint32_t* qsq = T.qsumsq + (size_t)ls * 4 * N;
             const int refb = nib(si.alleles2acgt, 0);
-            const int nObs = (A == 5) ? nA - 1 : nA;
             v[0] = (float)acc[5 + refb]; v[1] = (float)(acc[1 + refb] - acc[5 + refb]);
             const float mq = (float)P.i16_mapq, mq2 = (float)(P.i16_mapq * P.i16_mapq);
             // integer totals (modulo 2^32: trusted while the site's reads cannot have wrapped them -- 3969 = 63^2 per read at most)
@@ -1030,17 +1031,8 @@ __global__ __launch_bounds__(64) void k_siteagg(const VglDevParams P, const VglT
                 v[2] += (float)acc[5 + b]; v[3] += (float)(acc[1 + b] - acc[5 + b]);
             }
             const unsigned long long lim = 1ULL << 24;
-            if (tot_ok && t4 <= lim && t5 <= lim && t6 <= lim && t7 <= lim) {
-                v[4] = (float)t4; v[5] = (float)t5; v[6] = (float)t6; v[7] = (float)t7;
-            } else {
-                // the running sums leave the exact range: the reference's own walk (vcfgl.cpp:997-1000, 1052-1056)
-                for (int s = 0; s < N; ++s) { v[4] += (float)(int)qsum[(size_t)refb * N + s]; v[5] += (float)(int)qsq[(size_t)refb * N + s]; }
-                for (int a = 1; a < nA; ++a) {
-                    if (a == nObs) continue;
-                    const int b = nib(si.alleles2acgt, a);
-                    for (int s = 0; s < N; ++s) { v[6] += (float)(int)qsum[(size_t)b * N + s]; v[7] += (float)(int)qsq[(size_t)b * N + s]; }
-                }
-            }
+            if (tot_ok && t4 <= lim && t5 <= lim && t6 <= lim && t7 <= lim) { v[4] = (float)t4; v[5] = (float)t5; v[6] = (float)t6; v[7] = (float)t7; }
+            else walk = true;
             // one addition of the mapping quality (and of its square) per read, reference allele / the others (vcfgl.cpp:1003-1024)
             v[8] = repeated_add(mq, k_ref); v[9] = repeated_add(mq2, k_ref);
             v[10] = repeated_add(mq, k_non); v[11] = repeated_add(mq2, k_non);
@@ -1054,8 +1046,52 @@ __global__ __launch_bounds__(64) void k_siteagg(const VglDevParams P, const VglT
                 }
             }
         }
+        // Sites whose sums leave the exact range (more than 2^24 / q^2 reads of a base: wide, deep tiles): the reference's own walks
+        // (vcfgl.cpp:997-1000 reference allele, 1052-1056 the other alleles one after the other), as float32 chains in sample order --
+        // by the same LDS transposition as the QS chains: pass `a` feeds chain (site, 0) the quality sums and chain (site, 1) the squared
+        // sums of the site's a-th allele (pass 0 into fields 5-6, the later passes into 7-8), 64 samples per coalesced row load.
+        const uint64_t walk_m = __ballot(walk);
+        if (walk_m) {
+            const int j_c = lane >> 2, k_c = lane & 3;
+            float ch = 0.0f, ch_ref = 0.0f;                             // this lane's chain (k_c < 2), and its value after pass 0
+            for (int a = 0; a < A; ++a) {
+                // base of the a-th allele of every walking site (wave-uniform mask; lanes j < 16 hold the sites)
+                const int b_mine = (walk && a < nA && a != nObs) ? nib(si.alleles2acgt, a) : -1;
+                const uint64_t pass_m = __ballot(b_mine >= 0 && b_mine < 4);
+                if (a == 1) { ch_ref = ch; ch = 0.0f; }
+                if (!pass_m) continue;
+                for (int c0 = 0; c0 < N; c0 += 64) {
+                    const int sidx = c0 + lane;
+                    for (int j = 0; j < n_w; ++j) {
+                        if (!((pass_m >> j) & 1)) continue;             // wave-uniform
+                        const int b = __builtin_amdgcn_readlane(b_mine, j);
+                        float x0 = 0.0f, x1 = 0.0f;
+                        if (sidx < N) {
+                            const size_t row = ((size_t)(ls_w + j) * 4 + (size_t)b) * N + (size_t)sidx;
+                            x0 = (float)(int)T.qsum[row]; x1 = (float)(int)T.qsumsq[row];
+                        }
+                        s_x[(size_t)(j * 4) * VGL_AGG_ROW + lane] = x0;
+                        s_x[(size_t)(j * 4 + 1) * VGL_AGG_ROW + lane] = x1;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (k_c < 2 && ((pass_m >> j_c) & 1)) {
+                        const float* mine_row = s_x + (size_t)lane * VGL_AGG_ROW;
+#pragma unroll 16
+                        for (int k = 0; k < 64; ++k) ch += mine_row[k];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+            }
+            // chain (j, 0): fields 5 (pass 0) and 7 (later passes); chain (j, 1): fields 6 and 8 -- back to the site's lane through LDS
+            s_x[lane] = ch_ref; s_x[64 + lane] = ch;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (walk) { v[4] = s_x[lane * 4]; v[5] = s_x[lane * 4 + 1]; v[6] = s_x[64 + lane * 4]; v[7] = s_x[64 + lane * 4 + 1]; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (mine) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) T.i16[(size_t)ls * 16 + k] = v[k];
+            for (int k = 0; k < 16; ++k) T.i16[(size_t)ls * 16 + k] = v[k];
+        }
     }
 }
 
