@@ -15,6 +15,10 @@ pools) are reached through volume, not only through debug hooks:
   eqs1     --error-qs 1 (one beta deviate per site), 1e7
   fixedq   --error-qs 0 with strand tags, 1e7: k_sample<0> with strand draws, k_depth
   c3sm     c3's flags + PL, VGL_LAYOUT_SAMPLE_MAJOR slabs and pl_u8 (ABI 4), multi-allelic input, 1e7: k_gl's sample-major stores
+  qsi16    (round 4) c3's flags + -addQS -addI16, 1e7: k_sample<2, LEAN 3> (quality sums by LDS atomics, k_redo adding to them), k_siteagg
+  fq20     (round 4) one fixed score at depth 20, default tags + PL, 2e7: sample_reads_fixed (haplotype bits, homozygous wavefronts), the
+           one-base run table of k_gl
+  c5wide   (round 4) config C5's flags at 1000 samples, 2e7: the fused kernel split over two workgroups per site
 
 The site ranges start far from 0 (absolute site indexing: the same values the full job produces there).  Integer fields, and GL
 wherever its per-read terms come from the qScore LUT or constants, must be EQUAL.  Where the device evaluates a logarithm or a
@@ -62,6 +66,13 @@ CASES = {
                  flags=dict(depth=20.0, gl_model=2, add_pl=1, add_fmt_ad=1, out_layout=_abi.VGL_LAYOUT_SAMPLE_MAJOR, **EQS2)),
     "fixedq": dict(N=1000, S=10_000, site0=15_000_000, gt="acgt", fields=[f for f in EVERY if f != "gp"], tile=4096,
                    flags=dict(depth=20.0, gl_model=2, error_rate=0.01, add_pl=1, add_qs=1, add_info_dp=1, add_fmt_ad=1, add_info_ad=1, **STRAND)),
+    # round 4
+    "qsi16": dict(N=1000, S=10_000, site0=19_000_000, gt="binary", fields=BASE + ["qs", "i16"], tile=4096,
+                  flags=dict(depth=20.0, gl_model=2, add_qs=1, add_i16=1, **EQS2)),
+    "fq20": dict(N=1000, S=20_000, site0=21_000_000, gt="binary", fields=BASE + ["pl"], tile=8192,
+                 flags=dict(depth=20.0, gl_model=2, error_rate=0.01, add_pl=1)),
+    "c5wide": dict(N=1000, S=20_000, site0=23_000_000, gt="homref", fields=BASE + ["pl"], tile=8192,
+                   flags=dict(depth=5.0, error_rate=0.01, gl_model=2, do_unobserved=2, add_pl=1)),
 }
 
 

@@ -1015,13 +1015,17 @@ int main(int argc, char** argv) {
     };
     alloc_entry(0);
     // one worker per device: simulates the tiles handed to it, in order
-    struct Worker { std::thread th; std::mutex m; std::condition_variable cv; std::vector<TileBufs*> q; size_t head = 0; bool stop = false; };
+    struct Worker { std::thread th; std::mutex m; std::condition_variable cv; std::vector<TileBufs*> q; size_t head = 0; bool stop = false;
+                    long tiles = 0, sites = 0; double t_first = -1.0, t_last = 0.0; };          // --verbose 1: what this device did (written by its own thread, read after the join)
+    // bytes a finished tile brings back over the link, per site (the FORMAT arrays dominate: sample-major slabs, copied whole)
+    const double bytes_per_site = (double)N * ((want_dp ? 4.0 : 0.0) + 4.0 * G * ((a.add_gl ? 1 : 0) + (a.add_pl ? 1 : 0) + (a.add_gp ? 1 : 0)) +
+                                               4.0 * A * ((a.add_fmt_ad ? 1 : 0) + (a.add_fmt_adf ? 1 : 0) + (a.add_fmt_adr ? 1 : 0))) + 64.0;
     std::vector<std::unique_ptr<Worker>> workers(D);
     for (int d = 0; d < D; d++) {
         workers[d].reset(new Worker());
         Worker* W = workers[d].get();
         vgl_ctx* ctx = ctxs[d];
-        W->th = std::thread([W, ctx]() {
+        W->th = std::thread([W, ctx, &now]() {
             // a tile is submitted (vgl_simulate_tile_async) before the previous one is waited for: its kernels run while the
             // previous tile's tags are still on their way to the host
             TileBufs* prev = nullptr; int32_t prev_ticket = 0;
@@ -1034,9 +1038,11 @@ int main(int argc, char** argv) {
                     else if (!prev) return;
                 }
                 int32_t ticket = 0;
+                if (B && W->t_first < 0.0) W->t_first = now();
                 if (B && vgl_simulate_tile_async(ctx, B->t0, B->ns, B->gt.data(), &B->o, &ticket) != VGL_OK) die("%s", vgl_last_error());
                 if (prev) {
                     if (vgl_tile_wait(ctx, prev_ticket) != VGL_OK) die("%s", vgl_last_error());
+                    W->tiles += 1; W->sites += prev->ns; W->t_last = now();
                     { std::lock_guard<std::mutex> lk(prev->m); prev->done = true; }
                     prev->cv.notify_all();
                 }
@@ -1203,6 +1209,19 @@ int main(int argc, char** argv) {
     // contexts and page-locked buffers are not torn down one by one (0.06 s): the process ends below with _exit(), after the run
     // log, and the driver releases everything at once
     lap(7);
+    if (a.verbose) {
+        // per device: tiles, sites, bytes of tags copied back and the rate over the device's own busy interval (first submit to last
+        // completed wait) -- a multi-GPU run shows an idle or slow device (or link) here at once
+        for (int d = 0; d < D; d++) {
+            const Worker& W = *workers[d];
+            vgl_ctx_info_t ci; memset(&ci, 0, sizeof ci); ci.size = (int32_t)sizeof ci;
+            (void)vgl_ctx_info(ctxs[d], &ci);
+            const double dt = W.t_last - W.t_first, gb = bytes_per_site * (double)W.sites / 1e9;
+            fprintf(stderr, "[device %d] %ld tiles, %ld sites, %.3f GB of tags copied back in %.3f s = %.1f GB/s, %.3g evaluations/s; context: %.2f GB workspace, k_sample build %d, fused %d (split %d)\n",
+                    devices[d], W.tiles, W.sites, gb, dt > 0 ? dt : 0.0, dt > 0 ? gb / dt : 0.0, dt > 0 ? (double)W.sites * N / dt : 0.0,
+                    (double)ci.workspace_bytes / 1e9, ci.sample_lean, ci.fused, ci.fused_split);
+        }
+    }
     if (a.verbose) fprintf(stderr, "\n[timing] read input %.3f s, decode sites %.3f s, device context(s) %.3f s, waiting for the device(s) (simulation incl. PCIe, overlapped with the writer) %.3f s, encode %.3f s, write/compress %.3f s, tile buffers %.3f s, teardown %.3f s\n",
                            t_stage[0], t_stage[1], t_stage[2], t_stage[3], t_stage[4], t_stage[5], t_stage[6], t_stage[7]);
     char sb[512];
