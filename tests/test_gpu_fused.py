@@ -38,8 +38,9 @@ def _is_fused(args, N, gt, hooks=False):
 @pytest.mark.parametrize("N", [128, 129, 200, 256, 257, 300, 500, 511, 512, 513, 777, 1000, 1024, 1025, 1537, 2000, 4096, 4097])
 @pytest.mark.parametrize("depth", [0.3, 5.0, 11.9, 12.0, 20.0, 45.0, 70.0])
 def test_fused_shapes_and_depths(oracle, N, depth, monkeypatch):
-    """(round 4) sites of more than 512 samples are split over consecutive workgroups (513 ... 4096: 2 ... 8 of them; 4097 runs the three
-    kernels), depths of 12 and more come from k_depth, up to 128 staged reads (depth 45: 115; depth 70 runs the three kernels)"""
+    """(round 4) sites of more than 512 samples are split over consecutive workgroups (513 ... 2048: 2 ... 4 of them; beyond -- 4096, 4097 --
+    the three kernels run: at eight workgroups per site the fused kernel measured no faster), depths of 12 and more come from k_depth,
+    up to 128 staged reads (depth 45: 115; depth 70 runs the three kernels)"""
     if N > 1100 and depth not in (5.0, 20.0):
         pytest.skip("wide sites: two depths are enough")
     args = VcfglArgs(seed=11, depth=depth, error_rate=0.01, **TAGS)
@@ -63,11 +64,12 @@ def test_the_fused_kernel_is_the_one_that_runs():
         assert not _is_fused(VcfglArgs(seed=11, depth=70.0, error_rate=0.01, **TAGS), 500, np.zeros((512, 500), dtype=np.uint8), hooks=True)   # 153 staged reads: three kernels
     finally:
         del os.environ["VGL_FUSE_DEEP"]
-    assert not _is_fused(VcfglArgs(seed=11, depth=5.0, error_rate=0.01, **TAGS), 4100, np.zeros((256, 4100), dtype=np.uint8))        # nine workgroups per site: three kernels
+    assert _is_fused(VcfglArgs(seed=11, depth=5.0, error_rate=0.01, **TAGS), 2048, np.zeros((512, 2048), dtype=np.uint8))            # four workgroups per site
+    assert not _is_fused(VcfglArgs(seed=11, depth=5.0, error_rate=0.01, **TAGS), 2049, np.zeros((512, 2049), dtype=np.uint8))        # five: three kernels (measured no faster from eight on)
     assert not _is_fused(VcfglArgs(seed=11, depth=5.0, error_rate=0.01, error_qs=1, beta_variance=1e-5, **TAGS), 500, gt)            # a per-site draw: three kernels
 
 
-@pytest.mark.parametrize("N,depth", [(600, 5.0), (1000, 20.0), (1500, 14.0), (4000, 3.0)])
+@pytest.mark.parametrize("N,depth", [(600, 5.0), (1000, 20.0), (1500, 14.0), (2048, 3.0)])
 def test_split_fused_workgroup_that_does_not_wait(oracle, N, depth, monkeypatch):
     """A site split over several fused workgroups: each adds its per-base depth sums to the site's record and waits, bounded, for the
     others; one that gives up samples the others' depths itself (nothing may depend on two workgroups being resident together).

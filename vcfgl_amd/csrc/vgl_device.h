@@ -181,6 +181,7 @@ struct VglTilePtrs {
     int32_t*  dp_pre;        // [n_sites][N] depth draws of k_depth (tile mode)
     uint64_t* site_base;     // [n_sites] tile mode: J^(block N H(site)) (x0), the generator state in front of the site's windows (k_sitebase)
     uint64_t* site_hash;     // [n_sites] tile mode: H(site) (GL model 1 deeper than 255 reads addresses htslib's stream by it)
+    unsigned long long* fslot;   // [n_sites][fused_split][2] split fused sites: each workgroup's flagged per-base depth sums (zero at the start of a tile)
     // outputs (caller owned device memory; may be null)
     int32_t* site_status; int32_t* n_alleles; int32_t* n_alleles_obs; int8_t* alleles2acgt;
     int32_t* info_dp; int32_t* info_ad; int32_t* info_adf; int32_t* info_adr;

@@ -193,9 +193,9 @@ __device__ __forceinline__ int cnt_of(uint64_t ad4, int b) { return b < 4 ? (int
 // record, row table and the staged reads (two bits each: the score is the same for all) from LDS.  One launch per tile instead of three.
 // FUSEDW (round 4): 0 = not fused; else the staged words per evaluation of the fused build, 4 (at most 64 reads) or 8 (at most 128: depth 20
 // has a staging capacity of 72).  A site with more samples than the workgroup has threads is SPLIT over P.fused_split consecutive
-// workgroups; each adds its per-base depth sums to the site's global record and waits, bounded, for the others (they are neighbours in
-// dispatch order); a workgroup that runs out of patience computes the others' sums itself -- nothing depends on two workgroups being
-// resident at the same time.  Mean depths of 12 and more take the depth draws from k_depth (T.dp_pre).
+// workgroups; each publishes its per-base depth sums in a flagged slot of the site (T.fslot) and waits, bounded, for the others' (they
+// are neighbours in dispatch order); a workgroup that runs out of patience computes the missing sums itself -- nothing depends on two
+// workgroups being resident at the same time.  Mean depths of 12 and more take the depth draws from k_depth (T.dp_pre).
 template <bool STORE, class Emit>
 __device__ __forceinline__ uint64_t fused_sample_eval(const VglDevParams& P, const VglTilePtrs& T, const int site, const int samp, const int N, int& dps_out, Emit&& emit) {
     // k_sample<0, LEAN> for the evaluation (site, samp): vcfgl.cpp:364-389, 469-613 (vgl_sample.hip)
@@ -300,32 +300,41 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
             for (int k = 1; k < 5; ++k) if (v[k]) atomicAdd(&s_lds.f_acc[k], v[k]);
         }
         if (S > 1) {
-            // ---- the other workgroups' shares: agent-scope atomics on the site's record (T.acc, zero at the start of the tile), [9] counts arrivals
+            // ---- the other workgroups' shares.  Every part publishes its four sums as TWO flagged 8-byte words (system-scope stores: A | C << 32
+            // and G | T << 32, bit 63 = valid; the slots are zero at the start of the tile) and lane q of the first wavefront polls part q's
+            // words with system-scope loads -- one store and, when the neighbour is already there, one load round trip (the first version's
+            // four returning atomics + counter + polls + four reads by one lane cost about 8 us per workgroup with seven wavefronts waiting)
             __syncthreads();
-            int32_t* const acc = T.acc + (size_t)site * VGL_ACC_STRIDE;
+            unsigned long long* const slots = T.fslot + (size_t)site * (size_t)S * 2;
             __shared__ int s_alone;
             if (tid == 0) {
-                int got = 0;
-#pragma unroll
-                for (int k = 1; k < 5; ++k) got += __hip_atomic_fetch_add(&acc[k], s_lds.f_acc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0;   // (returning: performed before the counter moves)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                int seen = __hip_atomic_fetch_add(&acc[9], 1 + got, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-                for (int spin = 0; seen < S && spin < VGL_FUSED_SPIN_LIMIT && !P.dbg_fuse_alone; ++spin) {
-                    __builtin_amdgcn_s_sleep(8);
-                    seen = __hip_atomic_fetch_add(&acc[9], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_alone = 0;
+                const unsigned long long V = 1ULL << 63;
+                __hip_atomic_store(&slots[part * 2], (unsigned long long)(uint32_t)s_lds.f_acc[1] | ((unsigned long long)(uint32_t)s_lds.f_acc[2] << 32) | V, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&slots[part * 2 + 1], (unsigned long long)(uint32_t)s_lds.f_acc[3] | ((unsigned long long)(uint32_t)s_lds.f_acc[4] << 32) | V, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            __syncthreads();                                            // (s_alone cleared; f_acc still holds this part's own sums)
+            if (tid < S && tid != part) {
+                const unsigned long long V = 1ULL << 63;
+                unsigned long long w0 = 0, w1 = 0;
+                for (int spin = 0; spin < VGL_FUSED_SPIN_LIMIT && !P.dbg_fuse_alone; ++spin) {
+                    w0 = __hip_atomic_load(&slots[tid * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    w1 = __hip_atomic_load(&slots[tid * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if ((w0 & w1 & V) != 0) break;
+                    __builtin_amdgcn_s_sleep(4);
                 }
-                s_alone = seen < S || P.dbg_fuse_alone;
-                if (!s_alone) {
-#pragma unroll
-                    for (int k = 1; k < 5; ++k) s_lds.f_acc[k] = __hip_atomic_fetch_add(&acc[k], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                if ((w0 & w1 & V) != 0 && !P.dbg_fuse_alone) {
+                    atomicAdd(&s_lds.f_acc[1], (int)(uint32_t)w0); atomicAdd(&s_lds.f_acc[2], (int)(uint32_t)((w0 & ~V) >> 32));
+                    atomicAdd(&s_lds.f_acc[3], (int)(uint32_t)w1); atomicAdd(&s_lds.f_acc[4], (int)(uint32_t)((w1 & ~V) >> 32));
+                } else atomicOr(&s_alone, 1 << tid);
             }
             __syncthreads();
-            if (s_alone) {
-                // the neighbours did not show up in time (nothing promises that they run beside this workgroup): their evaluations' depths are
+            const int alone_m = s_alone;
+            if (alone_m) {
+                // those neighbours did not show up in time (nothing promises that they run beside this workgroup): their evaluations' depths are
                 // sampled here as well, counts only -- same streams, same sums
                 for (int p2 = 0; p2 < S; ++p2) {
-                    if (p2 == part) continue;
+                    if (!((alone_m >> p2) & 1)) continue;
                     const int s2 = p2 * WG + tid;
                     uint64_t ad2 = 0;
                     if (s2 < N) { int d2; ad2 = fused_sample_eval<false>(P, T, site, s2, N, d2, [](const int, const uint32_t) {}); }

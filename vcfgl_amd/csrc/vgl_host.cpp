@@ -184,7 +184,7 @@ struct vgl_ctx {
     // device tables
     VglAffine* d_depth_tab = nullptr; int32_t* d_dp_pre = nullptr; uint64_t* d_site_base = nullptr; uint64_t* d_site_hash = nullptr;
     VglAffine* d_samp_tab = nullptr; VglAffine* d_qs_read_tab = nullptr; VglPois* d_pois = nullptr;
-    float* d_gl2_run = nullptr;
+    float* d_gl2_run = nullptr; unsigned long long* d_fslot = nullptr;
     double* d_q2gl = nullptr; double* d_gamma_ln = nullptr; double* d_gl1_fk = nullptr; double* d_gl1_beta = nullptr; double* d_gl1_bsum = nullptr; double* d_gl1_lhet = nullptr;
     // workspace
     uint8_t* d_reads = nullptr; double* d_errp = nullptr; uint64_t* d_ad4 = nullptr; uint64_t* d_adf4 = nullptr;
@@ -297,7 +297,7 @@ template <typename T> static int dmalloc(T** p, size_t n) {
 extern "C" int vgl_ctx_destroy(vgl_ctx* c) {
     if (!c) return VGL_OK;
     (void)hipSetDevice(c->device);
-    void* ptrs[] = {c->d_gl2_run, c->d_gl1_fk, c->d_gl1_beta, c->d_gamma_ln, c->d_samp_tab, c->d_qs_read_tab, c->d_pois, c->d_q2gl, c->d_gl1_bsum, c->d_gl1_lhet, c->d_reads, c->d_errp, c->d_ad4,
+    void* ptrs[] = {c->d_fslot, c->d_gl2_run, c->d_gl1_fk, c->d_gl1_beta, c->d_gamma_ln, c->d_samp_tab, c->d_qs_read_tab, c->d_pois, c->d_q2gl, c->d_gl1_bsum, c->d_gl1_lhet, c->d_reads, c->d_errp, c->d_ad4,
                     c->d_adf4, c->d_qsum, c->d_qsumsq, c->d_acc, c->d_sinfo, c->d_rowmap, c->d_errflag, c->d_dbg, c->d_redo_list, c->d_redo_count, c->d_redo_bits,
                     c->d_serial, c->d_sst, c->d_site_thresh, c->d_scout_dp, c->d_site_tail, c->d_sdp, c->d_step_tab,
                     c->d_depth_tab, c->d_site_base, c->d_site_hash, c->d_dp_pre, c->d_hts_off, c->d_hts_base, c->d_roff, c->d_rtotal, c->d_errp_lin, c->d_cw, c->d_ccons, c->d_cexit,
@@ -450,12 +450,12 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
                   !D.gx.changed && !D.gy.changed && D.gx.alpha0 >= 8.0 && D.gy.alpha0 >= 8.0 && !hook_env("VGL_NO_DEFER") && !hook_env("VGL_DEBUG_QS_EXACT") && !hook_env("VGL_NO_LEAN")) ? 1 : 0;
     // one workgroup per site does everything (k_gl<.., FUSED>, vgl_gl.hip): sampling with one fixed score, the site's allele order and the
     // likelihoods, with nothing staged in HBM between them
-    // (round 4: sites of more than 512 samples split over consecutive workgroups, up to 128 staged reads, depths from k_depth where the
+    // (round 4: sites of more than 512 samples split over up to four consecutive workgroups, up to 128 staged reads, depths from k_depth where the
     // rejection method draws them -- the reference's default error model at depth 20 runs fused too; VGL_FUSE_MAX_SPLIT: tuning hook)
     D.fused_split = N <= 512 ? 1 : (N + 511) / 512;
     D.fused = (!D.serial && p->error_qs == 0 && p->gl_model == 2 && !p->precise_gl && (D.depth_pre == 2 || D.depth_pre == 1) && !D.need_qsum && !D.sample_strand &&
                (D.depth_pre == 2 || hook_int("VGL_FUSE_DEEP", 0)) &&      // measured (tools/fuse_ab.sh): at depth 20 the three kernels are faster (1.50e10 against 1.40e10 at N = 500, 1.55e10 against 1.36e10 at N = 1000)
-               !D.need_adf && p->adjust_qs == 0 && N > 128 && D.fused_split <= hook_int("VGL_FUSE_MAX_SPLIT", 8) && D.read_cap <= 128 &&
+               !D.need_adf && p->adjust_qs == 0 && N > 128 && D.fused_split <= hook_int("VGL_FUSE_MAX_SPLIT", 4) && D.read_cap <= 128 &&
                !hook_env("VGL_NO_FUSE") && !hook_env("VGL_NO_LEAN")) ? 1 : 0;
     if (!D.fused) D.fused_split = 0;
     D.qsum_lds = (D.defer_ok && !D.lean_ok && ((p->adjust_qs & 3) == 0 || (p->adjust_qs & 3) == 3) && D.read_cap <= 132) ? 1 : 0;
@@ -617,6 +617,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     TRY(dmalloc(&c->d_sinfo, (size_t)max_sites));
     if (p->gl_model == 2) TRY(dmalloc(&c->d_rowmap, (size_t)max_sites * 16));
     TRY(dmalloc(&c->d_errflag, (size_t)1));
+    if (D.fused && D.fused_split > 1) TRY(dmalloc(&c->d_fslot, (size_t)max_sites * D.fused_split * 2));
     if (D.defer_ok) {
         // about 6 reads in 10^4 take this path at C3 / C4 (tools/redo_rate.py); the list has room for 1 in 64 of the staging capacity
         // (VGL_DEBUG_REDO_CAP: test hook), what does not fit is marked in a bitmap over the staged reads (all zero between tiles)
@@ -766,7 +767,7 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     T.site0 = site0; T.n_sites = n_sites; T.gt = gt;
     T.reads = c->d_reads; T.errp = c->d_errp; T.ad4 = c->d_ad4; T.adf4 = c->d_adf4; T.qsum = c->d_qsum; T.qsumsq = c->d_qsumsq;
     T.acc = c->d_acc; T.sinfo = c->d_sinfo; T.rowmap = c->d_rowmap; T.errflag = c->d_errflag; T.dbg = c->d_dbg; T.dp_pre = c->d_dp_pre;
-    T.site_base = c->d_site_base; T.site_hash = c->d_site_hash;
+    T.site_base = c->d_site_base; T.site_hash = c->d_site_hash; T.fslot = c->d_fslot;
     T.redo_list = c->d_redo_list; T.redo_count = c->d_redo_count; T.redo_cap = c->redo_cap; T.redo_bits = c->d_redo_bits;
     if (D.serial) {
         const size_t E = (size_t)c->max_sites * D.n_samples;
@@ -800,6 +801,7 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     if (c->timing) for (int k = 0; k < VGL_NEV; k++) HIPCHK(hipEventCreate(&e[k]));
     HIPCHK(hipMemsetAsync(c->d_acc, 0, sizeof(int32_t) * VGL_ACC_STRIDE * (size_t)n_sites, st));
     if (c->d_redo_count) HIPCHK(hipMemsetAsync(c->d_redo_count, 0, sizeof(uint32_t), st));
+    if (c->d_fslot) HIPCHK(hipMemsetAsync(c->d_fslot, 0, sizeof(unsigned long long) * 2 * (size_t)D.fused_split * (size_t)n_sites, st));
     if (c->timing) HIPCHK(hipEventRecord(e[VGL_T_DEPTH], st));        // depth draws ahead of k_sample (k_sitebase + k_depth; the scouts in serial mode)
     if (D.serial) {
         if (vgl_launch_scout(&D, &T, c->d_serial, st)) return fail(VGL_E_NODEVICE, "k_scout launch failed");
