@@ -531,10 +531,13 @@ __device__ __forceinline__ void wave_add_qsum_totals(int32_t* acc, const int lan
 // per step), u < 0.5 is the sign bit, floor(4u) the top two bits.  err_thresh16 = err_thresh << 16, saturated (sample_thresh16).
 __device__ __forceinline__ uint64_t lcg_next16(const uint64_t x) { return x * VGL_LCG_A + (VGL_LCG_C << 16); }
 __device__ __forceinline__ uint64_t sample_thresh16(const uint64_t t) { return t >= (1ULL << 48) ? ~0ULL : (t << 16); }
+// HOM (wave-uniform: every evaluation of the wavefront is homozygous): the haplotype stream is not stepped -- both alleles are the same
+// base, and in VGL_RNG_TILE the stream is the evaluation's own window, which nobody else reads
+template <bool HOM = false>
 __device__ __forceinline__ int sample_read_base16(uint64_t& st_hap, uint64_t& st_base, const int a0, const int a1,
                                                   const uint64_t err_thresh16, const bool sample_strand, bool& fwd) {
-    st_hap = lcg_next16(st_hap);
-    const int true_base = ((int64_t)st_hap >= 0) ? a0 : a1;
+    if (!HOM) st_hap = lcg_next16(st_hap);
+    const int true_base = HOM ? a0 : (((int64_t)st_hap >= 0) ? a0 : a1);
     int r_base = true_base;
     st_base = lcg_next16(st_base);
     if (st_base < err_thresh16) {

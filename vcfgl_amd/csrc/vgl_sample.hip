@@ -6,6 +6,7 @@
 // quality-score sampling of the wave's reads is an LDS-staged pool dealt dynamically to the lanes,
 // each lane a select-only state machine over normal-deviate attempts.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "vgl_common.hip.h"
 
@@ -288,6 +289,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
         if (!DUMP) asm volatile("" : "+v"(reads_v));
         else asm volatile("" : "+v"(reads_v), "+v"(reads_out_v), "+v"(reads_out_cap_v));
 
+        const bool homw = __ballot(active && dp > 0 && a0 != a1) == 0;   // every evaluation of the wavefront with reads is homozygous
         // the pool holds `cap` items; a wavefront with more reads works through segments of equal length
         const int nseg = (total + cap - 1) / (cap > 0 ? cap : 1);
         const int seglen = nseg > 1 ? (total + nseg - 1) / nseg : cap;
@@ -305,16 +307,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 const uint32_t sv_end = ((uint32_t)lane << 19) | ((uint32_t)r_end << 4);
                 uint32_t ka = 576u + 4u * (uint32_t)(offs + rdone - seg0);                     // l_it[k]  (the dynamic LDS block starts at 0)
                 uint32_t pa = 576u + 4u * ((uint32_t)cap + 2u) + (uint32_t)(offs + rdone - seg0);   // l_pb[k]
-                while (sv < sv_end) {
-                    bool fwd;
-                    const int r_base = sample_read_base16(st_hap16, st_base16, a0, a1, err_thresh16, k_strand, fwd);
-                    const uint64_t one = 1ULL << (16 * r_base);
-                    ad4 += one;
-                    if (!SLIM) { if (fwd) adf4 += one; }
-                    *(lds_u32o*)(uintptr_t)ka = sv;
-                    *(lds_u8o*)(uintptr_t)pa = (uint8_t)((LEAN == 3) ? (lane4 | (uint32_t)r_base) : (uint32_t)r_base);   // (LEAN 3: the dense pass finds the item's owner here)
-                    sv += 16u; ka += 4u; pa += 1u;
-                }
+                auto owner_reads = [&](auto hom_tag) {
+                    constexpr bool HOMW = decltype(hom_tag)::value;
+                    while (sv < sv_end) {
+                        bool fwd;
+                        const int r_base = sample_read_base16<HOMW>(st_hap16, st_base16, a0, a1, err_thresh16, k_strand, fwd);
+                        const uint64_t one = 1ULL << (16 * r_base);
+                        ad4 += one;
+                        if (!SLIM) { if (fwd) adf4 += one; }
+                        *(lds_u32o*)(uintptr_t)ka = sv;
+                        *(lds_u8o*)(uintptr_t)pa = (uint8_t)((LEAN == 3) ? (lane4 | (uint32_t)r_base) : (uint32_t)r_base);   // (LEAN 3: the dense pass finds the item's owner here)
+                        sv += 16u; ka += 4u; pa += 1u;
+                    }
+                };
+                // a wavefront of homozygous evaluations (most wavefronts of a rare variant's site) does not step the haplotype stream
+                if (homw) owner_reads(std::true_type{}); else owner_reads(std::false_type{});
             }
             if (lane == 0) { l_it[segT] = 0u; *l_ctr = 128u * 4u; }   // the "no item" slot of this segment's prefetches; first unclaimed item
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
