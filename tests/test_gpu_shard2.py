@@ -104,3 +104,9 @@ def test_bench_two_ranks_on_one_gpu_prints_a_self_describing_line():
     c = d["comm"]
     assert c["world"] == 2 and c["gather_ms"] > 0 and c["records_sample_bytes_into_writer"] > 0 and c["records_sample_GBps"] > 0
     assert "AFTER the timed steps" in c["records_sample_note"]
+    # (round 4) every rank's own rate and kernel buckets: a multi-GPU run shows a slow rank at once
+    rk = d["ranks"]
+    assert len(rk["evals_per_s"]["per_rank"]) == 2 and rk["evals_per_s"]["min"] > 0 and rk["evals_per_s"]["min"] <= rk["evals_per_s"]["max"]
+    assert len(rk["kernel_ms_per_launch"]) == 2 and all(set(k) == {"k_depth", "k_sample", "k_redo", "k_site", "k_gl", "k_siteagg"} for k in rk["kernel_ms_per_launch"])
+    assert all(k["k_sample"] > 0 and k["k_gl"] > 0 for k in rk["kernel_ms_per_launch"])
+    assert abs(d["value"] - 2 * 8192 * 1000 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]      # value = all ranks' evaluations / the slowest rank's time
