@@ -1,4 +1,4 @@
-# usage (GPU box): bash tools/r4_full.sh <tag> [workload ...]  -> the whole -m gpu suite, then bench lines of the given workloads
+# usage (GPU box): bash tools/gpu_suite_and_bench.sh <tag> [workload ...]  -> the whole -m gpu suite, then bench lines of the given workloads
 set -e
 export TMPDIR=/tmp
 tag=${1:-r4x}; shift || true

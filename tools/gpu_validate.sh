@@ -1,4 +1,4 @@
-# usage (GPU box): bash tools/r4_validate.sh  -> the whole -m gpu suite, a long fuzz run with fresh seeds, the host-program fuzz, full-size parity one-offs
+# usage (GPU box): bash tools/gpu_validate.sh  -> the whole -m gpu suite, a long fuzz run with fresh seeds, the host-program fuzz, full-size parity one-offs
 set -e
 export TMPDIR=/tmp
 out=gpurun_out/r4val; mkdir -p $out

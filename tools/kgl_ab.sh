@@ -1,3 +1,4 @@
+# usage (GPU box): tools/kgl_ab.sh -> k_gl tuning overrides of the hooks build (workgroup size, sort, XCD map, run table) on fixed-q and C3
 export VGL_LIB=$PWD/vcfgl_amd/lib/libvcfgl_hip_hooks.so
 Q="--no-cpu-baseline --no-extra --no-pack-rate --steps 3 --warmup 1"
 run() { python3 bench.py --workload $1 $Q 2>/dev/null | python3 -c "
