@@ -16,7 +16,7 @@ from vcfgl_amd import _abi
 
 pytestmark = pytest.mark.gpu
 
-FAST_LN, GAMMA_LU, GAMMA_SERIES, GAMMA_REFEXPR, QS_TF, RCP, TANF, EXP2, DIV, QUOT = range(10)
+FAST_LN, GAMMA_LU, GAMMA_SERIES, GAMMA_REFEXPR, QS_TF, RCP, TANF, EXP2, DIV, QUOT, DIV10 = range(11)
 
 
 def f2b(x):
@@ -93,3 +93,11 @@ def test_quot_int24_equals_ieee_float_division():
     every pair up to 4096, then 4e9 pseudo-random pairs up to 2^24 incl. sums at and next to powers of two"""
     r = sweep(QUOT, 0, 0, count=(1 << 24) + 4_000_000_000)
     check("quot_int24", r, 4e9)
+
+
+def test_div10_equals_the_reference_division_for_every_nonnegative_float():
+    """k_gl, GL model 1: GL = -cost / 10 (gl_methods.cpp:285) as x RN(1/10) + one residual correction: the same float32 as
+    (float)((double)x / 10.0) for EVERY non-negative finite float32 (zero, subnormals and the largest value included)"""
+    r = sweep(DIV10, 0, f2b(3.4028234663852886e38))
+    print(f"div10: {r['n']} arguments, violations {r['violations']}")
+    assert r["n"] >= 2.1e9 and r["violations"] == 0, r

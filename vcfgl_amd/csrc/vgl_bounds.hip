@@ -21,6 +21,7 @@ enum {
     VGL_BOUND_EXP2 = 7,         // v_exp_f32 on [-126, 8]                                 (poisson_attempt)
     VGL_BOUND_DIV = 8,          // div_inrange == IEEE quotient, operands shaped like the pool loop's (count = pairs)
     VGL_BOUND_QUOT = 9,         // quot_int24 == IEEE float32 quotient of integers q <= sum <= 2^24 (k_siteagg; count = pairs)
+    VGL_BOUND_DIV10 = 10,       // div10_f32(x) == (float)((double)x / 10.0) for every float32 bit pattern of the sweep (k_gl, GL model 1)
     VGL_BOUND_N
 };
 
@@ -52,6 +53,10 @@ __global__ __launch_bounds__(256) void k_bound_sweep(const uint32_t lo, const un
             const float b = fabsf(lu) * 0x1p-20f + 0x1p-21f;   // the log part of gamma_test_margin
             // d = lu + g is rounded once more (2^-24 of the larger term, g <= |lu| near the decision): 2^-24 |lu| reserved
             acc_update(mr, arg, viol, fabs((double)lu - log(xd)), (double)b - 5.97e-8 - fabs((double)lu) * 0x1p-24, bits);
+        } else if (MODE == VGL_BOUND_DIV10) {
+            // exact equality wanted: error 0 against a bound of 0 passes, anything else is a violation (acc_update)
+            const float want = (float)(xd / 10.0);
+            acc_update(mr, arg, viol, (__float_as_uint(div10_f32(x)) == __float_as_uint(want)) ? 0.0 : 1.0, 0.0, bits);
         } else if (MODE == VGL_BOUND_GAMMA_SERIES || MODE == VGL_BOUND_GAMMA_REFEXPR) {
             if (!(fabsf(x) <= 0.3333f)) { --n; continue; }
             const float a1f = (float)param;
@@ -173,6 +178,7 @@ extern "C" __attribute__((visibility("default"))) int vgl_dbg_bound_sweep(int mo
         case VGL_BOUND_RCP: hipLaunchKernelGGL((k_bound_sweep<VGL_BOUND_RCP>), g, b, 0, 0, lo_bits, count, param, d); break;
         case VGL_BOUND_TANF: hipLaunchKernelGGL((k_bound_sweep<VGL_BOUND_TANF>), g, b, 0, 0, lo_bits, count, param, d); break;
         case VGL_BOUND_EXP2: hipLaunchKernelGGL((k_bound_sweep<VGL_BOUND_EXP2>), g, b, 0, 0, lo_bits, count, param, d); break;
+        case VGL_BOUND_DIV10: hipLaunchKernelGGL((k_bound_sweep<VGL_BOUND_DIV10>), g, b, 0, 0, lo_bits, count, param, d); break;
         case VGL_BOUND_DIV: hipLaunchKernelGGL(k_bound_div, g, b, 0, 0, count, d); break;
         case VGL_BOUND_QUOT: hipLaunchKernelGGL(k_bound_quot, g, b, 0, 0, count, d); break;
         default: (void)hipFree(d); return -2;

@@ -284,6 +284,22 @@ __device__ __forceinline__ double recip_int24(const float sum) {
 }
 __device__ __forceinline__ float quot_int24(const float q, const double recip_sum) { return (float)((double)q * recip_sum); }
 
+// x / 10 in float32, correctly rounded, for finite x >= 0 (GL model 1: GL = -cost / 10, gl_methods.cpp:271-290 -- the reference divides in
+// double and rounds to float, which for a float numerator IS the float quotient): q0 = x RN(1/10), the exact residual, one correction
+// (Markstein) -- three instructions where the IEEE sequence takes ten.  Compared with the division over EVERY non-negative finite
+// float32 by tests/test_gpu_bounds.py (vgl_bounds.hip).
+__device__ __forceinline__ float div10_f32(const float x) {
+    const float y = 0.1f;                                            // RN(1/10)
+    const float q0 = x * y;
+    const float r = __builtin_fmaf(-10.0f, q0, x);
+    float q = __builtin_fmaf(r, y, q0);
+    if (__builtin_expect(__ballot(x != 0.0f && x < 0x1p-100f) != 0, 0)) {    // next to the subnormal range the residual is no longer exact: the division itself (never seen on real costs)
+        asm volatile("" ::: "memory");
+        q = (x < 0x1p-100f) ? x / 10.0f : q;
+    }
+    return q;
+}
+
 // error probability -> qScore / adjusted qScore, vcfgl.cpp:500-523
 static __device__ void errprob_to_qs(const VglDevParams& P, double ep, int& q, int& aq, uint32_t* errflag) {
     q = -1; aq = -1;

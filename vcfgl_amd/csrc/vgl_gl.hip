@@ -733,9 +733,13 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
                 bs[b] = (ob[0] == (uint32_t)b) ? acck[0] : ((ob[1] == (uint32_t)b) ? acck[1] : ((ob[2] == (uint32_t)b) ? acck[2] : acck[3]));
         }
         float mx = -INFINITY;
+        // (round 4) only the genotypes some evaluation of the wavefront has: alleles beyond the largest allele count among its sites are
+        // never written (C3's binary sites: 3 of 5 alleles, 6 of 15 genotypes)
+        const int nA_w = 1 + (__ballot(on && nA >= 2) != 0) + (__ballot(on && nA >= 3) != 0) + (__ballot(on && nA >= 4) != 0) + (__ballot(on && nA >= 5) != 0);
         if (on) {
 #pragma unroll
             for (int i = 0; i < A; ++i) {
+                if (i >= nA_w) continue;                                  // wave-uniform
 #pragma unroll
                 for (int j = 0; j <= i; ++j) {
                     const int idx = i * (i + 1) / 2 + j;
@@ -756,7 +760,7 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
                         q = tmp2 ? (float)(-4.343 * lh + (double)tmp1) : (float)(-4.343 * lh);
                     }
                     if (q < 0.0f) q = 0.0f;
-                    const float v = (float)((-1.0 * (double)q) / 10.0);
+                    const float v = -div10_f32(q);                          // = (float)((-1.0 * (double)q) / 10.0), gl_methods.cpp:285 (q >= 0, finite)
                     acc[idx] = v;
                     if (i < nA) mx = (v > mx) ? v : mx;
                 }
