@@ -16,7 +16,7 @@ from vcfgl_amd import _abi
 
 pytestmark = pytest.mark.gpu
 
-FAST_LN, GAMMA_LU, GAMMA_SERIES, GAMMA_REFEXPR, QS_TF, RCP, TANF, EXP2, DIV, QUOT, DIV10 = range(11)
+FAST_LN, GAMMA_LU, GAMMA_SERIES, GAMMA_REFEXPR, QS_TF, RCP, TANF, EXP2, DIV, QUOT, DIV10, POISSON = range(12)
 
 
 def f2b(x):
@@ -101,3 +101,17 @@ def test_div10_equals_the_reference_division_for_every_nonnegative_float():
     r = sweep(DIV10, 0, f2b(3.4028234663852886e38))
     print(f"div10: {r['n']} arguments, violations {r['violations']}")
     assert r["n"] >= 2.1e9 and r["violations"] == 0, r
+
+
+@pytest.mark.parametrize("depth", [12.0, 20.0, 30.5, 100.0, 1000.25, 40000.0])
+def test_poisson_attempt_float32_decisions_equal_the_exact_ones(depth):
+    """k_depth / poisson_attempt: the rejection method's attempt (rng.h:302-309) decided in float32 -- sign of sq tan(PI u) + lm, its floor,
+    the acceptance test, and the two shortcuts (certainly negative; beyond e_hi certainly rejected) -- equals the float64 evaluation
+    wherever poisson_fast() does not ask for it: 2^32 attempts per mean depth (half pseudo-random, half next to the pole of tan, next to
+    integer values of the scaled tangent, next to zero, and with the smallest acceptance draws).  The ambiguous share of the
+    pseudo-random attempts is what sends a wavefront of k_depth into the float64 path: on record, and bounded for the usual depths."""
+    r = sweep(POISSON, 0, 0, param=depth, count=1 << 32)
+    print(f"poisson depth {depth}: {r['n']} attempts, violations {r['violations']} (last at index {r['arg_bits']}), ambiguous share of random attempts {r['max_ratio']:.3e}")
+    assert r["n"] == 1 << 32 and r["violations"] == 0, r
+    if depth <= 100.0:
+        assert r["max_ratio"] < 2e-4, r

@@ -22,6 +22,7 @@ enum {
     VGL_BOUND_DIV = 8,          // div_inrange == IEEE quotient, operands shaped like the pool loop's (count = pairs)
     VGL_BOUND_QUOT = 9,         // quot_int24 == IEEE float32 quotient of integers q <= sum <= 2^24 (k_siteagg; count = pairs)
     VGL_BOUND_DIV10 = 10,       // div10_f32(x) == (float)((double)x / 10.0) for every float32 bit pattern of the sweep (k_gl, GL model 1)
+    VGL_BOUND_POISSON = 11,     // poisson_fast == poisson_exact wherever it does not call the attempt ambiguous (param = mean depth; count = attempts)
     VGL_BOUND_N
 };
 
@@ -164,8 +165,53 @@ __global__ __launch_bounds__(256) void k_bound_quot(const unsigned long long cou
     if (viol) { atomicAdd(&out->viol, viol); out->arg_bits = arg; }
 }
 
+// poisson_fast against poisson_exact (param = the mean depth).  Attempts by class (i & 7):
+//   0-3  pseudo-random st1, st2 = the generator's next state (as the kernels pair them) -- the ambiguous share of THESE is reported;
+//   4    a = PI u next to the pole PI / 2, 2^-k away on either side (k = 8 .. 47);
+//   5    sq tan(a) + lm next to an integer m in [0, 4 lm]: st1 = 2^48 atan((m - lm) / sq) / PI +- 2^k (k = 0 .. 31);
+//   6    the same next to m = 0 (the sign test);
+//   7    acceptance draws from the low end (st2 < 2^k, zero included) with a far out on the tail (large y).
+// A violation: poisson_fast() does not call the attempt ambiguous and `neg`, or (when not neg) `rej`, or (when accepted) em differ.
+__global__ __launch_bounds__(256) void k_bound_poisson(const unsigned long long count, const VglPois p, const double* glt, const int glt_n, BoundAcc* out) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long viol = 0, n = 0, n_rand = 0, amb_rand = 0; uint32_t arg = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const uint64_t h = mix64(i * 2 + 1), h2 = mix64(i * 2 + 2);
+        const int cls = (int)(i & 7);
+        uint64_t st1 = h & VGL_MASK48, st2;
+        if (cls == 4) {
+            const double pole = (1.5707963267948966 / VGL_PI) * 281474976710656.0;
+            const uint64_t off = (h2 & VGL_MASK48) >> (8 + (uint32_t)((i >> 3) % 40));
+            st1 = (uint64_t)((h >> 60) & 1 ? pole + (double)off : pole - (double)off) & VGL_MASK48;
+        } else if (cls == 5 || cls == 6) {
+            const double m = (cls == 6) ? 0.0 : floor((double)((h >> 48) & 0xFFFF) * (1.0 / 65536.0) * 4.0 * p.lm);
+            double u = atan((m - p.lm) / p.sq) / VGL_PI;
+            if (u < 0.0) u += 1.0;
+            const uint64_t off = (h2 & 0xFFFFFFFFULL) >> ((uint32_t)((i >> 3) & 31));
+            st1 = (uint64_t)((h >> 47) & 1 ? u * 281474976710656.0 + (double)off : u * 281474976710656.0 - (double)off) & VGL_MASK48;
+        } else if (cls == 7) {
+            st1 = ((1ULL << 47) - ((h & VGL_MASK48) >> (9 + (uint32_t)((i >> 3) % 38)))) & VGL_MASK48;     // a just below PI / 2 .. a quarter turn
+        }
+        st2 = lcg_next(st1);
+        if (cls == 7) st2 = (h2 & VGL_MASK48) >> (8 + (uint32_t)((i >> 9) % 41));                       // down to 0
+        bool neg, rej, amb, nege, reje; int em, eme;
+        poisson_fast(p, st1, st2, glt, glt_n, neg, rej, em, amb);
+        poisson_exact(p, st1, st2, glt, glt_n, nege, reje, eme);
+        ++n;
+        if (cls < 4) { ++n_rand; amb_rand += amb ? 1u : 0u; }
+        if (!amb) {
+            const bool bad = (neg != nege) || (!nege && rej != reje) || (!nege && !reje && em != eme);
+            if (bad) { ++viol; arg = (uint32_t)i; }
+        }
+    }
+    atomicAdd(&out->n, n);
+    atomicAdd(&out->max_ratio_bits, amb_rand);                      // (this mode: the count of ambiguous attempts among the pseudo-random ones)
+    if (viol) { atomicAdd(&out->viol, viol); out->arg_bits = arg; }
+    (void)n_rand;
+}
+
 extern "C" __attribute__((visibility("default"))) int vgl_dbg_bound_sweep(int mode, uint32_t lo_bits, unsigned long long count, double param, double out[4]) {
-    BoundAcc* d = nullptr;
+    BoundAcc* d = nullptr; double* d_glt = nullptr;
     if (hipMalloc((void**)&d, sizeof(BoundAcc)) != hipSuccess) return -1;
     if (hipMemset(d, 0, sizeof(BoundAcc)) != hipSuccess) { (void)hipFree(d); return -1; }
     const dim3 g(256 * 16), b(256);
@@ -181,13 +227,30 @@ extern "C" __attribute__((visibility("default"))) int vgl_dbg_bound_sweep(int mo
         case VGL_BOUND_DIV10: hipLaunchKernelGGL((k_bound_sweep<VGL_BOUND_DIV10>), g, b, 0, 0, lo_bits, count, param, d); break;
         case VGL_BOUND_DIV: hipLaunchKernelGGL(k_bound_div, g, b, 0, 0, count, d); break;
         case VGL_BOUND_QUOT: hipLaunchKernelGGL(k_bound_quot, g, b, 0, 0, count, d); break;
+        case VGL_BOUND_POISSON: {
+            if (!(param >= 12.0)) { (void)hipFree(d); return -2; }
+            VglPois pp;
+            vgl_pois_init(&pp, param);
+            const int gn = 2048;
+            double* hg = (double*)malloc(sizeof(double) * gn);
+            if (!hg) { (void)hipFree(d); return -1; }
+            hg[0] = 0.0;
+            for (int k = 1; k < gn; k++) hg[k] = vgl_gamma_ln_host((double)k);
+            if (hipMalloc((void**)&d_glt, sizeof(double) * gn) != hipSuccess || hipMemcpy(d_glt, hg, sizeof(double) * gn, hipMemcpyHostToDevice) != hipSuccess) {
+                free(hg); (void)hipFree(d_glt); (void)hipFree(d); return -1;
+            }
+            free(hg);
+            hipLaunchKernelGGL(k_bound_poisson, g, b, 0, 0, count, pp, d_glt, gn, d);
+            break;
+        }
         default: (void)hipFree(d); return -2;
     }
     BoundAcc h;
-    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipFree(d); return -1; }
-    (void)hipFree(d);
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipFree(d_glt); (void)hipFree(d); return -1; }
+    (void)hipFree(d_glt); (void)hipFree(d);
     out[0] = (double)h.n; out[1] = (double)h.viol;
-    out[2] = __builtin_bit_cast(double, h.max_ratio_bits);
+    out[2] = (mode == VGL_BOUND_POISSON) ? (double)h.max_ratio_bits / (0.5 * (double)(h.n ? h.n : 1))     // ambiguous share of the pseudo-random half
+                                         : __builtin_bit_cast(double, h.max_ratio_bits);
     out[3] = (double)h.arg_bits;
     return 0;
 }

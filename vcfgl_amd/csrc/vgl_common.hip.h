@@ -141,50 +141,77 @@ __device__ __forceinline__ float vgl_tanf_0pi(const float a) {
     const float t = __builtin_fmaf(p * z, r, r);
     return (n == 1.0f) ? -__builtin_amdgcn_rcpf(t) : t;
 }
-// |tanf(af) - tan(a)| for af = (float)a: 4 ulp of the result + the argument's rounding (half of the second term) through tan' = 1 + y^2
-__device__ __forceinline__ float tanf_err_bound(const float yf, const float y2, const float af) {
-    return fabsf(yf) * 0x1p-21f + (1.0f + y2) * af * 0x1p-23f;
-}
-// relative error of tt = 0.9f (1 + y2) v_exp_f32((float)(z log2 e)) against 0.9 (1 + y^2) exp(z), given dy = tanf_err_bound().
-// The factor (1 + y^2) contributes 2 |y| dy / (1 + y^2) <= dy (1 + y^2 >= 2 |y|): the bound itself is used -- an IEEE float32 division
-// (eleven instructions per attempt) bought a narrower band only where |tan| is far from 1, and the band only decides how often the exact
-// evaluation runs
-__device__ __forceinline__ float poisson_t_rel_err(const float yf, const float y2, const float dy, const float zf) {
-    (void)yf; (void)y2;
-    return dy + fabsf(zf) * 0x1p-22f + 0x1p-19f;
-}
-// one rejection attempt (rng.h:302-309) from the two generator states it would consume: `neg`: em < 0
-// (only st1 is consumed, no acceptance draw), else `rej` = the acceptance draw u(st2) exceeds t.
-__device__ __forceinline__ void poisson_attempt(const VglPois& p, const uint64_t st1, const uint64_t st2, const bool need,
-                                                const double* __restrict__ glt, const int glt_n, bool& neg, bool& rej, double& em) {
-    const double a = VGL_PI * u01(st1);
-    const float af = (float)a;
+// One rejection attempt (rng.h:302-309) decided in float32 (round 4: no float64 arithmetic but the three operations of the exponent).
+//   a = PI u1, u1 = st1 2^-48.  af = (float)(st1 >> 16) * (float)(PI 2^-32): |af - a| <= a 2.5 x 2^-24 + PI 2^-32 (the truncated 16 bits,
+//   the conversion, the constant -- 2^-25.1 -- and the product).
+//   yf = vgl_tanf_0pi(af):  |yf - tan(af)| <= |yf| 2^-21 + (1 + yf^2) af 2^-24 for EVERY float of the range (VGL_BOUND_TANF), and
+//   tan(af + d) - tan(af) = tan d (1 + Y^2) / (1 - Y tan d), Y = tan(af): at most 2 |d| (1 + Y^2) while |Y d| <= 1/2.  Hence
+//       dy = |yf| 2^-21 + (1 + yf^2) (af 7 x 2^-24 + 2e-9)  >=  |yf - tan(a)|          [7 > 1 + 2 x 2.5 with room for yf^2 against Y^2]
+//   in that regime; outside it (next to the pole at PI/2) dy > |yf|, which (a) puts sq dy > 1 over every test of the floor below and
+//   (b) fails the explicit guard dy <= |yf| / 2 in front of the two shortcuts -- nothing is decided from an invalid bound.
+//   e0f = fma(sqf, yf, lmf) against e0 = sq tan(a) + lm:  derr = sqf dy + 2^-22 (|sqf yf| + lmf) + 1e-7 (the float parameters, the fma, the
+//   subtraction 1 - fr below, with a factor 2 in hand).
+//   Decisions: e0 < 0 (`neg`; nothing else of the attempt is then used) when e0f < -derr; e0 >= 0 when e0f > derr, and then either
+//     * the attempt is rejected whatever floor(e0) is: e0f - derr >= p.e_hi, the host's bound beyond which 0.9 (1 + y^2) exp(..) < 2^-60
+//       for every em (pois_init), against an acceptance draw u2 >= 2^-32 -- the Lorentzian's tail: |y| > 300 in one attempt of 500, which
+//       the float bounds of the floor cannot resolve and the gamma_ln table does not reach;
+//     * or floor(e0) = floorf(e0f) (both distances to the neighbouring integers exceed derr), inside the table, and the acceptance test
+//       u2 > t is decided from tt = 0.9f (1 + yf^2) v_exp_f32(z log2 e) with relative error dy + |z| 2^-22 + 2^-19 (VGL_BOUND_EXP2; the
+//       factor (1 + y^2) contributes 2 |y| dy / (1 + y^2) <= dy) against u2f = (float)(st2 >> 16) 2^-32 (2^-24 relative + 2^-32).
+//   Anything else is `amb`: the caller evaluates the attempt exactly (poisson_exact), behind a wave-uniform branch.
+// tests/test_gpu_bounds.py (VGL_BOUND_POISSON) runs both on 2^32 attempts per mean depth -- pseudo-random, next to the pole, next to
+// integer e0 -- and requires every decision poisson_fast() does not call ambiguous to equal the exact one; it prints the ambiguous share.
+__device__ __forceinline__ void poisson_fast(const VglPois& p, const uint64_t st1, const uint64_t st2, const double* __restrict__ glt, const int glt_n,
+                                             bool& neg, bool& rej, int& em, bool& amb) {
+    const float af = (float)(uint32_t)(st1 >> 16) * ((float)VGL_PI * 0x1p-32f);    // (the constant: 0x1.921fb6p-31)
     const float yf = vgl_tanf_0pi(af);
-    const float y2 = yf * yf;
-    const float dy = tanf_err_bound(yf, y2, af);                             // |yf - tan(a)|
-    const double e0 = p.sq * (double)yf + p.lm;
-    const double derr = p.sq * (double)dy + 1e-9;
-    em = floor(e0);
-    const bool amb_em = (e0 - em < derr) | (em + 1.0 - e0 < derr) | !(fabs(e0) < 1.0e6);
-    neg = e0 < 0.0;
-    const bool in_tab = (em >= 0.0) & (em < (double)(glt_n - 1));
-    const double gl = glt[in_tab ? (int)em + 1 : 1];
-    const double z = em * p.alxm - gl - p.g;
+    const float y2 = yf * yf, ay = fabsf(yf);
+    const float dy = __builtin_fmaf(ay, 0x1p-21f, (1.0f + y2) * __builtin_fmaf(af, 7.0f * 0x1p-24f, 2e-9f));
+    const float e0f = __builtin_fmaf(p.sqf, yf, p.lmf);
+    const float derr = __builtin_fmaf(p.sqf, dy, 0x1p-22f * (fabsf(p.sqf * yf) + p.lmf)) + 1e-7f;
+    const bool guard = dy <= 0.5f * ay;
+    const float emf = __builtin_floorf(e0f);
+    const float fr = e0f - emf;                                              // exact
+    const bool floor_ok = (fr > derr) & (1.0f - fr > derr) & (fabsf(e0f) < 1.0e6f);
+    const bool sure_neg = guard & (e0f < -derr);
+    const bool sure_pos = e0f > derr;
+    const uint32_t hi2 = (uint32_t)(st2 >> 16);
+    const bool sure_rej = guard & (e0f - derr >= p.e_hi) & (hi2 != 0u);
+    em = (int)emf;                                                           // (saturates; used only where floor_ok)
+    const bool in_tab = (em >= 0) & (em < glt_n - 1);
+    const double gl = glt[in_tab ? em + 1 : 1];
+    const double z = (double)emf * p.alxm - gl - p.g;
     const float ex = __builtin_amdgcn_exp2f((float)(z * 1.4426950408889634));
     const float tt = 0.9f * (1.0f + y2) * ex;
-    const float rel_t = poisson_t_rel_err(yf, y2, dy, (float)z);
-    const double u2 = u01(st2);
-    rej = u2 > (double)tt;
-    const bool amb_t = fabs(u2 - (double)tt) <= (double)(tt * rel_t) + 1e-30;
-    const bool amb = need & (amb_em | (!neg & (amb_t | !in_tab)));
+    const float rel_t = dy + fabsf((float)z) * 0x1p-22f + 0x1p-19f;
+    const float u2f = (float)hi2 * 0x1p-32f;
+    const bool t_ok = fabsf(u2f - tt) > __builtin_fmaf(tt, rel_t, __builtin_fmaf(u2f, 0x1p-22f, 0x1p-30f));
+    neg = sure_neg;
+    rej = sure_rej | (u2f > tt);
+    amb = !(sure_neg | (sure_pos & (sure_rej | (floor_ok & in_tab & t_ok))));
+}
+// the attempt as the reference evaluates it (rng.h:302-309)
+__device__ __forceinline__ void poisson_exact(const VglPois& p, const uint64_t st1, const uint64_t st2, const double* __restrict__ glt, const int glt_n,
+                                              bool& neg, bool& rej, int& em) {
+    const double y = tan(VGL_PI * u01(st1));
+    double eme = p.sq * y + p.lm;
+    neg = eme < 0.0;
+    eme = floor(eme);
+    const double t = 0.9 * (1.0 + y * y) * exp(eme * p.alxm - ((eme >= 0.0 && eme < (double)(glt_n - 1)) ? glt[(int)eme + 1] : gamma_ln_dev(eme + 1.0)) - p.g);
+    rej = u01(st2) > t;
+    em = (int)eme;
+}
+// one rejection attempt from the two generator states it would consume: `neg`: em < 0
+// (only st1 is consumed, no acceptance draw), else `rej` = the acceptance draw u(st2) exceeds t, else the draw is `em`.
+__device__ __forceinline__ void poisson_attempt(const VglPois& p, const uint64_t st1, const uint64_t st2, const bool need,
+                                                const double* __restrict__ glt, const int glt_n, bool& neg, bool& rej, int& em) {
+    bool amb;
+    poisson_fast(p, st1, st2, glt, glt_n, neg, rej, em, amb);
+    amb &= need;
     if (__builtin_expect(__ballot(amb) != 0, 0)) {               // exact evaluation (rare, wave-uniform branch)
         asm volatile("" ::: "memory");
-        const double y = tan(a);
-        double eme = p.sq * y + p.lm;
-        const bool nege = eme < 0.0;
-        eme = floor(eme);
-        const double t = 0.9 * (1.0 + y * y) * exp(eme * p.alxm - ((eme >= 0.0 && eme < (double)(glt_n - 1)) ? glt[(int)eme + 1] : gamma_ln_dev(eme + 1.0)) - p.g);
-        const bool reje = u2 > t;
+        bool nege, reje; int eme;
+        poisson_exact(p, st1, st2, glt, glt_n, nege, reje, eme);
         neg = amb ? nege : neg; em = amb ? eme : em; rej = amb ? reje : rej;
     }
 }
@@ -196,18 +223,18 @@ static __device__ int poisson_draw_fast(const VglPois& p, uint64_t& st, const do
         return (int)em;
     }
     bool done = false;
-    double em_res = 0.0;
+    int em_res = 0;
     while (__ballot(!done)) {
         const uint64_t st1 = lcg_next(st);
         const uint64_t st2 = lcg_next(st1);
-        bool neg, reject; double em;
+        bool neg, reject; int em;
         poisson_attempt(p, st1, st2, !done, glt, glt_n, neg, reject, em);
         const bool acc = !done & !neg & !reject;
         st = done ? st : (neg ? st1 : st2);                          // em < 0 consumes one draw, an attempt two
         em_res = acc ? em : em_res;
         done = done | acc;
     }
-    return (int)em_res;
+    return em_res;
 }
 
 // sample_NormalSampler_0_1_0, rng.h:70-80

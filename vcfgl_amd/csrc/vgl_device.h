@@ -40,7 +40,9 @@ static inline uint64_t vgl_site_hash(uint64_t x, const int W) {
 }
 
 // PoissonSampler (rng.h:249-280), one per run or one per sample
-struct VglPois { double lm, sq, alxm, g; int32_t st12; int32_t pad; };
+// sqf, lmf: sq and lm rounded to float32; e_hi: an attempt of the rejection method whose sq tan(..) + lm is at least e_hi is rejected
+// by every acceptance draw >= 2^-32 (poisson_fast, vgl_common.hip.h; pois_init, vgl_host.cpp)
+struct VglPois { double lm, sq, alxm, g; float sqf, lmf, e_hi; int32_t st12; };
 
 // Gamma1Sampler (rng.h:122-173)
 struct VglGamma1 { double alpha0, a1, a2; int32_t changed; int32_t pad; };
@@ -253,6 +255,9 @@ int vgl_chain_chunk(const VglDevParams* p, struct VglSerialState* S, struct VglC
                     uint32_t* snap, long long* snap_words, void* stream);
 int vgl_chain_emit(const VglDevParams* p, struct VglSerialState* S, const struct VglChainCtl* ctl, const uint32_t* W, const uint32_t* pos,
                    long long n_chunk, double* out, const uint32_t* snap, const long long* snap_words, long long n_snap, void* stream);
+// vgl_host.cpp (host): PoissonSampler_init with the float32 parameters of poisson_fast; the reference's gamma_ln -- also what vgl_bounds.hip sweeps with
+void vgl_pois_init(struct VglPois* o, double lambda);
+double vgl_gamma_ln_host(double x);
 #ifdef __cplusplus
 }
 #endif

@@ -262,7 +262,7 @@ static double gamma_ln_host(double xx) {                      // gamma_ln, rng.h
 }
 
 static void pois_init(VglPois* o, double lambda) {            // PoissonSampler_init, rng.h:259-280
-    o->lm = lambda; o->sq = -1.0; o->alxm = -1.0; o->g = -1.0; o->st12 = 1; o->pad = 0;
+    o->lm = lambda; o->sq = -1.0; o->alxm = -1.0; o->g = -1.0; o->st12 = 1; o->sqf = -1.0f; o->lmf = (float)lambda; o->e_hi = INFINITY;
     if (lambda < 12.0) o->g = exp(-lambda);
     else {
         o->st12 = 0; o->sq = sqrt(2.0 * lambda); o->alxm = log(lambda);
@@ -274,8 +274,30 @@ static void pois_init(VglPois* o, double lambda) {            // PoissonSampler_
         double ser = 1.000000000190015;
         for (int j = 0; j <= 5; j++) ser += cof[j] / ++y;
         o->g = lambda * o->alxm - (-tmp + log(2.5066282746310005 * ser / x));
+        // poisson_fast (vgl_common.hip.h): the float32 parameters, and e_hi = the smallest integer E with
+        //     B(em) = 0.9 (1 + ((em + 1 - lm) / sq + 1e-6)^2) exp(em alxm - lgamma(em + 1) - g) < 2^-60   for every em >= E.
+        // B(em) bounds the acceptance threshold t of every attempt whose floor is em (y < (em + 1 - lm) / sq), and B decreases from
+        // em + 1 - lm = k0 >= 2 sqrt(lm) + 8 on: B(em + 1) / B(em) <= (1 + 2.2 / k) / (1 + k / lm) < 1 for k^2 > 2.2 lm -- so E is found by
+        // bisection above k0.  (lgamma against the reference's six-term gamma_ln: 2e-10 relative, against a margin of 2^28.)
+        o->sqf = (float)o->sq;
+        const double lim = -60.0 * 0.6931471805599453;
+        auto logB = [&](double em) {
+            const double yb = (em + 1.0 - lambda) / o->sq + 1e-6;
+            return log(0.9) + log1p(yb * yb) + em * o->alxm - lgamma(em + 1.0) - o->g;
+        };
+        double lo = ceil(lambda + 2.0 * sqrt(lambda) + 8.0);                // B decreases from here on
+        if (logB(lo) >= lim) {
+            double hi = 2.0 * lo + 64.0;
+            while (logB(hi) >= lim && hi < 1e12) hi *= 2.0;
+            while (hi - lo > 1.0) { const double mid = floor(0.5 * (lo + hi)); if (logB(mid) >= lim) lo = mid; else hi = mid; }
+            lo = hi;
+        }
+        o->e_hi = (lo < 8.0e6) ? (float)lo : INFINITY;                      // (integers below 2^23 are float32 values)
     }
 }
+
+extern "C" void vgl_pois_init(VglPois* o, double lambda) { pois_init(o, lambda); }
+extern "C" double vgl_gamma_ln_host(double x) { return gamma_ln_host(x); }
 
 static void gamma1_init(VglGamma1* g, double shape) {         // Gamma1Sampler_init, rng.h:155-173
     double alpha = shape;
@@ -450,8 +472,9 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
                   !D.gx.changed && !D.gy.changed && D.gx.alpha0 >= 8.0 && D.gy.alpha0 >= 8.0 && !hook_env("VGL_NO_DEFER") && !hook_env("VGL_DEBUG_QS_EXACT") && !hook_env("VGL_NO_LEAN")) ? 1 : 0;
     // one workgroup per site does everything (k_gl<.., FUSED>, vgl_gl.hip): sampling with one fixed score, the site's allele order and the
     // likelihoods, with nothing staged in HBM between them
-    // (round 4: sites of more than 512 samples split over up to four consecutive workgroups, up to 128 staged reads, depths from k_depth where the
-    // rejection method draws them -- the reference's default error model at depth 20 runs fused too; VGL_FUSE_MAX_SPLIT: tuning hook)
+    // (round 4: sites of more than 512 samples split over up to four consecutive workgroups, up to 128 staged reads.  The kernel also takes its
+    // depths from k_depth where the rejection method draws them, but at depth 20 the three kernels measure faster, so that stays behind the
+    // hooks build's VGL_FUSE_DEEP; VGL_FUSE_MAX_SPLIT: tuning hook)
     D.fused_split = N <= 512 ? 1 : (N + 511) / 512;
     D.fused = (!D.serial && p->error_qs == 0 && p->gl_model == 2 && !p->precise_gl && (D.depth_pre == 2 || D.depth_pre == 1) && !D.need_qsum && !D.sample_strand &&
                (D.depth_pre == 2 || hook_int("VGL_FUSE_DEEP", 0)) &&      // measured (tools/fuse_ab.sh): at depth 20 the three kernels are faster (1.50e10 against 1.40e10 at N = 500, 1.55e10 against 1.36e10 at N = 1000)

@@ -67,11 +67,10 @@ __global__ __launch_bounds__(256) void k_depth(const VglDevParams P, const VglTi
     while (__ballot(busy)) {
         // one rejection attempt (rng.h:300-312); k_depth runs only when every sample uses this method
         const uint64_t st1 = lcg_next(st), st2 = lcg_next(st1);
-        bool neg, reject; double e2;
-        poisson_attempt(pp, st1, st2, busy, P.gamma_ln_tab, P.gamma_ln_n, neg, reject, e2);
+        bool neg, reject; int result;
+        poisson_attempt(pp, st1, st2, busy, P.gamma_ln_tab, P.gamma_ln_n, neg, reject, result);
         st = neg ? st1 : st2;                                            // em < 0 consumes one draw, an attempt two
         const bool done = busy && !neg && !reject;
-        const int result = (int)e2;
         if (done) T.dp_pre[c0 + i] = result;
         // lanes that finished take the next undealt evaluation of the chunk
         const uint64_t dm = __ballot(done);
