@@ -103,15 +103,17 @@ def test_div10_equals_the_reference_division_for_every_nonnegative_float():
     assert r["n"] >= 2.1e9 and r["violations"] == 0, r
 
 
+@pytest.mark.parametrize("table", [False, True])
 @pytest.mark.parametrize("depth", [12.0, 20.0, 30.5, 100.0, 1000.25, 40000.0])
-def test_poisson_attempt_float32_decisions_equal_the_exact_ones(depth):
+def test_poisson_attempt_float32_decisions_equal_the_exact_ones(depth, table):
     """k_depth / poisson_attempt: the rejection method's attempt (rng.h:302-309) decided in float32 -- sign of sq tan(PI u) + lm, its floor,
     the acceptance test, and the two shortcuts (certainly negative; beyond e_hi certainly rejected) -- equals the float64 evaluation
     wherever poisson_fast() does not ask for it: 2^32 attempts per mean depth (half pseudo-random, half next to the pole of tan, next to
     integer values of the scaled tangent, next to zero, and with the smallest acceptance draws).  The ambiguous share of the
-    pseudo-random attempts is what sends a wavefront of k_depth into the float64 path: on record, and bounded for the usual depths."""
-    r = sweep(POISSON, 0, 0, param=depth, count=1 << 32)
-    print(f"poisson depth {depth}: {r['n']} attempts, violations {r['violations']} (last at index {r['arg_bits']}), ambiguous share of random attempts {r['max_ratio']:.3e}")
+    pseudo-random attempts is what sends a wavefront of k_depth into the float64 path: on record, and bounded for the usual depths.
+    table: the acceptance bound's exponent from the float32 table of the one-depth build (k_depth<true>) instead of the float64 expression."""
+    r = sweep(POISSON, 0, 0, param=-depth if table else depth, count=1 << 32)
+    print(f"poisson depth {depth}{' (exponent table)' if table else ''}: {r['n']} attempts, violations {r['violations']} (last at index {r['arg_bits']}), ambiguous share of random attempts {r['max_ratio']:.3e}")
     assert r["n"] == 1 << 32 and r["violations"] == 0, r
     if depth <= 100.0:
         assert r["max_ratio"] < 2e-4, r

@@ -112,6 +112,35 @@ def test_depth_kernel_chunks_span_sites(oracle, N, n_sites):
     assert np.array_equal(want.numpy("gl").view(np.uint32), got.numpy("gl").view(np.uint32))
 
 
+@pytest.mark.parametrize("chunk", [2048, 4096])
+@pytest.mark.parametrize("N,n_sites", [(1, 9000), (3, 3000), (100, 90), (1000, 9), (2047, 5), (2048, 5), (2500, 4), (4095, 3), (4097, 3)])
+def test_depth_kernel_large_chunks(oracle, monkeypatch, N, n_sites, chunk):
+    """k_depth's chunk grows with the tile (2048 evaluations per wavefront from 2^23 evaluations, 4096 from 2^24): forced here on small
+    tiles (hooks build) -- chunks spanning up to thousands of sites, sample counts around the chunk size (the one-compare site lookup
+    needs N >= chunk, the multiply-high t < N + chunk), a ragged last chunk"""
+    monkeypatch.setenv("VGL_DEPTH_CHUNK", str(chunk))
+    args = VcfglArgs(seed=5, depth=13.0, error_rate=0.01, add_fmt_ad=1)
+    want, got = run_both(oracle, args, synth.binary_sites(19, n_sites, N), site0=19, hooks=True)
+    for f in ("site_status", "fmt_dp", "info_dp", "fmt_ad"):
+        assert np.array_equal(want.numpy(f), got.numpy(f)), f
+    assert np.array_equal(want.numpy("gl").view(np.uint32), got.numpy("gl").view(np.uint32))
+
+
+@pytest.mark.parametrize("depth", [12.0, 17.3, 48.0, 260.0])
+def test_depth_kernel_without_the_exponent_table(oracle, monkeypatch, depth):
+    """k_depth<ZT>: with one mean depth the acceptance bound's exponent comes from a float32 table (VglDevParams::pois_zt); with per-sample
+    depths, and here with VGL_NO_POIS_ZT (hooks build), from the float64 expression -- the same draws either way"""
+    args = VcfglArgs(seed=23, depth=depth, error_rate=0.01, add_fmt_ad=1)
+    gt = synth.binary_sites(0, 40, 257)
+    want, got = run_both(oracle, args, gt)
+    monkeypatch.setenv("VGL_NO_POIS_ZT", "1")
+    _, plain = run_both(oracle, args, gt, hooks=True)
+    for f in ("fmt_dp", "info_dp", "fmt_ad"):
+        assert np.array_equal(want.numpy(f), got.numpy(f)), f
+        assert np.array_equal(plain.numpy(f), got.numpy(f)), f
+    assert np.array_equal(want.numpy("gl").view(np.uint32), got.numpy("gl").view(np.uint32))
+
+
 @pytest.mark.parametrize("du", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("rm", [(0, 0), (4, 1)])
 def test_unobserved_and_skip_modes(oracle, du, rm):

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void k_bound_quot(const unsigned long long cou
 //   6    the same next to m = 0 (the sign test);
 //   7    acceptance draws from the low end (st2 < 2^k, zero included) with a far out on the tail (large y).
 // A violation: poisson_fast() does not call the attempt ambiguous and `neg`, or (when not neg) `rej`, or (when accepted) em differ.
-__global__ __launch_bounds__(256) void k_bound_poisson(const unsigned long long count, const VglPois p, const double* glt, const int glt_n, BoundAcc* out) {
+__global__ __launch_bounds__(256) void k_bound_poisson(const unsigned long long count, const VglPois p, const double* glt, const int glt_n, const float* zt, BoundAcc* out) {
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
     unsigned long long viol = 0, n = 0, n_rand = 0, amb_rand = 0; uint32_t arg = 0;
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
@@ -195,7 +195,8 @@ __global__ __launch_bounds__(256) void k_bound_poisson(const unsigned long long 
         st2 = lcg_next(st1);
         if (cls == 7) st2 = (h2 & VGL_MASK48) >> (8 + (uint32_t)((i >> 9) % 41));                       // down to 0
         bool neg, rej, amb, nege, reje; int em, eme;
-        poisson_fast(p, st1, st2, glt, glt_n, neg, rej, em, amb);
+        if (zt) poisson_fast<true>(p, st1, st2, glt, glt_n, zt, neg, rej, em, amb);
+        else poisson_fast<false>(p, st1, st2, glt, glt_n, nullptr, neg, rej, em, amb);
         poisson_exact(p, st1, st2, glt, glt_n, nege, reje, eme);
         ++n;
         if (cls < 4) { ++n_rand; amb_rand += amb ? 1u : 0u; }
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256) void k_bound_poisson(const unsigned long long 
 }
 
 extern "C" __attribute__((visibility("default"))) int vgl_dbg_bound_sweep(int mode, uint32_t lo_bits, unsigned long long count, double param, double out[4]) {
-    BoundAcc* d = nullptr; double* d_glt = nullptr;
+    BoundAcc* d = nullptr; double* d_glt = nullptr; float* d_zt = nullptr;
     if (hipMalloc((void**)&d, sizeof(BoundAcc)) != hipSuccess) return -1;
     if (hipMemset(d, 0, sizeof(BoundAcc)) != hipSuccess) { (void)hipFree(d); return -1; }
     const dim3 g(256 * 16), b(256);
@@ -228,6 +229,9 @@ extern "C" __attribute__((visibility("default"))) int vgl_dbg_bound_sweep(int mo
         case VGL_BOUND_DIV: hipLaunchKernelGGL(k_bound_div, g, b, 0, 0, count, d); break;
         case VGL_BOUND_QUOT: hipLaunchKernelGGL(k_bound_quot, g, b, 0, 0, count, d); break;
         case VGL_BOUND_POISSON: {
+            // param > 0: the exponent from the float64 expression (per-sample depths); param < 0: mean depth -param with the float32 exponent table
+            const bool tab = param < 0.0;
+            if (tab) param = -param;
             if (!(param >= 12.0)) { (void)hipFree(d); return -2; }
             VglPois pp;
             vgl_pois_init(&pp, param);
@@ -236,18 +240,22 @@ extern "C" __attribute__((visibility("default"))) int vgl_dbg_bound_sweep(int mo
             if (!hg) { (void)hipFree(d); return -1; }
             hg[0] = 0.0;
             for (int k = 1; k < gn; k++) hg[k] = vgl_gamma_ln_host((double)k);
-            if (hipMalloc((void**)&d_glt, sizeof(double) * gn) != hipSuccess || hipMemcpy(d_glt, hg, sizeof(double) * gn, hipMemcpyHostToDevice) != hipSuccess) {
-                free(hg); (void)hipFree(d_glt); (void)hipFree(d); return -1;
+            float* hz = (float*)malloc(sizeof(float) * gn);
+            if (!hz) { free(hg); (void)hipFree(d); return -1; }
+            vgl_pois_zt_host(&pp, hg, gn, hz);
+            if (hipMalloc((void**)&d_glt, sizeof(double) * gn) != hipSuccess || hipMemcpy(d_glt, hg, sizeof(double) * gn, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMalloc((void**)&d_zt, sizeof(float) * gn) != hipSuccess || hipMemcpy(d_zt, hz, sizeof(float) * gn, hipMemcpyHostToDevice) != hipSuccess) {
+                free(hg); free(hz); (void)hipFree(d_glt); (void)hipFree(d_zt); (void)hipFree(d); return -1;
             }
-            free(hg);
-            hipLaunchKernelGGL(k_bound_poisson, g, b, 0, 0, count, pp, d_glt, gn, d);
+            free(hg); free(hz);
+            hipLaunchKernelGGL(k_bound_poisson, g, b, 0, 0, count, pp, d_glt, gn, tab ? d_zt : (const float*)nullptr, d);
             break;
         }
         default: (void)hipFree(d); return -2;
     }
     BoundAcc h;
-    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipFree(d_glt); (void)hipFree(d); return -1; }
-    (void)hipFree(d_glt); (void)hipFree(d);
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipFree(d_glt); (void)hipFree(d_zt); (void)hipFree(d); return -1; }
+    (void)hipFree(d_glt); (void)hipFree(d_zt); (void)hipFree(d);
     out[0] = (double)h.n; out[1] = (double)h.viol;
     out[2] = (mode == VGL_BOUND_POISSON) ? (double)h.max_ratio_bits / (0.5 * (double)(h.n ? h.n : 1))     // ambiguous share of the pseudo-random half
                                          : __builtin_bit_cast(double, h.max_ratio_bits);

@@ -161,8 +161,11 @@ __device__ __forceinline__ float vgl_tanf_0pi(const float a) {
 //   Anything else is `amb`: the caller evaluates the attempt exactly (poisson_exact), behind a wave-uniform branch.
 // tests/test_gpu_bounds.py (VGL_BOUND_POISSON) runs both on 2^32 attempts per mean depth -- pseudo-random, next to the pole, next to
 // integer e0 -- and requires every decision poisson_fast() does not call ambiguous to equal the exact one; it prints the ambiguous share.
+// ZT: the exponent (em alxm - gamma_ln(em + 1) - g) log2 e comes from `zt`, tabulated in float32 for THIS p (VglDevParams::pois_zt: one mean
+// depth for all samples) -- its rounding, 2^-24 |zt|, is the rounding of (float)(z log2 e) in the other branch, with the same allowance.
+template <bool ZT>
 __device__ __forceinline__ void poisson_fast(const VglPois& p, const uint64_t st1, const uint64_t st2, const double* __restrict__ glt, const int glt_n,
-                                             bool& neg, bool& rej, int& em, bool& amb) {
+                                             const float* __restrict__ zt, bool& neg, bool& rej, int& em, bool& amb) {
     const float af = (float)(uint32_t)(st1 >> 16) * ((float)VGL_PI * 0x1p-32f);    // (the constant: 0x1.921fb6p-31)
     const float yf = vgl_tanf_0pi(af);
     const float y2 = yf * yf, ay = fabsf(yf);
@@ -179,11 +182,16 @@ __device__ __forceinline__ void poisson_fast(const VglPois& p, const uint64_t st
     const bool sure_rej = guard & (e0f - derr >= p.e_hi) & (hi2 != 0u);
     em = (int)emf;                                                           // (saturates; used only where floor_ok)
     const bool in_tab = (em >= 0) & (em < glt_n - 1);
-    const double gl = glt[in_tab ? em + 1 : 1];
-    const double z = (double)emf * p.alxm - gl - p.g;
-    const float ex = __builtin_amdgcn_exp2f((float)(z * 1.4426950408889634));
+    float zl, za;                                                            // z log2 e, and |z| (or more)
+    if (ZT) { zl = zt[in_tab ? em : 0]; za = fabsf(zl); }
+    else {
+        const double gl = glt[in_tab ? em + 1 : 1];
+        const double z = (double)emf * p.alxm - gl - p.g;
+        zl = (float)(z * 1.4426950408889634); za = fabsf((float)z);
+    }
+    const float ex = __builtin_amdgcn_exp2f(zl);
     const float tt = 0.9f * (1.0f + y2) * ex;
-    const float rel_t = dy + fabsf((float)z) * 0x1p-22f + 0x1p-19f;
+    const float rel_t = dy + za * 0x1p-22f + 0x1p-19f;
     const float u2f = (float)hi2 * 0x1p-32f;
     const bool t_ok = fabsf(u2f - tt) > __builtin_fmaf(tt, rel_t, __builtin_fmaf(u2f, 0x1p-22f, 0x1p-30f));
     neg = sure_neg;
@@ -203,10 +211,11 @@ __device__ __forceinline__ void poisson_exact(const VglPois& p, const uint64_t s
 }
 // one rejection attempt from the two generator states it would consume: `neg`: em < 0
 // (only st1 is consumed, no acceptance draw), else `rej` = the acceptance draw u(st2) exceeds t, else the draw is `em`.
+template <bool ZT>
 __device__ __forceinline__ void poisson_attempt(const VglPois& p, const uint64_t st1, const uint64_t st2, const bool need,
-                                                const double* __restrict__ glt, const int glt_n, bool& neg, bool& rej, int& em) {
+                                                const double* __restrict__ glt, const int glt_n, const float* __restrict__ zt, bool& neg, bool& rej, int& em) {
     bool amb;
-    poisson_fast(p, st1, st2, glt, glt_n, neg, rej, em, amb);
+    poisson_fast<ZT>(p, st1, st2, glt, glt_n, zt, neg, rej, em, amb);
     amb &= need;
     if (__builtin_expect(__ballot(amb) != 0, 0)) {               // exact evaluation (rare, wave-uniform branch)
         asm volatile("" ::: "memory");
@@ -228,7 +237,7 @@ static __device__ int poisson_draw_fast(const VglPois& p, uint64_t& st, const do
         const uint64_t st1 = lcg_next(st);
         const uint64_t st2 = lcg_next(st1);
         bool neg, reject; int em;
-        poisson_attempt(p, st1, st2, !done, glt, glt_n, neg, reject, em);
+        poisson_attempt<false>(p, st1, st2, !done, glt, glt_n, nullptr, neg, reject, em);
         const bool acc = !done & !neg & !reject;
         st = done ? st : (neg ? st1 : st2);                          // em < 0 consumes one draw, an attempt two
         em_res = acc ? em : em_res;

@@ -8,7 +8,9 @@
 #define VGL_LCG_C  0xBULL
 #define VGL_WAVE   64
 #define VGL_MAX_QS_BINS 32
-#define VGL_DEPTH_CHUNK 1024     // evaluations dealt to one wavefront of k_depth
+#define VGL_DEPTH_CHUNK 1024     // evaluations dealt to one wavefront of k_depth: 1024, 2048 or 4096 (vgl_launch_depth: the larger the tile, the
+                                 // larger the chunk -- the chunk's last items keep a wavefront going with few busy lanes)
+#define VGL_DEPTH_CHUNK_MAX 4096
 // htslib's errmod_cal() subsamples a pileup deeper than 255 reads with ks_shuffle() on htslib's OWN rand48 generator
 // (hts_drand48: never seeded by its callers, state {0x330e, 0xabcd, 0x1234}); GL model 1 reaches it with --depth > ~200
 #define VGL_HTS_RAND48_X0 0x1234ABCD330EULL
@@ -113,6 +115,7 @@ struct VglDevParams {
     int32_t slow_period_n;   //              that of the normal sampler every slow_period_n-th
     int32_t xcd_map;         // k_gl: workgroup index -> XCD-contiguous logical index (VGL_XCD_MAP=0 turns it off; k_sample, which is
                              // bound by its arithmetic, measured 1-3 % slower with it and keeps the hardware order)
+    int32_t dbg_depth_chunk; // test hook (VGL_DEPTH_CHUNK=1024 / 2048 / 4096): k_depth's chunk whatever the tile's size
     int32_t dbg_fuse_alone;  // test hook (VGL_DEBUG_FUSE_ALONE=1): a split fused workgroup does not wait for its neighbours and samples their depths itself
     int32_t dbg_phase;       // diagnostic (VGL_DEBUG_PHASE=n): k_sample returns after phase n; 0 = off
     int32_t dbg_qs_exact;    // test hook (VGL_DEBUG_QS_EXACT=1): k_sample<2> treats every read as undecided in float32
@@ -145,6 +148,8 @@ struct VglDevParams {
     const double* q2gl;                // [3][257]
     const double* gamma_ln_tab;        // [gamma_ln_n] gamma_ln(k), k >= 1 (entry 0 unused)
     int32_t gamma_ln_n;
+    const float* pois_zt;              // [gamma_ln_n - 1] one mean depth >= 12 for all samples: (float)((k alxm - gamma_ln(k + 1) - g) log2 e), the exponent of the
+                                       // rejection method's acceptance bound (rng.h:308) ready for v_exp_f32 (poisson_fast); null with per-sample depths
     const float* gl2_run;              // [2][read_cap + 1][3] GL model 2 with ONE fixed score: the accumulators (hom present, present / absent, absent / absent) of an
                                        // evaluation whose n reads all show the same base -- the reference's n update / subtract-the-maximum steps
                                        // (gl_methods.cpp:22-59) run once on the host per n instead of once per evaluation; [0] the site has an allele the
@@ -258,6 +263,7 @@ int vgl_chain_emit(const VglDevParams* p, struct VglSerialState* S, const struct
 // vgl_host.cpp (host): PoissonSampler_init with the float32 parameters of poisson_fast; the reference's gamma_ln -- also what vgl_bounds.hip sweeps with
 void vgl_pois_init(struct VglPois* o, double lambda);
 double vgl_gamma_ln_host(double x);
+void vgl_pois_zt_host(const struct VglPois* p, const double* gamma_ln_tab, int n, float* zt);    // VglDevParams::pois_zt from the [n] table of gamma_ln(k)
 #ifdef __cplusplus
 }
 #endif

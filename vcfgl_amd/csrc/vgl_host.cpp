@@ -184,7 +184,7 @@ struct vgl_ctx {
     // device tables
     VglAffine* d_depth_tab = nullptr; int32_t* d_dp_pre = nullptr; uint64_t* d_site_base = nullptr; uint64_t* d_site_hash = nullptr;
     VglAffine* d_samp_tab = nullptr; VglAffine* d_qs_read_tab = nullptr; VglPois* d_pois = nullptr;
-    float* d_gl2_run = nullptr; unsigned long long* d_fslot = nullptr;
+    float* d_gl2_run = nullptr; float* d_pois_zt = nullptr; unsigned long long* d_fslot = nullptr;
     double* d_q2gl = nullptr; double* d_gamma_ln = nullptr; double* d_gl1_fk = nullptr; double* d_gl1_beta = nullptr; double* d_gl1_bsum = nullptr; double* d_gl1_lhet = nullptr;
     // workspace
     uint8_t* d_reads = nullptr; double* d_errp = nullptr; uint64_t* d_ad4 = nullptr; uint64_t* d_adf4 = nullptr;
@@ -298,6 +298,11 @@ static void pois_init(VglPois* o, double lambda) {            // PoissonSampler_
 
 extern "C" void vgl_pois_init(VglPois* o, double lambda) { pois_init(o, lambda); }
 extern "C" double vgl_gamma_ln_host(double x) { return gamma_ln_host(x); }
+// VglDevParams::pois_zt: zt[k] = (float)((k alxm - gamma_ln(k + 1) - g) log2 e), k < n - 1 (the float64 operations of poisson_fast's other branch)
+extern "C" void vgl_pois_zt_host(const VglPois* p, const double* gl, int n, float* zt) {
+    for (int k = 0; k + 1 < n; k++) zt[k] = (float)((((double)k * p->alxm - gl[k + 1]) - p->g) * 1.4426950408889634);
+    zt[n - 1] = 0.0f;
+}
 
 static void gamma1_init(VglGamma1* g, double shape) {         // Gamma1Sampler_init, rng.h:155-173
     double alpha = shape;
@@ -319,7 +324,7 @@ template <typename T> static int dmalloc(T** p, size_t n) {
 extern "C" int vgl_ctx_destroy(vgl_ctx* c) {
     if (!c) return VGL_OK;
     (void)hipSetDevice(c->device);
-    void* ptrs[] = {c->d_fslot, c->d_gl2_run, c->d_gl1_fk, c->d_gl1_beta, c->d_gamma_ln, c->d_samp_tab, c->d_qs_read_tab, c->d_pois, c->d_q2gl, c->d_gl1_bsum, c->d_gl1_lhet, c->d_reads, c->d_errp, c->d_ad4,
+    void* ptrs[] = {c->d_fslot, c->d_gl2_run, c->d_pois_zt, c->d_gl1_fk, c->d_gl1_beta, c->d_gamma_ln, c->d_samp_tab, c->d_qs_read_tab, c->d_pois, c->d_q2gl, c->d_gl1_bsum, c->d_gl1_lhet, c->d_reads, c->d_errp, c->d_ad4,
                     c->d_adf4, c->d_qsum, c->d_qsumsq, c->d_acc, c->d_sinfo, c->d_rowmap, c->d_errflag, c->d_dbg, c->d_redo_list, c->d_redo_count, c->d_redo_bits,
                     c->d_serial, c->d_sst, c->d_site_thresh, c->d_scout_dp, c->d_site_tail, c->d_sdp, c->d_step_tab,
                     c->d_depth_tab, c->d_site_base, c->d_site_hash, c->d_dp_pre, c->d_hts_off, c->d_hts_base, c->d_roff, c->d_rtotal, c->d_errp_lin, c->d_cw, c->d_ccons, c->d_cexit,
@@ -426,6 +431,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     D.xcd_map = hook_int("VGL_XCD_MAP", 1);
     D.dbg_phase = hook_int("VGL_DEBUG_PHASE", 0);
     D.dbg_fuse_alone = hook_int("VGL_DEBUG_FUSE_ALONE", 0);
+    D.dbg_depth_chunk = hook_int("VGL_DEPTH_CHUNK", 0);
     D.dbg_qs_exact = hook_int("VGL_DEBUG_QS_EXACT", 0);
     for (int i = 0; i < p->n_qs_bins * 3; i++) D.qs_bins[i] = p->qs_bins[i];
     D.err_thresh = (uint64_t)ceil(ldexp(p->error_rate, 48));
@@ -544,6 +550,13 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
         TRY(dmalloc(&c->d_gamma_ln, (size_t)n));
         TRYHIP(hipMemcpy(c->d_gamma_ln, gl.data(), sizeof(double) * n, hipMemcpyHostToDevice));
         D.gamma_ln_tab = c->d_gamma_ln; D.gamma_ln_n = n;
+        if (!p->depths && !D.pois0.st12 && !hook_env("VGL_NO_POIS_ZT")) {
+            std::vector<float> zt(n);
+            vgl_pois_zt_host(&D.pois0, gl.data(), n, zt.data());
+            TRY(dmalloc(&c->d_pois_zt, (size_t)n));
+            TRYHIP(hipMemcpy(c->d_pois_zt, zt.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+            D.pois_zt = c->d_pois_zt;
+        }
     }
     TRY(dmalloc(&c->d_q2gl, (size_t)3 * 257));
     TRYHIP(hipMemcpy(c->d_q2gl, q2gl.data(), sizeof(double) * 3 * 257, hipMemcpyHostToDevice));

@@ -41,18 +41,20 @@ __global__ __launch_bounds__(256) void k_sitebase(const VglDevParams P, const Vg
 // (site, sample) starts its depth stream at J^(off0 + block sample) (site_base[site]): the site's state from k_sitebase, one table
 // jump per evaluation.  A chunk spans sites: the site of item i is found from the chunk's first (site, sample) by one compare
 // (N >= 1024) or one multiply-high (P.depth_magic).
-__global__ __launch_bounds__(256) void k_depth(const VglDevParams P, const VglTilePtrs T) {
+// ZT: one mean depth for all samples, the acceptance bound's exponent from P.pois_zt
+template <bool ZT>
+__global__ __launch_bounds__(256) void k_depth(const VglDevParams P, const VglTilePtrs T, const int chunk) {
     const int lane = threadIdx.x & 63;
     const uint32_t N = (uint32_t)P.n_samples;
     const int64_t E = (int64_t)T.n_sites * N;
-    const int64_t c0 = ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * VGL_DEPTH_CHUNK;
+    const int64_t c0 = ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * chunk;
     if (c0 >= E) return;
-    const int cn = (int)((E - c0 < VGL_DEPTH_CHUNK) ? (E - c0) : VGL_DEPTH_CHUNK);
+    const int cn = (int)((E - c0 < chunk) ? (E - c0) : chunk);
     const uint32_t ls_c0 = (uint32_t)(c0 / (int64_t)N);                  // site and sample of the chunk's first evaluation (wave-uniform)
     const uint32_t s_c0 = (uint32_t)(c0 - (int64_t)ls_c0 * N);
-    const bool big_n = N >= (uint32_t)VGL_DEPTH_CHUNK;
+    const bool big_n = N >= (uint32_t)chunk;
     auto start_of = [&](const int i, uint32_t& s_out) -> uint64_t {      // stream start of the chunk's item i (i < cn)
-        const uint32_t t = s_c0 + (uint32_t)i;                           // < N + 1024
+        const uint32_t t = s_c0 + (uint32_t)i;                           // < N + chunk
         const uint32_t add = big_n ? (uint32_t)(t >= N) : (N == 1u ? t : __umulhi(t, P.depth_magic));   // t / N (the magic number needs N >= 2 to fit 32 bits)
         s_out = t - add * N;
         return aff(P.depth_tab[s_out], T.site_base[ls_c0 + add]);
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256) void k_depth(const VglDevParams P, const VglTi
         // one rejection attempt (rng.h:300-312); k_depth runs only when every sample uses this method
         const uint64_t st1 = lcg_next(st), st2 = lcg_next(st1);
         bool neg, reject; int result;
-        poisson_attempt(pp, st1, st2, busy, P.gamma_ln_tab, P.gamma_ln_n, neg, reject, result);
+        poisson_attempt<ZT>(pp, st1, st2, busy, P.gamma_ln_tab, P.gamma_ln_n, P.pois_zt, neg, reject, result);
         st = neg ? st1 : st2;                                            // em < 0 consumes one draw, an attempt two
         const bool done = busy && !neg && !reject;
         if (done) T.dp_pre[c0 + i] = result;
@@ -670,8 +672,13 @@ extern "C" int vgl_launch_sitebase(const VglDevParams* p, const VglTilePtrs* t, 
 extern "C" int vgl_launch_depth(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
     const int64_t E = (int64_t)t->n_sites * p->n_samples;
     if (E == 0) return 0;
-    const int64_t waves = (E + VGL_DEPTH_CHUNK - 1) / VGL_DEPTH_CHUNK;
-    hipLaunchKernelGGL(k_depth, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *p, *t);
+    // measured at 65536 x 1000 / x 2000 evaluations, depth 20 / 30: 0.478 / 0.904 ms with chunks of 1024, 0.446 / 0.841 with 2048, 0.438 / 0.820
+    // with 4096; a small tile keeps the short chunks (a wavefront works its chunk off alone: 35 us per 1024 evaluations)
+    int chunk = E >= ((int64_t)1 << 24) ? 4096 : (E >= ((int64_t)1 << 23) ? 2048 : VGL_DEPTH_CHUNK);
+    if (p->dbg_depth_chunk == 1024 || p->dbg_depth_chunk == 2048 || p->dbg_depth_chunk == 4096) chunk = p->dbg_depth_chunk;
+    const int64_t waves = (E + chunk - 1) / chunk;
+    if (!p->per_sample_depth && p->pois_zt) hipLaunchKernelGGL(k_depth<true>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *p, *t, chunk);
+    else hipLaunchKernelGGL(k_depth<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *p, *t, chunk);
     return (int)hipGetLastError();
 }
 

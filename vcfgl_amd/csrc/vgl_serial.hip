@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64) void k_scout_wave(const VglDevParams P, const V
                 const uint64_t x1 = aff(stp[lane + 1], st1);
                 const uint64_t x2 = lcg_next(x1);
                 bool neg, rej; int emi;
-                poisson_attempt(P.pois0, x1, x2, true, P.gamma_ln_tab, P.gamma_ln_n, neg, rej, emi);
+                poisson_attempt<false>(P.pois0, x1, x2, true, P.gamma_ln_tab, P.gamma_ln_n, nullptr, neg, rej, emi);
                 const uint64_t negm = __ballot(neg), rejm = __ballot(rej & !neg);
                 int pos = 0;
                 while (s < N && pos <= 63) {                       // scalar walk of the attempt chain
