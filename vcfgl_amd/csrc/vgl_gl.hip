@@ -12,6 +12,23 @@
 // insertion sort leaves them -- and the two allele tables are built as words of 4-bit entries (0xF = none), the form VglSiteInfo keeps
 struct VglSiteOrder { int status, nAll, nObs; uint32_t a2b, b2a; };      // a2b: allele -> base (4 = unobserved), b2a: base -> allele; entries 0..4
 __device__ __forceinline__ int site_nib(const uint32_t w, const int i) { const int v = (int)((w >> (4 * i)) & 0xFu); return v == 0xF ? -1 : v; }
+// status and allele count alone (the part of site_order() that needs no ordering): what the likelihood loops of the fused kernel look at,
+// worked out by every thread while the allele order itself is off the workgroup's critical path
+__device__ __forceinline__ void site_status_nall(const VglDevParams& P, const int info_dp, const int ad[4], int& status, int& nAll) {
+    const bool add_unobs = (P.A == 5);
+    status = SITE_OK; nAll = 0;
+    if (0 == info_dp) {
+        if (P.rm_empty_sites) status = SITE_SKIP_EMPTY;
+        else {
+            status = SITE_NO_READS;
+            nAll = (P.do_unobserved <= 2) ? 1 : (P.do_unobserved == 3 ? 4 : 5);
+        }
+    } else {
+        const int nObservedBases = (ad[0] > 0) + (ad[1] > 0) + (ad[2] > 0) + (ad[3] > 0);
+        if ((P.rm_invar_sites & 4) && 1 == nObservedBases) status = SITE_SKIP_INVAR;
+        else nAll = (P.do_unobserved >= 3 ? 4 : nObservedBases) + (add_unobs ? 1 : 0);
+    }
+}
 __device__ __forceinline__ VglSiteOrder site_order(const VglDevParams& P, const int info_dp, const int ad[4]) {
     VglSiteOrder o;
     const bool add_unobs = (P.A == 5);
@@ -200,6 +217,7 @@ template <bool STORE, class Emit>
 __device__ __forceinline__ uint64_t fused_sample_eval(const VglDevParams& P, const VglTilePtrs& T, const int site, const int samp, const int N, int& dps_out, Emit&& emit) {
     // k_sample<0, LEAN> for the evaluation (site, samp): vcfgl.cpp:364-389, 469-613 (vgl_sample.hip)
     const size_t ev = (size_t)site * N + (size_t)samp;
+    const uint32_t g = T.gt[ev];                                        // (first: the one load of this phase that misses every cache, in flight during the depth loop)
     const uint64_t xe = aff(P.samp_tab[samp], T.site_base[site]);
     uint64_t st_hap16 = aff(P.off[1], xe) << 16, st_base16 = aff(P.off[2], xe) << 16;      // sample_read_base16: states carried shifted by 16
     int em;
@@ -215,7 +233,6 @@ __device__ __forceinline__ uint64_t fused_sample_eval(const VglDevParams& P, con
         asm volatile("" : "+v"(k3ff));
         do { ++em; s52 = lcg_next52r(s52); t *= bits_1xxx_52r(s52, k3ff) - 1.0; } while (t > pc.g);
     }
-    const uint32_t g = T.gt[ev];
     const int a0 = (int)(g & 0xF), a1 = (int)((g >> 4) & 0xF);
     int dps = (a0 == 0xF || a1 == 0xF) ? 0 : em;
     if (dps > P.read_cap) { if (STORE) atomicOr(T.errflag, VGL_DEVERR_CAPACITY); dps = P.read_cap; }
@@ -273,11 +290,87 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
     const uint32_t nwaves = (uint32_t)T.n_sites * chunks_k;                             // < 2^31 (checked by the launcher)
     const uint32_t bx = P.xcd_map ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x;     // logical workgroup (XCD-contiguous)
     uint64_t f_a = 0;                                                   // FUSED: this thread's per-base depths
+    // wave k of this workgroup is wave 4 bx + k of the tile = (site, 64-sample chunk).  One scalar division per workgroup; a lane
+    // then finds the site of ANY of the four waves with three compares (a per-lane 64-bit division was 60+ vector instructions,
+    // three times per lane)
+    const uint32_t wg_ls = (bx * (uint32_t)WPB) / chunks_k, wg_rem = (bx * (uint32_t)WPB) - wg_ls * chunks_k;
+    auto wave_site = [&](const int k, int& ls_, int& s_base) {
+        const int t = (int)wg_rem + k, c = (int)chunks_k;
+        int add = 0;
+#pragma unroll
+        for (int j = 1; j < WPB; ++j) add += (t >= j * c) ? 1 : 0;
+        ls_ = (int)wg_ls + add;
+        s_base = (t - add * c) * 64;
+    };
+    // ---- depth of the evaluation this thread would own in natural order
+    int dp0 = -1;                                                      // -1: no evaluation (padding lane)
+    int k0 = 1;                                                        // GL model 2: distinct bases among its reads
+    // In natural order a wavefront is 64 consecutive samples of ONE site: its site, first sample and site record are wave-uniform
+    // and are kept in scalar registers (the compiler cannot see that tid >> 6 is uniform), so that the natural-order loads and the
+    // epilogue's stores address memory as scalar base + lane offset and the allele table is decoded by scalar instructions
+    int ls0 = 0, sb0 = 0, s0 = N;
+    uint64_t a = 0;                                                    // its per-base depths (kept for the epilogue, which runs in natural order)
+    uint64_t rmap = 0;                                                 // GL model 2: accumulator row of each genotype for this evaluation's set of bases (k_site's table)
+    uint32_t rmask = 0;                                                // FUSED: which bases the evaluation shows (index of its row-table entry, fetched once the site's order is known)
+    auto natural_setup = [&]() {
+        const int wv_s = (GLM == 2) ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
+        const uint32_t w = bx * (uint32_t)WPB + (uint32_t)wv_s;
+        if (w < nwaves) {
+            wave_site(wv_s, ls0, sb0);
+            if (GLM == 2) { ls0 = __builtin_amdgcn_readfirstlane(ls0); sb0 = __builtin_amdgcn_readfirstlane(sb0); }   // (measured: the GL model 1 kernel is 8 % slower with it)
+            if (P.gl_sort && (tid & 63) == 0) { s_ws[2 * (tid >> 6)] = ls0; s_ws[2 * (tid >> 6) + 1] = sb0; }       // for the lane the sort hands an evaluation of this wavefront to
+            s0 = sb0 + (tid & 63);
+            if (s0 < N) {
+                if constexpr (FUSED) a = f_a;
+                else a = T.ad4[(size_t)ls0 * N + (size_t)sb0 + (size_t)(tid & 63)];
+                dp0 = (int)((a & 0xFFFF) + ((a >> 16) & 0xFFFF) + ((a >> 32) & 0xFFFF) + ((a >> 48) & 0xFFFF));
+                if (dp0 > 1023) dp0 = 1023;
+                if (GLM == 2) {
+                    const uint32_t q0 = (a & 0xFFFFULL) != 0, q1 = ((a >> 16) & 0xFFFF) != 0, q2 = ((a >> 32) & 0xFFFF) != 0, q3 = (a >> 48) != 0;
+                    k0 = (int)(q0 + q1 + q2 + q3);
+                    if constexpr (FUSED) rmask = q0 | (q1 << 1) | (q2 << 2) | (q3 << 3);
+                    else rmap = T.rowmap[(size_t)ls0 * 16 + (q0 | (q1 << 1) | (q2 << 2) | (q3 << 3))];   // (in flight during the loop)
+                }
+            }
+        }
+    };
+    // order of the sort: (GL model 2) most distinct bases first -- the loop a wavefront runs is the one of its lane with the most -- then
+    // deepest first; evaluations without reads and padding lanes last.  At most 4 * 256 + 2 bins.
+    constexpr int NK = (GLM == 2) ? 4 : 1;
+    const int sort_sh = P.read_cap > 511 ? 2 : (P.read_cap > 255 ? 1 : 0);
+    const int nbd = (P.read_cap >> sort_sh) + 1;                       // depth bins
+    const int nb = NK * nbd + 2;
+    auto sort_key = [&]() -> int {
+        int key = nb - 1;
+        if (dp0 == 0) key = nb - 2;
+        else if (dp0 > 0) {
+            const int dq = (dp0 > P.read_cap ? P.read_cap : dp0) >> sort_sh;
+            // deepest first, except the two-base group: its shallow end shares a wavefront with the (few, expensive) evaluations of
+            // three or four bases, whose loop then ends sooner; its deep end joins the cheap one-base loop's wavefronts
+            key = (NK - k0) * nbd + ((GLM == 2 && k0 == 2 && P.gl_flip2) ? dq : nbd - 1 - dq);
+        }
+        return key;
+    };
+    auto sort_scan = [&](const int ln) {                               // exclusive scan of the bins by one wavefront (ln = its lane)
+        uint32_t run = 0;
+        for (int base = 0; base < nb; base += 64) {
+            const int i = base + ln;
+            const uint32_t v = (i < nb) ? s_hist[i] : 0u;
+            const uint32_t incl = wave_incl_scan_u32(v);
+            if (i < nb) s_hist[i] = run + incl - v;
+            run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+    };
+    int key = 0;
+    int f_status = SITE_OK, f_nall = 0;                                 // FUSED: the site's status and allele count (site_status_nall)
     if constexpr (FUSED) {
         const int S = P.fused_split;                                    // workgroups of this site
         const int site = (int)(bx / (uint32_t)S), part = (int)bx - site * S;
         const int samp = part * WG + tid;
         if (tid < 16) s_lds.f_acc[tid] = 0;
+        // (round 4) the depth sort's histogram is filled in the same barrier interval as the site's sums, and its scan runs (second
+        // wavefront) beside the sixteen threads of the allele order (first): six barriers per site instead of nine
+        if (P.gl_sort) for (int i = tid; i < nb; i += WG) s_hist[i] = 0;
         __syncthreads();
         uint64_t ad4s = 0;
         if (samp < N) {
@@ -299,6 +392,7 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
 #pragma unroll
             for (int k = 1; k < 5; ++k) if (v[k]) atomicAdd(&s_lds.f_acc[k], v[k]);
         }
+        if (P.gl_sort) { natural_setup(); key = sort_key(); atomicAdd(&s_hist[key], 1u); }
         if (S > 1) {
             // ---- the other workgroups' shares.  Every part publishes its four sums as TWO flagged 8-byte words (system-scope stores: A | C << 32
             // and G | T << 32, bit 63 = valid; the slots are zero at the start of the tile) and lane q of the first wavefront polls part q's
@@ -348,92 +442,31 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
             }
         }
         __syncthreads();
-        // ---- k_site: sixteen threads work out the allele order, thread m writes row-table entry m, thread 0 the site's outputs
-        if (tid < 16) {
-            int32_t acc9[9];
-#pragma unroll
-            for (int k = 1; k < 5; ++k) { acc9[k] = s_lds.f_acc[k]; acc9[4 + k] = acc9[k]; }
-            acc9[0] = acc9[1] + acc9[2] + acc9[3] + acc9[4];
-            const VglSiteOrder o = site_order(P, acc9[0], &acc9[1]);
-            s_lds.f_rowmap[tid] = site_rowmap_entry(P.A, o.a2b, (uint32_t)tid);
-            if (tid == 0) { s_lds.f_si = site_info_of(o); if (part == 0) site_outputs(P, T, site, o, acc9); }
+        // ---- the site's sums are complete.  The likelihood loops need the site's status and allele COUNT only: every thread works them
+        // out itself (a dozen instructions); the allele ORDER, the row table and the site's outputs (k_site's code, sixteen threads) are
+        // needed by the epilogue only and are left to the wavefront with the lightest share of the sorted evaluations, after its loops
+        // and ahead of the deposit barrier -- no wavefront waits for them (they held all eight for a tenth of the site's time)
+        {
+            const int ad_s[4] = {s_lds.f_acc[1], s_lds.f_acc[2], s_lds.f_acc[3], s_lds.f_acc[4]};
+            site_status_nall(P, ad_s[0] + ad_s[1] + ad_s[2] + ad_s[3], ad_s, f_status, f_nall);
         }
+        if (P.gl_sort && tid >= 64 && tid < 128) sort_scan(tid - 64);   // (bins complete behind the barrier above)
         __syncthreads();
-    }
-    // wave k of this workgroup is wave 4 bx + k of the tile = (site, 64-sample chunk).  One scalar division per workgroup; a lane
-    // then finds the site of ANY of the four waves with three compares (a per-lane 64-bit division was 60+ vector instructions,
-    // three times per lane)
-    const uint32_t wg_ls = (bx * (uint32_t)WPB) / chunks_k, wg_rem = (bx * (uint32_t)WPB) - wg_ls * chunks_k;
-    auto wave_site = [&](const int k, int& ls_, int& s_base) {
-        const int t = (int)wg_rem + k, c = (int)chunks_k;
-        int add = 0;
-#pragma unroll
-        for (int j = 1; j < WPB; ++j) add += (t >= j * c) ? 1 : 0;
-        ls_ = (int)wg_ls + add;
-        s_base = (t - add * c) * 64;
-    };
-    // ---- depth of the evaluation this thread would own in natural order
-    int dp0 = -1;                                                      // -1: no evaluation (padding lane)
-    int k0 = 1;                                                        // GL model 2: distinct bases among its reads
-    // In natural order a wavefront is 64 consecutive samples of ONE site: its site, first sample and site record are wave-uniform
-    // and are kept in scalar registers (the compiler cannot see that tid >> 6 is uniform), so that the natural-order loads and the
-    // epilogue's stores address memory as scalar base + lane offset and the allele table is decoded by scalar instructions
-    int ls0 = 0, sb0 = 0, s0 = N;
-    uint64_t a = 0;                                                    // its per-base depths (kept for the epilogue, which runs in natural order)
-    uint64_t rmap = 0;                                                 // GL model 2: accumulator row of each genotype for this evaluation's set of bases (k_site's table)
-    {
-        const int wv_s = (GLM == 2) ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
-        const uint32_t w = bx * (uint32_t)WPB + (uint32_t)wv_s;
-        if (w < nwaves) {
-            wave_site(wv_s, ls0, sb0);
-            if (GLM == 2) { ls0 = __builtin_amdgcn_readfirstlane(ls0); sb0 = __builtin_amdgcn_readfirstlane(sb0); }   // (measured: the GL model 1 kernel is 8 % slower with it)
-            if (P.gl_sort && (tid & 63) == 0) { s_ws[2 * (tid >> 6)] = ls0; s_ws[2 * (tid >> 6) + 1] = sb0; }       // for the lane the sort hands an evaluation of this wavefront to
-            s0 = sb0 + (tid & 63);
-            if (s0 < N) {
-                if constexpr (FUSED) a = f_a;
-                else a = T.ad4[(size_t)ls0 * N + (size_t)sb0 + (size_t)(tid & 63)];
-                dp0 = (int)((a & 0xFFFF) + ((a >> 16) & 0xFFFF) + ((a >> 32) & 0xFFFF) + ((a >> 48) & 0xFFFF));
-                if (dp0 > 1023) dp0 = 1023;
-                if (GLM == 2) {
-                    const uint32_t q0 = (a & 0xFFFFULL) != 0, q1 = ((a >> 16) & 0xFFFF) != 0, q2 = ((a >> 32) & 0xFFFF) != 0, q3 = (a >> 48) != 0;
-                    k0 = (int)(q0 + q1 + q2 + q3);
-                    if constexpr (FUSED) rmap = s_lds.f_rowmap[q0 | (q1 << 1) | (q2 << 2) | (q3 << 3)];
-                    else rmap = T.rowmap[(size_t)ls0 * 16 + (q0 | (q1 << 1) | (q2 << 2) | (q3 << 3))];   // (in flight during the loop)
-                }
-            }
-        }
+        if (!P.gl_sort) natural_setup();
+    } else {
+        if (P.gl_sort) for (int i = tid; i < nb; i += WG) s_hist[i] = 0;   // (ahead of natural_setup(): the bins are cleared while its loads are in flight)
+        natural_setup();
     }
     int otid = tid;
     if (P.gl_sort) {
-        // order: (GL model 2) most distinct bases first -- the loop a wavefront runs is the one of its lane with the most -- then
-        // deepest first; evaluations without reads and padding lanes last.  At most 4 * 256 + 2 bins.
-        constexpr int NK = (GLM == 2) ? 4 : 1;
-        const int sh = P.read_cap > 511 ? 2 : (P.read_cap > 255 ? 1 : 0);
-        const int nbd = (P.read_cap >> sh) + 1;                        // depth bins
-        const int nb = NK * nbd + 2;
-        for (int i = tid; i < nb; i += WG) s_hist[i] = 0;
-        __syncthreads();
-        int key = nb - 1;
-        if (dp0 == 0) key = nb - 2;
-        else if (dp0 > 0) {
-            const int dq = (dp0 > P.read_cap ? P.read_cap : dp0) >> sh;
-            // deepest first, except the two-base group: its shallow end shares a wavefront with the (few, expensive) evaluations of
-            // three or four bases, whose loop then ends sooner; its deep end joins the cheap one-base loop's wavefronts
-            key = (NK - k0) * nbd + ((GLM == 2 && k0 == 2 && P.gl_flip2) ? dq : nbd - 1 - dq);
+        if constexpr (!FUSED) {
+            __syncthreads();
+            key = sort_key();
+            atomicAdd(&s_hist[key], 1u);
+            __syncthreads();
+            if (tid < 64) sort_scan(tid);
+            __syncthreads();
         }
-        atomicAdd(&s_hist[key], 1u);
-        __syncthreads();
-        if (tid < 64) {                                                // exclusive scan of the bins by one wavefront
-            uint32_t run = 0;
-            for (int base = 0; base < nb; base += 64) {
-                const int i = base + tid;
-                const uint32_t v = (i < nb) ? s_hist[i] : 0u;
-                const uint32_t incl = wave_incl_scan_u32(v);
-                if (i < nb) s_hist[i] = run + incl - v;
-                run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            }
-        }
-        __syncthreads();
         s_perm[atomicAdd(&s_hist[key], 1u)] = (uint16_t)tid;
         __syncthreads();
         // thread id whose evaluation this lane processes.  Which wavefront of the workgroup takes the deepest 64 evaluations
@@ -444,8 +477,8 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
     const int lane = tid & 63;
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t w = bx * (uint32_t)WPB + (uint32_t)(otid >> 6);
-    VglSiteInfo si_nv;                                                 // the natural evaluation's site (epilogue); in flight during the loop
-    if constexpr (FUSED) si_nv = s_lds.f_si; else si_nv = T.sinfo[ls0];
+    VglSiteInfo si_nv;                                                 // the natural evaluation's site (epilogue); in flight during the loop (FUSED: taken from LDS behind the deposit barrier)
+    if constexpr (!FUSED) si_nv = T.sinfo[ls0];
     int ls = 0, s = N;
     if (w < nwaves) {
         int sb;
@@ -459,7 +492,7 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
     const size_t plane = (size_t)T.n_sites * N;
     VglSiteInfo si;
     uint64_t ad4;
-    if constexpr (FUSED) { si = s_lds.f_si; ad4 = s_lds.f_ad4[otid]; }
+    if constexpr (FUSED) { si.status = f_status; si.n_alleles = f_nall; si.acgt2alleles = 0; si.alleles2acgt = 0; ad4 = s_lds.f_ad4[otid]; }   // (GL model 2 looks at the count and the status only)
     else { si = T.sinfo[ls]; ad4 = T.ad4[ev]; }
     const int nA = si.n_alleles;
     const bool have = (si.status == SITE_OK);
@@ -777,7 +810,28 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
     // The lanes have worked in sorted order and left their accumulators in LDS column (natural position); from here every
     // thread handles the evaluation at its own natural position, so that each store of a wavefront is one contiguous segment of
     // a plane and no tag needs a transposition of its own.
+    if constexpr (FUSED) {
+        // ---- k_site (see above): sixteen threads of the wavefront that took the END of the sorted order (evaluations without reads, padding)
+        // work out the allele order, thread m writes row-table entry m, the first one the site's record and outputs
+        const int w_light = (WPB - 1 - (int)(bx & (WPB - 1))) & (WPB - 1);
+        const int m = tid - 64 * w_light;
+        if (m >= 0 && m < 16) {
+            const int S = P.fused_split;
+            const int site = (int)(bx / (uint32_t)S), part = (int)bx - site * S;
+            int32_t acc9[9];
+#pragma unroll
+            for (int k = 1; k < 5; ++k) { acc9[k] = s_lds.f_acc[k]; acc9[4 + k] = acc9[k]; }
+            acc9[0] = acc9[1] + acc9[2] + acc9[3] + acc9[4];
+            const VglSiteOrder o = site_order(P, acc9[0], &acc9[1]);
+            s_lds.f_rowmap[m] = site_rowmap_entry(P.A, o.a2b, (uint32_t)m);
+            if (m == 0) { s_lds.f_si = site_info_of(o); if (part == 0) site_outputs(P, T, site, o, acc9); }
+        }
+    }
     __syncthreads();
+    if constexpr (FUSED) {
+        si_nv = s_lds.f_si;
+        if (s0 < N && dp0 >= 0) rmap = s_lds.f_rowmap[rmask];
+    }
     const bool live0 = (bx * (uint32_t)WPB + (uint32_t)(tid >> 6) < nwaves) && (s0 < N);
     VglSiteInfo si_n;                                                    // wave-uniform: to scalar registers, here where it is first needed
     if (GLM == 2) {
