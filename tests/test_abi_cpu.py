@@ -47,7 +47,7 @@ def test_shipped_library_exports_the_header_and_nothing_else():
     hooks = _dynamic_functions(os.path.join(lib_dir, "libvcfgl_hip_hooks.so"))
     assert hooks == set(_abi.EXPORTS) | set(_abi.HOOK_EXPORTS), hooks ^ (set(_abi.EXPORTS) | set(_abi.HOOK_EXPORTS))
     blob = open(os.path.join(lib_dir, "libvcfgl_hip.so"), "rb").read()
-    for name in (b"VGL_NO_FUSE", b"VGL_DEBUG_READ_CAP", b"VGL_GL_SORT", b"VGL_DEBUG_STAMPS"):
+    for name in (b"VGL_NO_FUSE", b"VGL_DEBUG_READ_CAP", b"VGL_GL_SORT", b"VGL_DEBUG_STAMPS", b"VGL_DEPTH_CHUNK", b"VGL_NO_POIS_ZT"):
         assert name not in blob, name                          # the shipped library reads no environment variable
     assert b"VGL_NO_FUSE" in open(os.path.join(lib_dir, "libvcfgl_hip_hooks.so"), "rb").read()
     hl = _abi.load_library(hooks=True)
