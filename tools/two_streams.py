@@ -1,3 +1,4 @@
+"""Diagnostic: does a second (third) context on its own stream overlap its tiles with the first's?  usage (GPU box): python tools/two_streams.py [c3|fixedq|alltags|c5]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
