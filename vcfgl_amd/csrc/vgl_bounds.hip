@@ -5,7 +5,7 @@
 // instead of silently changing an integer somewhere in 10^9 evaluations.
 //
 // Every mode evaluates the SAME inline helper the kernels use (fast_ln, gamma_test_lu, gamma_rhs_series, qs_tf,
-// tanf_err_bound, div_inrange ...) against a float64 evaluation of the exact quantity, and compares the difference with
+// the bound expressions of poisson_fast, div_inrange ...) against a float64 evaluation of the exact quantity, and compares the difference with
 // the SAME bound expression the kernels use, minus the part of that bound which is reserved for the rounding of the
 // argument from double to float (stated per mode).
 #include "vgl_common.hip.h"
@@ -17,7 +17,7 @@ enum {
     VGL_BOUND_GAMMA_REFEXPR = 3,// gamma_rhs_series against the reference's own double expression (param = a1)
     VGL_BOUND_QS_TF = 4,        // qs_tf / qs_tf_margin on (1e-37, 1)                    (qs_decide_pf)
     VGL_BOUND_RCP = 5,          // v_rcp_f32 within 1 ulp on every normal float           (qs_stage_pf)
-    VGL_BOUND_TANF = 6,         // tanf / tanf_err_bound on (0, VGL_PI]                   (poisson_attempt)
+    VGL_BOUND_TANF = 6,         // vgl_tanf_0pi against tan on (0, VGL_PI]: the function's share of poisson_fast's dy
     VGL_BOUND_EXP2 = 7,         // v_exp_f32 on [-126, 8]                                 (poisson_attempt)
     VGL_BOUND_DIV = 8,          // div_inrange == IEEE quotient, operands shaped like the pool loop's (count = pairs)
     VGL_BOUND_QUOT = 9,         // quot_int24 == IEEE float32 quotient of integers q <= sum <= 2^24 (k_siteagg; count = pairs)
@@ -93,14 +93,14 @@ __global__ __launch_bounds__(256) void k_bound_sweep(const uint32_t lo, const un
         } else if (MODE == VGL_BOUND_TANF) {
             const float yf = vgl_tanf_0pi(x);
             const float y2 = yf * yf;
-            // half of the second term of tanf_err_bound belongs to the rounding of a to af
+            // poisson_fast's dy = |yf| 2^-21 + (1 + yf^2) (af 7 x 2^-24 + 2e-9): one of the seven parts of the second term is the function's (this bound), the rest the argument's
             const double bound = (double)(fabsf(yf) * 0x1p-21f) + (double)((1.0f + y2) * x * 0x1p-24f);
             acc_update(mr, arg, viol, fabs((double)yf - tan(xd)), bound, bits);
         } else if (MODE == VGL_BOUND_EXP2) {
             if (!(x >= -126.0f && x <= 8.0f)) { --n; continue; }
             const float e = __builtin_amdgcn_exp2f(x);
             const double ex = exp2(xd);
-            // poisson_t_rel_err grants 2^-19 beyond the argument's |z| 2^-22; 2^-22 of it covers the three float
+            // poisson_fast's rel_t grants 2^-19 beyond the argument's |z| 2^-22; 2^-22 of it covers the three float
             // multiplications of tt = 0.9f (1 + y2) ex
             acc_update(mr, arg, viol, fabs((double)e - ex), ex * (0x1p-19 - 0x1p-22), bits);
         }

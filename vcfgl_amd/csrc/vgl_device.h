@@ -133,7 +133,7 @@ struct VglDevParams {
     VglAffine site_pow[40];            // J^(block * N * 2^b)  (k_sitebase)
     int32_t out_layout;                // VGL_LAYOUT_*: k_gl stores the multi-valued FORMAT arrays as planes or sample-major
     int32_t site_hash_bits;            // W of vgl_site_hash(): sites [0, 2^W) are addressable
-    uint32_t depth_magic;              // k_depth, 2 <= N < 1024: floor(2^32 / N) + 1, so that t / N = mulhi(t, magic) for t < 2048
+    uint32_t depth_magic;              // k_depth, 2 <= N < chunk: floor(2^32 / N) + 1, so that t / N = mulhi(t, magic) for t < N + chunk <= 2 VGL_DEPTH_CHUNK_MAX (t N < 2^32)
     const VglAffine* samp_tab;         // [N] J^(block * s)
     const VglAffine* qs_read_tab;      // [read_cap] J^(qs_read_stride * r)
     const VglAffine* step_tab;         // [192] J^k (serial-mode scout)

@@ -35,12 +35,12 @@ __global__ __launch_bounds__(256) void k_sitebase(const VglDevParams P, const Vg
 
 // Depth draws of a tile (vcfgl.cpp:364-389; rng.h:284-351), ahead of k_sample.  The rejection sampler
 // needs 2 attempts on average but about 7 for the slowest of 64 lanes, so evaluations are not tied to
-// lanes here: a wavefront owns VGL_DEPTH_CHUNK consecutive evaluations of the tile and deals them to its lanes as
-// lanes finish; one rejection attempt of every busy lane per iteration, lane state advanced by selects
+// lanes here: a wavefront owns `chunk` consecutive evaluations of the tile (1024, 2048 or 4096: vgl_launch_depth) and deals them to its
+// lanes as lanes finish; one rejection attempt of every busy lane per iteration (poisson_attempt: decided in float32), lane state advanced by selects
 // (launched only when every sample's mean depth is >= 12; the short product-method loops stay in k_sample).  Evaluation
 // (site, sample) starts its depth stream at J^(off0 + block sample) (site_base[site]): the site's state from k_sitebase, one table
 // jump per evaluation.  A chunk spans sites: the site of item i is found from the chunk's first (site, sample) by one compare
-// (N >= 1024) or one multiply-high (P.depth_magic).
+// (N >= chunk) or one multiply-high (P.depth_magic).
 // ZT: one mean depth for all samples, the acceptance bound's exponent from P.pois_zt
 template <bool ZT>
 __global__ __launch_bounds__(256) void k_depth(const VglDevParams P, const VglTilePtrs T, const int chunk) {
@@ -674,7 +674,7 @@ extern "C" int vgl_launch_depth(const VglDevParams* p, const VglTilePtrs* t, voi
     if (E == 0) return 0;
     // measured at 65536 x 1000 / x 2000 evaluations, depth 20 / 30: 0.478 / 0.904 ms with chunks of 1024, 0.446 / 0.841 with 2048, 0.438 / 0.820
     // with 4096; a small tile keeps the short chunks (a wavefront works its chunk off alone: 35 us per 1024 evaluations)
-    int chunk = E >= ((int64_t)1 << 24) ? 4096 : (E >= ((int64_t)1 << 23) ? 2048 : VGL_DEPTH_CHUNK);
+    int chunk = E >= ((int64_t)1 << 24) ? VGL_DEPTH_CHUNK_MAX : (E >= ((int64_t)1 << 23) ? 2048 : VGL_DEPTH_CHUNK);
     if (p->dbg_depth_chunk == 1024 || p->dbg_depth_chunk == 2048 || p->dbg_depth_chunk == 4096) chunk = p->dbg_depth_chunk;
     const int64_t waves = (E + chunk - 1) / chunk;
     if (!p->per_sample_depth && p->pois_zt) hipLaunchKernelGGL(k_depth<true>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *p, *t, chunk);
