@@ -126,6 +126,22 @@ def test_depth_kernel_large_chunks(oracle, monkeypatch, N, n_sites, chunk):
     assert np.array_equal(want.numpy("gl").view(np.uint32), got.numpy("gl").view(np.uint32))
 
 
+@pytest.mark.parametrize("chunk", [1024, 4096])
+def test_depth_kernel_per_sample_depths(oracle, monkeypatch, chunk):
+    """k_depth<false>: every sample has its own mean depth of 12 or more (its own sq / alxm / g / e_hi, loaded when a lane takes an
+    evaluation of that sample) -- the float64 exponent, both chunk sizes, chunks spanning many sites"""
+    monkeypatch.setenv("VGL_DEPTH_CHUNK", str(chunk))
+    N = 300
+    rng = np.random.default_rng(chunk)
+    depths = list(np.round(rng.uniform(12.0, 60.0, N), 3))
+    depths[0], depths[1], depths[-1] = 12.0, 12.000001, 59.999
+    args = VcfglArgs(seed=29, depths=depths, error_rate=0.01, add_fmt_ad=1)
+    want, got = run_both(oracle, args, synth.binary_sites(7, 120, N), site0=7, hooks=True)
+    for f in ("site_status", "fmt_dp", "info_dp", "fmt_ad"):
+        assert np.array_equal(want.numpy(f), got.numpy(f)), f
+    assert np.array_equal(want.numpy("gl").view(np.uint32), got.numpy("gl").view(np.uint32))
+
+
 @pytest.mark.parametrize("depth", [12.0, 17.3, 48.0, 260.0])
 def test_depth_kernel_without_the_exponent_table(oracle, monkeypatch, depth):
     """k_depth<ZT>: with one mean depth the acceptance bound's exponent comes from a float32 table (VglDevParams::pois_zt); with per-sample
