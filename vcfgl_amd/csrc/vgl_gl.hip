@@ -288,7 +288,10 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
     }
     const uint32_t chunks_k = FUSED ? (uint32_t)(WPB * P.fused_split) : (uint32_t)P.chunks;   // FUSED: a site takes fused_split whole workgroups (wavefronts beyond its samples idle)
     const uint32_t nwaves = (uint32_t)T.n_sites * chunks_k;                             // < 2^31 (checked by the launcher)
-    const uint32_t bx = P.xcd_map ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x;     // logical workgroup (XCD-contiguous)
+    // logical workgroup: XCD-contiguous (xcd_block) -- except for the fused build with one workgroup per site, whose workgroups share
+    // nothing: there the dispatch order measured 1 % faster (C5 k_gl 1.062 / 1.068 against 1.073 / 1.081 ms; the three-kernel k_gl loses
+    // 4 % without the mapping)
+    const uint32_t bx = (P.xcd_map && !(FUSED && P.fused_split == 1)) ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x;
     uint64_t f_a = 0;                                                   // FUSED: this thread's per-base depths
     // wave k of this workgroup is wave 4 bx + k of the tile = (site, 64-sample chunk).  One scalar division per workgroup; a lane
     // then finds the site of ANY of the four waves with three compares (a per-lane 64-bit division was 60+ vector instructions,
