@@ -483,9 +483,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
-            // -- quality scores of the segment's reads (vcfgl.cpp:500-523), item kb + lane per lane
-            for (int kb = 0; kb < segT; kb += 64) {
-                const int kk = kb + lane;
+            // -- quality scores of the segment's reads (vcfgl.cpp:500-523): pass j takes item 64 j + lane per lane.  LEAN 3 with the LDS sums
+            // (qfast): lane l takes items l dB + j instead, dB = the passes, made odd -- the items of one owner are neighbours in the pool, so
+            // with neighbouring items in neighbouring lanes about twenty lanes of every pass added to the SAME LDS word (one evaluation, one
+            // base), and the LDS serialises same-address atomics: 0.53 ms of the 14.3 ms launch; a stride of about twenty items puts the
+            // lanes of a pass on different owners, the odd stride keeps their slot reads on different banks
+            const int n_pass = (segT + 63) >> 6;
+            const int dB = qfast ? (n_pass | 1) : 0;
+            for (int jp = 0; jp < (qfast ? dB : n_pass); ++jp) {
+                const int kb = qfast ? jp : 64 * jp;                    // item of lane b in this pass: kb + b * kstep
+                const int kstep = qfast ? dB : 1;
+                const int kk = kb + lane * kstep;
                 const bool inb = kk < segT;
                 const float pf = __uint_as_float(l_it[inb ? kk : cap]);
                 int q_i, aq_i;
@@ -498,7 +506,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     while (amb) {
                         const int b = __builtin_ctzll(amb);
                         amb &= amb - 1;
-                        const int Kb = seg0 + kb + b;                   // index of the read in the wave's pool
+                        const int Kb = seg0 + kb + b * kstep;           // index of the read in the wave's pool
                         if (active && Kb >= offs && Kb < offs + dp) {
                             if (DEFER) {
                                 const uint32_t idx = atomicAdd(T.redo_count, 1u);
@@ -511,7 +519,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                                 int qe, aqe;
                                 errprob_raw(P, ep, qe, aqe);
                                 if (aqe < 0 && (P.adjust_qs & 3)) atomicOr(T.errflag, VGL_DEVERR_ADJQ);   // vcfgl.cpp:558, gl_methods.cpp:101
-                                l_it[kb + b] = (uint32_t)(uint16_t)qe | ((uint32_t)(uint16_t)aqe << 16);
+                                l_it[kb + b * kstep] = (uint32_t)(uint16_t)qe | ((uint32_t)(uint16_t)aqe << 16);
                             }
                         }
                     }
