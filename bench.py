@@ -36,6 +36,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E vendor peak (MI355X_MICROARCH.md)
 # instruction roofline: 256 CUs x 4 SIMDs, 2.4 GHz, one wavefront instruction of the float64 / three-operand class this path
 # is made of per ~4 cycles of a SIMD (MI355X_MICROARCH.md "vector-instruction ISSUE cost"; tools/valu_rates.hip measured 4.3)
 VALU_PEAK_WAVE_INST_PER_S = 1024 * 2.4e9 / 4.0
+LOOP_COST_FILE = "r04_loop_cost.json"          # tools/loop_cost.py over the pool loop of k_sample<2>
 
 RTA3 = [(0, 2, 2), (3, 14, 12), (15, 30, 23), (31, 40, 37)]
 WORKLOADS = {
@@ -105,7 +106,7 @@ def workload_args(name="c3"):
 # ---------------------------------------------------------------------------------------------------------------------
 # CPU baseline (the oracle = a port of the reference algorithm; test infrastructure used here only as the thing timed beside)
 
-def cpu_baseline(args, n_samples, budget_s=15.0):
+def cpu_single_core(args, n_samples, budget_s=12.0):
     """The CPU oracle (a port of the reference algorithm, same inputs, one core) on a bounded sample."""
     import synth
     so = os.path.join(ROOT, "oracle", "libvgl_oracle.so")
@@ -120,18 +121,21 @@ def cpu_baseline(args, n_samples, budget_s=15.0):
     n = int(max(n0, min(200000, budget_s / (dt / n0))))
     gt = synth.binary_sites(0, n, n_samples)
     t0 = time.perf_counter(); o.simulate(0, gt, fields=fields); dt = time.perf_counter() - t0
-    res = {"value": n * n_samples / dt, "unit": "site-sample GL evals/s", "cores": 1, "kind": "port",
-           "sample": f"first {n} sites x {n_samples} samples of the same workload, oracle/vgl_oracle.c (gcc -O2), {dt:.1f} s",
-           "sampler": "rand48 beta sampler (rng.h:426-446), as the GPU path in tile mode; the reference's default build draws quality "
-                      "scores from std::mt19937 + std::gamma_distribution, measured at ~2.0e5 evals/s on this configuration (BASELINE.md section 2)"}
-    # All host cores, site-sharded in tile mode (NOT reference behaviour: the reference simulates on one
-    # thread; SURVEY 8d asks for this figure beside the faithful one).  One process per core, each on its
-    # own site range, about 8 s each.
+    return {"value": n * n_samples / dt, "unit": "site-sample GL evals/s", "cores": 1, "kind": "port", "n_sites": n,
+            "sample": f"first {n} sites x {n_samples} samples of the same workload, oracle/vgl_oracle.c (gcc -O2), {dt:.1f} s",
+            "sampler": "rand48 beta sampler (rng.h:426-446), as the GPU path in tile mode; the reference's default build draws quality "
+                       "scores from std::mt19937 + std::gamma_distribution, measured at ~2.0e5 evals/s on this configuration (BASELINE.md section 2)"}
+
+
+def cpu_all_cores(res, workload, n_samples, budget_s=6.0):
+    """All host cores, site-sharded in tile mode (NOT reference behaviour: the reference simulates on one thread; SURVEY 8d asks
+    for this figure beside the faithful one).  One process per core, each on its own site range, about `budget_s` each."""
     try:
         cores = min(os.cpu_count() or 1, 64)
-        per = int(max(256, min(n, 8.0 * res["value"] / n_samples)))
+        n = res["n_sites"]
+        per = int(max(256, min(n, budget_s * res["value"] / n_samples)))
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", f"{n + k * per},{per}",
-                                   "--workload", args._workload, "--samples", str(n_samples)],
+                                   "--workload", workload, "--samples", str(n_samples)],
                                   stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for k in range(cores)]
         dts = [float(json.loads(p.communicate(timeout=300)[0].strip().splitlines()[-1])["dt"]) for p in procs]
         res["all_cores"] = {"value": cores * per * n_samples / max(dts), "cores": cores,
@@ -222,15 +226,29 @@ def profile_entry(workload):
         return {}
 
 
-def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_cpu=False, gather="index"):
-    """K timed passes of the hot path over one workload; returns the result dictionary (rank 0) or None."""
+class _HostStream:
+    """stand-in of a HIP stream for the CPU rehearsal of the N-rank path (BENCH_TEST_STUB, tests/bench_stub.py)"""
+    cuda_stream = 0
+
+    def synchronize(self):
+        pass
+
+
+def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_cpu=False, gather="index", early=None):
+    """K timed passes of the hot path over one workload; returns the result dictionary (rank 0) or None.
+    `early(res)`: called on rank 0 as soon as the timed value exists, BEFORE anything that is allowed to fail or stall afterwards
+    (the sampled record gather over RCCL): the line is on stdout by then."""
+    import contextlib
     import ctypes as C
+    import threading
     import numpy as np
     import torch
     import synth
     from vcfgl_amd import Simulator, _abi
     from vcfgl_amd.shard import gather_records, gather_site_index, pack_records, reduce_site_counters, site_range
     rank, world, dist, dev, local_dev = env["rank"], env["world"], env["dist"], env["dev"], env["local_dev"]
+    group = env.get("group")                                     # the data-plane process group (RCCL), None = the default group
+    on_gpu = dev.type == "cuda"
     args = workload_args(name)
     wl = WORKLOADS[name]
     S_wl = sites if sites is not None else wl["sites"]
@@ -241,10 +259,14 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
     else:
         S, site_base, S_total = S_wl, rank * S_wl, S_wl * world      # every rank its own full-size range
     TS = max(1, min(opt.tile_sites, S))
-    sim = Simulator(args, N, device=local_dev, max_sites_per_tile=TS)
+    sim = (env.get("make_sim") or Simulator)(args, N, device=local_dev, max_sites_per_tile=TS)
     G = sim.G
     info = sim.info()
     log(f"{name}: rank {rank}/{world} sites [{site_base}, {site_base + S}) x {N} samples, tiles of {TS}")
+
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize()
 
     # ---- inputs resident in HBM before the timed region
     gt = torch.empty((S, N), dtype=torch.uint8, device=dev)
@@ -268,8 +290,10 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
         for k, v in out.items():
             setattr(t, k, v[s0:s0 + n].data_ptr())
         structs.append((s0, n, t))
-    stream = torch.cuda.Stream(device=dev)
-    transport = torch.device("cpu") if (dist is not None and opt.backend == "gloo") else None
+    stream = torch.cuda.Stream(device=dev) if on_gpu else _HostStream()
+    on_stream = (lambda: torch.cuda.stream(stream)) if on_gpu else contextlib.nullcontext
+    transport = torch.device("cpu") if (dist is not None and env.get("data_backend", opt.backend) == "gloo" and on_gpu) else None
+    ctl_dev = torch.device("cpu") if (transport is not None or not on_gpu) else dev       # where the small control tensors live
     gathered_bytes = [0]
 
     def to_transport(x):
@@ -282,18 +306,18 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
             sim._check(sim.lib.vgl_simulate_tile_device(sim.ctx, site_base + s0, n, gt[s0:s0 + n].data_ptr(), C.byref(t),
                                                         C.c_void_p(stream.cuda_stream)))
             if dist is not None and gather == "records":           # the tile's records to the writer rank, variable length
-                with torch.cuda.stream(stream):
+                with on_stream():
                     p = pack_records({k: v[s0:s0 + n] for k, v in out.items()}, site0=site_base + s0)
-                    got = gather_records(p, world, rank, transport=transport, always_collective=True)
+                    got = gather_records(p, world, rank, transport=transport, always_collective=True, group=group)
                     if got is not None:
                         gathered_bytes[0] += sum(q.nbytes() for q in got)
         if dist is not None:                                      # record-index gather to the writer rank + the summary's counters
             stream.synchronize()
             t_c = time.perf_counter()
             gather_site_index(to_transport(out["site_status"]), to_transport(out["n_alleles"]), world, rank, S_total if opt.scaling == "strong" else S * world,
-                              always_collective=True)
-            reduce_site_counters(to_transport(out["site_status"]), world, always_collective=True)
-            torch.cuda.synchronize()
+                              always_collective=True, group=group)
+            reduce_site_counters(to_transport(out["site_status"]), world, always_collective=True, group=group)
+            sync()
             comm["gather_s"] += time.perf_counter() - t_c
 
     def sampled_record_gather():
@@ -301,29 +325,31 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
         travel to the writer (point to point, one xGMI link per peer), so that the link rate is on record without moving the whole
         step's 65 GB per GPU through one writer.  Twice; the second pass is the one reported."""
         s0, n, _ = structs[-1]
+        if os.environ.get("BENCH_TEST_STALL_RANK") == str(rank):  # tests/test_bench_world8_cpu.py: one rank never arrives
+            time.sleep(3600)
         for rep in range(2):
             # every rank first says whether its packing worked: a rank that failed (out of memory in pack_records, say) must not
             # leave its peers waiting in the barriers and transfers below until the process group times out
             p, err = None, None
             try:
-                with torch.cuda.stream(stream):
+                with on_stream():
                     p = pack_records({k: v[s0:s0 + n] for k, v in out.items()}, site0=site_base + s0)
                 stream.synchronize()
             except Exception as e:
                 err = repr(e)[:300]
-            ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev if transport is None else transport)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=ctl_dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
             if int(ok.item()) == 0:
                 comm["sample_error"] = err or "another rank failed to pack its records: sampled gather skipped on every rank"
                 return
-            dist.barrier()
-            torch.cuda.synchronize()
+            dist.barrier(group=group)
+            sync()
             t_c = time.perf_counter()
-            with torch.cuda.stream(stream):
-                got = gather_records(p, world, rank, transport=transport, always_collective=True)
+            with on_stream():
+                got = gather_records(p, world, rank, transport=transport, always_collective=True, group=group)
             stream.synchronize()
-            torch.cuda.synchronize()
-            dist.barrier()
+            sync()
+            dist.barrier(group=group)
             comm["sample_s"] = time.perf_counter() - t_c
             comm["sample_packed_bytes"] = p.nbytes()
             comm["sample_bytes"] = sum(q.nbytes() for q in got[1:]) if got is not None else 0      # bytes that crossed a link into the writer
@@ -332,9 +358,9 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
     if dist is not None and gather == "records":
         # the writer receives one packed tile from every peer at a time: refuse up front when that cannot fit beside its own arrays
         need = (world - 1) * algorithmic_bytes_per_eval(fields, G) * TS * N * 2           # receive buffers + their unpacked view
-        free = torch.cuda.mem_get_info(dev)[0] if rank == 0 else 0
-        okt = torch.tensor([1 if (rank != 0 or free > need) else 0], dtype=torch.int32, device=dev if transport is None else transport)
-        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        free = torch.cuda.mem_get_info(dev)[0] if (rank == 0 and on_gpu) else (1 << 62)
+        okt = torch.tensor([1 if (rank != 0 or free > need) else 0], dtype=torch.int32, device=ctl_dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN, group=group)
         if int(okt.item()) == 0:
             if rank == 0:
                 log(f"--gather records: the writer needs about {need / 1e9:.1f} GB for the peers' packed tiles but has {free / 1e9:.1f} GB free: "
@@ -344,10 +370,10 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
 
     def barrier():
         stream.synchronize()
-        torch.cuda.synchronize()
+        sync()
         if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+            dist.barrier(group=group)
+        sync()
 
     for _ in range(warmup):
         step()
@@ -369,23 +395,18 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
     per_rank = None
     if dist is not None:
         # every rank's own clock and kernel buckets to rank 0 (the first multi-GPU run must show a load imbalance at once), then the max
-        mine = torch.tensor([dt] + [float(x) for x in kms] + [float(x) for x in klaunch], dtype=torch.float64, device=dev if transport is None else transport)
+        mine = torch.tensor([dt] + [float(x) for x in kms] + [float(x) for x in klaunch], dtype=torch.float64, device=ctl_dev)
         allr = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
+        dist.all_gather(allr, mine, group=group)
         per_rank = [t.cpu().tolist() for t in allr]
         dt = max(r[0] for r in per_rank)
-        if gather == "sample":
-            try:                                                   # (after the timed steps: a failure here is reported in `comm`, it must not cost the line)
-                sampled_record_gather()
-            except Exception as e:
-                comm["sample_error"] = repr(e)[:300]
 
     res = None
     if rank == 0:
         evals_total = float(S_total) * N * steps
         b_eval = algorithmic_bytes_per_eval(fields, G)
         dom = int(np.argmax(kms))
-        avg_ms = kms[dom] / max(klaunch[dom], 1)
+        avg_ms = max(kms[dom] / max(klaunch[dom], 1), 1e-9)
         evals_per_launch = float(S) * N * steps / max(klaunch[dom], 1)     # average over the launches, partial last tile included
         achieved = b_eval * evals_per_launch / (avg_ms * 1e-3) / 1e9
         prof = profile_entry(name)
@@ -406,14 +427,14 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
             # cost-weighted: the instruction mix of the kernel's hot loop priced with the issue costs measured on this part (tools/loop_cost.py
             # over the compiler's ISA, tools/valu_rates.hip), instead of a flat 4 cycles per instruction
             try:
-                lc = json.load(open(os.path.join(ROOT, "profiles", "r04_loop_cost.json")))
+                lc = json.load(open(os.path.join(ROOT, "profiles", LOOP_COST_FILE)))
                 if KERNELS[dom] == "k_sample" and args.error_qs == 2:
                     cyc = kprof["valu_insts_per_wave"] * lc["avg_cycles_per_valu_inst"] * waves          # SIMD cycles of vector issue per launch
                     valu["cost_weighted"] = {"avg_cycles_per_valu_inst": lc["avg_cycles_per_valu_inst"], "valu_per_pool_iteration": lc["valu_per_iteration_weighted"],
                                              "simd_cycles_per_pool_iteration": lc["simd_cycles_per_iteration_weighted"],
                                              "frac": cyc / (1024 * 2.4e9 * avg_ms * 1e-3),
                                              "note": "wavefront VALU instructions x the pool loop's average issue cost / (1024 SIMDs x 2.4 GHz x launch time): share of the chip's vector issue time the kernel uses",
-                                             "source": "profiles/r04_loop_cost.json (tools/loop_cost.py)"}
+                                             "source": f"profiles/{LOOP_COST_FILE} (tools/loop_cost.py)"}
             except Exception:
                 pass
         traffic = kprof.get("hbm_bytes_per_launch") * scale if kprof.get("hbm_bytes_per_launch") else None
@@ -451,23 +472,47 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
                 "kernel_ms_per_launch": [{k: (r[1 + i] / r[1 + nb + i] if r[1 + nb + i] else 0.0) for i, k in enumerate(KERNELS)} for r in per_rank],
                 "note": "each rank's own wall clock over the timed steps (value uses the slowest) and its kernel buckets: equal work per rank, so a spread here is the machine, not the sharding"}
         if dist is not None:
-            res["comm"] = {"backend": opt.backend, "world": dist.get_world_size(), "gather": gather,
+            res["comm"] = {"backend": env.get("data_backend", opt.backend), "world": dist.get_world_size(), "gather": gather,
                            "gather_ms": comm["gather_s"] / steps * 1e3,
                            "gather_note": "per step on the writer: gather of the per-site record index (status, allele count) + all-reduce of the site counters"}
-            if comm.get("sample_error"):
-                res["comm"]["records_sample_error"] = comm["sample_error"]
-            if gather == "sample" and comm["sample_s"] > 0:
-                gbps = comm["sample_bytes"] / comm["sample_s"] / 1e9
-                full_bytes = b_eval * float(S) * N * (world - 1)            # what a full record gather would move into the writer per step (upper bound: unpacked size)
-                res["comm"].update({"records_sample_ms": comm["sample_s"] * 1e3, "records_sample_bytes_into_writer": comm["sample_bytes"],
-                                    "records_sample_GBps": gbps,
-                                    "full_record_gather_s_per_step_at_that_rate": (full_bytes / 1e9 / gbps) if gbps > 0 else None,
-                                    "records_sample_note": f"packed records of one {structs[-1][1]}-site tile per rank ({comm['sample_packed_bytes'] / 1e9:.2f} GB), point to point "
-                                                           "to rank 0, measured once AFTER the timed steps (not part of `value`; --gather records puts every tile's "
-                                                           "records inside the timed steps)"})
+            if gather == "sample":
+                res["comm"]["records_sample"] = "pending"          # replaced below; stays if the sampled gather stalls and the watchdog ends the run
         if dist is not None and gather == "records":
             res["records_gather"] = {"bytes_per_step_at_writer": gathered_bytes[0] / steps, "GBps_into_writer": gathered_bytes[0] / dt / 1e9}
-        if name == opt.workload and not opt.no_pack_rate:
+        if early is not None:
+            early(res)
+
+    if dist is not None and gather == "sample":
+        # AFTER the timed steps and after rank 0 has printed the line: a failure is reported in `comm`, a stall ends the run with the
+        # line already on stdout (the first 8-GPU run is the first time these point-to-point transfers execute over xGMI)
+        def stalled():
+            log(f"rank {rank}: sampled record gather stalled for more than {opt.comm_timeout:g} s: ending the run; the line already printed stands")
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(0)
+        dog = threading.Timer(opt.comm_timeout, stalled)
+        dog.daemon = True
+        dog.start()
+        try:
+            sampled_record_gather()
+        except Exception as e:
+            comm["sample_error"] = repr(e)[:300]
+        dog.cancel()
+        if res is not None:
+            c = res["comm"]
+            if comm.get("sample_error"):
+                c["records_sample"] = "error"
+                c["records_sample_error"] = comm["sample_error"]
+            elif comm["sample_s"] > 0:
+                gbps = comm["sample_bytes"] / comm["sample_s"] / 1e9
+                full_bytes = b_eval * float(S) * N * (world - 1)            # what a full record gather would move into the writer per step (upper bound: unpacked size)
+                c.update({"records_sample": "ok", "records_sample_ms": comm["sample_s"] * 1e3, "records_sample_bytes_into_writer": comm["sample_bytes"],
+                          "records_sample_GBps": gbps,
+                          "full_record_gather_s_per_step_at_that_rate": (full_bytes / 1e9 / gbps) if gbps > 0 else None,
+                          "records_sample_note": f"packed records of one {structs[-1][1]}-site tile per rank ({comm['sample_packed_bytes'] / 1e9:.2f} GB), point to point "
+                                                 "to rank 0, measured once AFTER the timed steps (not part of `value`; --gather records puts every tile's "
+                                                 "records inside the timed steps)"})
+    if res is not None:
+        if name == opt.workload and not opt.no_pack_rate and on_gpu:
             # device-side packing of one tile's records (what precedes the gather): an HBM-bound gather
             s0, n, _ = structs[0]
             tile = {k: v[s0:s0 + n] for k, v in out.items()}
@@ -483,7 +528,7 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
             res["record_packing"] = {"tile_sites": n, "kept_sites": p.n_kept, "packed_bytes": p.nbytes(), "ms": e0.elapsed_time(e1),
                                      "GBps": 2 * p.nbytes() / (e0.elapsed_time(e1) * 1e-3) / 1e9, "note": "read + write bytes of shard.pack_records on one tile"}
             del p
-        if with_cpu:
+        if with_cpu and on_gpu:
             # the box's own device-copy bandwidth (read + write bytes of a 1 GiB device-to-device copy), the
             # second denominator SURVEY 8d asks for beside the vendor peak
             src = out["gl"].view(-1)[: min(out["gl"].numel(), 1 << 28)]
@@ -501,10 +546,8 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
             res["roofline"]["frac_of_copy_bw"] = achieved / copy_gbs
     sim.close()
     del gt, out, structs
-    torch.cuda.empty_cache()
-    if res is not None and with_cpu:
-        log("cpu baseline ...")
-        res["cpu_baseline"] = cpu_baseline(args, N)
+    if on_gpu:
+        torch.cuda.empty_cache()
     return res
 
 
@@ -572,6 +615,192 @@ def host_path_rate(opt, env, workload="c3"):
                     f"sample-major slabs, {'GL+PL(u8)+DP' if args.add_pl else 'GL+DP'} copied back ({b} B per evaluation); PCIe-inclusive, never the bench value"}
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# the line the driver parses: <= 4 KB, scalars and short strings only (a 26.5 KB line was dropped).  Everything else --
+# per-workload roofline blocks of the extras, notes, per-rank kernel buckets -- goes to the detail file and to one compact
+# `bench_extra` line printed BEFORE the headline.
+
+LINE_LIMIT = 4096
+
+
+def _r(x, nd=4):
+    """floats to `nd` significant digits (the line is a report, not a checkpoint)"""
+    if isinstance(x, float):
+        return float(f"{x:.{nd}g}") if x == x and x not in (float("inf"), float("-inf")) else None
+    return x
+
+
+def compact_roofline(rf):
+    v = rf.get("valu") or {}
+    out = {"bound": rf["bound"], "kernel": rf["kernel"], "achieved": _r(rf["achieved"], 5), "peak": rf["peak"], "unit": rf["unit"], "frac": _r(rf["frac"], 4),
+           "traffic": _r(rf.get("traffic"), 5), "traffic_frac_of_peak": _r(rf.get("traffic_frac_of_peak")),
+           "traffic_source": (rf.get("traffic_source") or "").split(" ")[0] or None,
+           "avg_launch_ms": _r(rf["avg_launch_ms"], 5), "algorithmic_bytes_per_eval": rf["algorithmic_bytes_per_eval"],
+           "step_frac": _r(rf["step"]["frac"]), "step_GBps": _r(rf["step"]["achieved"], 5),
+           "valu_frac": _r(v.get("frac")), "valu_frac_cost_weighted": _r((v.get("cost_weighted") or {}).get("frac")),
+           "valu_busy_pmc": _r(v.get("valu_busy_frac_pmc")), "valu_insts_per_wave": _r(v.get("valu_insts_per_wave"), 5),
+           "profile_matches_build": v.get("profile_matches_build"),
+           "kernel_ms_per_launch": {k: _r(rf["kernel_ms_total"][k] / max(rf["launches"][k], 1)) for k in rf["kernel_ms_total"] if rf["launches"][k]},
+           "note": "achieved/frac = algorithmic bytes of the dominant kernel / its HIP-event time; bound valu = instruction issue (valu_frac of 1024 SIMD x 2.4 GHz / 4)"}
+    if "copy_bw_measured" in rf:
+        out["copy_bw_measured"] = _r(rf["copy_bw_measured"], 5)
+    return out
+
+
+def compact_line(main_res, extra, opt, world, metric, dist_info=None):
+    """the headline object: what bench.py prints as its LAST stdout line"""
+    cb = main_res.get("cpu_baseline")
+    line = {
+        "metric": metric, "value": main_res["value"], "unit": main_res["unit"],
+        "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": _r(main_res["ms_per_step"], 6),
+        "higher_is_better": True, "scaling": opt.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": main_res["workload"][:200], "tile_sites": opt.tile_sites,
+                   "parallelism": f"site-sharded x{world}"},
+        "roofline": compact_roofline(main_res["roofline"]),
+    }
+    if dist_info:
+        line["config"].update(dist_info)
+    if cb:
+        line["cpu_baseline"] = {"value": _r(cb["value"], 5), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"][:120],
+                                "sampler": "rand48 beta (rng.h:426-446) on both sides; reference default std-beta: ~2.0e5/s (BASELINE.md)"}
+        ac = cb.get("all_cores") or {}
+        if "value" in ac:
+            line["cpu_baseline"]["all_cores_value"] = _r(ac["value"], 5)
+            line["cpu_baseline"]["all_cores"] = ac["cores"]
+    if "ctx" in main_res:
+        line["ctx"] = main_res["ctx"]
+    if "ranks" in main_res:
+        rk = main_res["ranks"]
+        line["ranks"] = {"evals_per_s_min": _r(rk["evals_per_s"]["min"], 5), "evals_per_s_max": _r(rk["evals_per_s"]["max"], 5),
+                         "ms_per_step_min": _r(rk["ms_per_step"]["min"], 5), "ms_per_step_max": _r(rk["ms_per_step"]["max"], 5)}
+    if "comm" in main_res:
+        line["comm"] = {k: (_r(v, 5) if not isinstance(v, str) else v[:160]) for k, v in main_res["comm"].items() if not k.endswith("_note")}
+    if "records_gather" in main_res:
+        line["records_gather"] = {k: _r(v, 5) for k, v in main_res["records_gather"].items()}
+    if "record_packing" in main_res:
+        line["record_packing_GBps"] = _r(main_res["record_packing"]["GBps"], 5)
+    if extra:
+        line["extra"] = {k: (_r(v.get("value"), 5) if isinstance(v, dict) and "value" in v else "error") for k, v in extra.items() if v is not None}
+        line["extra_detail"] = "line `bench_extra` above + " + os.path.relpath(detail_path(opt), ROOT)
+    return line
+
+
+def compact_extra(extra):
+    """one short object per extra workload (printed as its own line before the headline)"""
+    out = {}
+    for k, v in extra.items():
+        if not isinstance(v, dict):
+            continue
+        if "error" in v:
+            out[k] = {"error": v["error"][:120]}
+        elif "roofline" in v:
+            rf = v["roofline"]
+            out[k] = {"value": _r(v["value"], 5), "ms_per_step": _r(v["ms_per_step"], 5), "steps": v["steps"], "kernel": rf["kernel"], "bound": rf["bound"],
+                      "frac": _r(rf["frac"]), "step_frac": _r(rf["step"]["frac"]), "valu_frac": _r((rf.get("valu") or {}).get("frac")),
+                      "avg_launch_ms": _r(rf["avg_launch_ms"], 5), "B_eval": rf["algorithmic_bytes_per_eval"]}
+        else:
+            out[k] = {"value": _r(v.get("value"), 5), "GBps_over_pcie": _r(v.get("GBps_over_pcie")),
+                      "sync_pageable": _r((v.get("sync_pageable") or {}).get("value"), 5)}
+    return {"bench_extra": out, "unit": "site-sample GL evals/s"}
+
+
+def detail_path(opt):
+    return opt.detail_file or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+
+
+def dumps_strict(obj):
+    return json.dumps(obj, allow_nan=False, separators=(",", ":"))
+
+
+def emit(main_res, extra, opt, world, metric, dist_info=None, final=True):
+    """rank 0: detail file, the `bench_extra` line, then the headline line (always the last thing on stdout)"""
+    line = compact_line(main_res, extra, opt, world, metric, dist_info)
+    text = dumps_strict(line)
+    if len(text) >= LINE_LIMIT:                                # never lose the line to its size: drop the optional blocks
+        for k in ("extra", "ctx", "comm", "ranks", "record_packing_GBps", "records_gather"):
+            line.pop(k, None)
+            text = dumps_strict(line)
+            if len(text) < LINE_LIMIT:
+                break
+    try:
+        path = detail_path(opt)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        full = dict(line, roofline=main_res["roofline"])
+        for k in ("cpu_baseline", "comm", "ranks", "record_packing", "records_gather"):
+            if k in main_res:
+                full[k] = main_res[k]
+        full["extra"] = extra
+        with open(path, "w") as f:
+            json.dump(full, f)
+    except Exception as e:
+        log(f"detail file not written: {e!r}")
+    if extra and final:
+        print(dumps_strict(compact_extra(extra)), flush=True)
+    print(text, flush=True)
+    return text
+
+
+def init_groups(opt, rank, world, local_dev, on_gpu):
+    """Process groups of an N-rank run.  The default group is gloo (control plane: agreement on errors, the fall-back);
+    the data plane is an RCCL group (`nccl` in torch.distributed) proved by one all-reduce before anything is timed.  If RCCL
+    raises on any rank, EVERY rank falls back to the gloo group for the collectives -- `value` needs no data-path collective
+    (sites shard with nothing exchanged), so an N-GPU line is still produced and says which transport carried the gathers.
+    A rank that stalls in the RCCL proof is ended by a watchdog with a clear message instead of hanging the launcher."""
+    import threading
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if dist.get_world_size() != opt.gpus:
+        sys.exit(f"bench.py: the process group has {dist.get_world_size()} ranks, --gpus says {opt.gpus}")
+    info = {"rccl_world": None, "backend": "gloo (host staging, rehearsal)", "rccl_version": None}
+    if opt.backend != "nccl":
+        return dist, None, "gloo", info
+    err, group = None, None
+
+    def stalled():
+        log(f"rank {rank}: the RCCL proof all-reduce did not finish in {opt.comm_timeout:g} s: ending the run (no line: the timed region needs its barrier)")
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(14)
+    dog = threading.Timer(opt.comm_timeout, stalled)
+    dog.daemon = True
+    dog.start()
+    try:
+        if not on_gpu:
+            raise RuntimeError("no GPU on this rank")
+        try:
+            group = dist.new_group(backend="nccl", device_id=torch.device("cuda", local_dev))
+        except TypeError:
+            group = dist.new_group(backend="nccl")
+        t = torch.ones(1, dtype=torch.int32, device=torch.device("cuda", local_dev))
+        dist.all_reduce(t, group=group)
+        torch.cuda.synchronize()
+        if int(t.item()) != world:
+            raise RuntimeError(f"RCCL all-reduce over {world} ranks returned {int(t.item())}")
+        info["rccl_world"] = dist.get_world_size(group)
+    except Exception as e:
+        err = repr(e)[:200]
+    ok = torch.tensor([0 if err else 1], dtype=torch.int32)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)                    # over gloo: every rank learns whether RCCL came up everywhere
+    dog.cancel()
+    try:
+        v = torch.cuda.nccl.version()
+        info["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:
+        pass
+    if int(ok.item()) == 1:
+        info["backend"] = "rccl (torch.distributed nccl)"
+        return dist, group, "nccl", info
+    errs = [None] * world
+    dist.all_gather_object(errs, err)
+    first = next((f"rank {r}: {e}" for r, e in enumerate(errs) if e), "unknown")
+    log(f"rank {rank}: RCCL did not come up on every rank ({first}); the collectives fall back to gloo over host memory")
+    info["backend"] = "gloo (FALLBACK: RCCL failed)"
+    info["rccl_error"] = first[:200]
+    return dist, None, "gloo", info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -584,17 +813,23 @@ def main():
                          "also the packed records of one tile per rank; records: the packed records of every tile")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL over xGMI; gloo stages through host memory (rehearsal)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a box with fewer GPUs than ranks: rank r uses device r %% device_count (needs --backend gloo)")
+    ap.add_argument("--comm-timeout", type=float, default=60.0, help="seconds a rank waits in the RCCL proof / the sampled record gather before it ends the run")
     ap.add_argument("--sites", type=int, default=None)
     ap.add_argument("--samples", type=int, default=None)
     ap.add_argument("--tile-sites", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the other configurations attached as `extra`")
     ap.add_argument("--no-pack-rate", action="store_true")
+    ap.add_argument("--detail-file", default=None, help="where the full (unabridged) result goes; default gpurun_out/bench_detail.json")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)     # internal: one shard of the all-cores CPU leg
+    ap.add_argument("--cpu-single-worker", action="store_true", help=argparse.SUPPRESS)   # internal: the one-core CPU leg in a process of its own
     ap.add_argument("--host-path-worker", default=None, help=argparse.SUPPRESS)   # internal: the PCIe-inclusive host path in a fresh process
     opt = ap.parse_args()
     if opt.cpu_worker:                                         # never touches the GPU
         cpu_worker(opt.cpu_worker, workload_args(opt.workload), opt.samples or WORKLOADS[opt.workload]["samples"])
+        return
+    if opt.cpu_single_worker:                                  # never touches the GPU
+        print(json.dumps(cpu_single_core(workload_args(opt.workload), opt.samples or WORKLOADS[opt.workload]["samples"])))
         return
     if opt.host_path_worker is not None:
         print(json.dumps({wl: host_path_rate(opt, {"local_dev": int(opt.host_path_worker)}, wl) for wl in ("c3", "c5")}))
@@ -614,31 +849,37 @@ def main():
     if world != opt.gpus:
         sys.exit(f"bench.py: --gpus {opt.gpus} but WORLD_SIZE is {world}: launch with --nproc-per-node {opt.gpus} (or plain `python bench.py --gpus {opt.gpus}`)")
     import torch
-    ndev = torch.cuda.device_count()
-    if opt.share_gpu:
-        if opt.backend != "gloo":
-            sys.exit("--share-gpu needs --backend gloo (RCCL refuses two ranks on one device)")
-        local_dev = local_rank % max(ndev, 1)
+    stub = os.environ.get("BENCH_TEST_STUB")                   # tests/test_bench_world8_cpu.py: the N-rank path on a box without GPUs
+    make_sim = None
+    if stub:
+        import bench_stub                                      # tests/bench_stub.py: fills the tile's status arrays, simulates nothing
+        make_sim, local_dev, dev = bench_stub.StubSimulator, 0, torch.device("cpu")
     else:
-        if local_rank >= ndev:
-            sys.exit(f"bench.py: rank {rank} needs GPU {local_rank} but this node shows {ndev} device(s)")
-        local_dev = local_rank
-    dist = None
-    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):        # BENCH_FORCE_DIST: exercise the collective path at world 1
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        if opt.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_dev))
+        ndev = torch.cuda.device_count()
+        if opt.share_gpu:
+            if opt.backend != "gloo":
+                sys.exit("--share-gpu needs --backend gloo (RCCL refuses two ranks on one device)")
+            local_dev = local_rank % max(ndev, 1)
         else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        if dist.get_world_size() != opt.gpus:
-            sys.exit(f"bench.py: the process group has {dist.get_world_size()} ranks, --gpus says {opt.gpus}")
-    torch.cuda.set_device(local_dev)
-    env = {"rank": rank, "world": world, "dist": dist, "dev": torch.device("cuda", local_dev), "local_dev": local_dev}
+            if local_rank >= ndev:
+                sys.exit(f"bench.py: rank {rank} needs GPU {local_rank} but this node shows {ndev} device(s)")
+            local_dev = local_rank
+        dev = torch.device("cuda", local_dev)
+        torch.cuda.set_device(local_dev)
+    dist, group, data_backend, dist_info = None, None, None, None
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):        # BENCH_FORCE_DIST: exercise the collective path at world 1
+        dist, group, data_backend, dist_info = init_groups(opt, rank, world, local_dev, dev.type == "cuda")
+        dist_info["gather"] = opt.gather
+    env = {"rank": rank, "world": world, "dist": dist, "group": group, "dev": dev, "local_dev": local_dev, "make_sim": make_sim}
+    if data_backend:
+        env["data_backend"] = data_backend
+    args = workload_args(opt.workload)
+    metric = METRIC if opt.workload in ("c3", "fixedq") else f"site-sample GL evals/s at depth {args.depth:g}"
+    solo = world == 1 and dist is None and not stub
+    want_extra = solo and not opt.no_extra and opt.sites is None and opt.samples is None
 
     host_first = None
-    if world == 1 and not opt.no_extra and opt.sites is None and opt.samples is None:
+    if want_extra:
         # The PCIe-inclusive host path, in a process of its own and BEFORE the device-resident workloads: device memory that has
         # been through 100+ GB of allocation and release (by this process or an earlier one on the GPU) copies back at 35 GB/s
         # instead of 53 (measured: tools/stream_alias_probe.py) -- a record loop creates its context at start, like this.
@@ -648,12 +889,22 @@ def main():
             host_first = json.loads(out.stdout.strip().splitlines()[-1])
         except Exception as e:
             host_first = {"error": repr(e)[:300]}
+
+    def early(res):                                            # N > 1: the line is on stdout before the sampled record gather is attempted
+        emit(res, {}, opt, world, metric, dist_info, final=False)
     main_res = run_workload(opt.workload, opt, env, opt.steps, opt.warmup, sites=opt.sites, samples=opt.samples,
-                            with_cpu=(not opt.no_cpu_baseline and world == 1), gather=opt.gather)
+                            with_cpu=(not opt.no_cpu_baseline and solo), gather=opt.gather, early=(early if dist is not None else None))
+    cpu_proc = None
+    if rank == 0 and solo and not opt.no_cpu_baseline:
+        # the one-core CPU leg runs in its own process BESIDE the extra GPU workloads (this thread only enqueues launches and waits);
+        # the all-cores leg afterwards, with the GPU idle
+        log("cpu baseline (one core) started ...")
+        cpu_proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-single-worker", "--workload", opt.workload] +
+                                    (["--samples", str(opt.samples)] if opt.samples else []), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
     extra = {}
-    if world == 1 and not opt.no_extra and opt.sites is None and opt.samples is None:
-        # the other BASELINE configurations on this GPU, a few passes each, attached to the same line (parity-test cases, not
-        # the headline: VERDICT r1 asked for driver-timed evidence of them)
+    if want_extra:
+        # the other BASELINE configurations on this GPU, a few passes each (parity-test cases, not the headline: VERDICT r1 asked
+        # for driver-timed evidence of them).  Their full blocks go to the detail file, one short object each to the `bench_extra` line.
         for name in ("c5", "c5u8", "fixedq", "c4", "c2", "gl1q", "precise", "alltags", "qsi16"):
             if name == opt.workload:
                 continue
@@ -664,31 +915,22 @@ def main():
                 extra[name] = {"error": repr(e)[:300]}
         extra["host_path_c3"] = host_first.get("c3", host_first) if isinstance(host_first, dict) else host_first
         extra["host_path_c5"] = host_first.get("c5") if isinstance(host_first, dict) else None
+    if cpu_proc is not None:
+        try:
+            cb = json.loads(cpu_proc.communicate(timeout=600)[0].strip().splitlines()[-1])
+            log("cpu baseline (all cores) ...")
+            main_res["cpu_baseline"] = cpu_all_cores(cb, opt.workload, opt.samples or WORKLOADS[opt.workload]["samples"])
+        except Exception as e:
+            log(f"cpu baseline failed: {e!r}")
 
     if rank == 0:
-        args = workload_args(opt.workload)
-        line = {
-            "metric": METRIC if opt.workload in ("c3", "fixedq") else f"site-sample GL evals/s at depth {args.depth:g}",
-            "value": main_res["value"], "unit": main_res["unit"],
-            "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": main_res["ms_per_step"],
-            "higher_is_better": True, "scaling": opt.scaling, "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": main_res["workload"], "tile_sites": opt.tile_sites,
-                       "parallelism": f"site-sharded x{world}" + (f", {opt.backend}" if world > 1 else ""),
-                       "gather": (opt.gather if world > 1 else None),
-                       "rccl_world": (dist.get_world_size() if dist is not None else None),
-                       "backend": (("rccl (torch.distributed nccl)" if opt.backend == "nccl" else "gloo (host staging, rehearsal)") if dist is not None else None)},
-            "roofline": main_res["roofline"],
-        }
-        for k in ("ctx", "cpu_baseline", "comm", "records_gather", "record_packing", "ranks"):
-            if k in main_res:
-                line[k] = main_res[k]
-        if extra:
-            line["extra"] = extra
-        print(json.dumps(line), flush=True)
+        emit(main_res, extra, opt, world, metric, dist_info, final=True)
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as e:                                 # the line is out; a teardown problem must not turn the run into a failure
+            log(f"rank {rank}: process-group teardown: {e!r}")
 
 
 if __name__ == "__main__":

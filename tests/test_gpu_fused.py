@@ -69,12 +69,14 @@ def test_the_fused_kernel_is_the_one_that_runs():
     assert not _is_fused(VcfglArgs(seed=11, depth=5.0, error_rate=0.01, error_qs=1, beta_variance=1e-5, **TAGS), 500, gt)            # a per-site draw: three kernels
 
 
+@pytest.mark.parametrize("alone", ["255", "5", "2"])            # every part / parts 0 and 2 / part 1 only count as neighbours that never arrive
 @pytest.mark.parametrize("N,depth", [(600, 5.0), (1000, 20.0), (1500, 14.0), (2048, 3.0)])
-def test_split_fused_workgroup_that_does_not_wait(oracle, N, depth, monkeypatch):
+def test_split_fused_workgroup_that_does_not_wait(oracle, N, depth, alone, monkeypatch):
     """A site split over several fused workgroups: each adds its per-base depth sums to the site's record and waits, bounded, for the
     others; one that gives up samples the others' depths itself (nothing may depend on two workgroups being resident together).
-    VGL_DEBUG_FUSE_ALONE=1 (hooks build) makes every workgroup take that path: same bits."""
-    monkeypatch.setenv("VGL_DEBUG_FUSE_ALONE", "1")
+    VGL_DEBUG_FUSE_ALONE=mask (hooks build) makes the workgroups treat the parts in the mask as absent: all of them, or a subset, so that
+    a workgroup adds the published sums of some neighbours and recomputes the others -- same bits."""
+    monkeypatch.setenv("VGL_DEBUG_FUSE_ALONE", alone)
     monkeypatch.setenv("VGL_FUSE_DEEP", "1")
     args = VcfglArgs(seed=23, depth=depth, error_rate=0.02, **TAGS)
     want, got = run_both(oracle, args, synth.acgt_sites(30, N, seed=N, missing=0.02), hooks=True)
@@ -187,9 +189,16 @@ def test_fused_through_the_host_program(tmp_path):
         for flags, tag in ((["-explode", "1", "-doGVCF", "1", "--gvcf-dps", "5,10,20", "-doUnobserved", "2", "-addPL", "1"], "g"),
                            (["-explode", "1", "-doUnobserved", "2", "-addPL", "1", "-addGP", "1", "-addFormatAD", "1", "-addInfoAD", "1"], "p")):
             out = str(tmp_path / f"o_{tag}_{int(nofuse)}")
-            r = subprocess.run([BIN, "-i", inp, "-o", out, "-O", "v", "--seed", "42", "--depth", "5", "--error-rate", "0.01", "--tile-sites", "700"] + flags,
+            r = subprocess.run([BIN, "-i", inp, "-o", out, "-O", "v", "--seed", "42", "--depth", "5", "--error-rate", "0.01", "--tile-sites", "700", "--verbose", "1"] + flags,
                                capture_output=True, text=True, timeout=600, env=env)
             assert r.returncode == 0, r.stderr[-800:]
+            # the comparison below is only worth something if the preloaded hooks build really switched the fused kernel off
+            dev_lines = [l for l in r.stderr.splitlines() if l.startswith("[device ")]
+            assert dev_lines, r.stderr[-800:]
+            if nofuse:
+                assert all(", fused 0 " in l for l in dev_lines), dev_lines
+            elif tag == "g":
+                assert all(", fused 1 " in l for l in dev_lines), dev_lines
             body = [l for l in open(out + ".vcf") if not l.startswith("##")]
             outs.append((tag, nofuse, body))
     by = {(t, n): b for t, n, b in outs}

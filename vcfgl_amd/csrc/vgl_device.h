@@ -116,12 +116,12 @@ struct VglDevParams {
     int32_t xcd_map;         // k_gl: workgroup index -> XCD-contiguous logical index (VGL_XCD_MAP=0 turns it off; k_sample, which is
                              // bound by its arithmetic, measured 1-3 % slower with it and keeps the hardware order)
     int32_t dbg_depth_chunk; // test hook (VGL_DEPTH_CHUNK=1024 / 2048 / 4096): k_depth's chunk whatever the tile's size
-    int32_t dbg_fuse_alone;  // test hook (VGL_DEBUG_FUSE_ALONE=1): a split fused workgroup does not wait for its neighbours and samples their depths itself
+    int32_t dbg_fuse_alone;  // test hook (VGL_DEBUG_FUSE_ALONE=mask): the parts in the mask count as neighbours that never arrive -- the other workgroups of the site do not wait for them and sample their depths themselves
     int32_t dbg_phase;       // diagnostic (VGL_DEBUG_PHASE=n): k_sample returns after phase n; 0 = off
     int32_t dbg_qs_exact;    // test hook (VGL_DEBUG_QS_EXACT=1): k_sample<2> treats every read as undecided in float32
     int32_t dbg_redo_every;  // test hook (VGL_DEBUG_REDO_EVERY=k): the deferred build sends every k-th read and slow-test lane to k_redo
     int32_t qsum_lds;        // k_sample<2, LEAN 3>: the owners' quality sums are gathered in LDS by the dense pass (one atomic per read) -- --adjust-qs 0 or 3
-                             // (one score for likelihoods and sums) and at most 132 staged reads (sum of squares << 13 | sum fits 32 bits)
+                             // (one score for likelihoods and sums) and at most 130 staged reads (sum of squares << 13 | sum: 130 x 63 = 8190 < 2^13, 130 x 63^2 < 2^19)
     int32_t defer_ok;        // the flag set allows the deferred build of k_sample<2> (vgl_ctx_create; VGL_NO_DEFER=1 turns it off)
     int32_t pre_q, pre_adjq;           // preCalc qScore / adj_qScore (vcfgl.cpp:1697-1702)
     double  adjust_by;

@@ -244,7 +244,10 @@ __device__ __forceinline__ uint64_t fused_sample_eval(const VglDevParams& P, con
     if (STORE && T.fmt_dp) T.fmt_dp[ev] = dps;
     return ad4s;
 }
-#define VGL_FUSED_SPIN_LIMIT 200000                                     // polls (with s_sleep) before a split workgroup stops waiting for its neighbours
+// polls (two system-scope loads + s_sleep(4): about a microsecond each) before a split workgroup stops waiting for a neighbour and samples
+// that part's depths itself.  Neighbours are consecutive workgroups and normally arrive within microseconds; when one is not resident
+// (several contexts sharing the GPU) waiting longer than the recomputation costs only holds a CU slot -- so the bound is about that cost
+#define VGL_FUSED_SPIN_LIMIT 2048
 
 template <int A, int GLM, bool PREC, int WPB, int FUSEDW = 0>
 __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const VglTilePtrs T) {
@@ -414,13 +417,14 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
             if (tid < S && tid != part) {
                 const unsigned long long V = 1ULL << 63;
                 unsigned long long w0 = 0, w1 = 0;
-                for (int spin = 0; spin < VGL_FUSED_SPIN_LIMIT && !P.dbg_fuse_alone; ++spin) {
+                const bool absent = (P.dbg_fuse_alone >> tid) & 1;     // test hook: part `tid` is treated as one that never arrives
+                for (int spin = 0; spin < VGL_FUSED_SPIN_LIMIT && !absent; ++spin) {
                     w0 = __hip_atomic_load(&slots[tid * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     w1 = __hip_atomic_load(&slots[tid * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     if ((w0 & w1 & V) != 0) break;
                     __builtin_amdgcn_s_sleep(4);
                 }
-                if ((w0 & w1 & V) != 0 && !P.dbg_fuse_alone) {
+                if ((w0 & w1 & V) != 0 && !absent) {
                     atomicAdd(&s_lds.f_acc[1], (int)(uint32_t)w0); atomicAdd(&s_lds.f_acc[2], (int)(uint32_t)((w0 & ~V) >> 32));
                     atomicAdd(&s_lds.f_acc[3], (int)(uint32_t)w1); atomicAdd(&s_lds.f_acc[4], (int)(uint32_t)((w1 & ~V) >> 32));
                 } else atomicOr(&s_alone, 1 << tid);

@@ -487,7 +487,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
                !D.need_adf && p->adjust_qs == 0 && N > 128 && D.fused_split <= hook_int("VGL_FUSE_MAX_SPLIT", 4) && D.read_cap <= 128 &&
                !hook_env("VGL_NO_FUSE") && !hook_env("VGL_NO_LEAN")) ? 1 : 0;
     if (!D.fused) D.fused_split = 0;
-    D.qsum_lds = (D.defer_ok && !D.lean_ok && ((p->adjust_qs & 3) == 0 || (p->adjust_qs & 3) == 3) && D.read_cap <= 132) ? 1 : 0;
+    D.qsum_lds = (D.defer_ok && !D.lean_ok && ((p->adjust_qs & 3) == 0 || (p->adjust_qs & 3) == 3) && D.read_cap <= 130) ? 1 : 0;    // 130 x 63 = 8190 < 2^13, 130 x 63^2 = 515970 < 2^19
     if (D.defer_ok && D.pool_cap > 1472) {      // 20 wavefronts' pools in a CU's 160 KB of LDS: 576 + 5 x 1472 + 8 B each
         D.pool_cap = 1472;
         D.pool_lds_bytes = (576 + 4 * (D.pool_cap + 2) + D.pool_cap + 7) & ~7;
@@ -832,8 +832,12 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     T.errp = (errp_always || dump_errp) ? c->d_errp : nullptr;
     T.site_pick_err = (D.error_qs == 1) ? o->site_pick_err : nullptr;
 
-    hipEvent_t e[VGL_NEV];
-    for (int k = 0; k < VGL_NEV; k++) e[k] = nullptr;
+    // the timing events belong to this call until the last one is recorded: any early return below destroys them (a failed call
+    // leaks nothing), the successful end hands them to the context
+    struct EvGuard { hipEvent_t e[VGL_NEV]; bool armed = true;
+                     EvGuard() { for (int k = 0; k < VGL_NEV; k++) e[k] = nullptr; }
+                     ~EvGuard() { if (armed) for (int k = 0; k < VGL_NEV; k++) if (e[k]) (void)hipEventDestroy(e[k]); } } evg;
+    hipEvent_t* const e = evg.e;
     if (c->timing) for (int k = 0; k < VGL_NEV; k++) HIPCHK(hipEventCreate(&e[k]));
     HIPCHK(hipMemsetAsync(c->d_acc, 0, sizeof(int32_t) * VGL_ACC_STRIDE * (size_t)n_sites, st));
     if (c->d_redo_count) HIPCHK(hipMemsetAsync(c->d_redo_count, 0, sizeof(uint32_t), st));
@@ -876,6 +880,7 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     }
     if (c->timing) HIPCHK(hipEventRecord(e[VGL_NEV - 1], st));
     if (c->timing) for (int k = 0; k < VGL_NEV; k++) c->ev.push_back(e[k]);
+    evg.armed = false;
     return VGL_OK;
 }
 
@@ -1000,8 +1005,10 @@ static int enqueue_host_tile(vgl_ctx* c, vgl_ctx::HostSlot& S, int64_t site0, in
         const size_t need = field_count(c, FIELDS[f].kind, (size_t)c->max_sites) * FIELDS[f].esz;
         if (S.d_out_bytes[f] < need) {
             if (S.d_out[f]) (void)hipFree(S.d_out[f]);
+            c->ws_bytes -= S.d_out_bytes[f];                 // vgl_ctx_info.workspace_bytes counts these buffers too (the largest of an all-tags run)
             S.d_out[f] = nullptr; S.d_out_bytes[f] = 0;
             HIPCHK(hipMalloc(&S.d_out[f], need));
+            c->ws_bytes += need;
             // VGL_LAYOUT_SAMPLE_MAJOR: the kernels write n_samples x nK(site) values of a slab, the copy below takes the slab whole --
             // what lies behind a record's array is then zeros from here, not another job's memory (once per buffer, not per tile)
             HIPCHK(hipMemsetAsync(S.d_out[f], 0, need, c->s_compute));

@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
         uint8_t* l_pb = wl + 576 + 4 * ((size_t)cap + 2);
         uint32_t* l_ctr = l_it + cap + 1;             // pool loop: first unclaimed item
         // LEAN 3, P.qsum_lds: the owners' per-base quality sums are gathered by the dense pass with one LDS atomic per read, into 32-bit
-        // words (sum of squares << 13 | sum: at most 132 reads of a score <= 63 each) -- bases A, C of owner o at l_stq[o] (free between
+        // words (sum of squares << 13 | sum: at most 130 reads of a score <= 63 each, 130 x 63 = 8190 < 2^13) -- bases A, C of owner o at l_stq[o] (free between
         // the pool loop and the next segment), bases G, T in 512 bytes behind the pool
         const bool qfast = (LEAN == 3) && (P.qsum_lds != 0);
         uint32_t* l_accB = (uint32_t*)(wl + ((576 + 4 * ((size_t)cap + 2) + (size_t)cap + 7) & ~(size_t)7));

@@ -34,18 +34,18 @@ def site_range(rank: int, world: int, n_sites: int) -> Tuple[int, int]:
     return begin, begin + base + (1 if rank < rem else 0)
 
 
-def reduce_site_counters(status: torch.Tensor, world: int, always_collective: bool = False) -> torch.Tensor:
+def reduce_site_counters(status: torch.Tensor, world: int, always_collective: bool = False, group=None) -> torch.Tensor:
     """[sites simulated, sites written, sites skipped] summed over the ranks: the run summary the reference prints at the
     end (vcfgl.cpp:1633) -- one small all-reduce, every rank gets the totals."""
     import torch.distributed as dist
     c = torch.stack([torch.tensor(status.numel(), device=status.device), (status >= 0).sum(), (status < 0).sum()]).to(torch.int64)
     if world > 1 or always_collective:
-        dist.all_reduce(c)
+        dist.all_reduce(c, group=group)
     return c
 
 
 def gather_site_index(status: torch.Tensor, n_alleles: torch.Tensor, world: int, rank: int,
-                      n_sites_total: int, dst: int = 0, always_collective: bool = False) -> Optional[torch.Tensor]:
+                      n_sites_total: int, dst: int = 0, always_collective: bool = False, group=None) -> Optional[torch.Tensor]:
     """Gather [status, n_alleles] rows of every rank's sites to `dst` in site order.
     Shards may differ by one site, so rows are padded to the largest shard."""
     import torch.distributed as dist
@@ -56,7 +56,7 @@ def gather_site_index(status: torch.Tensor, n_alleles: torch.Tensor, world: int,
     idx[: status.shape[0], 0] = status
     idx[: status.shape[0], 1] = n_alleles
     bufs = [torch.empty_like(idx) for _ in range(world)] if rank == dst else None
-    dist.gather(idx, bufs, dst=dst)
+    dist.gather(idx, bufs, dst=dst, group=group)
     if rank != dst:
         return None
     parts = []
@@ -165,13 +165,14 @@ def unpack_records(p: PackedRecords, A: int, G: int) -> Dict[str, torch.Tensor]:
 
 
 def gather_records(p: PackedRecords, world: int, rank: int, dst: int = 0, transport: Optional[torch.device] = None,
-                   always_collective: bool = False) -> Optional[List[PackedRecords]]:
+                   always_collective: bool = False, group=None) -> Optional[List[PackedRecords]]:
     """Send this rank's packed records to `dst`; on `dst` returns the ranks' records in rank (= site) order.
 
     Step 1: one all_gather of the tensor shapes (a few int64 per rank).  Step 2: for every peer and tensor one
     point-to-point transfer of exactly that many bytes (`batch_isend_irecv`: RCCL groups them, each peer's bytes travel
     over its own xGMI link to the writer).  `transport`: device the bytes travel on when it differs from the tensors'
-    (gloo moves host memory: transport=torch.device("cpu"))."""
+    (gloo moves host memory: transport=torch.device("cpu")).  `group`: the process group the bytes travel on (all ranks; default group
+    when None) -- bench.py keeps a gloo control group beside the RCCL data group."""
     import torch.distributed as dist
     if world == 1 and not always_collective:
         return [p]
@@ -180,7 +181,7 @@ def gather_records(p: PackedRecords, world: int, rank: int, dst: int = 0, transp
     shape = torch.tensor([p.site0, p.n_samples] + [d for _, t in p.tensors() for d in (t.shape[0], t.shape[1] if t.dim() > 1 else 1)],
                          dtype=torch.int64, device=dev)
     shapes = [torch.empty_like(shape) for _ in range(world)]
-    dist.all_gather(shapes, shape)
+    dist.all_gather(shapes, shape, group=group)
     ops, received = [], {}
     if rank == dst:
         for r in range(world):
@@ -193,12 +194,12 @@ def gather_records(p: PackedRecords, world: int, rank: int, dst: int = 0, transp
                 b = torch.empty((d0, d1) if t.dim() > 1 else (d0,), dtype=t.dtype, device=dev)
                 bufs.append(b)
                 if b.numel():
-                    ops.append(dist.P2POp(dist.irecv, b, r))
+                    ops.append(dist.P2POp(dist.irecv, b, r, group=group))
             received[r] = (sh, bufs)
     else:
         for _, t in p.tensors():
             if t.numel():
-                ops.append(dist.P2POp(dist.isend, t.contiguous().to(dev), dst))
+                ops.append(dist.P2POp(dist.isend, t.contiguous().to(dev), dst, group=group))
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
