@@ -754,7 +754,7 @@ def init_groups(opt, rank, world, local_dev, on_gpu):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     if dist.get_world_size() != opt.gpus:
         sys.exit(f"bench.py: the process group has {dist.get_world_size()} ranks, --gpus says {opt.gpus}")
-    info = {"rccl_world": None, "backend": "gloo (host staging, rehearsal)", "rccl_version": None}
+    info = {"world": dist.get_world_size(), "rccl_world": None, "backend": "gloo (host staging, rehearsal)", "rccl_version": None}
     if opt.backend != "nccl":
         return dist, None, "gloo", info
     err, group = None, None

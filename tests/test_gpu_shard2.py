@@ -86,27 +86,33 @@ def test_two_ranks_on_one_gpu_gather_the_records_of_the_hip_path(oracle):
 
 
 @pytest.mark.timeout(600)
-def test_bench_two_ranks_on_one_gpu_prints_a_self_describing_line():
+def test_bench_two_ranks_on_one_gpu_prints_a_self_describing_line(tmp_path):
     """`bench.py --gpus 2 --share-gpu --backend gloo`: the launcher starts two ranks, both simulate their site range on the one GPU,
-    the index gather / counter all-reduce run inside the timed steps and the sampled record gather after them; rank 0 prints ONE
-    line that says what ran (n_gpus, the process group's size and backend, the comm block) -- the rehearsal of the driver's SCALE run"""
+    the index gather / counter all-reduce run inside the timed steps and the sampled record gather after them; rank 0 prints the line
+    as soon as the timed value exists and once more, as the last line, with what the sampled record gather measured -- a short line
+    that says what ran (n_gpus, the process group's size and backend, the comm block); the per-rank blocks are in the detail file --
+    the rehearsal of the driver's SCALE run"""
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo", "--sites", "8192", "--tile-sites", "4096",
-                        "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--no-pack-rate"], env=env, capture_output=True, text=True, timeout=540)
+                        "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--no-pack-rate", "--detail-file", str(tmp_path / "d.json")],
+                       env=env, capture_output=True, text=True, timeout=540)
     assert r.returncode == 0, r.stderr[-1500:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["rccl_world"] == 2 and d["config"]["backend"].startswith("gloo") and d["config"]["gather"] == "sample"
+    assert len(lines) == 2 and all(len(l) < 4096 for l in lines)
+    early, d = json.loads(lines[0]), json.loads(lines[1])
+    assert early["comm"]["records_sample"] == "pending" and early["value"] == d["value"]
+    assert d["n_gpus"] == 2 and d["config"]["world"] == 2 and d["config"]["rccl_world"] is None and d["config"]["backend"].startswith("gloo") and d["config"]["gather"] == "sample"
     assert d["scaling"] == "weak" and d["value"] > 0 and d["roofline"]["frac"] > 0
     c = d["comm"]
-    assert c["world"] == 2 and c["gather_ms"] > 0 and c["records_sample_bytes_into_writer"] > 0 and c["records_sample_GBps"] > 0
-    assert "AFTER the timed steps" in c["records_sample_note"]
-    # (round 4) every rank's own rate and kernel buckets: a multi-GPU run shows a slow rank at once
-    rk = d["ranks"]
+    assert c["world"] == 2 and c["gather_ms"] > 0 and c["records_sample"] == "ok" and c["records_sample_bytes_into_writer"] > 0 and c["records_sample_GBps"] > 0
+    assert d["ranks"]["evals_per_s_min"] > 0 and d["ranks"]["evals_per_s_min"] <= d["ranks"]["evals_per_s_max"]
+    assert abs(d["value"] - 2 * 8192 * 1000 / (d["ms_per_step"] * 1e-3)) < 1e-5 * d["value"]      # value = all ranks' evaluations / the slowest rank's time
+    # every rank's own rate and kernel buckets (a multi-GPU run shows a slow rank at once): unabridged in the detail file
+    full = json.load(open(tmp_path / "d.json"))
+    assert "AFTER the timed steps" in full["comm"]["records_sample_note"]
+    rk = full["ranks"]
     assert len(rk["evals_per_s"]["per_rank"]) == 2 and rk["evals_per_s"]["min"] > 0 and rk["evals_per_s"]["min"] <= rk["evals_per_s"]["max"]
     assert len(rk["kernel_ms_per_launch"]) == 2 and all(set(k) == {"k_depth", "k_sample", "k_redo", "k_site", "k_gl", "k_siteagg"} for k in rk["kernel_ms_per_launch"])
     assert all(k["k_sample"] > 0 and k["k_gl"] > 0 for k in rk["kernel_ms_per_launch"])
-    assert abs(d["value"] - 2 * 8192 * 1000 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]      # value = all ranks' evaluations / the slowest rank's time

@@ -3,6 +3,6 @@
 for rep in 1 2; do for lib in "$@"; do for w in ${AB_WORKLOADS:-c3 c5 fixedq gl1q precise}; do
 VGL_LIB=$PWD/vcfgl_amd/lib_ab/$lib.so python bench.py --workload $w --sites 262144 --steps 3 --no-cpu-baseline --no-extra --no-pack-rate 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['roofline']['kernel_ms_total']; n=d['roofline']['launches']
-print('$lib $w rep$rep', '%.3e'%d['value'], {x:round(k[x]/max(n[x],1),3) for x in k})"
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$lib $w rep$rep', '%.3e'%d['value'], d['roofline']['kernel_ms_per_launch'])"
 done; done; done

@@ -10,6 +10,6 @@ for spec in ${SPECS:-"fixedq 500" "fixedq 1000" "fixedq 2000" "c5 500" "c5 1000"
     python3 bench.py --workload $wl --samples $n --sites $sites $Q 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
-print('$wl N=$n', 'three kernels' if $nf else 'fused        ', '%.3e'%d['value'], {k:round(r['kernel_ms_total'][k]/max(r['launches'][k],1),3) for k in ('k_depth','k_sample','k_gl')}, 'split', d['ctx']['fused_split'])"
+print('$wl N=$n', 'three kernels' if $nf else 'fused        ', '%.3e'%d['value'], {k:r['kernel_ms_per_launch'].get(k) for k in ('k_depth','k_sample','k_gl')}, 'split', d['ctx']['fused_split'])"
   done
 done

@@ -11,6 +11,6 @@ for wl in ${*:-c3}; do
   python - <<PY
 import json
 d=json.loads(open("gpurun_out/$tag/bench_$wl.json").read().strip().splitlines()[-1]); r=d["roofline"]
-print("$wl", "%.3e"%d["value"], {k:round(r["kernel_ms_total"][k]/max(r["launches"][k],1),3) for k in r["kernel_ms_total"]})
+print("$wl", "%.3e"%d["value"], r["kernel_ms_per_launch"])
 PY
 done

@@ -4,7 +4,7 @@ Q="--no-cpu-baseline --no-extra --no-pack-rate --steps 3 --warmup 1"
 run() { python3 bench.py --workload $1 $Q 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
-print('$1 $2', '%.3e'%d['value'], {k:round(r['kernel_ms_total'][k]/max(r['launches'][k],1),3) for k in ('k_sample','k_gl')})"; }
+print('$1 $2', '%.3e'%d['value'], {k:r['kernel_ms_per_launch'].get(k) for k in ('k_sample','k_gl')})"; }
 for wl in fixedq c3; do
 run $wl base
 VGL_GL_WPB=4 run $wl wpb4

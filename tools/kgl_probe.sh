@@ -9,7 +9,7 @@ for wl in c5 c3; do
     VGL_GL_SORT=$gs python3 bench.py --workload $wl --steps 3 --warmup 1 $Q 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
-print('$wl gl_sort $gs: %.4g evals/s, k_gl %.3f ms/launch, k_sample %.3f' % (d['value'], r['kernel_ms_total']['k_gl']/r['launches']['k_gl'], r['kernel_ms_total']['k_sample']/r['launches']['k_sample']))"
+print('$wl gl_sort $gs: %.4g evals/s, k_gl %.3f ms/launch, k_sample %.3f' % (d['value'], r['kernel_ms_per_launch']['k_gl'], r['kernel_ms_per_launch']['k_sample']))"
   done
 done
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $out/SQ -- python3 bench.py --workload c5 --sites 131072 --steps 1 --warmup 0 $Q > $out/log 2>&1
