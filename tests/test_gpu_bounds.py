@@ -16,7 +16,7 @@ from vcfgl_amd import _abi
 
 pytestmark = pytest.mark.gpu
 
-FAST_LN, GAMMA_LU, GAMMA_SERIES, GAMMA_REFEXPR, QS_TF, RCP, TANF, EXP2, DIV, QUOT, DIV10, POISSON = range(12)
+FAST_LN, GAMMA_LU, GAMMA_SERIES, GAMMA_REFEXPR, QS_TF, RCP, TANF, EXP2, DIV, QUOT, DIV10, POISSON, POOL32 = range(13)
 
 
 def f2b(x):
@@ -117,3 +117,18 @@ def test_poisson_attempt_float32_decisions_equal_the_exact_ones(depth, table):
     assert r["n"] == 1 << 32 and r["violations"] == 0, r
     if depth <= 100.0:
         assert r["max_ratio"] < 2e-4, r
+
+
+@pytest.mark.parametrize("alpha", [8.0, 9.889, 979.011, 55.5, 2.0e5])
+def test_float32_pool_loop_decisions_equal_the_float64_ones(alpha):
+    """k_sample<2>'s float32 pool loop (round 5; vgl_common.hip.h: lcg52_step, pool32_*): on 2^32 attempts per beta shape parameter -- three
+    eighths pseudo-random states, one eighth consecutive generator outputs, the rest placed next to the curves q = 0.27597 / 0.27846,
+    next to the squeeze and the sure-accept bound, and at small u around the acceptance region's edge -- the three-instruction generator
+    step equals the 64-bit one, q_f lies within its band of q, every attempt the loop decides itself (normal attempt accepted /
+    rejected, gamma step accepted / rejected) is decided as rng.h:72-78 / :139-145 decide it in float64, and a1 w^3 is within
+    40 x 2^-24 wherever the loop uses it.  9.889 / 979.011: config C3's shapes (--error-rate 0.01 --beta-variance 1e-5).
+    The share of pseudo-random attempts handed to k_redo is on record and bounded."""
+    r = sweep(POOL32, 0, 0, param=alpha, count=1 << 32)
+    print(f"pool32 alpha {alpha}: {r['n']} attempts, violations {r['violations']} (last at index {r['arg_bits']}), share of random attempts sent to k_redo {r['max_ratio']:.3e}")
+    assert r["n"] == 1 << 32 and r["violations"] == 0, r
+    assert r["max_ratio"] < 2e-4, r

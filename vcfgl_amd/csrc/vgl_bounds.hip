@@ -23,6 +23,7 @@ enum {
     VGL_BOUND_QUOT = 9,         // quot_int24 == IEEE float32 quotient of integers q <= sum <= 2^24 (k_siteagg; count = pairs)
     VGL_BOUND_DIV10 = 10,       // div10_f32(x) == (float)((double)x / 10.0) for every float32 bit pattern of the sweep (k_gl, GL model 1)
     VGL_BOUND_POISSON = 11,     // poisson_fast == poisson_exact wherever it does not call the attempt ambiguous (param = mean depth; count = attempts)
+    VGL_BOUND_POOL32 = 12,      // the float32 pool loop of k_sample<2>: every decision it takes equals the float64 one, values within their bounds (param = shape alpha >= 8; count = attempts)
     VGL_BOUND_N
 };
 
@@ -211,6 +212,116 @@ __global__ __launch_bounds__(256) void k_bound_poisson(const unsigned long long 
     (void)n_rand;
 }
 
+
+// The float32 pool loop (vgl_common.hip.h: lcg52_step, pool32_*) against the reference's float64 expressions (rng.h:72-78, 139-145) on `count`
+// attempts = triples of generator states (the states of an attempt's three uniforms; the helpers do not depend on their being consecutive
+// outputs, so the classes below place them freely):
+//   0-2  pseudo-random states;                       3  consecutive outputs of the generator (as the loop draws them)
+//   4    v placed next to the curve q = 0.27597 or q = 0.27846 for the drawn u, 2^-k 2^48 away (k = 0 .. 47);
+//   5    u2 next to the squeeze 1 - 0.0331 x^4;      6  u2 next to the sure-accept bound 1 - 0.15 a2^2 x^4;
+//   7    small u (2^-k, k up to 40) with v inside or next to the acceptance region: the range checks and the logarithm test's margin.
+// Violations: lcg52_step differs from the 64-bit step in bits 0-51; |q_f - q| > VGL_P32_QBAND; the loop decides an attempt (no redo)
+// differently from the float64 expressions; a1 w^3 off by more than 40 x 2^-24 where the loop says its value bound holds.
+// out->max_ratio_bits: the attempts of classes 0-3 the loop hands to k_redo (the rate, on record).
+__global__ __launch_bounds__(256) void k_bound_pool32(const unsigned long long count, const double a1, const double a2, const double sure_margin, BoundAcc* out) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long viol = 0, n = 0, redo_rand = 0; uint32_t arg = 0;
+    const float ga1 = (float)a1, ga2 = (float)a2;
+    const float c015s = (float)((((a2 * a2) * 0.15) * (1.0 + 1e-5) + 1e-8) * 4294967296.0), sure_ms = (float)((sure_margin + 3e-7) * 4294967296.0);
+    const double TWO48 = 281474976710656.0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const uint64_t h1 = mix64(i * 4 + 1), h2 = mix64(i * 4 + 2), h3 = mix64(i * 4 + 3), h4 = mix64(i * 4 + 4);
+        const int cls = (int)(i & 7);
+        uint64_t X1 = h1 & VGL_MASK48, X2 = h2 & VGL_MASK48, X3 = h3 & VGL_MASK48;
+        const uint32_t k = (uint32_t)((i >> 3) % 48);
+        if (cls == 3) { X2 = lcg_next(X1); X3 = lcg_next(X2); }
+        if (cls == 7) {
+            X1 = (h1 & VGL_MASK48) >> (k % 41);
+            const double u = (double)X1 / TWO48;
+            if (u > 0.0) {
+                const double vmax = 2.0 * u * sqrt(-log(u));                 // the acceptance region's edge
+                const double v = vmax * ((double)(h4 & 0xFFFFF) / 524288.0 - 1.0) * 1.01;
+                const double t = v / 1.7156 + 0.5;
+                if (t >= 0.0 && t < 1.0) X2 = (uint64_t)(t * TWO48) & VGL_MASK48;
+            }
+        }
+        if (cls == 4) {
+            const double u = (double)X1 / TWO48, x = u - 0.449871, T = (h4 & 1) ? 0.27597 : 0.27846;
+            const double disc = (0.25472 * x) * (0.25472 * x) - 4.0 * 0.196 * (x * x - T);
+            if (disc >= 0.0) {
+                const double y = (0.25472 * x + sqrt(disc)) / (2.0 * 0.196), v = ((h4 >> 1) & 1) ? (y - 0.386595) : -(y - 0.386595);
+                const double t = v / 1.7156 + 0.5;
+                if (y >= 0.386595 && t >= 0.0 && t < 1.0) {
+                    const double off = (double)((h4 >> 2) & VGL_MASK48) / (double)(1ULL << k);
+                    const double X = t * TWO48 + (((h4 >> 60) & 1) ? off : -off);
+                    if (X >= 0.0 && X < TWO48) X2 = (uint64_t)X & VGL_MASK48;
+                }
+            }
+        }
+        // ---- float64, as the reference writes it
+        const double ud = (double)X1 / TWO48, vd = 1.7156 * ((double)X2 / TWO48 - 0.5);
+        const double xd = ud - 0.449871, yd = fabs(vd) + 0.386595, qd = (xd * xd) + yd * (0.19600 * yd - 0.25472 * xd);
+        const double xnd = vd / ud, wd = 1.0 + a2 * xnd, xsqd = xnd * xnd;
+        if (cls == 5 || cls == 6) {
+            const double edge = (cls == 5) ? 1.0 - 0.0331 * (xsqd * xsqd) : 1.0 - ((0.15 * a2 * a2) * (xsqd * xsqd) + sure_margin);
+            const double off = (double)(h4 & VGL_MASK48) / (double)(1ULL << k);
+            const double X = edge * TWO48 + (((h4 >> 60) & 1) ? off : -off);
+            if (X >= 0.0 && X < TWO48) X3 = (uint64_t)X & VGL_MASK48;
+        }
+        const double u2d = (double)X3 / TWO48;
+        const bool rejN = (ud > 0.0) ? ((qd > 0.27597) && (qd > 0.27846 || (vd * vd) > -4.0 * log(ud) * (ud * ud))) : true;
+        // ---- the loop's float32
+        ++n;
+        bool bad = false;
+        {   // the three-instruction step against the 64-bit one
+            const uint64_t s52 = X1 << 4, want = lcg_next52r(s52);
+            uint32_t nl, nh;
+            lcg52_step((uint32_t)s52, (uint32_t)(s52 >> 32) | (uint32_t)(h4 & 0xFFF00000u), nl, nh);       // (garbage above bit 51, as the raw form carries)
+            if (nl != (uint32_t)want || ((nh ^ (uint32_t)(want >> 32)) & 0xFFFFFu)) bad = true;
+        }
+        const uint32_t T1 = (uint32_t)(X1 >> 16), T2 = (uint32_t)(X2 >> 16), T3 = (uint32_t)(X3 >> 16);
+        if (lcg52_top32((uint32_t)(X1 << 4), (uint32_t)((X1 << 4) >> 32)) != T1) bad = true;
+        const float uf = pool32_u(T1), sv = pool32_sv(T2), q = pool32_q(uf, sv);
+        if (!(fabs((double)q - qd) <= (double)VGL_P32_QBAND)) bad = true;
+        const bool q_lo = q > VGL_P32_QLO - VGL_P32_QBAND, q_hi = q > VGL_P32_QHI + VGL_P32_QBAND;
+        const bool n_amb = q_lo && !q_hi;
+        bool redo = false, slow_n = false;
+        if (n_amb) { bool und; slow_n = pool32_normal_slow(sv, uf, q, true, und); redo = und; }
+        const bool acc_n = !(q_lo && (q_hi || slow_n));
+        if (!redo && acc_n == rejN) bad = true;                              // decided, and not as the reference decides
+        if (!redo && acc_n) {
+            const float xn = sv * __builtin_amdgcn_rcpf(uf);
+            const float w = __builtin_fmaf(ga2, xn, 1.0f);
+            const float vv = (w * w) * w;
+            const float u2f = pool32_u(T3);
+            const float xsq = xn * xn, x4 = xsq * xsq;
+            const bool in_range = (w >= 0.5f) && (uf >= VGL_P32_UMIN);
+            if (!in_range) redo = true;
+            else {
+                const double vvd = (wd * wd) * wd, vald = a1 * vvd;
+                if (!(wd > 0.0) || !(fabs((double)(ga1 * vv) - vald) <= vald * 40.0 * 0x1p-24)) bad = true;
+                const bool sqd = u2d > 1.0 - 0.0331 * (xsqd * xsqd);
+                const bool logd = (u2d > 0.0) ? (log(u2d) > 0.5 * xsqd + a1 * (1.0 - vvd + log(vvd))) : false;
+                const bool rejG = sqd && logd;
+                const bool sq_may_fail = u2f > __builtin_fmaf(x4, VGL_P32_SQ_K_LO, VGL_P32_SQ_C_LO);
+                const bool sure = (0x1p32f - u2f) >= __builtin_fmaf(x4, c015s, sure_ms);
+                if (!sq_may_fail && sqd) bad = true;                         // the band must cover the squeeze's own float32 error
+                if (sq_may_fail && !sure) {
+                    bool und;
+                    const bool slow_g = pool32_gamma_slow(u2f, ga2 * xn, ga1, x4, true, und);
+                    if (und) redo = true;
+                    else if (slow_g != rejG) bad = true;
+                } else if (rejG) bad = true;                                 // accepted on the squeeze or the sure bound, rejected by the reference
+            }
+        }
+        if (cls < 4 && redo) ++redo_rand;
+        if (bad) { ++viol; arg = (uint32_t)i; }
+    }
+    atomicAdd(&out->n, n);
+    atomicAdd(&out->max_ratio_bits, redo_rand);
+    if (viol) { atomicAdd(&out->viol, viol); out->arg_bits = arg; }
+}
+
 extern "C" __attribute__((visibility("default"))) int vgl_dbg_bound_sweep(int mode, uint32_t lo_bits, unsigned long long count, double param, double out[4]) {
     BoundAcc* d = nullptr; double* d_glt = nullptr; float* d_zt = nullptr;
     if (hipMalloc((void**)&d, sizeof(BoundAcc)) != hipSuccess) return -1;
@@ -251,13 +362,19 @@ extern "C" __attribute__((visibility("default"))) int vgl_dbg_bound_sweep(int mo
             hipLaunchKernelGGL(k_bound_poisson, g, b, 0, 0, count, pp, d_glt, gn, tab ? d_zt : (const float*)nullptr, d);
             break;
         }
+        case VGL_BOUND_POOL32: {
+            if (!(param >= 8.0)) { (void)hipFree(d); return -2; }
+            const double a1 = param - 1.0 / 3.0, a2 = 1.0 / sqrt(9. * a1);                       // Gamma1Sampler_init, rng.h:155-173
+            hipLaunchKernelGGL(k_bound_pool32, g, b, 0, 0, count, a1, a2, 1e-9 + 1e-14 * a1, d);
+            break;
+        }
         default: (void)hipFree(d); return -2;
     }
     BoundAcc h;
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipFree(d_glt); (void)hipFree(d_zt); (void)hipFree(d); return -1; }
     (void)hipFree(d_glt); (void)hipFree(d_zt); (void)hipFree(d);
     out[0] = (double)h.n; out[1] = (double)h.viol;
-    out[2] = (mode == VGL_BOUND_POISSON) ? (double)h.max_ratio_bits / (0.5 * (double)(h.n ? h.n : 1))     // ambiguous share of the pseudo-random half
+    out[2] = (mode == VGL_BOUND_POISSON || mode == VGL_BOUND_POOL32) ? (double)h.max_ratio_bits / (0.5 * (double)(h.n ? h.n : 1))     // ambiguous share of the pseudo-random half
                                          : __builtin_bit_cast(double, h.max_ratio_bits);
     out[3] = (double)h.arg_bits;
     return 0;

@@ -483,6 +483,95 @@ __device__ __forceinline__ bool gamma_slow_test(const double u, const double xsq
     return gamma_slow_test_t<false>(u, xsq, a1, v, s, need, und);
 }
 
+// ---- the pool loop of k_sample<2> in float32 (round 5; the deferred builds without --precise-gl 1) ------------------------------------
+// What a read's quality score needs from the beta sampler (rng.h:433-444: two gamma deviates, each a chain of ratio-of-uniforms normal
+// attempts, rng.h:72-78 / :133-145) is (a) the DECISIONS of the rejection loops, exactly as the reference's doubles take them, and (b) the
+// quotient X / (X + Y) closely enough for floor(-10 log10 p).  Neither needs float64 arithmetic on every attempt: the loop below forms the
+// uniforms as float32 straight from the generator's integer state (no conversion from double anywhere), evaluates every expression in
+// float32 (two-operand float32 forms issue in 2.6 cycles per wavefront on this part, float64 in 4.3: DESIGN.md section 5) and compares
+// against thresholds moved by an explicit bound of the float32 error; an attempt whose comparison falls inside a bound -- and every
+// attempt outside the range the value bound below is stated for (u < 2^-9, w < 0.5) -- sends its READ to k_redo, which draws it in
+// double like the reads the dense pass cannot settle.  Every decision that is taken here is therefore the reference's (the bounds are
+// derived below and swept by tests/test_gpu_bounds.py, mode VGL_BOUND_POOL32, against the float64 expressions).
+//
+// Units: a uniform u = X / 2^48 is carried as uf = (float)T, T = the top 32 bits of X, i.e. u 2^32 within |T| 2^-24 + 1; the normal
+// attempt's v = 1.7156 (u' - 0.5) as sv = 1.7156f (float)(int32)(T' - 2^31), i.e. v 2^32 within |sv| 3 x 2^-24 + 1.8 (the integer
+// subtraction is exact, so the relative precision holds next to v = 0).  eps = 2^-24 below.
+//
+// q = x^2 + y (0.196 y - 0.25472 x), x = u - 0.449871, y = |v| + 0.386595 (|x| <= 0.55, y <= 1.2444, |0.196 y - 0.25472 x| <= 0.38):
+// |dx| <= 1.1e-7, |dy| <= 2.3e-7, |dt| <= 1.3e-7, |d(x^2)| <= 1.3e-7, |d(y t)| <= 2.4e-7, last rounding 6e-8: |dq| <= 4.4e-7 < VGL_P32_QBAND.
+#define VGL_P32_QBAND 1.0e-6f
+#define VGL_P32_QLO 0.27597f
+#define VGL_P32_QHI 0.27846f
+// gamma step, stated for u >= 2^-9 (T >= 2^23: the 16 state bits below T are then <= 2^-23 of u) and w >= 0.5:
+// rel(xn = v / u) <= 9 eps (+ 2e-7 absolute, from the bits below T'), rel(w = 1 + a2 xn) <= 12 eps (|a2 xn| / w <= 1 for w >= 0.5),
+// rel(w^3) <= 38 eps, rel(a1 w^3) <= 40 eps = 2.4e-6; p = X / (X + Y) through v_rcp_f32: <= 84 eps = 5.0e-6, i.e. 2.2e-5 in
+// tf = -10 log10 p (VGL_P32_TF_EXTRA, added to qs_tf_margin by the dense pass of these builds).
+#define VGL_P32_TF_EXTRA 2.2e-5f
+#define VGL_P32_UMIN 0x1p23f
+// squeeze u2 > 1 - 0.0331 x^4 (rng.h:143), in units of 2^-32: |d u2| <= 6e-8, |d(0.0331 x^4)| <= 0.0331 (34 eps x^4 + 1.7e-6 |xn|^3)
+// <= 1.2e-7 (1 + x^4) -> a band of 3e-7 (1 + x^4) on either side, folded into the constants of one fused multiply-add each:
+// u2f > R_lo: the squeeze MAY fail (everything else: it surely holds); u2f > R_hi: it surely fails.
+#define VGL_P32_SQ_K_LO (-(0.0331f + 3.0e-7f) * 0x1p32f)
+#define VGL_P32_SQ_C_LO ((1.0f - 3.0e-7f) * 0x1p32f)
+#define VGL_P32_SQ_K_HI (-(0.0331f - 3.0e-7f) * 0x1p32f)
+#define VGL_P32_SQ_C_HI ((1.0f + 3.0e-7f) * 0x1p32f)
+
+// one step of x' <- A x' + 16 C on a state carried as (lo, hi) of the raw 52-bit form (lcg_next52r): the low product and the constant
+// in one v_mad_u64_u32; of the high word only bits 0-19 are ever looked at, so hi * A_lo and lo * A_hi (A_hi = 5) go through the 24-bit
+// multiply-add (bits 20 and up of either operand reach bits 20 and up of the result only): three instructions (four with v_mul_lo_u32)
+__device__ __forceinline__ void lcg52_step(const uint32_t lo, const uint32_t hi, uint32_t& nlo, uint32_t& nhi) {
+    const uint64_t p = (uint64_t)lo * (uint32_t)(VGL_LCG_A & 0xFFFFFFFFULL) + (uint64_t)(VGL_LCG_C << 4);
+    uint32_t h = (uint32_t)(p >> 32);
+    asm("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(h) : "v"(hi), "s"((uint32_t)(VGL_LCG_A & 0xFFFFFFULL)));
+    asm("v_mad_u32_u24 %0, %1, 5, %0" : "+v"(h) : "v"(lo));
+    nlo = (uint32_t)p; nhi = h;
+}
+// T = the top 32 bits of the 48-bit state = bits 20-51 of the scaled form
+__device__ __forceinline__ uint32_t lcg52_top32(const uint32_t lo, const uint32_t hi) { return __builtin_amdgcn_alignbit(hi, lo, 20); }
+__device__ __forceinline__ float pool32_u(const uint32_t T) { return (float)T; }                                   // u 2^32
+__device__ __forceinline__ float pool32_sv(const uint32_t T) { return (float)(int32_t)(T ^ 0x80000000u) * 1.7156f; }   // v 2^32
+__device__ __forceinline__ float pool32_q(const float uf, const float sv) {
+    const float x = __builtin_fmaf(uf, 0x1p-32f, -0.449871f);
+    const float y = __builtin_fmaf(fabsf(sv), 0x1p-32f, 0.386595f);
+    float t = 0.19600f * y;
+    t = __builtin_fmaf(-0.25472f, x, t);
+    return __builtin_fmaf(y, t, x * x);
+}
+// (v*v) > -4.0*log(u)*(u*u) (rng.h:78) for an attempt whose q_f lies in (QLO - band, QHI + band]: the reference looks at this test
+// only when q > 0.27597 and q <= 0.27846.  Returns the loop's `reject`; `undecided`: the float32 values cannot tell (the read goes to k_redo).
+// ln(u) from v_log_f32(uf 2^-32): |l - ln u| <= |l| 2^-20 + 2^-21 (gamma_test_lu's bound, argument rounding included) + 4 eps + 2 / uf
+// (uf against u); lhs = sv^2 within (3 x 2^-23 + 2^-24) lhs + 3.6 |sv|, rhs = -4 l uf^2 within the logarithm's share + (5 eps + 2 / uf) rhs.
+__device__ __forceinline__ bool pool32_normal_slow(const float sv, const float uf, const float q, const bool need, bool& undecided) {
+    const float lhs = sv * sv;
+    const float l = gamma_test_lu(uf * 0x1p-32f);
+    const float uu = uf * uf;
+    const float rhs = -4.0f * l * uu;
+    const float er = 2.0f * __builtin_amdgcn_rcpf(uf);                       // the state bits below T, relative to u
+    const float el = fabsf(l) * 0x1p-20f + 0x1p-21f + 0x1p-22f + er;
+    const float m = 4.0f * uu * (el + fabsf(l) * er) + (lhs + rhs) * 0x1p-20f + 8.0f * fabsf(sv);
+    const bool hi = lhs > rhs + m, lo = lhs < rhs - m;
+    const bool near_lo = q < VGL_P32_QLO + VGL_P32_QBAND;      // q may be <= 0.27597: accepted without the test
+    const bool near_hi = q > VGL_P32_QHI - VGL_P32_QBAND;      // q may be > 0.27846: rejected without the test
+    undecided = need && (!(hi || lo) || (near_lo && hi) || (near_hi && lo) || !(uf >= 1.0f));
+    return hi;
+}
+// log(u2) > 0.5 xsq + a1 (1 - v + log v) (rng.h:144) for a lane whose squeeze may fail and whose sure-accept bound did not hold.
+// s = a2 xn within |s| 10 eps + 2.4e-8, so g = 3 a1 s^4 P(s) (gamma_rhs_series) within g (40 eps + 1e-7 / |s|) on top of the series' own
+// 4e-6 g; ln(u2) as above (u2f >= 2^23 asked for).  Returns the loop's `reject`: the logarithm test says reject AND the squeeze surely fails;
+// undecided when the test is inside its margin, or says reject while the squeeze is inside its band.
+__device__ __forceinline__ bool pool32_gamma_slow(const float u2f, const float sf, const float a1f, const float x4, const bool need, bool& undecided) {
+    const float lu = gamma_test_lu(u2f * 0x1p-32f);
+    const float g = gamma_rhs_series(sf, a1f);
+    const float d = lu + g;
+    const float m = gamma_test_margin(lu, g) + 0x1p-21f + g * (4.0e-6f + 1.0e-7f * __builtin_amdgcn_rcpf(fabsf(sf)));
+    const bool rej_log = d > m, acc_log = d < -m;
+    const bool sq_sure = u2f > __builtin_fmaf(x4, VGL_P32_SQ_K_HI, VGL_P32_SQ_C_HI);
+    const bool ok = (fabsf(sf) <= 0.3333f) && (u2f >= VGL_P32_UMIN) && (acc_log || (rej_log && sq_sure));
+    undecided = need && !ok;
+    return rej_log;
+}
+
 // error probability -> qScore / adjusted qScore (vcfgl.cpp:500-523) in two steps.  k_sample<2> leaves
 // p = gx / (gx + gy) (rng.h:438) of every finished read in LDS as a float32 (qs_stage_pf), and a dense pass over
 // the wave's reads -- 64 useful lanes per instruction, where the pool loop would spend the same instructions
@@ -499,9 +588,10 @@ __device__ __forceinline__ float qs_tf(const float pf) { return -3.0103f * __bui
 __device__ __forceinline__ float qs_tf_margin(const float tf) { return tf * 0x1p-19f + 4e-6f; }
 // returns false where the float32 value cannot decide (the caller then needs the exact evaluation)
 // adj: P.adjust_qs, or 0 where the caller knows it at compile time (the lean builds of k_sample<2>)
-__device__ __forceinline__ bool qs_decide_pf(const VglDevParams& P, const float pf, int& q, int& aq, const int adj) {
+// extra: what the caller's p carries beyond qs_stage_pf's own error (the float32 pool loop: VGL_P32_TF_EXTRA)
+__device__ __forceinline__ bool qs_decide_pf(const VglDevParams& P, const float pf, int& q, int& aq, const int adj, const float extra = 0.0f) {
     const float tf = qs_tf(pf);
-    const float m = qs_tf_margin(tf);
+    const float m = qs_tf_margin(tf) + extra;
     const float fl = floorf(tf);
     bool ok = (pf > 1.0e-37f) && (pf < 1.0f) && (tf - fl > m) && (fl + 1.0f - tf > m);
     q = (int)fl; aq = -1;

@@ -110,6 +110,13 @@ __global__ __launch_bounds__(256) void k_depth(const VglDevParams P, const VglTi
 template <int EQS, bool DBG, int DM, bool PREC, int LEAN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? (LEAN >= 2 ? 5 : 4) : 1, EQS == 2 ? (LEAN >= 2 ? 5 : 4) : 8))) void k_sample(const VglDevParams P, const VglTilePtrs T) {
     constexpr bool DEFER = (LEAN >= 2);
+    // round 5: the deferred builds without --precise-gl 1 run their pool loop in float32 (vgl_common.hip.h, "the pool loop of k_sample<2>
+    // in float32"); -DVGL_POOL_F64 keeps the float64 loop in every build (A/B timing)
+#ifdef VGL_POOL_F64
+    constexpr bool F32 = false;
+#else
+    constexpr bool F32 = DEFER && !PREC;
+#endif
     constexpr bool SLIM = (LEAN == 1 || LEAN == 2);                  // default tag surface: none of the optional per-read state
     constexpr bool DUMP = (LEAN == 0);                               // a per-read dump (reads_out) may be asked for
 #ifdef VGL_TEST_HOOKS
@@ -274,8 +281,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
         l_stq[lane] = st_qs << 4;                      // the pool loop works on states scaled by 16 (lcg_next52)
         if (lane == 0) {
             l_it[cap] = 0u;
+            if (F32) {
+                // a1, a2, the sure-accept bound's coefficient and margin in units of 2^-32, with the float32 error of either side
+                // added (vgl_common.hip.h): 1 - u2 >= 0.15 a2^2 x^4 + margin holds whenever the float32 comparison says so
+                float* const gf = (float*)l_gc;
+                gf[0] = (float)P.gx.a1; gf[1] = (float)P.gx.a2; gf[2] = (float)((((P.gx.a2 * P.gx.a2) * 0.15) * (1.0 + 1e-5) + 1e-8) * 4294967296.0); gf[3] = (float)((P.sure_margin + 3e-7) * 4294967296.0);
+                gf[4] = (float)P.gy.a1; gf[5] = (float)P.gy.a2; gf[6] = (float)((((P.gy.a2 * P.gy.a2) * 0.15) * (1.0 + 1e-5) + 1e-8) * 4294967296.0); gf[7] = (float)((P.sure_margin + 3e-7) * 4294967296.0);
+            } else {
             l_gc[0] = P.gx.a1; l_gc[1] = P.gx.a2; l_gc[2] = (P.gx.a2 * P.gx.a2) * 0.15; l_gc[3] = P.sure_margin;
             l_gc[4] = P.gy.a1; l_gc[5] = P.gy.a2; l_gc[6] = (P.gy.a2 * P.gy.a2) * 0.15; l_gc[7] = P.sure_margin;
+            }
         }
         int rdone = 0;
         uint32_t carry_w = 0;                          // the staged word the last segment ended in
@@ -365,6 +380,89 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 __attribute__((address_space(3))) uint32_t* ctr_p = (__attribute__((address_space(3))) uint32_t*)l_ctr;
                 uint32_t four_v = 4u;
                 asm volatile("" : "+v"(ctr_p), "+v"(four_v));
+                if constexpr (F32) {
+                    // ---- float32 loop (vgl_common.hip.h): same dealing, same hold / period logic; every quantity a float32 built from the
+                    // integer state, every comparison against a threshold moved by the float32 error bound, `redo` where a bound cannot tell
+                    typedef __attribute__((address_space(3))) float lds_f32;
+                    uint32_t s_lo = (uint32_t)st, s_hi = (uint32_t)(st >> 32);
+                    float gxf = 0.0f;
+                    do {
+                        const bool full = (--slow_cnt == 0);
+                        if (full) slow_cnt = P.slow_period;
+                        const bool full_n = (--slow_cnt_n == 0);
+                        if (full_n) slow_cnt_n = P.slow_period_n;
+                        uint32_t goff = stage1 ? 528u : 512u;                       // this stage's four constants: LDS bytes 512 / 528 (the dynamic LDS block starts at 0)
+                        asm volatile("" : "+v"(goff));
+                        const lds_f32* const gc = (const lds_f32*)(uintptr_t)goff;
+                        const float ga1 = gc[0], ga2 = gc[1], c015s = gc[2], sure_ms = gc[3];
+                        // normal attempt (rng.h:72-78)
+                        uint32_t l1, h1, l2, h2, l3, h3;
+                        lcg52_step(s_lo, s_hi, l1, h1);
+                        lcg52_step(l1, h1, l2, h2);
+                        lcg52_step(l2, h2, l3, h3);
+                        const float uf = pool32_u(lcg52_top32(l1, h1));
+                        const float sv = pool32_sv(lcg52_top32(l2, h2));
+                        const float q = pool32_q(uf, sv);
+                        const bool q_lo = q > VGL_P32_QLO - VGL_P32_QBAND, q_hi = q > VGL_P32_QHI + VGL_P32_QBAND;
+                        bool slow_n = false;
+                        const bool n_amb = have && q_lo && !q_hi;                   // the reference may look at the logarithm test (1.2 % of the attempts)
+                        bool hold = n_amb && !full_n;
+                        bool redo = false;
+                        if (full_n && __builtin_amdgcn_ballot_w64(n_amb)) {
+                            bool und;
+                            slow_n = pool32_normal_slow(sv, uf, q, n_amb, und);
+                            redo = und || (n_amb && dbg_redo_every && (l1 >> 8) % (uint32_t)(dbg_redo_every | (dbg_redo_every == 0)) == 0u);
+                        }
+                        const bool acc_n = !(q_lo && (q_hi || slow_n));
+                        // operands of this lane's next item (as in the float64 loop)
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kn));
+                        const uint32_t kc = (uint32_t)(kn < segT4 ? kn : segT4);
+                        uint32_t rd16 = *(const lds_u16*)(uintptr_t)(576u + kc);
+                        uint32_t ow8 = *(const lds_u16*)(uintptr_t)(578u + kc);
+                        asm volatile("" : "+v"(rd16), "+v"(ow8));
+                        const VglAffine tab_n = *(const VglAffine*)((const uint8_t*)P.qs_read_tab + rd16);
+                        const uint64_t base_n = *(__attribute__((address_space(3))) const uint64_t*)(uintptr_t)ow8;
+                        // gamma step (rng.h:139-145)
+                        const float xn = sv * __builtin_amdgcn_rcpf(uf);
+                        const float w = __builtin_fmaf(ga2, xn, 1.0f);
+                        const float vv = (w * w) * w;
+                        const float u2f = pool32_u(lcg52_top32(l3, h3));
+                        const float xsq = xn * xn;
+                        const float x4 = xsq * xsq;
+                        const bool sq_may_fail = u2f > __builtin_fmaf(x4, VGL_P32_SQ_K_LO, VGL_P32_SQ_C_LO);
+                        const bool sure = (0x1p32f - u2f) >= __builtin_fmaf(x4, c015s, sure_ms);
+                        const bool in_range = (w >= 0.5f) && (uf >= VGL_P32_UMIN);   // where the value bound (and the sure-accept bound) is stated
+                        const bool g_try0 = have && acc_n && !hold;
+                        redo = redo || (g_try0 && !in_range);
+                        const bool g_try = g_try0 && in_range;
+                        const bool g_amb = g_try && sq_may_fail && !sure;
+                        hold = hold || (g_amb && !full);
+                        bool slow_g = false;
+                        if (full && __builtin_amdgcn_ballot_w64(g_amb)) {
+                            bool und;
+                            slow_g = pool32_gamma_slow(u2f, ga2 * xn, ga1, x4, g_amb, und);
+                            redo = redo || und || (g_amb && dbg_redo_every && (l3 >> 8) % (uint32_t)(dbg_redo_every | (dbg_redo_every == 0)) == 1u);
+                        }
+                        const bool acc_g = g_try && !(g_amb && slow_g) && !hold;
+                        s_lo = hold ? s_lo : (g_try0 ? l3 : l2);                    // u2 is drawn only when w > 0 (rng.h:140-142; w <= 0 is out of range here)
+                        s_hi = hold ? s_hi : (g_try0 ? h3 : h2);
+                        const float val = ga1 * vv;
+                        const bool fin = (acc_g && stage1) || redo;
+                        const uint64_t st_n = tab_n.a * base_n + tab_n.c;
+                        const float gx_prev = gxf;
+                        gxf = (acc_g && !stage1) ? val : gxf;
+                        stage1 = (stage1 != acc_g) && !redo;
+                        if (fin) {
+                            // the read's error probability X / (X + Y) (rng.h:438) as a float32 in the item's slot; NaN: undecided (k_redo draws the read)
+                            *(lds_u32*)(uintptr_t)(576u + (uint32_t)k) = redo ? 0x7FC00000u : __float_as_uint(gx_prev * __builtin_amdgcn_rcpf(gx_prev + val));
+                            s_lo = (uint32_t)st_n; s_hi = (uint32_t)(st_n >> 32);
+                            k = kn;
+                            asm volatile("" : "+v"(k));
+                            asm volatile("ds_add_rtn_u32 %0, %1, %2" : "+v"(kn) : "v"(ctr_p), "v"(four_v) : "memory");
+                        }
+                        have = k < segT4;
+                    } while (__builtin_amdgcn_ballot_w64(have));
+                } else
                 do {                                         // segT >= 1: lane 0 has an item
                     if (DBG) c_iter++;
                     const bool full = (--slow_cnt == 0);     // bounded gamma test (needed by ~0.2 % of the lanes of an iteration)
@@ -497,7 +595,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 const bool inb = kk < segT;
                 const float pf = __uint_as_float(l_it[inb ? kk : cap]);
                 int q_i, aq_i;
-                bool ok = qs_decide_pf(P, pf, q_i, aq_i, k_adj) && !dbg_qs_exact;
+                bool ok = qs_decide_pf(P, pf, q_i, aq_i, k_adj, F32 ? VGL_P32_TF_EXTRA : 0.0f) && !dbg_qs_exact;
                 if (DEFER) { if (dbg_redo_every) ok = ok && ((uint32_t)(seg0 + kk) % (uint32_t)(dbg_redo_every | (dbg_redo_every == 0))) != 2u; }    // test hook
                 uint64_t amb = __ballot(inb && !ok);
                 if (__builtin_expect(amb != 0, 0)) {
