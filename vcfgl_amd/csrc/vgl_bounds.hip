@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void k_bound_poisson(const unsigned long long 
 // outputs, so the classes below place them freely):
 //   0-2  pseudo-random states;                       3  consecutive outputs of the generator (as the loop draws them)
 //   4    v placed next to the curve q = 0.27597 or q = 0.27846 for the drawn u, 2^-k 2^48 away (k = 0 .. 47);
-//   5    u2 next to the squeeze 1 - 0.0331 x^4;      6  u2 next to the sure-accept bound 1 - 0.15 a2^2 x^4;
+//   5    u2 next to the squeeze 1 - 0.0331 x^4;      6  u2 next to the sure-accept bound 1 - 0.15 a2^2 x^4 (half of them with a small deviate, |xn| < 0.1: where the squeeze is the weaker of the two);
 //   7    small u (2^-k, k up to 40) with v inside or next to the acceptance region: the range checks and the logarithm test's margin.
 // Violations: lcg52_step differs from the 64-bit step in bits 0-51; |q_f - q| > VGL_P32_QBAND; the loop decides an attempt (no redo)
 // differently from the float64 expressions; a1 w^3 off by more than 40 x 2^-24 where the loop says its value bound holds.
@@ -286,11 +286,11 @@ __global__ __launch_bounds__(256) void k_bound_pool32(const unsigned long long c
         const bool q_lo = q > VGL_P32_QLO - VGL_P32_QBAND, q_hi = q > VGL_P32_QHI + VGL_P32_QBAND;
         const bool n_amb = q_lo && !q_hi;
         bool redo = false, slow_n = false;
-        if (n_amb) { bool und; slow_n = pool32_normal_slow(sv, uf, q, true, und); redo = und; }
+        const float xn = sv * __builtin_amdgcn_rcpf(uf);
+        if (n_amb) { bool und; slow_n = pool32_normal_slow(xn, uf, q, true, und); redo = und; }
         const bool acc_n = !(q_lo && (q_hi || slow_n));
         if (!redo && acc_n == rejN) bad = true;                              // decided, and not as the reference decides
         if (!redo && acc_n) {
-            const float xn = sv * __builtin_amdgcn_rcpf(uf);
             const float w = __builtin_fmaf(ga2, xn, 1.0f);
             const float vv = (w * w) * w;
             const float u2f = pool32_u(T3);
@@ -303,15 +303,13 @@ __global__ __launch_bounds__(256) void k_bound_pool32(const unsigned long long c
                 const bool sqd = u2d > 1.0 - 0.0331 * (xsqd * xsqd);
                 const bool logd = (u2d > 0.0) ? (log(u2d) > 0.5 * xsqd + a1 * (1.0 - vvd + log(vvd))) : false;
                 const bool rejG = sqd && logd;
-                const bool sq_may_fail = u2f > __builtin_fmaf(x4, VGL_P32_SQ_K_LO, VGL_P32_SQ_C_LO);
                 const bool sure = (0x1p32f - u2f) >= __builtin_fmaf(x4, c015s, sure_ms);
-                if (!sq_may_fail && sqd) bad = true;                         // the band must cover the squeeze's own float32 error
-                if (sq_may_fail && !sure) {
+                if (!sure) {
                     bool und;
                     const bool slow_g = pool32_gamma_slow(u2f, ga2 * xn, ga1, x4, true, und);
                     if (und) redo = true;
                     else if (slow_g != rejG) bad = true;
-                } else if (rejG) bad = true;                                 // accepted on the squeeze or the sure bound, rejected by the reference
+                } else if (rejG) bad = true;                                 // accepted on the sure bound, rejected by the reference
             }
         }
         if (cls < 4 && redo) ++redo_rand;

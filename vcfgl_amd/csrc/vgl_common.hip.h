@@ -527,6 +527,14 @@ __device__ __forceinline__ void lcg52_step(const uint32_t lo, const uint32_t hi,
     asm("v_mad_u32_u24 %0, %1, 5, %0" : "+v"(h) : "v"(lo));
     nlo = (uint32_t)p; nhi = h;
 }
+// a x + c for a jump (a, c) of the generator on the same (lo, hi) form: three instructions likewise
+__device__ __forceinline__ void aff52_step(const VglAffine m, const uint32_t lo, const uint32_t hi, uint32_t& nlo, uint32_t& nhi) {
+    const uint64_t p = (uint64_t)lo * (uint32_t)m.a + m.c;
+    uint32_t h = (uint32_t)(p >> 32);
+    asm("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(h) : "v"(hi), "v"((uint32_t)m.a));
+    asm("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(h) : "v"(lo), "v"((uint32_t)(m.a >> 32)));
+    nlo = (uint32_t)p; nhi = h;
+}
 // T = the top 32 bits of the 48-bit state = bits 20-51 of the scaled form
 __device__ __forceinline__ uint32_t lcg52_top32(const uint32_t lo, const uint32_t hi) { return __builtin_amdgcn_alignbit(hi, lo, 20); }
 __device__ __forceinline__ float pool32_u(const uint32_t T) { return (float)T; }                                   // u 2^32
@@ -540,36 +548,38 @@ __device__ __forceinline__ float pool32_q(const float uf, const float sv) {
 }
 // (v*v) > -4.0*log(u)*(u*u) (rng.h:78) for an attempt whose q_f lies in (QLO - band, QHI + band]: the reference looks at this test
 // only when q > 0.27597 and q <= 0.27846.  Returns the loop's `reject`; `undecided`: the float32 values cannot tell (the read goes to k_redo).
-// ln(u) from v_log_f32(uf 2^-32): |l - ln u| <= |l| 2^-20 + 2^-21 (gamma_test_lu's bound, argument rounding included) + 4 eps + 2 / uf
-// (uf against u); lhs = sv^2 within (3 x 2^-23 + 2^-24) lhs + 3.6 |sv|, rhs = -4 l uf^2 within the logarithm's share + (5 eps + 2 / uf) rhs.
-__device__ __forceinline__ bool pool32_normal_slow(const float sv, const float uf, const float q, const bool need, bool& undecided) {
-    const float lhs = sv * sv;
-    const float l = gamma_test_lu(uf * 0x1p-32f);
-    const float uu = uf * uf;
-    const float rhs = -4.0f * l * uu;
-    const float er = 2.0f * __builtin_amdgcn_rcpf(uf);                       // the state bits below T, relative to u
-    const float el = fabsf(l) * 0x1p-20f + 0x1p-21f + 0x1p-22f + er;
-    const float m = 4.0f * uu * (el + fabsf(l) * er) + (lhs + rhs) * 0x1p-20f + 8.0f * fabsf(sv);
+// Divided by u^2 the test reads xn^2 > -4 ln u with xn = v / u, the quotient the gamma step needs anyway.  For uf >= 2^23 (asked for):
+// xn within 9 eps |xn| + 2.1e-7, so xn^2 within 18 eps xn^2 + 4.2e-7 |xn|; ln u = ln 2 log2(uf 2^-32) with v_log_f32 on [2^-9, 1)
+// (|error| <= 2^-22.9 |log2| <= 1.2e-6: VGL_BOUND_FAST_LN's sweep), the argument within 3 eps and the float32 constant and product
+// within 2^-23 of the result (<= 25): -4 ln u within 7e-6.  Margin: 2^-19 xn^2 + 1.5e-5.
+__device__ __forceinline__ bool pool32_normal_slow(const float xn, const float uf, const float q, const bool need, bool& undecided) {
+    const float lhs = xn * xn;
+    const float rhs = __builtin_amdgcn_logf(uf * 0x1p-32f) * -2.7725887f;     // -4 ln 2 log2 u
+    const float m = __builtin_fmaf(lhs, 0x1p-19f, 1.5e-5f);
     const bool hi = lhs > rhs + m, lo = lhs < rhs - m;
     const bool near_lo = q < VGL_P32_QLO + VGL_P32_QBAND;      // q may be <= 0.27597: accepted without the test
     const bool near_hi = q > VGL_P32_QHI - VGL_P32_QBAND;      // q may be > 0.27846: rejected without the test
-    undecided = need && (!(hi || lo) || (near_lo && hi) || (near_hi && lo) || !(uf >= 1.0f));
+    undecided = need && (!(hi || lo) || (near_lo && hi) || (near_hi && lo) || !(uf >= VGL_P32_UMIN));
     return hi;
 }
-// log(u2) > 0.5 xsq + a1 (1 - v + log v) (rng.h:144) for a lane whose squeeze may fail and whose sure-accept bound did not hold.
+// The gamma step's acceptance (rng.h:143-144: reject while u2 > 1 - 0.0331 x^4 && log(u2) > 0.5 xsq + a1 (1 - v + log v)) for a lane whose
+// sure-accept bound did not hold.  (The loop's common path tests only that bound: for x^4 >= 1e-5 it is implied by the squeeze --
+// 0.15 a2^2 < 0.0331 -- and below that the squeeze fails for 3e-7 of the draws; so the squeeze is looked at here, with its band.)
 // s = a2 xn within |s| 10 eps + 2.4e-8, so g = 3 a1 s^4 P(s) (gamma_rhs_series) within g (40 eps + 1e-7 / |s|) on top of the series' own
-// 4e-6 g; ln(u2) as above (u2f >= 2^23 asked for).  Returns the loop's `reject`: the logarithm test says reject AND the squeeze surely fails;
-// undecided when the test is inside its margin, or says reject while the squeeze is inside its band.
+// 4e-6 g; ln(u2) from v_log_f32 of u2f 2^-32 (u2f >= 2^23 asked for; the argument within 3 eps < 2^-21).  Returns the loop's `reject`;
+// decided when the squeeze surely holds (accept), the logarithm test is outside its margin on the accepting side (accept), or on the
+// rejecting side with the squeeze surely failing (reject); undecided otherwise.
 __device__ __forceinline__ bool pool32_gamma_slow(const float u2f, const float sf, const float a1f, const float x4, const bool need, bool& undecided) {
+    const bool sq_holds = !(u2f > __builtin_fmaf(x4, VGL_P32_SQ_K_LO, VGL_P32_SQ_C_LO));
+    const bool sq_fails = u2f > __builtin_fmaf(x4, VGL_P32_SQ_K_HI, VGL_P32_SQ_C_HI);
     const float lu = gamma_test_lu(u2f * 0x1p-32f);
     const float g = gamma_rhs_series(sf, a1f);
     const float d = lu + g;
     const float m = gamma_test_margin(lu, g) + 0x1p-21f + g * (4.0e-6f + 1.0e-7f * __builtin_amdgcn_rcpf(fabsf(sf)));
     const bool rej_log = d > m, acc_log = d < -m;
-    const bool sq_sure = u2f > __builtin_fmaf(x4, VGL_P32_SQ_K_HI, VGL_P32_SQ_C_HI);
-    const bool ok = (fabsf(sf) <= 0.3333f) && (u2f >= VGL_P32_UMIN) && (acc_log || (rej_log && sq_sure));
-    undecided = need && !ok;
-    return rej_log;
+    const bool log_ok = (fabsf(sf) <= 0.3333f) && (u2f >= VGL_P32_UMIN);
+    undecided = need && !(sq_holds || (log_ok && (acc_log || (rej_log && sq_fails))));
+    return !sq_holds && rej_log;
 }
 
 // error probability -> qScore / adjusted qScore (vcfgl.cpp:500-523) in two steps.  k_sample<2> leaves

@@ -404,13 +404,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                         const float sv = pool32_sv(lcg52_top32(l2, h2));
                         const float q = pool32_q(uf, sv);
                         const bool q_lo = q > VGL_P32_QLO - VGL_P32_QBAND, q_hi = q > VGL_P32_QHI + VGL_P32_QBAND;
+                        const float xn = sv * __builtin_amdgcn_rcpf(uf);             // v / u: the gamma step's deviate, and the logarithm test's left side
                         bool slow_n = false;
                         const bool n_amb = have && q_lo && !q_hi;                   // the reference may look at the logarithm test (1.2 % of the attempts)
                         bool hold = n_amb && !full_n;
                         bool redo = false;
                         if (full_n && __builtin_amdgcn_ballot_w64(n_amb)) {
                             bool und;
-                            slow_n = pool32_normal_slow(sv, uf, q, n_amb, und);
+                            slow_n = pool32_normal_slow(xn, uf, q, n_amb, und);
                             redo = und || (n_amb && dbg_redo_every && (l1 >> 8) % (uint32_t)(dbg_redo_every | (dbg_redo_every == 0)) == 0u);
                         }
                         const bool acc_n = !(q_lo && (q_hi || slow_n));
@@ -423,19 +424,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                         const VglAffine tab_n = *(const VglAffine*)((const uint8_t*)P.qs_read_tab + rd16);
                         const uint64_t base_n = *(__attribute__((address_space(3))) const uint64_t*)(uintptr_t)ow8;
                         // gamma step (rng.h:139-145)
-                        const float xn = sv * __builtin_amdgcn_rcpf(uf);
                         const float w = __builtin_fmaf(ga2, xn, 1.0f);
                         const float vv = (w * w) * w;
                         const float u2f = pool32_u(lcg52_top32(l3, h3));
                         const float xsq = xn * xn;
                         const float x4 = xsq * xsq;
-                        const bool sq_may_fail = u2f > __builtin_fmaf(x4, VGL_P32_SQ_K_LO, VGL_P32_SQ_C_LO);
                         const bool sure = (0x1p32f - u2f) >= __builtin_fmaf(x4, c015s, sure_ms);
                         const bool in_range = (w >= 0.5f) && (uf >= VGL_P32_UMIN);   // where the value bound (and the sure-accept bound) is stated
                         const bool g_try0 = have && acc_n && !hold;
                         redo = redo || (g_try0 && !in_range);
                         const bool g_try = g_try0 && in_range;
-                        const bool g_amb = g_try && sq_may_fail && !sure;
+                        const bool g_amb = g_try && !sure;                          // squeeze and logarithm test in the bounded block (0.2 % of the lanes)
                         hold = hold || (g_amb && !full);
                         bool slow_g = false;
                         if (full && __builtin_amdgcn_ballot_w64(g_amb)) {
@@ -448,14 +447,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                         s_hi = hold ? s_hi : (g_try0 ? h3 : h2);
                         const float val = ga1 * vv;
                         const bool fin = (acc_g && stage1) || redo;
-                        const uint64_t st_n = tab_n.a * base_n + tab_n.c;
                         const float gx_prev = gxf;
                         gxf = (acc_g && !stage1) ? val : gxf;
                         stage1 = (stage1 != acc_g) && !redo;
                         if (fin) {
                             // the read's error probability X / (X + Y) (rng.h:438) as a float32 in the item's slot; NaN: undecided (k_redo draws the read)
                             *(lds_u32*)(uintptr_t)(576u + (uint32_t)k) = redo ? 0x7FC00000u : __float_as_uint(gx_prev * __builtin_amdgcn_rcpf(gx_prev + val));
-                            s_lo = (uint32_t)st_n; s_hi = (uint32_t)(st_n >> 32);
+                            aff52_step(tab_n, (uint32_t)base_n, (uint32_t)(base_n >> 32), s_lo, s_hi);     // the next item's stream: its read's jump on its owner's base
                             k = kn;
                             asm volatile("" : "+v"(k));
                             asm volatile("ds_add_rtn_u32 %0, %1, %2" : "+v"(kn) : "v"(ctr_p), "v"(four_v) : "memory");
