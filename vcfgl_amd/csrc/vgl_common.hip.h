@@ -374,15 +374,16 @@ __device__ __forceinline__ uint32_t xcd_block(const uint32_t b, const uint32_t n
 
 // wave -> (local site, 64-sample chunk); everything here is wave-uniform (SGPRs)
 struct WavePos { int ls; int chunk; int wib; bool valid; };
-__device__ __forceinline__ WavePos wave_pos(const VglDevParams& P, const VglTilePtrs& T) {
-    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t w = (int64_t)blockIdx.x * (blockDim.x >> 6) + wib;
+__device__ __forceinline__ WavePos wave_pos_of(const VglDevParams& P, const VglTilePtrs& T, const int64_t w) {
     WavePos r;
-    r.wib = wib;
+    r.wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     r.valid = w < (int64_t)T.n_sites * P.chunks;
     r.ls = (int)(w / P.chunks);
     r.chunk = (int)(w - (int64_t)r.ls * P.chunks);
     return r;
+}
+__device__ __forceinline__ WavePos wave_pos(const VglDevParams& P, const VglTilePtrs& T) {
+    return wave_pos_of(P, T, (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
 }
 
 // ---- decisions of the rejection samplers without a float64 logarithm ---------------------

@@ -488,8 +488,11 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
                !hook_env("VGL_NO_FUSE") && !hook_env("VGL_NO_LEAN")) ? 1 : 0;
     if (!D.fused) D.fused_split = 0;
     D.qsum_lds = (D.defer_ok && !D.lean_ok && ((p->adjust_qs & 3) == 0 || (p->adjust_qs & 3) == 3) && D.read_cap <= 130) ? 1 : 0;    // 130 x 63 = 8190 < 2^13, 130 x 63^2 = 515970 < 2^19
-    if (D.defer_ok && D.pool_cap > 1472) {      // 20 wavefronts' pools in a CU's 160 KB of LDS: 576 + 5 x 1472 + 8 B each
-        D.pool_cap = 1472;
+#ifndef VGL_POOL_CAP_DEFER
+#define VGL_POOL_CAP_DEFER 1472
+#endif
+    if (D.defer_ok && D.pool_cap > VGL_POOL_CAP_DEFER) {      // 20 wavefronts' pools in a CU's 160 KB of LDS: 576 + 5 x 1472 + 8 B each
+        D.pool_cap = VGL_POOL_CAP_DEFER;
         D.pool_lds_bytes = (576 + 4 * (D.pool_cap + 2) + D.pool_cap + 7) & ~7;
     }
     if (D.qsum_lds) {                           // + 512 B of quality-sum words behind the pool (vgl_sample.hip): 576 + 5 x 1416 + 8 + 512 <= 8192

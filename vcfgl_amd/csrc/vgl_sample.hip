@@ -107,11 +107,18 @@ __global__ __launch_bounds__(256) void k_depth(const VglDevParams P, const VglTi
 // score to the evaluation's quality sums and to the site totals, which took a placeholder of 0.  The eight quality sums of an owner
 // live only inside a segment's flush (stored, or added to what earlier segments stored, at its end) instead of across the pool loop.
 // LEAN 0 keeps the inline fallbacks: per-read dumps, beta shapes below 8, VGL_NO_DEFER.
+// wavefronts' worth of work one launched wavefront of k_sample<2> runs, one after the other (consecutive 64-sample chunks): see k_sample below
+#ifndef VGL_SAMPLE_WPW
+#define VGL_SAMPLE_WPW 1
+#endif
 template <int EQS, bool DBG, int DM, bool PREC, int LEAN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? (LEAN >= 2 ? 5 : 4) : 1, EQS == 2 ? (LEAN >= 2 ? 5 : 4) : 8))) void k_sample(const VglDevParams P, const VglTilePtrs T) {
+__device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTilePtrs& T, const int64_t wave_index) {
     constexpr bool DEFER = (LEAN >= 2);
     // round 5: the deferred builds without --precise-gl 1 run their pool loop in float32 (vgl_common.hip.h, "the pool loop of k_sample<2>
     // in float32"); -DVGL_POOL_F64 keeps the float64 loop in every build (A/B timing)
+#ifndef VGL_POOL_GROUPS
+#define VGL_POOL_GROUPS 4
+#endif
 #ifdef VGL_POOL_F64
     constexpr bool F32 = false;
 #else
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
     constexpr int dbg_redo_every = 0, dbg_qs_exact = 0;              // (the shipped library carries neither)
 #endif
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    const WavePos wp = wave_pos(P, T);
+    const WavePos wp = wave_pos_of(P, T, wave_index);
     if (!wp.valid) return;
     const int lane = threadIdx.x & 63;
     const int N = P.n_samples;
@@ -325,6 +332,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 uint32_t pa = 576u + 4u * ((uint32_t)cap + 2u) + (uint32_t)(offs + rdone - seg0);   // l_pb[k]
                 auto owner_reads = [&](auto hom_tag) {
                     constexpr bool HOMW = decltype(hom_tag)::value;
+                    if constexpr (SLIM) {
+                        // default tag surface: the per-base depths from the number of second-haplotype picks and the errors' corrections
+                        // (as sample_reads_fixed) instead of a 64-bit shift-and-add per read
+                        uint32_t n1 = 0;
+                        const uint32_t nrd = (sv_end > sv) ? ((sv_end - sv) >> 4) : 0u;
+                        while (sv < sv_end) {
+                            uint32_t rb = (uint32_t)a0;
+                            if (!HOMW) {
+                                st_hap16 = lcg_next16(st_hap16);
+                                const uint32_t h = (uint32_t)(st_hap16 >> 63);          // u >= 0.5: the second allele (vcfgl.cpp:473)
+                                n1 += h;
+                                rb = h ? (uint32_t)a1 : (uint32_t)a0;
+                            }
+                            st_base16 = lcg_next16(st_base16);
+                            if (st_base16 < err_thresh16) {                               // vcfgl.cpp:486-488
+                                const uint32_t tb = rb;
+                                do { st_base16 = lcg_next16(st_base16); rb = (uint32_t)(st_base16 >> 62); } while (rb == tb);
+                                ad4 += (1ULL << (16 * rb)) - (1ULL << (16 * tb));
+                            }
+                            *(lds_u32o*)(uintptr_t)ka = sv;
+                            *(lds_u8o*)(uintptr_t)pa = (uint8_t)rb;
+                            sv += 16u; ka += 4u; pa += 1u;
+                        }
+                        ad4 += (((uint64_t)(nrd - n1)) << (16 * (a0 & 3))) + (((uint64_t)n1) << (16 * (a1 & 3)));
+                    } else
                     while (sv < sv_end) {
                         bool fwd;
                         const int r_base = sample_read_base16<HOMW>(st_hap16, st_base16, a0, a1, err_thresh16, k_strand, fwd);
@@ -360,12 +392,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 // bumped by 4, so a claim is an LDS address without a shift)
                 typedef __attribute__((address_space(3))) uint32_t lds_u32;
                 typedef __attribute__((address_space(3))) uint16_t lds_u16;
-                const int segT4 = segT * 4;
-                int k = lane * 4, kn = (lane + 64) * 4;
+                // float32 loop (round 5): FOUR counters instead of one -- lanes 16 g .. 16 g + 15 deal the g-th quarter of the segment's items
+                // among themselves.  Every finishing lane's ds_add_rtn went to ONE LDS word, and the LDS unit serialises same-address
+                // atomics: with the loop's vector work cut by a third that queue, not instruction issue, set the kernel's time.  Four words
+                // in four banks run side by side; the quarters end within an iteration or two of one another (320 items over 16 lanes each)
+                constexpr int NGRP = F32 ? VGL_POOL_GROUPS : 1;
+                const int grpQ = (segT + NGRP - 1) / NGRP;
+                const int grp = (NGRP > 1) ? (lane / (64 / NGRP)) : 0, gl = (NGRP > 1) ? (lane % (64 / NGRP)) : lane;
+                const int beg = grp * grpQ;
+                const int endg = (beg + grpQ < segT) ? (beg + grpQ) : segT;
+                const int segT4 = (NGRP > 1) ? endg * 4 : segT * 4;      // this lane's limit (wave-uniform with one group)
+                int k = (beg + gl) * 4, kn = (beg + gl + 64 / NGRP) * 4;
                 bool have = k < segT4;                       // == (k < segT4) throughout: the loop tests that compare
                 bool stage1 = false;                         // false: first gamma deviate (x), true: second (y)
                 uint64_t st = 0; double gx = 0.0; uint32_t it_m = 0;
-                if (have) { it_m = l_it[lane]; st = aff52(P.qs_read_tab[(it_m & 0xFFFFu) >> 4], l_stq[it_m >> 19]); }
+                if (have) { it_m = l_it[beg + gl]; st = aff52(P.qs_read_tab[(it_m & 0xFFFFu) >> 4], l_stq[it_m >> 19]); }
+                if (NGRP > 1) {
+                    // the groups' counters: LDS bytes 544 .. 559 (behind the float32 loop's eight constants), first unclaimed item of each
+                    if (gl == 0) *(lds_u32*)(uintptr_t)(544u + 4u * (uint32_t)grp) = (uint32_t)(beg + 2 * (64 / NGRP)) * 4u;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
                 const bool any_changed = (P.gx.changed | P.gy.changed) != 0;
                 // The bounded-log tests are needed by a few lanes per iteration but cost every lane of the
                 // wave; they run only every P.slow_period-th iteration.  In between, a lane that needs one
@@ -377,7 +425,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                 // kn's own register -- the other lanes keep theirs without a select
                 // address of the counter and the increment live in vector registers across the loop (the compiler would otherwise
                 // rebuild both with two moves in front of every atomic)
-                __attribute__((address_space(3))) uint32_t* ctr_p = (__attribute__((address_space(3))) uint32_t*)l_ctr;
+                __attribute__((address_space(3))) uint32_t* ctr_p = (NGRP > 1) ? (__attribute__((address_space(3))) uint32_t*)(uintptr_t)(544u + 4u * (uint32_t)grp)
+                                                                                : (__attribute__((address_space(3))) uint32_t*)l_ctr;
                 uint32_t four_v = 4u;
                 asm volatile("" : "+v"(ctr_p), "+v"(four_v));
                 if constexpr (F32) {
@@ -386,6 +435,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     typedef __attribute__((address_space(3))) float lds_f32;
                     uint32_t s_lo = (uint32_t)st, s_hi = (uint32_t)(st >> 32);
                     float gxf = 0.0f;
+#if defined(VGL_EXP_NOTAB) || defined(VGL_EXP_NOBASE)
+                    VglAffine exp_tab = P.qs_read_tab[lane & 7];
+                    asm volatile("" : "+v"(exp_tab.a), "+v"(exp_tab.c));
+#endif
                     do {
                         const bool full = (--slow_cnt == 0);
                         if (full) slow_cnt = P.slow_period;
@@ -399,30 +452,71 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                         uint32_t l1, h1, l2, h2, l3, h3;
                         lcg52_step(s_lo, s_hi, l1, h1);
                         lcg52_step(l1, h1, l2, h2);
+#ifdef VGL_EXP_EXTRA_MAD64
+                        { uint64_t dz = ((uint64_t)h1 << 32) | l1;                       // EXPERIMENT: three extra v_mad_u64_u32 per iteration (results unchanged)
+                          asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(dz) : "v"(l2), "v"(h2) : "vcc"); }
+#endif
+#ifdef VGL_EXP_EXTRA_MULF
+                        { float dz = __uint_as_float(l1);                                   // EXPERIMENT: six extra v_mul_f32 per iteration (results unchanged)
+                          asm volatile("v_mul_f32 %0, %1, %0\n v_mul_f32 %0, %1, %0\n v_mul_f32 %0, %1, %0\n v_mul_f32 %0, %1, %0\n v_mul_f32 %0, %1, %0\n v_mul_f32 %0, %1, %0" : "+v"(dz) : "v"(h2)); }
+#endif
+#ifdef VGL_EXP_EXTRA_SALU
+                        { uint32_t dz = (uint32_t)slow_cnt;                                 // EXPERIMENT: six extra SALU instructions per iteration (results unchanged)
+                          asm volatile("s_add_u32 %0, %0, 1\n s_xor_b32 %0, %0, 5\n s_add_u32 %0, %0, 1\n s_xor_b32 %0, %0, 5\n s_add_u32 %0, %0, 1\n s_xor_b32 %0, %0, 5" : "+s"(dz) : : "scc"); }
+#endif
+#ifdef VGL_EXP_EXTRA_MAD24
+                        { uint32_t dz = l1;                                                 // EXPERIMENT: six extra v_mad_u32_u24 per iteration (results unchanged)
+                          asm volatile("v_mad_u32_u24 %0, %1, %2, %0\n v_mad_u32_u24 %0, %1, %2, %0\n v_mad_u32_u24 %0, %1, %2, %0\n v_mad_u32_u24 %0, %1, %2, %0\n v_mad_u32_u24 %0, %1, %2, %0\n v_mad_u32_u24 %0, %1, %2, %0" : "+v"(dz) : "v"(h2), "v"(l2)); }
+#endif
+#ifdef VGL_EXP_NOSTEP3
+                        l3 = l2 ^ 0x9E3779B9u; h3 = h2;                                   // EXPERIMENT (wrong results): the third generator step costs one xor
+#else
                         lcg52_step(l2, h2, l3, h3);
+#endif
                         const float uf = pool32_u(lcg52_top32(l1, h1));
                         const float sv = pool32_sv(lcg52_top32(l2, h2));
+#ifdef VGL_EXP_NOQ
+                        const float q = uf * 0x1p-33f;                                     // EXPERIMENT (wrong results): q costs one multiplication
+#else
                         const float q = pool32_q(uf, sv);
+#endif
                         const bool q_lo = q > VGL_P32_QLO - VGL_P32_QBAND, q_hi = q > VGL_P32_QHI + VGL_P32_QBAND;
                         const float xn = sv * __builtin_amdgcn_rcpf(uf);             // v / u: the gamma step's deviate, and the logarithm test's left side
                         bool slow_n = false;
                         const bool n_amb = have && q_lo && !q_hi;                   // the reference may look at the logarithm test (1.2 % of the attempts)
                         bool hold = n_amb && !full_n;
                         bool redo = false;
+#ifdef VGL_EXP_NOSLOW
+                        hold = false; redo = n_amb;                                 // EXPERIMENT: every attempt that needs a bounded test goes to k_redo
+                        if (false) {
+                            bool und;
+                            slow_n = pool32_normal_slow(xn, uf, q, n_amb, und);
+#else
                         if (full_n && __builtin_amdgcn_ballot_w64(n_amb)) {
                             bool und;
                             slow_n = pool32_normal_slow(xn, uf, q, n_amb, und);
+#endif
                             redo = und || (n_amb && dbg_redo_every && (l1 >> 8) % (uint32_t)(dbg_redo_every | (dbg_redo_every == 0)) == 0u);
                         }
                         const bool acc_n = !(q_lo && (q_hi || slow_n));
                         // operands of this lane's next item (as in the float64 loop)
+#ifndef VGL_EXP_NOWAIT
                         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kn));
-                        const uint32_t kc = (uint32_t)(kn < segT4 ? kn : segT4);
+#endif
+                        const uint32_t kc = (uint32_t)(kn < segT4 ? kn : segT * 4);     // l_it[segT] = 0 stands for "none" (a quarter's own limit is another quarter's live item)
                         uint32_t rd16 = *(const lds_u16*)(uintptr_t)(576u + kc);
                         uint32_t ow8 = *(const lds_u16*)(uintptr_t)(578u + kc);
                         asm volatile("" : "+v"(rd16), "+v"(ow8));
+#ifdef VGL_EXP_NOTAB
+                        const VglAffine tab_n = exp_tab;                                  // EXPERIMENT (wrong results): no per-iteration table load
+#else
                         const VglAffine tab_n = *(const VglAffine*)((const uint8_t*)P.qs_read_tab + rd16);
+#endif
+#ifdef VGL_EXP_NOBASE
+                        const uint64_t base_n = exp_tab.c + ow8;                          // EXPERIMENT (wrong results): no LDS read of the owner's base
+#else
                         const uint64_t base_n = *(__attribute__((address_space(3))) const uint64_t*)(uintptr_t)ow8;
+#endif
                         // gamma step (rng.h:139-145)
                         const float w = __builtin_fmaf(ga2, xn, 1.0f);
                         const float vv = (w * w) * w;
@@ -435,11 +529,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                         redo = redo || (g_try0 && !in_range);
                         const bool g_try = g_try0 && in_range;
                         const bool g_amb = g_try && !sure;                          // squeeze and logarithm test in the bounded block (0.2 % of the lanes)
+#ifdef VGL_EXP_NOSLOW
+                        redo = redo || g_amb;
+                        bool slow_g = false;
+                        if (false) {
+                            bool und;
+                            slow_g = pool32_gamma_slow(u2f, ga2 * xn, ga1, x4, g_amb, und);
+#else
                         hold = hold || (g_amb && !full);
                         bool slow_g = false;
                         if (full && __builtin_amdgcn_ballot_w64(g_amb)) {
                             bool und;
                             slow_g = pool32_gamma_slow(u2f, ga2 * xn, ga1, x4, g_amb, und);
+#endif
                             redo = redo || und || (g_amb && dbg_redo_every && (l3 >> 8) % (uint32_t)(dbg_redo_every | (dbg_redo_every == 0)) == 1u);
                         }
                         const bool acc_g = g_try && !(g_amb && slow_g) && !hold;
@@ -659,6 +761,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
                     const int lo = rdone > r0 ? rdone - r0 : 0, hi = r_end - r0 < 4 ? r_end - r0 : 4;
                     const uint32_t mask = (0xFFFFFFFFu << (8 * lo)) & (0xFFFFFFFFu >> (8 * (4 - hi)));
                     const uint32_t rw = (w4 & mask) | ((r0 < rdone) ? carry_w : 0u);
+#ifdef VGL_EXP_NOSTORE
+                    if (rw == 0x12345678u)                                   // EXPERIMENT (wrong results): no staged-read stores
+#endif
                     ((uint32_t*)reads_v)[(size_t)(r0 >> 2) * plane + ev] = rw;
                     carry_w = rw;
                 }
@@ -766,6 +871,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? 
     }
 }
 
+template <int EQS, bool DBG, int DM, bool PREC, int LEAN>
+#ifndef VGL_SAMPLE_WAVES_DEFER
+#define VGL_SAMPLE_WAVES_DEFER 5
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? (LEAN >= 2 ? VGL_SAMPLE_WAVES_DEFER : 4) : 1, EQS == 2 ? (LEAN >= 2 ? VGL_SAMPLE_WAVES_DEFER : 4) : 8))) void k_sample(const VglDevParams P, const VglTilePtrs T) {
+    constexpr int WPW = (EQS == 2 && !DBG) ? VGL_SAMPLE_WPW : 1;
+    const int64_t w0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * WPW;
+#pragma unroll 1
+    for (int rep = 0; rep < WPW; ++rep) k_sample_body<EQS, DBG, DM, PREC, LEAN>(P, T, w0 + rep);
+}
+
 // ------------------------------------------------------------------------------------
 extern "C" int vgl_launch_sitebase(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
     if (t->n_sites == 0) return 0;
@@ -864,7 +980,8 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
     // wavefronts never cooperate here, and a workgroup's wave slots and LDS are only handed on when its last
     // wavefront retires: one wavefront per workgroup keeps every SIMD at its full complement of waves
     const int wpb = 1;
-    const dim3 g((unsigned)((waves + wpb - 1) / wpb)), b(64 * wpb);
+    const int wpw = (p->error_qs == 2 && !(dbg && !t->errp)) ? VGL_SAMPLE_WPW : 1;   // chunks per launched wavefront (k_sample; the stamped build runs one)
+    const dim3 g((unsigned)((waves + (int64_t)wpb * wpw - 1) / ((int64_t)wpb * wpw))), b(64 * wpb);
     const size_t lds = (size_t)wpb * p->pool_lds_bytes;
     hipStream_t s = (hipStream_t)stream;
     const int dm = p->depth_pre;                                  // 0 mixed / 1 k_depth / 2 product method only
