@@ -518,7 +518,7 @@ def test_undecided_quality_scores_are_redrawn_exactly(oracle, monkeypatch, depth
     assert_parity(want, got)
 
 
-@pytest.mark.parametrize("every,cap", [(0, None), (3, None), (7, None), (3, 16)])
+@pytest.mark.parametrize("every,cap", [(0, None), (3, None), (7, None), (3, 16), (3, 256)])
 @pytest.mark.parametrize("depth,N,bins", [(20, 300, False), (30, 130, True), (70, 64, False)])
 def test_deferred_reads_are_redrawn_by_k_redo(oracle, monkeypatch, every, cap, depth, N, bins):
     """The default tag surface runs k_sample<2> without any double-precision fallback code: a read that one of the float32
@@ -526,7 +526,8 @@ def test_deferred_reads_are_redrawn_by_k_redo(oracle, monkeypatch, every, cap, d
     again in double by k_redo, which patches the staged read.  VGL_DEBUG_REDO_EVERY=k sends every k-th candidate of each of the
     three sources down that path (0: only the genuine ones); the GLs -- which are all that depends on the scores here -- must not
     change.  Cases: one segment per wavefront, --qs-bins (k_redo applies them), several LDS segments per wavefront; cap 16: the
-    list overflows and the rest of the reads travels through the bitmap."""
+    list overflows and the rest of the reads travels through the bitmap (round 5: the list has 64 partitions with a counter each -- cap 16
+    leaves them no entry at all, cap 256 four entries each, so that list and bitmap are both in use)."""
     if every:
         monkeypatch.setenv("VGL_DEBUG_REDO_EVERY", str(every))
     if cap is not None:
@@ -537,7 +538,7 @@ def test_deferred_reads_are_redrawn_by_k_redo(oracle, monkeypatch, every, cap, d
     assert_parity(want, got, check_gp=False)
 
 
-@pytest.mark.parametrize("every,cap", [(0, None), (3, None), (5, 16)])
+@pytest.mark.parametrize("every,cap", [(0, None), (3, None), (5, 16), (5, 256)])
 @pytest.mark.parametrize("depth,N,adj,bins", [(20, 300, 0, False), (20, 130, 3, True), (70, 64, 0, False), (70, 64, 3, False), (12, 200, 1, False),
                                               (12, 200, 2, True), (100, 64, 0, False), (100, 70, 2, False)])
 def test_deferred_build_with_the_optional_tags(oracle, monkeypatch, every, cap, depth, N, adj, bins):

@@ -58,6 +58,8 @@ __device__ __forceinline__ size_t vgl_read_byte(const int r, const size_t plane,
     return ((((size_t)(r >> 2)) * plane + ev) << 2) | (size_t)(r & 3);
 }
 #endif
+#define VGL_REDO_PARTS 64
+#define VGL_REDO_STRIDE 32
 #define VGL_DEVERR_CAPACITY 1u
 #define VGL_DEVERR_QSBIN    2u
 #define VGL_DEVERR_GL1DEPTH 4u
@@ -171,9 +173,12 @@ struct VglTilePtrs {
     const uint8_t* gt;
     // staging / scratch (ctx owned)
     uint8_t* reads;          // [read_cap / 4][n_sites][N] words, four reads each (vgl_read_byte)
-    unsigned long long* redo_list;   // k_sample<2, deferred>: (evaluation << 10 | read) of the reads whose quality score k_redo draws in double
-    uint32_t* redo_count;    // entries appended this tile (may exceed redo_cap: the rest is marked in redo_bits)
-    uint32_t redo_cap;
+    unsigned long long* redo_list;   // k_sample<2, deferred>: (evaluation << 10 | read) of the reads whose quality score k_redo draws in double --
+                             // VGL_REDO_PARTS partitions of redo_cap entries each; a wavefront appends to partition (wave index mod VGL_REDO_PARTS)
+    uint32_t* redo_count;    // entries appended this tile, one counter per partition at redo_count[VGL_REDO_STRIDE * p] (a cache line each: round 5 --
+                             // ONE counter took 8.6e5 returning atomics per tile, and same-address atomics are served one at a time: they, not the
+                             // sampling, set k_sample<2>'s time).  A count may exceed redo_cap: the rest is marked in redo_bits
+    uint32_t redo_cap;       // entries per partition
     uint32_t* redo_bits;     // one bit per (evaluation, read) of the tile, all zero between tiles: overflow of the list
     double*  errp;           // [read_cap][n_sites][N]   (precise_gl with error_qs 2)
     uint64_t* ad4;           // [n_sites][N]  4 x u16 ACGT depth

@@ -664,9 +664,10 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
         c->redo_cap = (uint32_t)std::min<size_t>(0xFFFFFFF0u, hook_env("VGL_DEBUG_REDO_CAP") ? (size_t)atol(hook_env("VGL_DEBUG_REDO_CAP")) : std::max<size_t>(65536, reads / 64));
         TRY(dmalloc(&c->d_redo_bits, (reads + 31) / 32));
         TRYHIP(hipMemset(c->d_redo_bits, 0, sizeof(uint32_t) * ((reads + 31) / 32)));
-        TRY(dmalloc(&c->d_redo_list, (size_t)c->redo_cap));
-        TRY(dmalloc(&c->d_redo_count, (size_t)1));
-        TRYHIP(hipMemset(c->d_redo_count, 0, sizeof(uint32_t)));
+        c->redo_cap /= VGL_REDO_PARTS;                                     // entries per partition (0 with a tiny VGL_DEBUG_REDO_CAP: every entry goes to the bitmap)
+        TRY(dmalloc(&c->d_redo_list, std::max<size_t>(1, (size_t)c->redo_cap * VGL_REDO_PARTS)));
+        TRY(dmalloc(&c->d_redo_count, (size_t)VGL_REDO_PARTS * VGL_REDO_STRIDE));
+        TRYHIP(hipMemset(c->d_redo_count, 0, sizeof(uint32_t) * VGL_REDO_PARTS * VGL_REDO_STRIDE));
     }
     TRYHIP(hipMemset(c->d_errflag, 0, sizeof(uint32_t)));
     if (hook_env("VGL_DEBUG_STAMPS") || hook_env("VGL_DEBUG_PHASE")) { TRY(dmalloc(&c->d_dbg, (size_t)16)); TRYHIP(hipMemset(c->d_dbg, 0, 128)); }
@@ -843,7 +844,7 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     hipEvent_t* const e = evg.e;
     if (c->timing) for (int k = 0; k < VGL_NEV; k++) HIPCHK(hipEventCreate(&e[k]));
     HIPCHK(hipMemsetAsync(c->d_acc, 0, sizeof(int32_t) * VGL_ACC_STRIDE * (size_t)n_sites, st));
-    if (c->d_redo_count) HIPCHK(hipMemsetAsync(c->d_redo_count, 0, sizeof(uint32_t), st));
+    if (c->d_redo_count) HIPCHK(hipMemsetAsync(c->d_redo_count, 0, sizeof(uint32_t) * VGL_REDO_PARTS * VGL_REDO_STRIDE, st));
     if (c->d_fslot) HIPCHK(hipMemsetAsync(c->d_fslot, 0, sizeof(unsigned long long) * 2 * (size_t)D.fused_split * (size_t)n_sites, st));
     if (c->timing) HIPCHK(hipEventRecord(e[VGL_T_DEPTH], st));        // depth draws ahead of k_sample (k_sitebase + k_depth; the scouts in serial mode)
     if (D.serial) {
@@ -923,7 +924,9 @@ extern "C" __attribute__((visibility("default"))) int vgl_dbg_redo_count(vgl_ctx
     if (!c->d_redo_count) return VGL_OK;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(n, c->d_redo_count, sizeof(unsigned), hipMemcpyDeviceToHost));
+    uint32_t h[VGL_REDO_PARTS * VGL_REDO_STRIDE];                         // one counter per partition of the list
+    HIPCHK(hipMemcpy(h, c->d_redo_count, sizeof h, hipMemcpyDeviceToHost));
+    for (int p = 0; p < VGL_REDO_PARTS; ++p) *n += h[p * VGL_REDO_STRIDE];
     return VGL_OK;
 }
 #endif

@@ -119,6 +119,9 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
 #ifndef VGL_POOL_GROUPS
 #define VGL_POOL_GROUPS 4
 #endif
+#ifndef VGL_POOL_ATTEMPTS
+#define VGL_POOL_ATTEMPTS 2
+#endif
 #ifdef VGL_POOL_F64
     constexpr bool F32 = false;
 #else
@@ -431,14 +434,15 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                 asm volatile("" : "+v"(ctr_p), "+v"(four_v));
                 if constexpr (F32) {
                     // ---- float32 loop (vgl_common.hip.h): same dealing, same hold / period logic; every quantity a float32 built from the
-                    // integer state, every comparison against a threshold moved by the float32 error bound, `redo` where a bound cannot tell
+                    // integer state, every comparison against a threshold moved by the float32 error bound, `redo` where a bound cannot tell.
+                    // TWO normal-deviate attempts per iteration (VGL_POOL_ATTEMPTS 2): the ratio-of-uniforms sampler rejects 27 % of its
+                    // attempts, and an iteration whose attempt is rejected has paid for the gamma step, the dealing and the loop's scalar
+                    // bookkeeping for nothing -- measured (round 5): extra vector instructions in this loop cost next to nothing, an
+                    // iteration does.  Attempt B (the generator's next two outputs) is looked at only when attempt A is rejected outright; the
+                    // gamma step takes whichever was accepted: 1.08 iterations per gamma deviate instead of 1.37.
                     typedef __attribute__((address_space(3))) float lds_f32;
                     uint32_t s_lo = (uint32_t)st, s_hi = (uint32_t)(st >> 32);
                     float gxf = 0.0f;
-#if defined(VGL_EXP_NOTAB) || defined(VGL_EXP_NOBASE)
-                    VglAffine exp_tab = P.qs_read_tab[lane & 7];
-                    asm volatile("" : "+v"(exp_tab.a), "+v"(exp_tab.c));
-#endif
                     do {
                         const bool full = (--slow_cnt == 0);
                         if (full) slow_cnt = P.slow_period;
@@ -448,105 +452,84 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                         asm volatile("" : "+v"(goff));
                         const lds_f32* const gc = (const lds_f32*)(uintptr_t)goff;
                         const float ga1 = gc[0], ga2 = gc[1], c015s = gc[2], sure_ms = gc[3];
-                        // normal attempt (rng.h:72-78)
+                        // normal attempt A (rng.h:72-78): the stream's next two outputs
                         uint32_t l1, h1, l2, h2, l3, h3;
                         lcg52_step(s_lo, s_hi, l1, h1);
                         lcg52_step(l1, h1, l2, h2);
-#ifdef VGL_EXP_EXTRA_MAD64
-                        { uint64_t dz = ((uint64_t)h1 << 32) | l1;                       // EXPERIMENT: three extra v_mad_u64_u32 per iteration (results unchanged)
-                          asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(dz) : "v"(l2), "v"(h2) : "vcc"); }
-#endif
-#ifdef VGL_EXP_EXTRA_MULF
-                        { float dz = __uint_as_float(l1);                                   // EXPERIMENT: six extra v_mul_f32 per iteration (results unchanged)
-                          asm volatile("v_mul_f32 %0, %1, %0\n v_mul_f32 %0, %1, %0\n v_mul_f32 %0, %1, %0\n v_mul_f32 %0, %1, %0\n v_mul_f32 %0, %1, %0\n v_mul_f32 %0, %1, %0" : "+v"(dz) : "v"(h2)); }
-#endif
-#ifdef VGL_EXP_EXTRA_SALU
-                        { uint32_t dz = (uint32_t)slow_cnt;                                 // EXPERIMENT: six extra SALU instructions per iteration (results unchanged)
-                          asm volatile("s_add_u32 %0, %0, 1\n s_xor_b32 %0, %0, 5\n s_add_u32 %0, %0, 1\n s_xor_b32 %0, %0, 5\n s_add_u32 %0, %0, 1\n s_xor_b32 %0, %0, 5" : "+s"(dz) : : "scc"); }
-#endif
-#ifdef VGL_EXP_EXTRA_MAD24
-                        { uint32_t dz = l1;                                                 // EXPERIMENT: six extra v_mad_u32_u24 per iteration (results unchanged)
-                          asm volatile("v_mad_u32_u24 %0, %1, %2, %0\n v_mad_u32_u24 %0, %1, %2, %0\n v_mad_u32_u24 %0, %1, %2, %0\n v_mad_u32_u24 %0, %1, %2, %0\n v_mad_u32_u24 %0, %1, %2, %0\n v_mad_u32_u24 %0, %1, %2, %0" : "+v"(dz) : "v"(h2), "v"(l2)); }
-#endif
-#ifdef VGL_EXP_NOSTEP3
-                        l3 = l2 ^ 0x9E3779B9u; h3 = h2;                                   // EXPERIMENT (wrong results): the third generator step costs one xor
-#else
                         lcg52_step(l2, h2, l3, h3);
-#endif
-                        const float uf = pool32_u(lcg52_top32(l1, h1));
-                        const float sv = pool32_sv(lcg52_top32(l2, h2));
-#ifdef VGL_EXP_NOQ
-                        const float q = uf * 0x1p-33f;                                     // EXPERIMENT (wrong results): q costs one multiplication
-#else
-                        const float q = pool32_q(uf, sv);
-#endif
-                        const bool q_lo = q > VGL_P32_QLO - VGL_P32_QBAND, q_hi = q > VGL_P32_QHI + VGL_P32_QBAND;
-                        const float xn = sv * __builtin_amdgcn_rcpf(uf);             // v / u: the gamma step's deviate, and the logarithm test's left side
+                        const float ufA = pool32_u(lcg52_top32(l1, h1));
+                        const float svA = pool32_sv(lcg52_top32(l2, h2));
+                        const float qA = pool32_q(ufA, svA);
+                        const bool q_lo = qA > VGL_P32_QLO - VGL_P32_QBAND, q_hi = qA > VGL_P32_QHI + VGL_P32_QBAND;
                         bool slow_n = false;
                         const bool n_amb = have && q_lo && !q_hi;                   // the reference may look at the logarithm test (1.2 % of the attempts)
                         bool hold = n_amb && !full_n;
                         bool redo = false;
-#ifdef VGL_EXP_NOSLOW
-                        hold = false; redo = n_amb;                                 // EXPERIMENT: every attempt that needs a bounded test goes to k_redo
-                        if (false) {
-                            bool und;
-                            slow_n = pool32_normal_slow(xn, uf, q, n_amb, und);
-#else
                         if (full_n && __builtin_amdgcn_ballot_w64(n_amb)) {
                             bool und;
-                            slow_n = pool32_normal_slow(xn, uf, q, n_amb, und);
-#endif
+                            slow_n = pool32_normal_slow(svA * __builtin_amdgcn_rcpf(ufA), ufA, qA, n_amb, und);
                             redo = und || (n_amb && dbg_redo_every && (l1 >> 8) % (uint32_t)(dbg_redo_every | (dbg_redo_every == 0)) == 0u);
                         }
-                        const bool acc_n = !(q_lo && (q_hi || slow_n));
-                        // operands of this lane's next item (as in the float64 loop)
-#ifndef VGL_EXP_NOWAIT
-                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kn));
+                        const bool accA = !(q_lo && (q_hi || slow_n));
+#if VGL_POOL_ATTEMPTS == 2
+                        // attempt B: outputs three and four; used when A is rejected (by q alone or by its logarithm test) and B is accepted by q
+                        // alone.  B inside the logarithm test's band: the state moves past A only, and B is the next iteration's attempt A
+                        uint32_t l4, h4, l5, h5;
+                        lcg52_step(l3, h3, l4, h4);
+                        lcg52_step(l4, h4, l5, h5);
+                        const float ufB = pool32_u(lcg52_top32(l3, h3));            // (also attempt A's third uniform)
+                        const float svB = pool32_sv(lcg52_top32(l4, h4));
+                        const float qB = pool32_q(ufB, svB);
+                        const bool rejA = have && !hold && !accA && !redo;
+                        const bool useB = rejA && !(qB > VGL_P32_QLO - VGL_P32_QBAND);
+                        const bool rejB = rejA && (qB > VGL_P32_QHI + VGL_P32_QBAND);           // both rejected: the state moves past four outputs
+                        const float uf = useB ? ufB : ufA, sv = useB ? svB : svA;
+                        const float u2f = useB ? pool32_u(lcg52_top32(l5, h5)) : ufB;
+                        const bool g_try0 = (have && accA && !hold) || useB;
+#else
+                        const float uf = ufA, sv = svA;
+                        const float u2f = pool32_u(lcg52_top32(l3, h3));
+                        const bool g_try0 = have && accA && !hold;
 #endif
+                        // operands of this lane's next item (as in the float64 loop)
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kn));
                         const uint32_t kc = (uint32_t)(kn < segT4 ? kn : segT * 4);     // l_it[segT] = 0 stands for "none" (a quarter's own limit is another quarter's live item)
                         uint32_t rd16 = *(const lds_u16*)(uintptr_t)(576u + kc);
                         uint32_t ow8 = *(const lds_u16*)(uintptr_t)(578u + kc);
                         asm volatile("" : "+v"(rd16), "+v"(ow8));
-#ifdef VGL_EXP_NOTAB
-                        const VglAffine tab_n = exp_tab;                                  // EXPERIMENT (wrong results): no per-iteration table load
-#else
                         const VglAffine tab_n = *(const VglAffine*)((const uint8_t*)P.qs_read_tab + rd16);
-#endif
-#ifdef VGL_EXP_NOBASE
-                        const uint64_t base_n = exp_tab.c + ow8;                          // EXPERIMENT (wrong results): no LDS read of the owner's base
-#else
                         const uint64_t base_n = *(__attribute__((address_space(3))) const uint64_t*)(uintptr_t)ow8;
-#endif
-                        // gamma step (rng.h:139-145)
+                        // gamma step (rng.h:139-145) on the accepted deviate
+                        const float xn = sv * __builtin_amdgcn_rcpf(uf);             // v / u
                         const float w = __builtin_fmaf(ga2, xn, 1.0f);
                         const float vv = (w * w) * w;
-                        const float u2f = pool32_u(lcg52_top32(l3, h3));
                         const float xsq = xn * xn;
                         const float x4 = xsq * xsq;
                         const bool sure = (0x1p32f - u2f) >= __builtin_fmaf(x4, c015s, sure_ms);
                         const bool in_range = (w >= 0.5f) && (uf >= VGL_P32_UMIN);   // where the value bound (and the sure-accept bound) is stated
-                        const bool g_try0 = have && acc_n && !hold;
                         redo = redo || (g_try0 && !in_range);
                         const bool g_try = g_try0 && in_range;
                         const bool g_amb = g_try && !sure;                          // squeeze and logarithm test in the bounded block (0.2 % of the lanes)
-#ifdef VGL_EXP_NOSLOW
-                        redo = redo || g_amb;
-                        bool slow_g = false;
-                        if (false) {
-                            bool und;
-                            slow_g = pool32_gamma_slow(u2f, ga2 * xn, ga1, x4, g_amb, und);
-#else
                         hold = hold || (g_amb && !full);
                         bool slow_g = false;
                         if (full && __builtin_amdgcn_ballot_w64(g_amb)) {
                             bool und;
                             slow_g = pool32_gamma_slow(u2f, ga2 * xn, ga1, x4, g_amb, und);
-#endif
                             redo = redo || und || (g_amb && dbg_redo_every && (l3 >> 8) % (uint32_t)(dbg_redo_every | (dbg_redo_every == 0)) == 1u);
                         }
                         const bool acc_g = g_try && !(g_amb && slow_g) && !hold;
-                        s_lo = hold ? s_lo : (g_try0 ? l3 : l2);                    // u2 is drawn only when w > 0 (rng.h:140-142; w <= 0 is out of range here)
+                        // the stream moves past the outputs this iteration used: u2 is drawn only when w > 0 (rng.h:140-142; w <= 0 is out of range here)
+#if VGL_POOL_ATTEMPTS == 2
+                        {
+                            const uint32_t t_lo = useB ? l5 : l3, t_hi = useB ? h5 : h3;           // a gamma step was tried on A / on B
+                            const uint32_t r_lo = rejB ? l4 : l2, r_hi = rejB ? h4 : h2;           // none: past A and B / past A only
+                            s_lo = hold ? s_lo : (g_try0 ? t_lo : r_lo);
+                            s_hi = hold ? s_hi : (g_try0 ? t_hi : r_hi);
+                        }
+#else
+                        s_lo = hold ? s_lo : (g_try0 ? l3 : l2);
                         s_hi = hold ? s_hi : (g_try0 ? h3 : h2);
+#endif
                         const float val = ga1 * vv;
                         const bool fin = (acc_g && stage1) || redo;
                         const float gx_prev = gxf;
@@ -707,8 +690,9 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                         const int Kb = seg0 + kb + b * kstep;           // index of the read in the wave's pool
                         if (active && Kb >= offs && Kb < offs + dp) {
                             if (DEFER) {
-                                const uint32_t idx = atomicAdd(T.redo_count, 1u);
-                                if (idx < T.redo_cap) T.redo_list[idx] = ((unsigned long long)ev << 10) | (unsigned long long)(Kb - offs);
+                                const uint32_t part = (uint32_t)wave_index & (VGL_REDO_PARTS - 1);      // neighbouring wavefronts append to different counters
+                                const uint32_t idx = atomicAdd(T.redo_count + VGL_REDO_STRIDE * part, 1u);
+                                if (idx < T.redo_cap) T.redo_list[(size_t)part * T.redo_cap + idx] = ((unsigned long long)ev << 10) | (unsigned long long)(Kb - offs);
                                 else { const size_t bit = ev * (size_t)P.read_cap + (size_t)(Kb - offs); atomicOr(&T.redo_bits[bit >> 5], 1u << (bit & 31)); }   // list full: the bitmap
                             } else {
                                 VglAffine jr = P.qs_read_tab[Kb - offs]; jr.c >>= 4;     // the table carries 16 c (aff52)
@@ -761,9 +745,6 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                     const int lo = rdone > r0 ? rdone - r0 : 0, hi = r_end - r0 < 4 ? r_end - r0 : 4;
                     const uint32_t mask = (0xFFFFFFFFu << (8 * lo)) & (0xFFFFFFFFu >> (8 * (4 - hi)));
                     const uint32_t rw = (w4 & mask) | ((r0 < rdone) ? carry_w : 0u);
-#ifdef VGL_EXP_NOSTORE
-                    if (rw == 0x12345678u)                                   // EXPERIMENT (wrong results): no staged-read stores
-#endif
                     ((uint32_t*)reads_v)[(size_t)(r0 >> 2) * plane + ev] = rw;
                     carry_w = rw;
                 }
@@ -935,15 +916,19 @@ __device__ __forceinline__ void redo_read(const VglDevParams& P, const VglTilePt
     }
 }
 __global__ __launch_bounds__(64) void k_redo(const VglDevParams P, const VglTilePtrs T) {
-    const uint32_t cnt = *T.redo_count;
-    const uint32_t n = cnt < T.redo_cap ? cnt : T.redo_cap;
-    for (uint32_t i = blockIdx.x * 64u + threadIdx.x; i < n; i += gridDim.x * 64u) {
-        const unsigned long long e = T.redo_list[i];
+    // workgroup b works on partition b mod VGL_REDO_PARTS of the list, together with the gridDim / VGL_REDO_PARTS - 1 others of that partition
+    const uint32_t part = blockIdx.x & (VGL_REDO_PARTS - 1), sub = blockIdx.x / VGL_REDO_PARTS, nsub = gridDim.x / VGL_REDO_PARTS;
+    const uint32_t cnt_p = T.redo_count[VGL_REDO_STRIDE * part];
+    const uint32_t n = cnt_p < T.redo_cap ? cnt_p : T.redo_cap;
+    for (uint32_t i = sub * 64u + threadIdx.x; i < n; i += nsub * 64u) {
+        const unsigned long long e = T.redo_list[(size_t)part * T.redo_cap + i];
         redo_read(P, T, (size_t)(e >> 10), (int)(e & 1023u));
     }
+    bool over = false;                                                   // some partition took more than it holds (wave-uniform)
+    for (int q = 0; q < VGL_REDO_PARTS; ++q) over = over || (T.redo_count[VGL_REDO_STRIDE * q] > T.redo_cap);
     // More undecided reads than the list holds (never seen with the flag sets this build is chosen for, but then the result must
     // still be right): the owners marked the rest in a bitmap over (evaluation, read), which is walked and cleared here.
-    if (cnt > T.redo_cap) {
+    if (over) {
         const size_t words = ((size_t)T.n_sites * (size_t)P.n_samples * (size_t)P.read_cap + 31) >> 5;
         for (size_t w = (size_t)blockIdx.x * 64u + threadIdx.x; w < words; w += (size_t)gridDim.x * 64u) {
             uint32_t m = T.redo_bits[w];
@@ -966,7 +951,7 @@ static bool sample_deferred(const VglDevParams* p, const VglTilePtrs* t) {
 }
 extern "C" int vgl_launch_redo(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
     if ((int64_t)t->n_sites * p->chunks == 0 || !sample_deferred(p, t)) return 0;
-    hipLaunchKernelGGL(k_redo, dim3(2048), dim3(64), 0, (hipStream_t)stream, *p, *t);
+    hipLaunchKernelGGL(k_redo, dim3(32 * VGL_REDO_PARTS), dim3(64), 0, (hipStream_t)stream, *p, *t);
     return (int)hipGetLastError();
 }
 
