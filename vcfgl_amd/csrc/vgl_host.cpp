@@ -385,6 +385,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     D.read_cap = (cap + 3) & ~3;
     if (hook_env("VGL_DEBUG_READ_CAP")) D.read_cap = (atoi(hook_env("VGL_DEBUG_READ_CAP")) + 3) & ~3;   // test hook: force the overflow path (a multiple of 4: staged reads are packed four per word)
     if (D.read_cap > 1023) { delete c; return fail(VGL_E_ARG, "mean depth too large for the staging layout"); }
+    double lmax_reads = 0.0;                                              // the largest summed mean depth of a wavefront's 64 samples
     {   // quality-score pool of one wavefront: the summed depth of its (up to) 64 samples
         double lmax = 0.0;
         for (int c0 = 0; c0 < N; c0 += 64) {
@@ -392,6 +393,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
             for (int s = c0; s < N && s < c0 + 64; s++) l += p->depths ? p->depths[s] : p->depth;
             if (l > lmax) lmax = l;
         }
+        lmax_reads = lmax;
         int pc = (int)ceil(lmax + 8.0 * sqrt(lmax) + 64.0);
         pc = (pc + 63) & ~63;
         if (pc > 1920) pc = 1920;                      // 520 + 5 x 1920 B per wavefront: 16 wavefronts (the 4 per SIMD the kernel is
@@ -488,12 +490,23 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
                !hook_env("VGL_NO_FUSE") && !hook_env("VGL_NO_LEAN")) ? 1 : 0;
     if (!D.fused) D.fused_split = 0;
     D.qsum_lds = (D.defer_ok && !D.lean_ok && ((p->adjust_qs & 3) == 0 || (p->adjust_qs & 3) == 3) && D.read_cap <= 130) ? 1 : 0;    // 130 x 63 = 8190 < 2^13, 130 x 63^2 = 515970 < 2^19
-#ifndef VGL_POOL_CAP_DEFER
-#define VGL_POOL_CAP_DEFER 1472
+    if (D.defer_ok) {
+        // pools of the deferred builds, sized by the wavefronts per SIMD their LDS leaves room for (160 KB per CU, 576 + 5 B x items + 8 each):
+        // 1472 items = 5 wavefronts, 1053 = 7, 906 = 8.  The float32 loop of the default tag surface (k_sample<2, LEAN 2>, built for 8
+        // wavefronts) takes 906 -- more resident wavefronts beat fewer segments (A/B, round 5: depth 20 two segments at 8 wavefronts 9.4 ms,
+        // one at 5 wavefronts 9.9) -- unless 1053 saves a segment of three or more (depth 30: 34.7 against 35.3 ms)
+        int cap_defer = 1472;
+#ifndef VGL_POOL_F64
+        if (D.lean_ok && !p->precise_gl) {
+            const double t3 = lmax_reads + 3.0 * sqrt(lmax_reads);                   // what a wavefront's pool typically has to take
+            const int s8 = (int)ceil(t3 / 906.0), s7 = (int)ceil(t3 / 1053.0);
+            cap_defer = (s8 >= 3 && s7 < s8) ? 1053 : 906;
+        }
 #endif
-    if (D.defer_ok && D.pool_cap > VGL_POOL_CAP_DEFER) {      // 20 wavefronts' pools in a CU's 160 KB of LDS: 576 + 5 x 1472 + 8 B each
-        D.pool_cap = VGL_POOL_CAP_DEFER;
-        D.pool_lds_bytes = (576 + 4 * (D.pool_cap + 2) + D.pool_cap + 7) & ~7;
+        if (D.pool_cap > cap_defer) {
+            D.pool_cap = cap_defer;
+            D.pool_lds_bytes = (576 + 4 * (D.pool_cap + 2) + D.pool_cap + 7) & ~7;
+        }
     }
     if (D.qsum_lds) {                           // + 512 B of quality-sum words behind the pool (vgl_sample.hip): 576 + 5 x 1416 + 8 + 512 <= 8192
         if (D.pool_cap > 1416) D.pool_cap = 1416;

@@ -853,10 +853,18 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
 }
 
 template <int EQS, bool DBG, int DM, bool PREC, int LEAN>
-#ifndef VGL_SAMPLE_WAVES_DEFER
-#define VGL_SAMPLE_WAVES_DEFER 5
+// wavefronts per SIMD the register allocator is asked for.  The float32 pool loop of the default tag surface (LEAN 2 without --precise-gl 1) runs at
+// EIGHT (64 VGPRs; pools of 906 items, vgl_host.cpp): with the redo list's counter out of the way more resident wavefronts pay (round 5,
+// A/B on one box: C3 9.9 -> 9.4 ms, depth 30 39.9 -> 34.7 with seven); the other deferred builds at five, the inline-fallback builds at four
+#ifndef VGL_SAMPLE_WAVES_F32
+#define VGL_SAMPLE_WAVES_F32 8
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? (LEAN >= 2 ? VGL_SAMPLE_WAVES_DEFER : 4) : 1, EQS == 2 ? (LEAN >= 2 ? VGL_SAMPLE_WAVES_DEFER : 4) : 8))) void k_sample(const VglDevParams P, const VglTilePtrs T) {
+#ifdef VGL_POOL_F64
+#define VGL_SAMPLE_WAVES(EQS, PREC, LEAN) ((EQS) == 2 ? ((LEAN) >= 2 ? 5 : 4) : 8)
+#else
+#define VGL_SAMPLE_WAVES(EQS, PREC, LEAN) ((EQS) == 2 ? ((LEAN) == 2 && !(PREC) ? VGL_SAMPLE_WAVES_F32 : ((LEAN) >= 2 ? 5 : 4)) : 8)
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? VGL_SAMPLE_WAVES(EQS, PREC, LEAN) : 1, VGL_SAMPLE_WAVES(EQS, PREC, LEAN)))) void k_sample(const VglDevParams P, const VglTilePtrs T) {
     constexpr int WPW = (EQS == 2 && !DBG) ? VGL_SAMPLE_WPW : 1;
     const int64_t w0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * WPW;
 #pragma unroll 1
