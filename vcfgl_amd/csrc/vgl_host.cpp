@@ -385,7 +385,6 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     D.read_cap = (cap + 3) & ~3;
     if (hook_env("VGL_DEBUG_READ_CAP")) D.read_cap = (atoi(hook_env("VGL_DEBUG_READ_CAP")) + 3) & ~3;   // test hook: force the overflow path (a multiple of 4: staged reads are packed four per word)
     if (D.read_cap > 1023) { delete c; return fail(VGL_E_ARG, "mean depth too large for the staging layout"); }
-    double lmax_reads = 0.0;                                              // the largest summed mean depth of a wavefront's 64 samples
     {   // quality-score pool of one wavefront: the summed depth of its (up to) 64 samples
         double lmax = 0.0;
         for (int c0 = 0; c0 < N; c0 += 64) {
@@ -393,7 +392,6 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
             for (int s = c0; s < N && s < c0 + 64; s++) l += p->depths ? p->depths[s] : p->depth;
             if (l > lmax) lmax = l;
         }
-        lmax_reads = lmax;
         int pc = (int)ceil(lmax + 8.0 * sqrt(lmax) + 64.0);
         pc = (pc + 63) & ~63;
         if (pc > 1920) pc = 1920;                      // 520 + 5 x 1920 B per wavefront: 16 wavefronts (the 4 per SIMD the kernel is
@@ -475,9 +473,13 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     // test then leaves its series' range |a2 x| <= 1/3 too often).
     D.dbg_redo_every = hook_int("VGL_DEBUG_REDO_EVERY", 0);
     // the tag surface needs none of the owners' optional per-read state (quality sums, strand draws, --adjust-qs): the LEAN builds of k_sample
+    bool bins_below_255 = true;
+    for (int i = 0; i < p->n_qs_bins; ++i) if (p->qs_bins[3 * i] > 254 || p->qs_bins[3 * i + 1] > 254) bins_below_255 = false;
     D.lean_ok = (!D.need_qsum && !D.sample_strand && !D.need_adf && p->adjust_qs == 0 && !hook_env("VGL_NO_LEAN")) ? 1 : 0;
     D.defer_ok = (!D.serial && p->error_qs == 2 &&
-                  !D.gx.changed && !D.gy.changed && D.gx.alpha0 >= 8.0 && D.gy.alpha0 >= 8.0 && !hook_env("VGL_NO_DEFER") && !hook_env("VGL_DEBUG_QS_EXACT") && !hook_env("VGL_NO_LEAN")) ? 1 : 0;
+                  !D.gx.changed && !D.gy.changed && D.gx.alpha0 >= 8.0 && D.gy.alpha0 >= 8.0 && !hook_env("VGL_NO_DEFER") && !hook_env("VGL_DEBUG_QS_EXACT") && !hook_env("VGL_NO_LEAN") &&
+                  !(D.lean_ok && !p->precise_gl && (D.read_cap > 256 || !bins_below_255))) ? 1 : 0;   // (the two-byte items of the lean float32 build hold a read index
+                                                                                            // of 8 bits and look binned scores up in a 256-entry table: other runs take the inline build)
     // one workgroup per site does everything (k_gl<.., FUSED>, vgl_gl.hip): sampling with one fixed score, the site's allele order and the
     // likelihoods, with nothing staged in HBM between them
     // (round 4: sites of more than 512 samples split over up to four consecutive workgroups, up to 128 staged reads.  The kernel also takes its
@@ -491,22 +493,18 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     if (!D.fused) D.fused_split = 0;
     D.qsum_lds = (D.defer_ok && !D.lean_ok && ((p->adjust_qs & 3) == 0 || (p->adjust_qs & 3) == 3) && D.read_cap <= 130) ? 1 : 0;    // 130 x 63 = 8190 < 2^13, 130 x 63^2 = 515970 < 2^19
     if (D.defer_ok) {
-        // pools of the deferred builds, sized by the wavefronts per SIMD their LDS leaves room for (160 KB per CU, 576 + 5 B x items + 8 each):
-        // 1472 items = 5 wavefronts, 1053 = 7, 906 = 8.  The float32 loop of the default tag surface (k_sample<2, LEAN 2>, built for 8
-        // wavefronts) takes 906 -- more resident wavefronts beat fewer segments (A/B, round 5: depth 20 two segments at 8 wavefronts 9.4 ms,
-        // one at 5 wavefronts 9.9) -- unless 1053 saves a segment of three or more (depth 30: 34.7 against 35.3 ms)
-        int cap_defer = 1472;
+        // pools of the deferred builds.  k_sample<2, LEAN 2> without --precise-gl 1 (float32 loop, round 5) keeps an item in TWO bytes and is
+        // built for eight wavefronts per SIMD: 2240 items (576 + 2 x 2242 B: 32 wavefronts in a CU's 160 KB) -- depth 30 in one segment.
+        // The others: 1472 items of five bytes = 5 wavefronts per SIMD (20 x (576 + 5 x 1472 + 8) B)
 #ifndef VGL_POOL_F64
-        if (D.lean_ok && !p->precise_gl) {
-            const double t3 = lmax_reads + 3.0 * sqrt(lmax_reads);                   // what a wavefront's pool typically has to take
-            const int s8 = (int)ceil(t3 / 906.0), s7 = (int)ceil(t3 / 1053.0);
-            cap_defer = (s8 >= 3 && s7 < s8) ? 1053 : 906;
-        }
+        const bool p16 = D.lean_ok && !p->precise_gl;
+#else
+        const bool p16 = false;
 #endif
-        if (D.pool_cap > cap_defer) {
-            D.pool_cap = cap_defer;
-            D.pool_lds_bytes = (576 + 4 * (D.pool_cap + 2) + D.pool_cap + 7) & ~7;
-        }
+        const int cap_defer = p16 ? (p->n_qs_bins ? 2112 : 2240) : 1472;           // (--qs-bins: 256 B of the LDS go to the score -> binned score table)
+        if (D.pool_cap > cap_defer) D.pool_cap = cap_defer;
+        D.pool_lds_bytes = p16 ? (((576 + 2 * (D.pool_cap + 2) + 7) & ~7) + (p->n_qs_bins ? 256 : 0))
+                               : ((576 + 4 * (D.pool_cap + 2) + D.pool_cap + 7) & ~7);   // (vgl_launch_sample sizes the LDS of the build it launches)
     }
     if (D.qsum_lds) {                           // + 512 B of quality-sum words behind the pool (vgl_sample.hip): 576 + 5 x 1416 + 8 + 512 <= 8192
         if (D.pool_cap > 1416) D.pool_cap = 1416;

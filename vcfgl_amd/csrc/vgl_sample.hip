@@ -127,6 +127,11 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
 #else
     constexpr bool F32 = DEFER && !PREC;
 #endif
+    // P16 (round 5): the float32 loop of the default tag surface keeps an item in TWO bytes -- owner << 10 | read << 2 | base until it is
+    // finished, then the read's staged byte (score << 2 | base; bit 8: undecided, k_redo draws the read) written by the lane that finishes
+    // it.  No base plane, no dense pass; a wavefront's pool of up to 2240 items (depth 30 in one segment) leaves LDS for eight wavefronts per SIMD
+    constexpr bool P16 = F32 && (LEAN == 2);
+    constexpr int ISZ = P16 ? 2 : 4;                                  // bytes of an item's slot
     constexpr bool SLIM = (LEAN == 1 || LEAN == 2);                  // default tag surface: none of the optional per-read state
     constexpr bool DUMP = (LEAN == 0);                               // a per-read dump (reads_out) may be asked for
 #ifdef VGL_TEST_HOOKS
@@ -289,8 +294,21 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
         const int total = __builtin_amdgcn_readlane(incl, 63);          // wave-uniform, and known to the compiler as such
         wave_total_reads = total;
         l_stq[lane] = st_qs << 4;                      // the pool loop works on states scaled by 16 (lcg_next52)
+        // P16 with --qs-bins: score -> binned score (vcfgl.cpp:57-64) as a 256-byte table behind the items (0xFF: in no bin); the lane that
+        // finishes a read looks its score up there -- the bins' search loop ran per finishing lane and iteration (depth 30, rta3 bins: 44.8 ms
+        // against 35.6 for the dense-pass build; with the table 2 x 2 instructions)
+        uint8_t* const l_lut = wl + ((576 + 2 * ((size_t)cap + 2) + 7) & ~(size_t)7);
+        if (P16 && P.n_qs_bins != 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int qv = lane * 4 + j;
+                int b = 0xFF;
+                for (int i = 0; i < P.n_qs_bins; ++i) if (b == 0xFF && qv >= P.qs_bins[3 * i] && qv <= P.qs_bins[3 * i + 1]) b = P.qs_bins[3 * i + 2] & 0xFF;
+                l_lut[qv] = (uint8_t)b;
+            }
+        }
         if (lane == 0) {
-            l_it[cap] = 0u;
+            if (!P16) l_it[cap] = 0u;
             if (F32) {
                 // a1, a2, the sure-accept bound's coefficient and margin in units of 2^-32, with the float32 error of either side
                 // added (vgl_common.hip.h): 1 - u2 >= 0.15 a2^2 x^4 + margin holds whenever the float32 comparison says so
@@ -328,10 +346,12 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                 // slot value ((8 owner) << 16 | 16 read), slot address and base address advance by constants per read
                 typedef __attribute__((address_space(3))) uint32_t lds_u32o;
                 typedef __attribute__((address_space(3))) uint8_t lds_u8o;
+                typedef __attribute__((address_space(3))) uint16_t lds_u16o;
                 const uint32_t lane4 = (uint32_t)lane << 2;
-                uint32_t sv = ((uint32_t)lane << 19) | ((uint32_t)rdone << 4);
-                const uint32_t sv_end = ((uint32_t)lane << 19) | ((uint32_t)r_end << 4);
-                uint32_t ka = 576u + 4u * (uint32_t)(offs + rdone - seg0);                     // l_it[k]  (the dynamic LDS block starts at 0)
+                // (P16: owner << 10 | read << 2, advancing by 4; the base goes into bits 0-1)
+                uint32_t sv = P16 ? (((uint32_t)lane << 10) | ((uint32_t)rdone << 2)) : (((uint32_t)lane << 19) | ((uint32_t)rdone << 4));
+                const uint32_t sv_end = P16 ? (((uint32_t)lane << 10) | ((uint32_t)r_end << 2)) : (((uint32_t)lane << 19) | ((uint32_t)r_end << 4));
+                uint32_t ka = 576u + (uint32_t)ISZ * (uint32_t)(offs + rdone - seg0);            // l_it[k]  (the dynamic LDS block starts at 0)
                 uint32_t pa = 576u + 4u * ((uint32_t)cap + 2u) + (uint32_t)(offs + rdone - seg0);   // l_pb[k]
                 auto owner_reads = [&](auto hom_tag) {
                     constexpr bool HOMW = decltype(hom_tag)::value;
@@ -339,7 +359,7 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                         // default tag surface: the per-base depths from the number of second-haplotype picks and the errors' corrections
                         // (as sample_reads_fixed) instead of a 64-bit shift-and-add per read
                         uint32_t n1 = 0;
-                        const uint32_t nrd = (sv_end > sv) ? ((sv_end - sv) >> 4) : 0u;
+                        const uint32_t nrd = (sv_end > sv) ? ((sv_end - sv) >> (P16 ? 2 : 4)) : 0u;
                         while (sv < sv_end) {
                             uint32_t rb = (uint32_t)a0;
                             if (!HOMW) {
@@ -354,9 +374,8 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                                 do { st_base16 = lcg_next16(st_base16); rb = (uint32_t)(st_base16 >> 62); } while (rb == tb);
                                 ad4 += (1ULL << (16 * rb)) - (1ULL << (16 * tb));
                             }
-                            *(lds_u32o*)(uintptr_t)ka = sv;
-                            *(lds_u8o*)(uintptr_t)pa = (uint8_t)rb;
-                            sv += 16u; ka += 4u; pa += 1u;
+                            if (P16) { *(lds_u16o*)(uintptr_t)ka = (uint16_t)(sv | rb); sv += 4u; ka += 2u; }
+                            else { *(lds_u32o*)(uintptr_t)ka = sv; *(lds_u8o*)(uintptr_t)pa = (uint8_t)rb; sv += 16u; ka += 4u; pa += 1u; }
                         }
                         ad4 += (((uint64_t)(nrd - n1)) << (16 * (a0 & 3))) + (((uint64_t)n1) << (16 * (a1 & 3)));
                     } else
@@ -374,7 +393,9 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                 // a wavefront of homozygous evaluations (most wavefronts of a rare variant's site) does not step the haplotype stream
                 if (homw) owner_reads(std::true_type{}); else owner_reads(std::false_type{});
             }
-            if (lane == 0) { l_it[segT] = 0u; *l_ctr = 128u * 4u; }   // the "no item" slot of this segment's prefetches; first unclaimed item
+            if (lane == 0) {                                          // the "no item" slot of this segment's prefetches; first unclaimed item
+                if (P16) ((uint16_t*)l_it)[segT] = 0; else { l_it[segT] = 0u; *l_ctr = 128u * 4u; }
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -404,15 +425,19 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                 const int grp = (NGRP > 1) ? (lane / (64 / NGRP)) : 0, gl = (NGRP > 1) ? (lane % (64 / NGRP)) : lane;
                 const int beg = grp * grpQ;
                 const int endg = (beg + grpQ < segT) ? (beg + grpQ) : segT;
-                const int segT4 = (NGRP > 1) ? endg * 4 : segT * 4;      // this lane's limit (wave-uniform with one group)
-                int k = (beg + gl) * 4, kn = (beg + gl + 64 / NGRP) * 4;
+                const int segT4 = (NGRP > 1 || P16) ? endg * ISZ : segT * ISZ;      // this lane's limit (wave-uniform with one group); byte offsets: ISZ per item
+                int k = (beg + gl) * ISZ, kn = (beg + gl + 64 / NGRP) * ISZ;
                 bool have = k < segT4;                       // == (k < segT4) throughout: the loop tests that compare
                 bool stage1 = false;                         // false: first gamma deviate (x), true: second (y)
                 uint64_t st = 0; double gx = 0.0; uint32_t it_m = 0;
-                if (have) { it_m = l_it[beg + gl]; st = aff52(P.qs_read_tab[(it_m & 0xFFFFu) >> 4], l_stq[it_m >> 19]); }
-                if (NGRP > 1) {
-                    // the groups' counters: LDS bytes 544 .. 559 (behind the float32 loop's eight constants), first unclaimed item of each
-                    if (gl == 0) *(lds_u32*)(uintptr_t)(544u + 4u * (uint32_t)grp) = (uint32_t)(beg + 2 * (64 / NGRP)) * 4u;
+                uint32_t sk = 0;                             // P16: the slot of the lane's current item (its base is wanted when the item is finished)
+                if (have) {
+                    if (P16) { sk = ((const uint16_t*)l_it)[beg + gl]; st = aff52(P.qs_read_tab[(sk >> 2) & 0xFFu], l_stq[sk >> 10]); }
+                    else { it_m = l_it[beg + gl]; st = aff52(P.qs_read_tab[(it_m & 0xFFFFu) >> 4], l_stq[it_m >> 19]); }
+                }
+                if (NGRP > 1 || P16) {
+                    // the groups' counters: LDS bytes 544 .. 575 (behind the float32 loop's eight constants), first unclaimed item of each
+                    if (gl == 0) *(lds_u32*)(uintptr_t)(544u + 4u * (uint32_t)grp) = (uint32_t)(beg + 2 * (64 / NGRP)) * (uint32_t)ISZ;
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -428,9 +453,9 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                 // kn's own register -- the other lanes keep theirs without a select
                 // address of the counter and the increment live in vector registers across the loop (the compiler would otherwise
                 // rebuild both with two moves in front of every atomic)
-                __attribute__((address_space(3))) uint32_t* ctr_p = (NGRP > 1) ? (__attribute__((address_space(3))) uint32_t*)(uintptr_t)(544u + 4u * (uint32_t)grp)
+                __attribute__((address_space(3))) uint32_t* ctr_p = (NGRP > 1 || P16) ? (__attribute__((address_space(3))) uint32_t*)(uintptr_t)(544u + 4u * (uint32_t)grp)
                                                                                 : (__attribute__((address_space(3))) uint32_t*)l_ctr;
-                uint32_t four_v = 4u;
+                uint32_t four_v = (uint32_t)ISZ;
                 asm volatile("" : "+v"(ctr_p), "+v"(four_v));
                 if constexpr (F32) {
                     // ---- float32 loop (vgl_common.hip.h): same dealing, same hold / period logic; every quantity a float32 built from the
@@ -493,10 +518,18 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
 #endif
                         // operands of this lane's next item (as in the float64 loop)
                         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kn));
-                        const uint32_t kc = (uint32_t)(kn < segT4 ? kn : segT * 4);     // l_it[segT] = 0 stands for "none" (a quarter's own limit is another quarter's live item)
-                        uint32_t rd16 = *(const lds_u16*)(uintptr_t)(576u + kc);
-                        uint32_t ow8 = *(const lds_u16*)(uintptr_t)(578u + kc);
-                        asm volatile("" : "+v"(rd16), "+v"(ow8));
+                        const uint32_t kc = (uint32_t)(kn < segT4 ? kn : segT * ISZ);   // l_it[segT] = 0 stands for "none" (a quarter's own limit is another quarter's live item)
+                        uint32_t rd16, ow8, skn = 0;
+                        if (P16) {
+                            skn = *(const lds_u16*)(uintptr_t)(576u + kc);                                // owner << 10 | read << 2 | base
+                            asm volatile("" : "+v"(skn));
+                            rd16 = (skn << 2) & 0xFF0u;                                                   // 16 x read: byte offset of its jump
+                            ow8 = (skn >> 7) & 0x1F8u;                                                    // 8 x owner: LDS address of l_stq[owner]
+                        } else {
+                            rd16 = *(const lds_u16*)(uintptr_t)(576u + kc);
+                            ow8 = *(const lds_u16*)(uintptr_t)(578u + kc);
+                            asm volatile("" : "+v"(rd16), "+v"(ow8));
+                        }
                         const VglAffine tab_n = *(const VglAffine*)((const uint8_t*)P.qs_read_tab + rd16);
                         const uint64_t base_n = *(__attribute__((address_space(3))) const uint64_t*)(uintptr_t)ow8;
                         // gamma step (rng.h:139-145) on the accepted deviate
@@ -536,8 +569,23 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                         gxf = (acc_g && !stage1) ? val : gxf;
                         stage1 = (stage1 != acc_g) && !redo;
                         if (fin) {
-                            // the read's error probability X / (X + Y) (rng.h:438) as a float32 in the item's slot; NaN: undecided (k_redo draws the read)
-                            *(lds_u32*)(uintptr_t)(576u + (uint32_t)k) = redo ? 0x7FC00000u : __float_as_uint(gx_prev * __builtin_amdgcn_rcpf(gx_prev + val));
+                            const float pf = gx_prev * __builtin_amdgcn_rcpf(gx_prev + val);   // the read's error probability X / (X + Y) (rng.h:438)
+                            if (P16) {
+                                // the read's quality score (vcfgl.cpp:500-523) here, by the lane that finished it: the staged byte into the item's
+                                // slot; bit 8 where the float32 value cannot decide it (the owner hands those reads to k_redo when it stages them)
+                                int q_i, aq_i;
+                                bool ok = qs_decide_pf(P, pf, q_i, aq_i, 0, VGL_P32_TF_EXTRA) && !redo;
+                                if (dbg_redo_every) ok = ok && ((uint32_t)(seg0 + (k >> 1)) % (uint32_t)(dbg_redo_every | (dbg_redo_every == 0))) != 2u;    // test hook
+                                if (P.n_qs_bins != 0) {                                    // (wave-uniform)
+                                    const uint32_t b = l_lut[q_i < 255 ? q_i : 255];       // host: every bin ends below 255 (vgl_ctx_create)
+                                    if (ok && b == 0xFFu) atomicOr(T.errflag, VGL_DEVERR_QSBIN);
+                                    q_i = (b == 0xFFu) ? 0 : (int)b;
+                                } else q_i = (q_i > CAP_BASEQ) ? CAP_BASEQ : q_i;
+                                *(lds_u16*)(uintptr_t)(576u + (uint32_t)k) = (uint16_t)(ok ? (((uint32_t)q_i << 2) | (sk & 3u)) : (0x100u | (sk & 3u)));
+                                sk = skn;
+                            } else
+                            // ... as a float32 in the item's slot; NaN: undecided (k_redo draws the read)
+                            *(lds_u32*)(uintptr_t)(576u + (uint32_t)k) = redo ? 0x7FC00000u : __float_as_uint(pf);
                             aff52_step(tab_n, (uint32_t)base_n, (uint32_t)(base_n >> 32), s_lo, s_hi);     // the next item's stream: its read's jump on its owner's base
                             k = kn;
                             asm volatile("" : "+v"(k));
@@ -669,7 +717,7 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
             // with neighbouring items in neighbouring lanes about twenty lanes of every pass added to the SAME LDS word (one evaluation, one
             // base), and the LDS serialises same-address atomics: 0.53 ms of the 14.3 ms launch; a stride of about twenty items puts the
             // lanes of a pass on different owners, the odd stride keeps their slot reads on different banks
-            const int n_pass = (segT + 63) >> 6;
+            const int n_pass = P16 ? 0 : ((segT + 63) >> 6);          // (P16: the scores were taken in the pool loop)
             const int dB = qfast ? (n_pass | 1) : 0;
             for (int jp = 0; jp < (qfast ? dB : n_pass); ++jp) {
                 const int kb = qfast ? jp : 64 * jp;                    // item of lane b in this pass: kb + b * kstep
@@ -736,7 +784,34 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
             // four reads per trip, one 32-bit store of the staged word (vgl_read_byte); a word cut by a segment boundary is
             // stored again, complete, by the next segment (carry_w)
             uint32_t sq0 = 0, sq1 = 0, sq2 = 0, sq3 = 0, sqq0 = 0, sqq1 = 0, sqq2 = 0, sqq3 = 0;   // this segment's share of the owner's quality sums
-            if (SLIM || qfast) {
+            if (P16) {
+                // the pool loop has left every read's staged byte in the low byte of its 16-bit slot (bit 8: undecided): two (unaligned)
+                // 32-bit LDS reads per word of four reads, the four bytes picked by one v_perm_b32, masked to the reads of this segment
+                const uint8_t* const it8 = (const uint8_t*)l_it;
+                for (int r0 = rdone & ~3; r0 < r_end; r0 += 4) {
+                    uint32_t w_lo, w_hi;
+                    __builtin_memcpy(&w_lo, it8 + 2 * (offs + r0 - seg0), 4);   // slots before / after the lane's reads are masked below
+                    __builtin_memcpy(&w_hi, it8 + 2 * (offs + r0 - seg0) + 4, 4);
+                    const uint32_t w4 = __builtin_amdgcn_perm(w_hi, w_lo, 0x06040200u);           // the low bytes of the four slots
+                    const int lo = rdone > r0 ? rdone - r0 : 0, hi = r_end - r0 < 4 ? r_end - r0 : 4;
+                    const uint32_t mask = (0xFFFFFFFFu << (8 * lo)) & (0xFFFFFFFFu >> (8 * (4 - hi)));
+                    const uint32_t rw = (w4 & mask) | ((r0 < rdone) ? carry_w : 0u);
+                    ((uint32_t*)reads_v)[(size_t)(r0 >> 2) * plane + ev] = rw;
+                    carry_w = rw;
+                    uint32_t und4 = __builtin_amdgcn_perm(w_hi, w_lo, 0x07050301u) & mask & 0x01010101u;   // the slots' high bytes: bit 0 = undecided
+                    if (__builtin_expect(und4 != 0u, 0)) {
+                        // this lane owns the read: (evaluation, read) to the tile's list for k_redo, which patches the staged byte
+                        while (und4) {
+                            const int j = __builtin_ctz(und4) >> 3;
+                            und4 &= und4 - 1;
+                            const uint32_t part = (uint32_t)wave_index & (VGL_REDO_PARTS - 1);      // neighbouring wavefronts append to different counters
+                            const uint32_t idx = atomicAdd(T.redo_count + VGL_REDO_STRIDE * part, 1u);
+                            if (idx < T.redo_cap) T.redo_list[(size_t)part * T.redo_cap + idx] = ((unsigned long long)ev << 10) | (unsigned long long)(r0 + j);
+                            else { const size_t bit = ev * (size_t)P.read_cap + (size_t)(r0 + j); atomicOr(&T.redo_bits[bit >> 5], 1u << (bit & 31)); }   // list full: the bitmap
+                        }
+                    }
+                }
+            } else if (SLIM || qfast) {
                 // the dense pass has left the staged bytes in l_pb: one (unaligned) 32-bit LDS read per word, masked to the reads of
                 // this segment
                 for (int r0 = rdone & ~3; r0 < r_end; r0 += 4) {
@@ -975,7 +1050,15 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
     const int wpb = 1;
     const int wpw = (p->error_qs == 2 && !(dbg && !t->errp)) ? VGL_SAMPLE_WPW : 1;   // chunks per launched wavefront (k_sample; the stamped build runs one)
     const dim3 g((unsigned)((waves + (int64_t)wpb * wpw - 1) / ((int64_t)wpb * wpw))), b(64 * wpb);
-    const size_t lds = (size_t)wpb * p->pool_lds_bytes;
+    // LDS per wavefront of the build that is launched: five bytes per item (slot + base plane; + 512 B of quality-sum words with qsum_lds), or two
+    // (k_sample<2, LEAN 2> without --precise-gl 1: P16)
+    const size_t lds5 = (size_t)wpb * ((((size_t)576 + 4 * ((size_t)p->pool_cap + 2) + (size_t)p->pool_cap + 7) & ~(size_t)7) + (p->qsum_lds ? 512 : 0));
+#ifdef VGL_POOL_F64
+    const size_t lds16 = lds5;
+#else
+    const size_t lds16 = (size_t)wpb * ((((size_t)576 + 2 * ((size_t)p->pool_cap + 2) + 7) & ~(size_t)7) + (p->n_qs_bins ? 256 : 0));
+#endif
+    const size_t lds = lds5;
     hipStream_t s = (hipStream_t)stream;
     const int dm = p->depth_pre;                                  // 0 mixed / 1 k_depth / 2 product method only
 #define VGL_LAUNCH_SAMPLE(EQS, DBG, PREC, LEAN, LDS) \
@@ -1011,7 +1094,7 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
 #endif
         if (t->errp && sample_deferred(p, t)) { if (lean) VGL_LAUNCH_SAMPLE(2, false, true, 2, lds); else VGL_LAUNCH_SAMPLE(2, false, true, 3, lds); }   // --precise-gl 1: the deferred builds, k_redo (vgl_launch_redo) also rewrites errp
         else if (t->errp) { if (lean) VGL_LAUNCH_SAMPLE(2, false, true, 1, lds); else VGL_LAUNCH_SAMPLE(2, false, true, 0, lds); }   // --precise-gl 1, or the deviates were asked for
-        else if (sample_deferred(p, t)) { if (lean) VGL_LAUNCH_SAMPLE(2, false, false, 2, lds); else VGL_LAUNCH_SAMPLE(2, false, false, 3, lds); }
+        else if (sample_deferred(p, t)) { if (lean) VGL_LAUNCH_SAMPLE(2, false, false, 2, lds16); else VGL_LAUNCH_SAMPLE(2, false, false, 3, lds); }
         else { if (lean) VGL_LAUNCH_SAMPLE(2, false, false, 1, lds); else VGL_LAUNCH_SAMPLE(2, false, false, 0, lds); }
     }
     // fixed quality score: the LEAN build (no strand draws, forward-strand depths, quality sums or per-read dump) keeps those
