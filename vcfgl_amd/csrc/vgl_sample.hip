@@ -576,12 +576,15 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                                 int q_i, aq_i;
                                 bool ok = qs_decide_pf(P, pf, q_i, aq_i, 0, VGL_P32_TF_EXTRA) && !redo;
                                 if (dbg_redo_every) ok = ok && ((uint32_t)(seg0 + (k >> 1)) % (uint32_t)(dbg_redo_every | (dbg_redo_every == 0))) != 2u;    // test hook
+                                uint32_t qv;
                                 if (P.n_qs_bins != 0) {                                    // (wave-uniform)
                                     const uint32_t b = l_lut[q_i < 255 ? q_i : 255];       // host: every bin ends below 255 (vgl_ctx_create)
-                                    if (ok && b == 0xFFu) atomicOr(T.errflag, VGL_DEVERR_QSBIN);
-                                    q_i = (b == 0xFFu) ? 0 : (int)b;
-                                } else q_i = (q_i > CAP_BASEQ) ? CAP_BASEQ : q_i;
-                                *(lds_u16*)(uintptr_t)(576u + (uint32_t)k) = (uint16_t)(ok ? (((uint32_t)q_i << 2) | (sk & 3u)) : (0x100u | (sk & 3u)));
+                                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(ok && b == 0xFFu) != 0, 0)) { if (ok && b == 0xFFu) atomicOr(T.errflag, VGL_DEVERR_QSBIN); }
+                                    qv = (b == 0xFFu) ? 0u : b;
+                                } else qv = (uint32_t)((q_i > CAP_BASEQ) ? CAP_BASEQ : q_i);
+                                uint32_t hi6 = ok ? (qv << 2) : 0x100u;                     // (one select: no divergent paths around the slot's store)
+                                asm volatile("" : "+v"(hi6));
+                                *(lds_u16*)(uintptr_t)(576u + (uint32_t)k) = (uint16_t)(hi6 | (sk & 3u));
                                 sk = skn;
                             } else
                             // ... as a float32 in the item's slot; NaN: undecided (k_redo draws the read)
