@@ -107,10 +107,6 @@ __global__ __launch_bounds__(256) void k_depth(const VglDevParams P, const VglTi
 // score to the evaluation's quality sums and to the site totals, which took a placeholder of 0.  The eight quality sums of an owner
 // live only inside a segment's flush (stored, or added to what earlier segments stored, at its end) instead of across the pool loop.
 // LEAN 0 keeps the inline fallbacks: per-read dumps, beta shapes below 8, VGL_NO_DEFER.
-// wavefronts' worth of work one launched wavefront of k_sample<2> runs, one after the other (consecutive 64-sample chunks): see k_sample below
-#ifndef VGL_SAMPLE_WPW
-#define VGL_SAMPLE_WPW 1
-#endif
 template <int EQS, bool DBG, int DM, bool PREC, int LEAN>
 __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTilePtrs& T, const int64_t wave_index) {
     constexpr bool DEFER = (LEAN >= 2);
@@ -932,8 +928,9 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
 
 template <int EQS, bool DBG, int DM, bool PREC, int LEAN>
 // wavefronts per SIMD the register allocator is asked for.  The float32 pool loop of the default tag surface (LEAN 2 without --precise-gl 1) runs at
-// EIGHT (64 VGPRs; pools of 906 items, vgl_host.cpp): with the redo list's counter out of the way more resident wavefronts pay (round 5,
-// A/B on one box: C3 9.9 -> 9.4 ms, depth 30 39.9 -> 34.7 with seven); the other deferred builds at five, the inline-fallback builds at four
+// EIGHT (64 VGPRs; two-byte items, pools of 2240: vgl_host.cpp): with the redo list's counter out of the way more resident wavefronts pay (round 5,
+// A/B on one box: 5 -> 8 wavefronts at depth 20 9.9 -> 9.4 ms with five-byte items in two segments, 8.5 with two-byte items in one); the other
+// deferred builds at five, the inline-fallback builds at four
 #ifndef VGL_SAMPLE_WAVES_F32
 #define VGL_SAMPLE_WAVES_F32 8
 #endif
@@ -943,10 +940,8 @@ template <int EQS, bool DBG, int DM, bool PREC, int LEAN>
 #define VGL_SAMPLE_WAVES(EQS, PREC, LEAN) ((EQS) == 2 ? ((LEAN) == 2 && !(PREC) ? VGL_SAMPLE_WAVES_F32 : ((LEAN) >= 2 ? 5 : 4)) : 8)
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? VGL_SAMPLE_WAVES(EQS, PREC, LEAN) : 1, VGL_SAMPLE_WAVES(EQS, PREC, LEAN)))) void k_sample(const VglDevParams P, const VglTilePtrs T) {
-    constexpr int WPW = (EQS == 2 && !DBG) ? VGL_SAMPLE_WPW : 1;
-    const int64_t w0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * WPW;
-#pragma unroll 1
-    for (int rep = 0; rep < WPW; ++rep) k_sample_body<EQS, DBG, DM, PREC, LEAN>(P, T, w0 + rep);
+    // (one 64-sample chunk per launched wavefront: several chunks per wavefront, one after the other, measured slower -- docs/tried.md)
+    k_sample_body<EQS, DBG, DM, PREC, LEAN>(P, T, (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
 }
 
 // ------------------------------------------------------------------------------------
@@ -1051,8 +1046,7 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
     // wavefronts never cooperate here, and a workgroup's wave slots and LDS are only handed on when its last
     // wavefront retires: one wavefront per workgroup keeps every SIMD at its full complement of waves
     const int wpb = 1;
-    const int wpw = (p->error_qs == 2 && !(dbg && !t->errp)) ? VGL_SAMPLE_WPW : 1;   // chunks per launched wavefront (k_sample; the stamped build runs one)
-    const dim3 g((unsigned)((waves + (int64_t)wpb * wpw - 1) / ((int64_t)wpb * wpw))), b(64 * wpb);
+    const dim3 g((unsigned)((waves + wpb - 1) / wpb)), b(64 * wpb);
     // LDS per wavefront of the build that is launched: five bytes per item (slot + base plane; + 512 B of quality-sum words with qsum_lds), or two
     // (k_sample<2, LEAN 2> without --precise-gl 1: P16)
     const size_t lds5 = (size_t)wpb * ((((size_t)576 + 4 * ((size_t)p->pool_cap + 2) + (size_t)p->pool_cap + 7) & ~(size_t)7) + (p->qsum_lds ? 512 : 0));
