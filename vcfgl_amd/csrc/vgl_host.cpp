@@ -478,8 +478,8 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     D.lean_ok = (!D.need_qsum && !D.sample_strand && !D.need_adf && p->adjust_qs == 0 && !hook_env("VGL_NO_LEAN")) ? 1 : 0;
     D.defer_ok = (!D.serial && p->error_qs == 2 &&
                   !D.gx.changed && !D.gy.changed && D.gx.alpha0 >= 8.0 && D.gy.alpha0 >= 8.0 && !hook_env("VGL_NO_DEFER") && !hook_env("VGL_DEBUG_QS_EXACT") && !hook_env("VGL_NO_LEAN") &&
-                  !(D.lean_ok && !p->precise_gl && (D.read_cap > 256 || !bins_below_255))) ? 1 : 0;   // (the two-byte items of the lean float32 build hold a read index
-                                                                                            // of 8 bits and look binned scores up in a 256-entry table: other runs take the inline build)
+                  !(!p->precise_gl && (D.read_cap > 256 || !bins_below_255))) ? 1 : 0;   // (the two-byte items of the float32 builds hold a read index of 8 bits
+                                                                             // and look binned scores up in a 256-entry table: other runs take the inline build)
     // one workgroup per site does everything (k_gl<.., FUSED>, vgl_gl.hip): sampling with one fixed score, the site's allele order and the
     // likelihoods, with nothing staged in HBM between them
     // (round 4: sites of more than 512 samples split over up to four consecutive workgroups, up to 128 staged reads.  The kernel also takes its
@@ -493,22 +493,20 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     if (!D.fused) D.fused_split = 0;
     D.qsum_lds = (D.defer_ok && !D.lean_ok && ((p->adjust_qs & 3) == 0 || (p->adjust_qs & 3) == 3) && D.read_cap <= 130) ? 1 : 0;    // 130 x 63 = 8190 < 2^13, 130 x 63^2 = 515970 < 2^19
     if (D.defer_ok) {
-        // pools of the deferred builds.  k_sample<2, LEAN 2> without --precise-gl 1 (float32 loop, round 5) keeps an item in TWO bytes and is
-        // built for eight wavefronts per SIMD: 2240 items (576 + 2 x 2242 B: 32 wavefronts in a CU's 160 KB) -- depth 30 in one segment.
-        // The others: 1472 items of five bytes = 5 wavefronts per SIMD (20 x (576 + 5 x 1472 + 8) B)
+        // pools of the deferred builds.  Without --precise-gl 1 (float32 loop, round 5) an item is TWO bytes: 576 B + 2 x (items + 2) (+ 1 KB of
+        // quality-sum words with qsum_lds, + 256 B of binned scores with --qs-bins) -- 2240 items (depth 30 in one segment) leave LDS for the eight
+        // wavefronts per SIMD k_sample<2, LEAN 2> is built for (32 x 5.1 KB in a CU's 160 KB).  With --precise-gl 1 (float64 loop): five bytes, 1472
+        // items = 5 wavefronts per SIMD (1416 with the 512 B of sum words)
 #ifndef VGL_POOL_F64
-        const bool p16 = D.lean_ok && !p->precise_gl;
+        const bool p16 = !p->precise_gl;
 #else
         const bool p16 = false;
 #endif
-        const int cap_defer = p16 ? (p->n_qs_bins ? 2112 : 2240) : 1472;           // (--qs-bins: 256 B of the LDS go to the score -> binned score table)
+        const int extra16 = (D.qsum_lds ? 1024 : 0) + (p->n_qs_bins ? 256 : 0);
+        const int cap_defer = p16 ? ((5120 - 576 - 8 - (D.lean_ok ? (p->n_qs_bins ? 256 : 0) : 0)) / 2 / 64 * 64) : (D.qsum_lds ? 1416 : 1472);
         if (D.pool_cap > cap_defer) D.pool_cap = cap_defer;
-        D.pool_lds_bytes = p16 ? (((576 + 2 * (D.pool_cap + 2) + 7) & ~7) + (p->n_qs_bins ? 256 : 0))
-                               : ((576 + 4 * (D.pool_cap + 2) + D.pool_cap + 7) & ~7);   // (vgl_launch_sample sizes the LDS of the build it launches)
-    }
-    if (D.qsum_lds) {                           // + 512 B of quality-sum words behind the pool (vgl_sample.hip): 576 + 5 x 1416 + 8 + 512 <= 8192
-        if (D.pool_cap > 1416) D.pool_cap = 1416;
-        D.pool_lds_bytes = ((576 + 4 * (D.pool_cap + 2) + D.pool_cap + 7) & ~7) + 512;
+        D.pool_lds_bytes = p16 ? (((576 + 2 * (D.pool_cap + 2) + 7) & ~7) + extra16)
+                               : (((576 + 4 * (D.pool_cap + 2) + D.pool_cap + 7) & ~7) + (D.qsum_lds ? 512 : 0));   // (vgl_launch_sample sizes the LDS of the build it launches)
     }
     pois_init(&D.pois0, p->depths ? 0.0 : p->depth);
 

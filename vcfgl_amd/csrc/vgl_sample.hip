@@ -126,7 +126,7 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
     // P16 (round 5): the float32 loop of the default tag surface keeps an item in TWO bytes -- owner << 10 | read << 2 | base until it is
     // finished, then the read's staged byte (score << 2 | base; bit 8: undecided, k_redo draws the read) written by the lane that finishes
     // it.  No base plane, no dense pass; a wavefront's pool of up to 2240 items (depth 30 in one segment) leaves LDS for eight wavefronts per SIMD
-    constexpr bool P16 = F32 && (LEAN == 2);
+    constexpr bool P16 = F32;                                         // (LEAN 2 and LEAN 3 without --precise-gl 1)
     constexpr int ISZ = P16 ? 2 : 4;                                  // bytes of an item's slot
     constexpr bool SLIM = (LEAN == 1 || LEAN == 2);                  // default tag surface: none of the optional per-read state
     constexpr bool DUMP = (LEAN == 0);                               // a per-read dump (reads_out) may be asked for
@@ -293,7 +293,10 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
         // P16 with --qs-bins: score -> binned score (vcfgl.cpp:57-64) as a 256-byte table behind the items (0xFF: in no bin); the lane that
         // finishes a read looks its score up there -- the bins' search loop ran per finishing lane and iteration (depth 30, rta3 bins: 44.8 ms
         // against 35.6 for the dense-pass build; with the table 2 x 2 instructions)
+        // P16 with the LDS quality sums (qfast): 64 owners x 4 bases x one 32-bit word (sum of squares << 13 | sum) behind the items, added to by
+        // the lane that finishes a read, read and cleared by the owner when it stages its reads
         uint8_t* const l_lut = wl + ((576 + 2 * ((size_t)cap + 2) + 7) & ~(size_t)7);
+        uint32_t* const l_qs = (uint32_t*)(l_lut + (P.n_qs_bins != 0 ? 256 : 0));
         if (P16 && P.n_qs_bins != 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -303,6 +306,7 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                 l_lut[qv] = (uint8_t)b;
             }
         }
+        if (P16 && LEAN == 3) { if (P.qsum_lds) { ((uint64_t*)l_qs)[2 * lane] = 0ULL; ((uint64_t*)l_qs)[2 * lane + 1] = 0ULL; } }
         if (lane == 0) {
             if (!P16) l_it[cap] = 0u;
             if (F32) {
@@ -381,9 +385,12 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                         const uint64_t one = 1ULL << (16 * r_base);
                         ad4 += one;
                         if (!SLIM) { if (fwd) adf4 += one; }
-                        *(lds_u32o*)(uintptr_t)ka = sv;
-                        *(lds_u8o*)(uintptr_t)pa = (uint8_t)((LEAN == 3) ? (lane4 | (uint32_t)r_base) : (uint32_t)r_base);   // (LEAN 3: the dense pass finds the item's owner here)
-                        sv += 16u; ka += 4u; pa += 1u;
+                        if (P16) { *(lds_u16o*)(uintptr_t)ka = (uint16_t)(sv | (uint32_t)r_base); sv += 4u; ka += 2u; }
+                        else {
+                            *(lds_u32o*)(uintptr_t)ka = sv;
+                            *(lds_u8o*)(uintptr_t)pa = (uint8_t)((LEAN == 3) ? (lane4 | (uint32_t)r_base) : (uint32_t)r_base);   // (LEAN 3: the dense pass finds the item's owner here)
+                            sv += 16u; ka += 4u; pa += 1u;
+                        }
                     }
                 };
                 // a wavefront of homozygous evaluations (most wavefronts of a rare variant's site) does not step the haplotype stream
@@ -570,17 +577,30 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                                 // the read's quality score (vcfgl.cpp:500-523) here, by the lane that finished it: the staged byte into the item's
                                 // slot; bit 8 where the float32 value cannot decide it (the owner hands those reads to k_redo when it stages them)
                                 int q_i, aq_i;
-                                bool ok = qs_decide_pf(P, pf, q_i, aq_i, 0, VGL_P32_TF_EXTRA) && !redo;
+                                bool ok = qs_decide_pf(P, pf, q_i, aq_i, k_adj, VGL_P32_TF_EXTRA) && !redo;
                                 if (dbg_redo_every) ok = ok && ((uint32_t)(seg0 + (k >> 1)) % (uint32_t)(dbg_redo_every | (dbg_redo_every == 0))) != 2u;    // test hook
-                                uint32_t qv;
+                                uint32_t qv, aqv = 0;
                                 if (P.n_qs_bins != 0) {                                    // (wave-uniform)
                                     const uint32_t b = l_lut[q_i < 255 ? q_i : 255];       // host: every bin ends below 255 (vgl_ctx_create)
-                                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(ok && b == 0xFFu) != 0, 0)) { if (ok && b == 0xFFu) atomicOr(T.errflag, VGL_DEVERR_QSBIN); }
-                                    qv = (b == 0xFFu) ? 0u : b;
-                                } else qv = (uint32_t)((q_i > CAP_BASEQ) ? CAP_BASEQ : q_i);
-                                uint32_t hi6 = ok ? (qv << 2) : 0x100u;                     // (one select: no divergent paths around the slot's store)
+                                    uint32_t b2 = 0;
+                                    if (!SLIM) { if (k_adj) { const int a_ = aq_i < 0 ? 0 : aq_i; b2 = l_lut[a_ < 255 ? a_ : 255]; } }
+                                    const bool nobin = ok && (b == 0xFFu || b2 == 0xFFu);
+                                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(nobin) != 0, 0)) { if (nobin) atomicOr(T.errflag, VGL_DEVERR_QSBIN); }
+                                    qv = (b == 0xFFu) ? 0u : b; aqv = (b2 == 0xFFu) ? 0u : b2;
+                                } else {
+                                    qv = (uint32_t)((q_i > CAP_BASEQ) ? CAP_BASEQ : q_i);
+                                    if (!SLIM) aqv = (uint32_t)((aq_i > CAP_BASEQ) ? CAP_BASEQ : (aq_i < 0 ? 0 : aq_i));
+                                }
+                                // the score the likelihoods take (vcfgl.cpp:525-531) in the staged byte; the score the quality sums take (:557-564) in
+                                // bits 9-14 (the owner's flush adds them up), or added to the owner's word of that base right here (qfast)
+                                const uint32_t q_gl = SLIM ? qv : ((k_adj & 1) ? aqv : qv), q_sum = SLIM ? 0u : ((k_adj & 2) ? aqv : qv);
+                                uint32_t hi6 = ok ? ((q_gl << 2) | (q_sum << 9)) : 0x100u;   // (one select: no divergent paths around the slot's store)
                                 asm volatile("" : "+v"(hi6));
                                 *(lds_u16*)(uintptr_t)(576u + (uint32_t)k) = (uint16_t)(hi6 | (sk & 3u));
+                                if (!SLIM) {
+                                    if (qfast && k_qsum && ok)
+                                        __hip_atomic_fetch_add(l_qs + ((sk >> 10) * 4u + (sk & 3u)), q_sum + ((q_sum * q_sum) << 13), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                                }
                                 sk = skn;
                             } else
                             // ... as a float32 in the item's slot; NaN: undecided (k_redo draws the read)
@@ -704,7 +724,7 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
 
             if (DBG) { const unsigned long long c = clock64(); c_pool += c - c_tmp; c_tmp = c; }
             if (DBG && P.dbg_phase == 3) return;
-            if (qfast && k_qsum) {                                      // the pool loop is done with l_stq: zero the 64 x 4 sum words
+            if (!P16 && qfast && k_qsum) {                              // the pool loop is done with l_stq: zero the 64 x 4 sum words
                 l_stq[lane] = 0ULL;
                 ((uint64_t*)l_accB)[lane] = 0ULL;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -717,7 +737,7 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
             // base), and the LDS serialises same-address atomics: 0.53 ms of the 14.3 ms launch; a stride of about twenty items puts the
             // lanes of a pass on different owners, the odd stride keeps their slot reads on different banks
             const int n_pass = P16 ? 0 : ((segT + 63) >> 6);          // (P16: the scores were taken in the pool loop)
-            const int dB = qfast ? (n_pass | 1) : 0;
+            const int dB = (qfast && !P16) ? (n_pass | 1) : 0;
             for (int jp = 0; jp < (qfast ? dB : n_pass); ++jp) {
                 const int kb = qfast ? jp : 64 * jp;                    // item of lane b in this pass: kb + b * kstep
                 const int kstep = qfast ? dB : 1;
@@ -809,6 +829,20 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                             else { const size_t bit = ev * (size_t)P.read_cap + (size_t)(r0 + j); atomicOr(&T.redo_bits[bit >> 5], 1u << (bit & 31)); }   // list full: the bitmap
                         }
                     }
+                    if (!SLIM) {
+                        if (k_qsum && !qfast) {
+                            // --adjust-qs 1 / 2 or deep staging: the score the sums take sits in bits 9-14 of each slot (0 for an undecided read:
+                            // k_redo adds its score later), vcfgl.cpp:557-564
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const uint32_t sl = ((j < 2 ? w_lo : w_hi) >> (16 * (j & 1))) & 0xFFFFu;
+                                const bool mine = (r0 + j >= rdone) && (r0 + j < r_end) && !(sl & 0x100u);
+                                const uint32_t qq = mine ? ((sl >> 9) & 63u) : 0u, q2 = (uint32_t)qs_to_qssq((int)qq), rb = sl & 3u;
+                                sq0 += (rb == 0) ? qq : 0u; sq1 += (rb == 1) ? qq : 0u; sq2 += (rb == 2) ? qq : 0u; sq3 += (rb == 3) ? qq : 0u;
+                                sqq0 += (rb == 0) ? q2 : 0u; sqq1 += (rb == 1) ? q2 : 0u; sqq2 += (rb == 2) ? q2 : 0u; sqq3 += (rb == 3) ? q2 : 0u;
+                            }
+                        }
+                    }
                 }
             } else if (SLIM || qfast) {
                 // the dense pass has left the staged bytes in l_pb: one (unaligned) 32-bit LDS read per word, masked to the reads of
@@ -852,7 +886,12 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
             }
             rdone = r_end;
             if (!SLIM) {
-                if (qfast && k_qsum) {                                  // this owner's sums of the segment, from the dense pass's LDS words
+                if (P16 && qfast && k_qsum) {                           // this owner's sums of the segment, from the words the finishing lanes added to
+                    const uint64_t v01 = ((const uint64_t*)l_qs)[2 * lane], v23 = ((const uint64_t*)l_qs)[2 * lane + 1];
+                    sq0 = (uint32_t)v01 & 0x1FFFu; sqq0 = (uint32_t)v01 >> 13; sq1 = (uint32_t)(v01 >> 32) & 0x1FFFu; sqq1 = (uint32_t)(v01 >> 32) >> 13;
+                    sq2 = (uint32_t)v23 & 0x1FFFu; sqq2 = (uint32_t)v23 >> 13; sq3 = (uint32_t)(v23 >> 32) & 0x1FFFu; sqq3 = (uint32_t)(v23 >> 32) >> 13;
+                    ((uint64_t*)l_qs)[2 * lane] = 0ULL; ((uint64_t*)l_qs)[2 * lane + 1] = 0ULL;     // (for the next segment)
+                } else if (qfast && k_qsum) {                           // this owner's sums of the segment, from the dense pass's LDS words
                     const uint64_t v01 = l_stq[lane], v23 = ((const uint64_t*)l_accB)[lane];
                     sq0 = (uint32_t)v01 & 0x1FFFu; sqq0 = (uint32_t)v01 >> 13; sq1 = (uint32_t)(v01 >> 32) & 0x1FFFu; sqq1 = (uint32_t)(v01 >> 32) >> 13;
                     sq2 = (uint32_t)v23 & 0x1FFFu; sqq2 = (uint32_t)v23 >> 13; sq3 = (uint32_t)(v23 >> 32) & 0x1FFFu; sqq3 = (uint32_t)(v23 >> 32) >> 13;
@@ -929,15 +968,19 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
 template <int EQS, bool DBG, int DM, bool PREC, int LEAN>
 // wavefronts per SIMD the register allocator is asked for.  The float32 pool loop of the default tag surface (LEAN 2 without --precise-gl 1) runs at
 // EIGHT (64 VGPRs; two-byte items, pools of 2240: vgl_host.cpp): with the redo list's counter out of the way more resident wavefronts pay (round 5,
-// A/B on one box: 5 -> 8 wavefronts at depth 20 9.9 -> 9.4 ms with five-byte items in two segments, 8.5 with two-byte items in one); the other
-// deferred builds at five, the inline-fallback builds at four
+// A/B on one box: 5 -> 8 wavefronts at depth 20 9.9 -> 9.4 ms with five-byte items in two segments, 8.5 with two-byte items in one); the
+// optional-tag float32 build (LEAN 3) at SEVEN (72 VGPRs: 11.4 -> 10.5 ms; 8 wavefronts 10.7); the --precise-gl 1 builds at five, the
+// inline-fallback builds at four
 #ifndef VGL_SAMPLE_WAVES_F32
 #define VGL_SAMPLE_WAVES_F32 8
 #endif
 #ifdef VGL_POOL_F64
 #define VGL_SAMPLE_WAVES(EQS, PREC, LEAN) ((EQS) == 2 ? ((LEAN) >= 2 ? 5 : 4) : 8)
 #else
-#define VGL_SAMPLE_WAVES(EQS, PREC, LEAN) ((EQS) == 2 ? ((LEAN) == 2 && !(PREC) ? VGL_SAMPLE_WAVES_F32 : ((LEAN) >= 2 ? 5 : 4)) : 8)
+#ifndef VGL_SAMPLE_WAVES_L3
+#define VGL_SAMPLE_WAVES_L3 7
+#endif
+#define VGL_SAMPLE_WAVES(EQS, PREC, LEAN) ((EQS) == 2 ? ((LEAN) == 2 && !(PREC) ? VGL_SAMPLE_WAVES_F32 : ((LEAN) == 3 && !(PREC) ? VGL_SAMPLE_WAVES_L3 : ((LEAN) >= 2 ? 5 : 4))) : 8)
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? VGL_SAMPLE_WAVES(EQS, PREC, LEAN) : 1, VGL_SAMPLE_WAVES(EQS, PREC, LEAN)))) void k_sample(const VglDevParams P, const VglTilePtrs T) {
     // (one 64-sample chunk per launched wavefront: several chunks per wavefront, one after the other, measured slower -- docs/tried.md)
@@ -1051,9 +1094,10 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
     // (k_sample<2, LEAN 2> without --precise-gl 1: P16)
     const size_t lds5 = (size_t)wpb * ((((size_t)576 + 4 * ((size_t)p->pool_cap + 2) + (size_t)p->pool_cap + 7) & ~(size_t)7) + (p->qsum_lds ? 512 : 0));
 #ifdef VGL_POOL_F64
-    const size_t lds16 = lds5;
+    const size_t lds16 = lds5, lds16x = lds5;
 #else
     const size_t lds16 = (size_t)wpb * ((((size_t)576 + 2 * ((size_t)p->pool_cap + 2) + 7) & ~(size_t)7) + (p->n_qs_bins ? 256 : 0));
+    const size_t lds16x = lds16 + (size_t)wpb * (p->qsum_lds ? 1024 : 0);          // LEAN 3: + the quality-sum words
 #endif
     const size_t lds = lds5;
     hipStream_t s = (hipStream_t)stream;
@@ -1091,7 +1135,7 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
 #endif
         if (t->errp && sample_deferred(p, t)) { if (lean) VGL_LAUNCH_SAMPLE(2, false, true, 2, lds); else VGL_LAUNCH_SAMPLE(2, false, true, 3, lds); }   // --precise-gl 1: the deferred builds, k_redo (vgl_launch_redo) also rewrites errp
         else if (t->errp) { if (lean) VGL_LAUNCH_SAMPLE(2, false, true, 1, lds); else VGL_LAUNCH_SAMPLE(2, false, true, 0, lds); }   // --precise-gl 1, or the deviates were asked for
-        else if (sample_deferred(p, t)) { if (lean) VGL_LAUNCH_SAMPLE(2, false, false, 2, lds16); else VGL_LAUNCH_SAMPLE(2, false, false, 3, lds); }
+        else if (sample_deferred(p, t)) { if (lean) VGL_LAUNCH_SAMPLE(2, false, false, 2, lds16); else VGL_LAUNCH_SAMPLE(2, false, false, 3, lds16x); }
         else { if (lean) VGL_LAUNCH_SAMPLE(2, false, false, 1, lds); else VGL_LAUNCH_SAMPLE(2, false, false, 0, lds); }
     }
     // fixed quality score: the LEAN build (no strand draws, forward-strand depths, quality sums or per-read dump) keeps those
