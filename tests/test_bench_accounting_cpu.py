@@ -25,12 +25,12 @@ def test_every_timed_workload_has_committed_counters():
     for wl in bench.WORKLOADS:
         assert wl in prof, wl
         e = prof[wl]
-        assert e["source"].startswith("r04_") and len(e["src_sha"]) == 16
+        assert e["source"].startswith("r05_") and len(e["src_sha"]) == 16
         k = e["kernels"]
         assert "k_gl" in k
         for name, v in k.items():
             assert v["sites_per_launch"] > 0 and v["valu_insts_per_wave"] > 0 and 0 < v["active_lanes_per_valu_inst"] < 70, (wl, name)
-            assert v["hbm_bytes_per_launch"] > 0 and 0 <= v["valu_busy_frac"] <= 1.0, (wl, name)
+            assert v["hbm_bytes_per_launch"] > 0 and 0 <= v["valu_busy_frac"] <= 1.0, (wl, name)       # (clamped at 1: SQ_ACTIVE_INST_VALU counts 4 cycles per instruction)
     assert "k_siteagg" in prof["alltags"]["kernels"] and "k_siteagg" in prof["qsi16"]["kernels"] and "k_redo" in prof["c3"]["kernels"]
     for wl in bench.WORKLOADS:                          # the per-workload summaries and kernel traces the line points at exist
         tag = prof[wl]["source"]

@@ -57,7 +57,7 @@ def test_headline_is_small_strict_and_complete(tmp_path, capsys):
     assert ex["bench_extra"]["fixedq"]["kernel"] == "k_gl" and ex["bench_extra"]["c5"]["value"] > 1e10
     # nothing is lost: the detail file holds the unabridged blocks
     full = json.load(open(tmp_path / "detail.json"))
-    assert full["roofline"]["valu"]["cost_weighted"]["frac"] > 0 and full["extra"]["precise"]["roofline"]["kernel_ms_total"]["k_gl"] > 0
+    assert full["roofline"]["valu"]["frac"] > 0 and full["extra"]["precise"]["roofline"]["kernel_ms_total"]["k_gl"] > 0
 
 
 def test_non_finite_numbers_never_reach_the_line(tmp_path, capsys):
