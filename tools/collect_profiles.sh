@@ -13,4 +13,4 @@ for wl in $wls; do
     python tools/pmc_summary.py gpurun_out/$tag/$wl/pmc ${tag}_${wl} $wl $n > /dev/null
     echo "$wl: $(grep -c . profiles/${tag}_${wl}_kernel_stats.csv) kernel rows"
 done
-[ -f gpurun_out/$tag/bench.json ] && tail -1 gpurun_out/$tag/bench.json > profiles/${tag}_bench.json || true
+[ -f gpurun_out/$tag/bench.json ] && tail -2 gpurun_out/$tag/bench.json > profiles/${tag}_bench.json || true
