@@ -16,7 +16,7 @@ from vcfgl_amd import _abi
 
 pytestmark = pytest.mark.gpu
 
-FAST_LN, GAMMA_LU, GAMMA_SERIES, GAMMA_REFEXPR, QS_TF, RCP, TANF, EXP2, DIV, QUOT, DIV10, POISSON, POOL32 = range(13)
+FAST_LN, GAMMA_LU, GAMMA_SERIES, GAMMA_REFEXPR, QS_TF, RCP, TANF, EXP2, DIV, QUOT, DIV10, POISSON, POOL32, QS_FIX = range(14)
 
 
 def f2b(x):
@@ -134,3 +134,15 @@ def test_float32_pool_loop_decisions_equal_the_float64_ones(alpha):
     # (alpha 8: 8.5e-4 -- nearly all of it gamma steps with |a2 xn| > 1/3 whose sure-accept bound does not hold: the range of the
     # bounded test's series, as in the float64 loop; C3's shapes: 3e-4 and 1e-5)
     assert r["max_ratio"] < 1.5e-3, r
+
+
+@pytest.mark.parametrize("adjust_by", [0.0, 0.499, 3.25])
+def test_fixed_point_score_decision_every_float_probability(adjust_by):
+    """qs_decide_fix (round 5: the finish block of k_sample<2>'s two-byte-item loop): for EVERY float32 p in (1e-37, 1) that it decides, the
+    score -- and the adjusted score (int)(tf + adjust_by) -- is the exact one for every true value within the float32 pool loop's
+    84 x 2^-24 of p; the undecided share is on record."""
+    r = sweep(QS_FIX, f2b(1.0e-37), f2b(1.0), param=adjust_by)
+    n_all = f2b(1.0) - f2b(1.0e-37) + 1
+    print(f"qs_fix adjust_by {adjust_by}: {r['n']} of {n_all} arguments decided, violations {r['violations']}")
+    assert r["violations"] == 0, r
+    assert r["n"] > 0.02 * n_all          # (p >= 4e-7, i.e. tf < 64, is 2.3 % of the float32 values below 1; all of them but a band of 3.7e-4 per score)

@@ -23,6 +23,7 @@ enum {
     VGL_BOUND_QUOT = 9,         // quot_int24 == IEEE float32 quotient of integers q <= sum <= 2^24 (k_siteagg; count = pairs)
     VGL_BOUND_DIV10 = 10,       // div10_f32(x) == (float)((double)x / 10.0) for every float32 bit pattern of the sweep (k_gl, GL model 1)
     VGL_BOUND_POISSON = 11,     // poisson_fast == poisson_exact wherever it does not call the attempt ambiguous (param = mean depth; count = attempts)
+    VGL_BOUND_QS_FIX = 13,      // qs_decide_fix: every float32 p it decides has ONE score over the whole interval its true value can lie in (param = adjust_by, 0 = none)
     VGL_BOUND_POOL32 = 12,      // the float32 pool loop of k_sample<2>: every decision it takes equals the float64 one, values within their bounds (param = shape alpha >= 8; count = attempts)
     VGL_BOUND_N
 };
@@ -84,6 +85,17 @@ __global__ __launch_bounds__(256) void k_bound_sweep(const uint32_t lo, const un
             // kernel: pf within 1.25 x 2^-22 relative of p (qs_stage_pf) => 10 log10(e) x 2.98e-7 < 1.3e-6 of the margin is the argument's
             const float tf = qs_tf(x);
             acc_update(mr, arg, viol, fabs((double)tf - (-10.0 * log10(xd))), (double)qs_tf_margin(tf) - 1.3e-6, bits);
+        } else if (MODE == VGL_BOUND_QS_FIX) {
+            // the float32 pool loop leaves p within 84 x 2^-24 (relative) of the reference's X / (X + Y) (vgl_common.hip.h): a decided score
+            // must be the exact (int)(-10 log10 p') for every p' in that interval, and so must the adjusted score
+            VglDevParams Pz; Pz.adjust_by = param;
+            int q, aq;
+            const bool ok = qs_decide_fix(Pz, x, q, aq, param != 0.0 ? 1 : 0);
+            if (!ok) { --n; continue; }
+            const double d = 84.0 * 0x1p-24;
+            const double t_lo = -10.0 * log10(xd * (1.0 + d)), t_hi = -10.0 * log10(xd * (1.0 - d));
+            const bool good = (int)t_lo == q && (int)t_hi == q && (param == 0.0 || ((int)(t_lo + param) == aq && (int)(t_hi + param) == aq)) && t_lo > 0.0;
+            acc_update(mr, arg, viol, good ? 0.0 : 1.0, 0.0, bits);
         } else if (MODE == VGL_BOUND_RCP) {
             const float r = __builtin_amdgcn_rcpf(x);
             const double ex = 1.0 / xd;
@@ -331,6 +343,7 @@ extern "C" __attribute__((visibility("default"))) int vgl_dbg_bound_sweep(int mo
         case VGL_BOUND_GAMMA_SERIES: hipLaunchKernelGGL((k_bound_sweep<VGL_BOUND_GAMMA_SERIES>), g, b, 0, 0, lo_bits, count, param, d); break;
         case VGL_BOUND_GAMMA_REFEXPR: hipLaunchKernelGGL((k_bound_sweep<VGL_BOUND_GAMMA_REFEXPR>), g, b, 0, 0, lo_bits, count, param, d); break;
         case VGL_BOUND_QS_TF: hipLaunchKernelGGL((k_bound_sweep<VGL_BOUND_QS_TF>), g, b, 0, 0, lo_bits, count, param, d); break;
+        case VGL_BOUND_QS_FIX: hipLaunchKernelGGL((k_bound_sweep<VGL_BOUND_QS_FIX>), g, b, 0, 0, lo_bits, count, param, d); break;
         case VGL_BOUND_RCP: hipLaunchKernelGGL((k_bound_sweep<VGL_BOUND_RCP>), g, b, 0, 0, lo_bits, count, param, d); break;
         case VGL_BOUND_TANF: hipLaunchKernelGGL((k_bound_sweep<VGL_BOUND_TANF>), g, b, 0, 0, lo_bits, count, param, d); break;
         case VGL_BOUND_EXP2: hipLaunchKernelGGL((k_bound_sweep<VGL_BOUND_EXP2>), g, b, 0, 0, lo_bits, count, param, d); break;

@@ -614,6 +614,24 @@ __device__ __forceinline__ bool qs_decide_pf(const VglDevParams& P, const float 
     }
     return ok;
 }
+// The same decision in fixed point (round 5: the finish block of the two-byte-item pool loop runs it once per iteration for the few
+// lanes that finish a read, so its instruction count is the loop's): tfs = tf x 2^16 (the scaling is exact: one float32 rounding as in
+// qs_tf), i = (int)tfs truncated, q = i >> 16, frac = i & 0xFFFF.  Decided iff 0 < tf < 64 and VGL_QS_FIX_M <= frac <= 2^16 - VGL_QS_FIX_M:
+// then frac(tf) >= M 2^-16 and 1 - frac(tf) > (M - 1) 2^-16, and (M - 1) 2^-16 = 1.53e-4 exceeds qs_tf_margin(63) + VGL_P32_TF_EXTRA =
+// 63 x 2^-19 + 4e-6 + 2.2e-5 = 1.46e-4.  tf >= 64 (p < 4e-7) is left to k_redo.  adj: the adjusted score (int)(tf + adjust_by) likewise.
+#define VGL_QS_FIX_M 11
+__device__ __forceinline__ bool qs_decide_fix(const VglDevParams& P, const float pf, int& q, int& aq, const int adj) {
+    const float tfs = __builtin_amdgcn_logf(pf) * (-3.0103f * 65536.0f);
+    const int i = (int)tfs;                                               // (NaN -> 0, +inf -> INT_MAX: both undecided below)
+    bool ok = ((uint32_t)i < (64u << 16)) && (((uint32_t)i & 0xFFFFu) - (uint32_t)VGL_QS_FIX_M <= 65536u - 2u * (uint32_t)VGL_QS_FIX_M);
+    q = i >> 16; aq = -1;
+    if (adj) {
+        const int i2 = (int)(tfs + (float)P.adjust_by * 65536.0f);        // (one more float32 rounding of a value below 2^23: within the slack of M)
+        ok = ok && ((uint32_t)i2 < (64u << 16)) && (((uint32_t)i2 & 0xFFFFu) - (uint32_t)VGL_QS_FIX_M <= 65536u - 2u * (uint32_t)VGL_QS_FIX_M);
+        aq = i2 >> 16;
+    }
+    return ok;
+}
 // vcfgl.cpp:500-507, exact
 static __device__ void errprob_raw(const VglDevParams& P, const double ep, int& q, int& aq) {
     q = -1; aq = -1;

@@ -577,7 +577,7 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                                 // the read's quality score (vcfgl.cpp:500-523) here, by the lane that finished it: the staged byte into the item's
                                 // slot; bit 8 where the float32 value cannot decide it (the owner hands those reads to k_redo when it stages them)
                                 int q_i, aq_i;
-                                bool ok = qs_decide_pf(P, pf, q_i, aq_i, k_adj, VGL_P32_TF_EXTRA) && !redo;
+                                bool ok = qs_decide_fix(P, pf, q_i, aq_i, k_adj) && !redo;
                                 if (dbg_redo_every) ok = ok && ((uint32_t)(seg0 + (k >> 1)) % (uint32_t)(dbg_redo_every | (dbg_redo_every == 0))) != 2u;    // test hook
                                 uint32_t qv, aqv = 0;
                                 if (P.n_qs_bins != 0) {                                    // (wave-uniform)
