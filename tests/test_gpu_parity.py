@@ -803,3 +803,32 @@ def test_async_tile_that_fails_after_its_first_enqueue_leaves_the_context_usable
         want = orc.simulate(k * S, gts[k], fields=["fmt_dp", "gl", "pl"])
         for f in ("fmt_dp", "pl", "gl"):
             assert np.array_equal(bits(want.numpy(f)), bits(tiles[k].numpy(f))), (k, f)
+
+
+@pytest.mark.parametrize("depth,tags,lean", [(140, {}, 2), (140, dict(add_qs=1, add_i16=1), 3), (150, {}, 1), (150, dict(add_qs=1), 0)])
+def test_two_byte_items_at_the_edge_of_their_read_index(oracle, depth, tags, lean):
+    """round 5: the float32 builds of k_sample<2> keep a work item in two bytes with 8 bits of read index -- mean depth 140 stages up to
+    251 reads (still those builds, several pool segments), depth 150 up to 264: the inline-fallback build (LEAN 0 / 1) takes over.
+    Both equal to the oracle."""
+    args = VcfglArgs(seed=5, depth=depth, error_rate=0.01, error_qs=2, beta_variance=1e-5, add_pl=1, **tags)
+    args.rng_mode, args.beta_sampler = _abi.VGL_RNG_TILE, _abi.VGL_BETA_RAND48
+    sim = Simulator(args, 70, device=0, max_sites_per_tile=6)
+    info = sim.info()
+    sim.close()
+    assert info["sample_lean"] == lean and (info["read_cap"] <= 256) == (lean >= 2), info
+    want, got = run_both(oracle, args, synth.binary_sites(0, 6, 70))
+    assert_parity(want, got, check_gp=False)
+
+
+@pytest.mark.parametrize("bins,lean", [([(0, 20, 10), (21, 254, 30)], 2), ([(0, 20, 10), (21, 300, 30)], 1)])
+def test_binned_scores_from_the_lds_table_and_beyond_it(oracle, bins, lean):
+    """--qs-bins in the two-byte-item builds: the finishing lane looks the binned score up in a 256-entry LDS table; a bin that reaches
+    beyond 254 cannot be tabulated and sends the run to the inline build (vgl_ctx_create)."""
+    args = VcfglArgs(seed=9, depth=12, error_rate=0.02, error_qs=2, beta_variance=1e-5, qs_bins=bins, add_pl=1)
+    args.rng_mode, args.beta_sampler = _abi.VGL_RNG_TILE, _abi.VGL_BETA_RAND48
+    sim = Simulator(args, 130, device=0, max_sites_per_tile=12)
+    info = sim.info()
+    sim.close()
+    assert info["sample_lean"] == lean, info
+    want, got = run_both(oracle, args, synth.binary_sites(0, 12, 130))
+    assert_parity(want, got, check_gp=False)
