@@ -337,7 +337,11 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
         // the pool holds `cap` items; a wavefront with more reads works through segments of equal length
         const int nseg = (total + cap - 1) / (cap > 0 ? cap : 1);
         const int seglen = nseg > 1 ? (total + nseg - 1) / nseg : cap;
-        for (int seg0 = 0; seg0 < total; seg0 += seglen) {              // normally one segment
+        // One segment is the rule (a pool holds 2240 items: depth 30).  For LEAN 3 the body is instantiated twice -- SINGLE: nothing of the
+        // owners' state (stream states, thresholds, alleles) lives across the pool loop, which is what the register allocator spilled (round 5)
+        auto run_segment = [&](auto single_tag, const int seg0) -> bool {     // true: a diagnostic phase ends the kernel here
+            constexpr bool SINGLE = decltype(single_tag)::value;
+            (void)SINGLE;
             const int segT = (total - seg0 < seglen) ? (total - seg0) : seglen;
             // -- owners: bases of their reads that fall into this segment
             if (DBG) c_tmp = clock64();
@@ -378,6 +382,36 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                             else { *(lds_u32o*)(uintptr_t)ka = sv; *(lds_u8o*)(uintptr_t)pa = (uint8_t)rb; sv += 16u; ka += 4u; pa += 1u; }
                         }
                         ad4 += (((uint64_t)(nrd - n1)) << (16 * (a0 & 3))) + (((uint64_t)n1) << (16 * (a1 & 3)));
+                    } else if constexpr (P16) {
+                        // LEAN 3, float32 build: the same counting with the strand draws (vcfgl.cpp:581-586: one more output of the base
+                        // stream per read, after the wrong-base draws) -- forward reads and forward second-haplotype picks counted, the
+                        // errors' corrections applied to both depth words
+                        uint32_t n1 = 0, nf = 0, nf1 = 0;
+                        const uint32_t nrd = (sv_end > sv) ? ((sv_end - sv) >> 2) : 0u;
+                        while (sv < sv_end) {
+                            uint32_t rb = (uint32_t)a0, h = 0;
+                            if (!HOMW) {
+                                st_hap16 = lcg_next16(st_hap16);
+                                h = (uint32_t)(st_hap16 >> 63);                         // u >= 0.5: the second allele (vcfgl.cpp:473)
+                                n1 += h;
+                                rb = h ? (uint32_t)a1 : (uint32_t)a0;
+                            }
+                            const uint32_t tb = rb;
+                            st_base16 = lcg_next16(st_base16);
+                            const bool err = st_base16 < err_thresh16;                    // vcfgl.cpp:486-488
+                            if (err) { do { st_base16 = lcg_next16(st_base16); rb = (uint32_t)(st_base16 >> 62); } while (rb == tb); }
+                            uint32_t f = 1u;
+                            if (k_strand) { st_base16 = lcg_next16(st_base16); f = (uint32_t)(~st_base16 >> 63); }   // forward: u < 0.5
+                            nf += f; nf1 += f & h;
+                            if (err) {
+                                const uint64_t d = (1ULL << (16 * rb)) - (1ULL << (16 * tb));
+                                ad4 += d;
+                                if (f) adf4 += d;
+                            }
+                            *(lds_u16o*)(uintptr_t)ka = (uint16_t)(sv | rb); sv += 4u; ka += 2u;
+                        }
+                        ad4 += (((uint64_t)(nrd - n1)) << (16 * (a0 & 3))) + (((uint64_t)n1) << (16 * (a1 & 3)));
+                        adf4 += (((uint64_t)(nf - nf1)) << (16 * (a0 & 3))) + (((uint64_t)nf1) << (16 * (a1 & 3)));
                     } else
                     while (sv < sv_end) {
                         bool fwd;
@@ -409,7 +443,7 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
             //    lanes in different stages of different reads share every instruction.  Real
             //    branches remain only around the rare bounded-log tests and the per-read epilogue.
             if (DBG) { const unsigned long long c = clock64(); c_owner += c - c_tmp; c_tmp = c; c_items += segT; }
-            if (DBG && P.dbg_phase == 2) return;
+            if (DBG && P.dbg_phase == 2) return true;
             {
                 // Items are dealt dynamically: a lane owns its current item k and an item kn claimed one
                 // item ahead (so that kn's operands are in flight while k is worked on); a lane that
@@ -723,7 +757,7 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
             if (DBG) { const unsigned long long c = clock64(); c_pool += c - c_tmp; c_tmp = c; }
-            if (DBG && P.dbg_phase == 3) return;
+            if (DBG && P.dbg_phase == 3) return true;
             if (!P16 && qfast && k_qsum) {                              // the pool loop is done with l_stq: zero the 64 x 4 sum words
                 l_stq[lane] = 0ULL;
                 ((uint64_t*)l_accB)[lane] = 0ULL;
@@ -920,8 +954,13 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
             }
             __builtin_amdgcn_wave_barrier();
             if (DBG) c_flush += clock64() - c_tmp;
-            if (DBG && P.dbg_phase == 4) return;
-        }
+            if (DBG && P.dbg_phase == 4) return true;
+            return false;
+        };
+        // (measured, same box: the two-instance form -3.6 % for LEAN 3 -- 10.25 -> 9.89 ms at qsi16 -- and +2.7 % for LEAN 2, whose single instance
+        //  at 64 VGPRs the allocator already serves best: profiles/r05_ab/ab_single.txt)
+        if (LEAN == 3 && nseg <= 1) { if (total > 0) { if (run_segment(std::true_type{}, 0)) return; } }
+        else for (int seg0 = 0; seg0 < total; seg0 += seglen) { if (run_segment(std::false_type{}, seg0)) return; }
     }
 
     if (active) {
