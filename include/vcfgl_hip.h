@@ -305,7 +305,7 @@ typedef struct vgl_ctx_info_t {
                                     fallbacks inline; 1 default tag surface; 2 = 1 with the fallbacks deferred to k_redo; 3 = 0 with the
                                     fallbacks deferred (optional tags: -addQS / -addI16 / strand tags / --adjust-qs)               */
     int32_t gl_sort;             /* k_gl re-deals a workgroup's evaluations in (distinct bases, depth) order                */
-    int32_t gl_wpb;              /* wavefronts per k_gl workgroup (4 or 8)                                                  */
+    int32_t gl_wpb;              /* natural wavefronts per k_gl workgroup (4 or 8; 16: k_gl2, two evaluations per thread)   */
     int32_t read_cap;            /* staged reads per (site, sample): a deeper draw is VGL_E_CAPACITY                        */
     int32_t pool_cap;            /* quality-score work items per wavefront and LDS segment (--error-qs 2)                   */
     int32_t pool_lds_bytes;      /* LDS bytes per wavefront of k_sample<2>                                                  */

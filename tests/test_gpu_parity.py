@@ -217,6 +217,31 @@ def test_gl2_one_base_run_table(oracle, kw, monkeypatch):
         assert np.array_equal(plain.numpy(f).view(np.uint32), got.numpy(f).view(np.uint32)), f
 
 
+@pytest.mark.parametrize("ovc", [0, 1, 40])
+@pytest.mark.parametrize("kw,N,n_sites", [(dict(depth=20.0, error_rate=0.01), 1000, 9), (dict(depth=20.0, error_rate=0.01), 1, 70), (dict(depth=14.0, error_rate=0.02), 63, 37),
+                                          (dict(depth=30.0, error_rate=0.01, error_qs=2, beta_variance=1e-5), 1027, 5), (dict(depth=20.0, error_rate=0.01, error_qs=2, beta_variance=1e-5), 2500, 3),
+                                          (dict(depth=60.0, error_rate=0.25), 300, 11), (dict(depth=150.0, error_rate=0.2, do_unobserved=0), 130, 6),
+                                          (dict(depth=26.0, error_rate=0.02, error_qs=1, beta_variance=1e-4), 257, 12), (dict(depth=12.0, error_rate=0.0), 640, 4)])
+def test_gl2_two_evaluations_per_thread(oracle, kw, N, n_sites, ovc, monkeypatch):
+    """k_gl2 (GL model 2, three-kernel path, planes layout): a workgroup of 512 threads takes 1024 evaluations, the accumulators lie in
+    a compact array (six full rows + nine rows of 128 columns for the three- / four-base evaluations at the head of the sorted order),
+    and a workgroup with more such evaluations than the upper rows hold is worked on again by k_gl's own body (k_gl2_scan, k_gl_redo).
+    Forced on (VGL_GL2X=1, hooks build) for one fixed score and per-read scores, N = 1 ... 2500 (workgroups spanning sites, ragged
+    ends), error rates that make most evaluations show three or four bases, sites without an absent allele; with the pool's limit at
+    its default, at 1 (nearly every workgroup goes through k_gl_redo) and at 40.  Equal to the oracle, every tag."""
+    args = VcfglArgs(seed=31, **kw, **ALLTAGS, **STRAND)
+    gt = synth.acgt_sites(n_sites, N, seed=N + n_sites, missing=0.03)
+    monkeypatch.setenv("VGL_GL2X", "1")
+    if ovc:
+        monkeypatch.setenv("VGL_DEBUG_GL2_OVC", str(ovc))
+    args.rng_mode, args.beta_sampler = _abi.VGL_RNG_TILE, _abi.VGL_BETA_RAND48
+    sim = Simulator(args, N, device=0, max_sites_per_tile=n_sites, hooks=True)
+    assert sim.info()["gl_wpb"] == 16, "k_gl2 is not what runs"
+    sim.close()
+    want, got = run_both(oracle, args, gt, site0=5, hooks=True)
+    assert_parity(want, got, i16=True)
+
+
 @pytest.mark.parametrize("N,n_sites", [(1, 40), (63, 17), (64, 16), (65, 15), (130, 1), (130, 33), (1000, 18), (1027, 5)])
 @pytest.mark.parametrize("eqs", [0, 2])
 def test_siteagg_sixteen_sites_per_wavefront(oracle, N, n_sites, eqs):

@@ -118,6 +118,7 @@ struct VglDevParams {
     int32_t xcd_map;         // k_gl: workgroup index -> XCD-contiguous logical index (VGL_XCD_MAP=0 turns it off; k_sample, which is
                              // bound by its arithmetic, measured 1-3 % slower with it and keeps the hardware order)
     int32_t dbg_depth_chunk; // test hook (VGL_DEPTH_CHUNK=1024 / 2048 / 4096): k_depth's chunk whatever the tile's size
+    int32_t dbg_gl2_ovc;     // test hook (VGL_DEBUG_GL2_OVC=n): a workgroup of k_gl2 with more than n three- / four-base evaluations goes to k_gl_redo (default: VGL_GL2_OVC)
     int32_t dbg_fuse_alone;  // test hook (VGL_DEBUG_FUSE_ALONE=mask): the parts in the mask count as neighbours that never arrive -- the other workgroups of the site do not wait for them and sample their depths themselves
     int32_t dbg_phase;       // diagnostic (VGL_DEBUG_PHASE=n): k_sample returns after phase n; 0 = off
     int32_t dbg_qs_exact;    // test hook (VGL_DEBUG_QS_EXACT=1): k_sample<2> treats every read as undecided in float32
@@ -159,6 +160,7 @@ struct VglDevParams {
     const double* gl1_bsum;            // [256][256]  sum_{i<c} fk[i]*beta[q][n][i]   (fixed qScore)
     const double* gl1_lhet;            // [256][256]
     const double* gl1_fkbeta;          // [60][gl1_nc][gl1_nc] fk[i] * beta[q][n][i] at [q - 4][n][i]  (per-read qScores only)
+    int32_t gl2x;                      // GL model 2, three-kernel path: k_gl2 (two evaluations per thread, compact accumulator rows) instead of k_gl
     int32_t gl1_nc;                    // min(255, read_cap) + 1: the table is compact in n and i, so that the part a run touches stays in L2
 };
 
@@ -187,6 +189,10 @@ struct VglTilePtrs {
     uint32_t* qsumsq;        // [n_sites][4][N]
     int32_t*  acc;           // [n_sites][16]
     VglSiteInfo* sinfo;      // [n_sites]
+    uint32_t* gl2_redo_list; // k_gl2_scan: the workgroups whose bit was set ...
+    uint32_t* gl2_redo_count;// ... and their number (zeroed before k_gl2)
+    uint32_t* gl2_redo;      // one bit per workgroup of k_gl2 (1024 evaluations), zero between tiles: the workgroup could not keep its accumulators
+    uint64_t* rowmap8;       // [n_sites][16][2] the same table as byte codes of k_gl2's compact accumulator rows (null: k_gl2 is not used)
     uint64_t* rowmap;        // [n_sites][16] GL model 2: for every set of bases an evaluation may show (4 bits), the accumulator row of each of
                              // the site's genotypes, 4 bits per genotype in bcf_alleles2gt order (k_site writes it, k_gl's epilogue reads one entry per lane)
     uint32_t* errflag;

@@ -119,6 +119,18 @@ __device__ __forceinline__ void site_outputs(const VglDevParams& P, const VglTil
         }
 }
 
+// k_gl2's compact accumulator array (below): the rows an evaluation leaves depend on how many bases its reads show -- 3 / 6 / 10 / 15 for
+// 1 .. 4 -- so the rows are kept in THAT order (physical row: 0, 10, 14 | 1, 2, 11 | 3, 4, 5, 12 | 6, 7, 8, 9, 13 of k_gl's numbering):
+// the first six, which all but a few per cent of the evaluations stop at, as full rows of the workgroup's 1024 columns (4096 bytes each),
+// the other nine as rows of VGL_GL2_OVC columns (512 bytes each) for the evaluations at the head of the sorted order, which are the ones
+// with three or four bases.  Code of a row = its offset in units of 512 bytes: 8 phys for the first six, 42 + phys for the rest.
+#define VGL_GL2_OVC 128
+__device__ __forceinline__ constexpr int gl2_row_phys(const int row) {
+    constexpr int ph[15] = {0, 3, 4, 6, 7, 8, 10, 11, 12, 13, 1, 5, 9, 14, 2};
+    return ph[row];
+}
+__device__ __forceinline__ constexpr int gl2_row_code(const int row) { return gl2_row_phys(row) < 6 ? 8 * gl2_row_phys(row) : 42 + gl2_row_phys(row); }
+
 // one lane per site.  With the row table of k_gl (T.rowmap, GL model 2) SIXTEEN lanes per site: all work out the site (a few hundred
 // instructions), lane `pm` writes table entry `pm`, lane 0 everything else
 __global__ __launch_bounds__(256) void k_site(const VglDevParams P, const VglTilePtrs T) {
@@ -130,7 +142,17 @@ __global__ __launch_bounds__(256) void k_site(const VglDevParams P, const VglTil
     const int ad[4] = {acc[1], acc[2], acc[3], acc[4]};
     const VglSiteOrder o = site_order(P, acc[0], ad);
     if (T.rowmap) {
-        T.rowmap[(size_t)ls * 16 + pm] = site_rowmap_entry(P.A, o.a2b, pm);
+        const uint64_t e = site_rowmap_entry(P.A, o.a2b, pm);
+        T.rowmap[(size_t)ls * 16 + pm] = e;
+        if (T.rowmap8) {                                               // k_gl2: the same entry as LDS offsets of its compact accumulator array, one byte per genotype
+            uint64_t lo = 0, hi = 0;
+#pragma unroll
+            for (int g = 0; g < 15; ++g) {
+                const uint64_t c = (uint64_t)gl2_row_code((int)((e >> (4 * g)) & 15u));
+                if (g < 8) lo |= c << (8 * g); else hi |= c << (8 * (g - 8));
+            }
+            T.rowmap8[((size_t)ls * 16 + pm) * 2] = lo; T.rowmap8[((size_t)ls * 16 + pm) * 2 + 1] = hi;
+        }
         if (pm != 0) return;
     }
     T.sinfo[ls] = site_info_of(o);
@@ -249,8 +271,9 @@ __device__ __forceinline__ uint64_t fused_sample_eval(const VglDevParams& P, con
 // (several contexts sharing the GPU) waiting longer than the recomputation costs only holds a CU slot -- so the bound is about that cost
 #define VGL_FUSED_SPIN_LIMIT 2048
 
+// (the kernel's body: hw_block = the hardware workgroup index of a grid of hw_grid, or -- hw_grid 0 -- the logical index itself: k_gl_redo)
 template <int A, int GLM, bool PREC, int WPB, int FUSEDW = 0>
-__global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const VglTilePtrs T) {
+__device__ __forceinline__ void k_gl_body(const VglDevParams& P, const VglTilePtrs& T, const uint32_t hw_block, const uint32_t hw_grid) {
     constexpr bool FUSED = FUSEDW != 0;
     static_assert(!FUSED || (GLM == 2 && !PREC), "the fused build exists for GL model 2 with the score table");
     static_assert(FUSEDW == 0 || FUSEDW == 4 || FUSEDW == 8, "staged words per evaluation of the fused build");
@@ -294,7 +317,7 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
     // logical workgroup: XCD-contiguous (xcd_block) -- except for the fused build with one workgroup per site, whose workgroups share
     // nothing: there the dispatch order measured 1 % faster (C5 k_gl 1.062 / 1.068 against 1.073 / 1.081 ms; the three-kernel k_gl loses
     // 4 % without the mapping)
-    const uint32_t bx = (P.xcd_map && !(FUSED && P.fused_split == 1)) ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    const uint32_t bx = (hw_grid != 0u && P.xcd_map && !(FUSED && P.fused_split == 1)) ? xcd_block(hw_block, hw_grid) : hw_block;
     uint64_t f_a = 0;                                                   // FUSED: this thread's per-base depths
     // wave k of this workgroup is wave 4 bx + k of the tile = (site, 64-sample chunk).  One scalar division per workgroup; a lane
     // then finds the site of ANY of the four waves with three compares (a per-lane 64-bit division was 60+ vector instructions,
@@ -974,6 +997,334 @@ __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const Vgl
 #undef VGL_PUT
 #undef VGL_ROWS
 }
+template <int A, int GLM, bool PREC, int WPB, int FUSEDW = 0>
+__global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const VglTilePtrs T) {
+    k_gl_body<A, GLM, PREC, WPB, FUSEDW>(P, T, blockIdx.x, gridDim.x);
+}
+// k_gl2's workgroups that could not keep their accumulators (their bit in T.gl2_redo): k_gl2_scan lists them, k_gl_redo runs k_gl's body on
+// the two 512-evaluation halves of each listed workgroup -- every tag of those evaluations is written again
+__global__ __launch_bounds__(256) void k_gl2_scan(const VglTilePtrs T, const uint32_t n_words) {
+    for (uint32_t w = threadIdx.x; w < n_words; w += 256u) {
+        uint32_t bits = T.gl2_redo[w];
+        if (bits) {
+            T.gl2_redo[w] = 0u;
+            while (bits) {
+                const uint32_t b = (uint32_t)__builtin_ctz(bits);
+                T.gl2_redo_list[atomicAdd(T.gl2_redo_count, 1u)] = 32u * w + b;
+                bits &= bits - 1u;
+            }
+        }
+    }
+}
+template <int A>
+__global__ __launch_bounds__(512) void k_gl_redo(const VglDevParams P, const VglTilePtrs T) {
+    const uint32_t n = *T.gl2_redo_count;
+    for (uint32_t li = blockIdx.x; li < 2u * n; li += gridDim.x) {
+        k_gl_body<A, 2, false, 8, 0>(P, T, 2u * T.gl2_redo_list[li >> 1] + (li & 1u), 0u);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_gl2 (round 5, second session): GL model 2 of the three-kernel path with TWO evaluations per thread.  k_gl is latency-bound in the
+// workgroups a CU holds (1.24 + 3.98 / n ms at fixed-q, n = 4: docs/tried.md), and a CU's 2048 thread slots and its LDS both stop at 2048
+// evaluations in flight.  Here a workgroup of 512 threads takes 1024 evaluations (sixteen natural wavefronts: thread t the positions t and
+// t + 512) -- one counting sort over all of them; thread t works on sorted position q = (t + rotation) mod 512 of the heavy half and on
+// 1023 - q of the light half, so that every wavefront has loop work -- and the accumulators lie in the compact array described at
+// gl2_row_code(): 6 full rows + 9 rows of VGL_GL2_OVC columns = 29 KB for 1024 evaluations (k_gl: 30 KB for 512).  Column = the
+// evaluation's sorted position (the natural thread knows it from its insertion).  A workgroup with more than VGL_GL2_OVC three- or
+// four-base evaluations cannot keep their upper rows: it sets its bit in T.gl2_redo and k_gl (REDO instantiation) works on it again.
+// Planes layout, no --precise-gl 1, sort on: everything else stays with k_gl.
+template <int A>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_gl2(const VglDevParams P, const VglTilePtrs T) {
+    constexpr int WPB = 8, WG = 512, WGE = 1024, NW = 16;               // threads, evaluations, natural wavefronts per workgroup
+    constexpr int QL = 96;
+    constexpr int NG = A * (A + 1) / 2;
+    constexpr int OVC = VGL_GL2_OVC;
+    struct Lds {
+        double q2gl[3 * QL];
+        uint32_t x[6 * WGE + 9 * OVC];
+        uint16_t perm[WGE];
+        int32_t ws[2 * NW];
+        int32_t n3p;
+    };
+    __shared__ Lds s_lds;
+    double* const s_q2gl = s_lds.q2gl;
+    uint32_t* const s_x = s_lds.x;
+    uint16_t* const s_perm = s_lds.perm;
+    int32_t* const s_ws = s_lds.ws;
+    uint32_t* const s_hist = s_x;
+    const int N = P.n_samples;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (P.error_qs == 2) for (int i = tid; i < 3 * QL; i += WG) s_q2gl[i] = P.q2gl[(i / QL) * 257 + (i % QL)];
+    const uint32_t chunks_k = (uint32_t)P.chunks;
+    const uint32_t nwaves = (uint32_t)T.n_sites * chunks_k;
+    const uint32_t bx = P.xcd_map ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    const uint32_t wg_ls = (bx * (uint32_t)NW) / chunks_k, wg_rem = (bx * (uint32_t)NW) - wg_ls * chunks_k;
+    auto wave_site = [&](const int k, int& ls_, int& s_base) {
+        const int t = (int)wg_rem + k, c = (int)chunks_k;
+        int add = 0;
+#pragma unroll
+        for (int j = 1; j < NW; ++j) add += (t >= j * c) ? 1 : 0;
+        ls_ = (int)wg_ls + add;
+        s_base = (t - add * c) * 64;
+    };
+    constexpr int NK = 4;
+    const int sort_sh = P.read_cap > 511 ? 2 : (P.read_cap > 255 ? 1 : 0);
+    const int nbd = (P.read_cap >> sort_sh) + 1;
+    const int nb = NK * nbd + 2;
+    for (int i = tid; i < nb; i += WG) s_hist[i] = 0;
+    // ---- the two evaluations at this thread's natural positions
+    int ls0[2] = {0, 0}, sb0[2] = {0, 0}, s0[2] = {N, N}, dp0[2] = {-1, -1}, key[2];
+    uint64_t a[2] = {0, 0}, rm_lo[2] = {0, 0}, rm_hi[2] = {0, 0};
+    bool wave_ok[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int wn = wv + WPB * h;                                   // natural wavefront of the workgroup
+        const uint32_t w = bx * (uint32_t)NW + (uint32_t)wn;
+        wave_ok[h] = w < nwaves;
+        int k0 = 1;
+        if (wave_ok[h]) {
+            wave_site(wn, ls0[h], sb0[h]);
+            ls0[h] = __builtin_amdgcn_readfirstlane(ls0[h]); sb0[h] = __builtin_amdgcn_readfirstlane(sb0[h]);
+            if (lane == 0) { s_ws[2 * wn] = ls0[h]; s_ws[2 * wn + 1] = sb0[h]; }
+            s0[h] = sb0[h] + lane;
+            if (s0[h] < N) {
+                a[h] = T.ad4[(size_t)ls0[h] * N + (size_t)sb0[h] + (size_t)lane];
+                dp0[h] = (int)((a[h] & 0xFFFF) + ((a[h] >> 16) & 0xFFFF) + ((a[h] >> 32) & 0xFFFF) + ((a[h] >> 48) & 0xFFFF));
+                if (dp0[h] > 1023) dp0[h] = 1023;
+                const uint32_t q0 = (a[h] & 0xFFFFULL) != 0, q1 = ((a[h] >> 16) & 0xFFFF) != 0, q2 = ((a[h] >> 32) & 0xFFFF) != 0, q3 = (a[h] >> 48) != 0;
+                k0 = (int)(q0 + q1 + q2 + q3);
+                const uint64_t* const e = T.rowmap8 + ((size_t)ls0[h] * 16 + (q0 | (q1 << 1) | (q2 << 2) | (q3 << 3))) * 2;
+                rm_lo[h] = e[0]; rm_hi[h] = e[1];                       // (in flight during the loops)
+            }
+        }
+        int kk = nb - 1;
+        if (dp0[h] == 0) kk = nb - 2;
+        else if (dp0[h] > 0) {
+            const int dq = (dp0[h] > P.read_cap ? P.read_cap : dp0[h]) >> sort_sh;
+            kk = (NK - k0) * nbd + ((k0 == 2 && P.gl_flip2) ? dq : nbd - 1 - dq);
+        }
+        key[h] = kk;
+    }
+    __syncthreads();
+    atomicAdd(&s_hist[key[0]], 1u);
+    atomicAdd(&s_hist[key[1]], 1u);
+    __syncthreads();
+    if (tid < 64) {
+        uint32_t run = 0;
+        for (int base = 0; base < nb; base += 64) {
+            const int i = base + tid;
+            const uint32_t v = (i < nb) ? s_hist[i] : 0u;
+            const uint32_t incl = wave_incl_scan_u32(v);
+            if (i < nb) s_hist[i] = run + incl - v;
+            run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        if (tid == 0) s_lds.n3p = (int32_t)s_hist[2 * nbd];            // evaluations with three or four bases: the head of the sorted order
+    }
+    __syncthreads();
+    uint32_t pos[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { pos[h] = atomicAdd(&s_hist[key[h]], 1u); s_perm[pos[h]] = (uint16_t)(tid + WG * h); }
+    __syncthreads();
+    const int n3p = s_lds.n3p;
+    if (n3p > (P.dbg_gl2_ovc > 0 ? P.dbg_gl2_ovc : OVC) && tid == 0) atomicOr(&T.gl2_redo[bx >> 5], 1u << (bx & 31u));     // (rare: k_gl_redo takes the workgroup's evaluations again)
+    const size_t plane = (size_t)T.n_sites * N;
+    const float MISS = f32_missing();
+    // ---- the two evaluations this thread works on: sorted position q of the heavy half, 1023 - q of the light half
+    const int rot_q = (tid + 64 * (int)(bx & (WPB - 1))) & (WG - 1);
+    // (asking for both evaluations' records ahead of the first loop, in either order, measured slower: the loops then spill)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int q = h ? (WGE - 1 - rot_q) : rot_q;                     // its column of the compact array
+        const int oe = s_perm[q];                                        // natural position (0 .. 1023) of the evaluation
+        const uint32_t w = bx * (uint32_t)NW + (uint32_t)(oe >> 6);
+        int ls = 0, s = N;
+        if (w < nwaves) { ls = s_ws[2 * (oe >> 6)]; s = s_ws[2 * (oe >> 6) + 1] + (oe & 63); }
+        const bool live = s < N;
+        if (!live) { ls = 0; s = 0; }
+        const size_t ev = (size_t)ls * N + s;
+        const VglSiteInfo si = T.sinfo[ls];
+        const uint64_t ad4 = T.ad4[ev];
+        const int nA = si.n_alleles;
+        const bool have = (si.status == SITE_OK);
+        const int dp = (have && live) ? (int)((ad4 & 0xFFFF) + ((ad4 >> 16) & 0xFFFF) + ((ad4 >> 32) & 0xFFFF) + ((ad4 >> 48) & 0xFFFF)) : 0;
+        if (dp > 0) {
+            const bool per_read = (P.error_qs == 2);
+            const uint32_t p0 = (ad4 & 0xFFFFULL) != 0, p1 = ((ad4 >> 16) & 0xFFFF) != 0, p2 = ((ad4 >> 32) & 0xFFFF) != 0, p3 = (ad4 >> 48) != 0;
+            const int k_pres = (int)(p0 + p1 + p2 + p3);
+            const uint32_t cmap = (p0 << 2) | ((p0 + p1) << 4) | ((p0 + p1 + p2) << 6);
+            const bool has_abs = nA > k_pres;
+            const int K = 1 + (__ballot(k_pres >= 2) != 0) + (__ballot(k_pres >= 3) != 0) + (__ballot(k_pres >= 4) != 0);
+            const bool ov_ok = q < OVC;                                  // (the upper rows of a three- / four-base evaluation)
+            uint32_t* const col = s_x + q;
+            // row r of k_gl's numbering -> this array (gl2_row_code): full rows of 4096 bytes, then rows of 512
+            auto put = [&](const int row, const float v, const int kmin) {
+                const int ph = gl2_row_phys(row);
+                if (k_pres >= kmin) {
+                    if (ph < 6) col[ph * WGE] = __float_as_uint(v);
+                    else if (ov_ok) col[6 * WGE + (ph - 6) * OVC] = __float_as_uint(v);
+                }
+            };
+            auto read_loop = [&](auto k_tag, auto full_tag) {
+                constexpr int KK = decltype(k_tag)::value;
+                constexpr bool FULL = decltype(full_tag)::value;
+                constexpr int NT = (KK + 1) * (KK + 2) / 2;
+                float tr[NT];
+#pragma unroll
+                for (int i = 0; i < NT; ++i) tr[i] = -0.0f;
+                double homT = P.pre_homT, het = P.pre_het, homF = P.pre_homF;
+                const uint32_t* colw = (const uint32_t*)T.reads + ev;
+                const int lastw = (dp - 1) >> 2;
+                uint32_t w0 = colw[0], w1 = colw[(size_t)(1 < lastw ? 1 : lastw) * plane], w2 = colw[(size_t)(2 < lastw ? 2 : lastw) * plane];
+                auto one_read = [&](const uint32_t rb) {
+                    const int ci = (int)((cmap >> ((rb & 3) * 2)) & 3);
+                    if (per_read) {
+                        const int qv = (int)(rb >> 2);
+                        if (__builtin_expect(qv < QL, 1)) { homT = s_q2gl[qv]; het = s_q2gl[QL + qv]; homF = s_q2gl[2 * QL + qv]; }
+                        else { homT = P.q2gl[qv]; het = P.q2gl[257 + qv]; homF = P.q2gl[514 + qv]; }
+                    }
+                    float mx = -INFINITY;
+                    auto step = [&](float& ac, const double t, const bool valid) {
+                        const float v = (float)((double)ac + t);
+                        ac = v;
+                        if (FULL) mx = __builtin_fmaxf(mx, v);
+                        else if (valid) mx = (v > mx) ? v : mx;
+                    };
+#pragma unroll
+                    for (int b = 0; b <= KK; ++b) {
+#pragma unroll
+                        for (int a_ = 0; a_ <= b; ++a_) {
+                            double t;
+                            if (b == KK) t = (a_ == KK) ? homF : ((KK == 1 || ci == a_) ? het : homF);
+                            else if (a_ == b) t = (KK == 1 || ci == a_) ? homT : homF;
+                            else t = (KK == 2 || ci == a_ || ci == b) ? het : homF;
+                            step(tr[b * (b + 1) / 2 + a_], t, b < k_pres || has_abs);
+                        }
+                    }
+                    {
+                        const v2f m2 = {mx, mx};
+#pragma unroll
+                        for (int i = 0; i + 1 < NT; i += 2) {
+                            v2f t2 = {tr[i], tr[i + 1]};
+                            t2 = t2 - m2;
+                            tr[i] = t2.x; tr[i + 1] = t2.y;
+                        }
+                        if (NT & 1) tr[NT - 1] -= mx;
+                    }
+                };
+                for (int r0 = 0; r0 < dp; r0 += 4) {
+                    const uint32_t cur = w0;
+                    w0 = w1; w1 = w2;
+                    const int nw = (r0 >> 2) + 3;
+                    w2 = colw[(size_t)(nw < lastw ? nw : lastw) * plane];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (r0 + j < dp) one_read((cur >> (8 * j)) & 0xFFu);
+                }
+                // deposit: the rows this evaluation's own set of bases reaches (the natural thread reads no others)
+#pragma unroll
+                for (int b = 0; b <= KK; ++b) {
+#pragma unroll
+                    for (int a_ = 0; a_ <= b; ++a_) {
+                        const int row = (b < KK) ? b * (b + 1) / 2 + a_ : (a_ < KK ? 10 + a_ : 14);
+                        const int kmin = (b < KK) ? b + 1 : (a_ < KK ? a_ + 1 : 1);     // the evaluation has this row iff it shows at least kmin bases
+                        put(row, tr[b * (b + 1) / 2 + a_], kmin);
+                    }
+                }
+            };
+            const bool all_full = __ballot(!has_abs) == 0;
+            if (K == 1 && !per_read && P.gl2_run != nullptr) {
+                const float* const rw = P.gl2_run + ((size_t)(has_abs ? 0 : (P.read_cap + 1)) + (size_t)(dp < P.read_cap ? dp : P.read_cap)) * 3;
+                const float t0 = rw[0], t1 = rw[1], t2 = rw[2];
+                put(0, t0, 1); put(10, t1, 1); put(14, t2, 1);
+            } else if (all_full) {
+                if (K == 1) read_loop(std::integral_constant<int, 1>{}, std::true_type{});
+                else if (K == 2) read_loop(std::integral_constant<int, 2>{}, std::true_type{});
+                else if (K == 3) read_loop(std::integral_constant<int, 3>{}, std::true_type{});
+                else read_loop(std::integral_constant<int, 4>{}, std::true_type{});
+            } else {
+                if (K == 1) read_loop(std::integral_constant<int, 1>{}, std::false_type{});
+                else if (K == 2) read_loop(std::integral_constant<int, 2>{}, std::false_type{});
+                else if (K == 3) read_loop(std::integral_constant<int, 3>{}, std::false_type{});
+                else read_loop(std::integral_constant<int, 4>{}, std::false_type{});
+            }
+        }
+    }
+    __syncthreads();
+    // ---- tags of the two evaluations at this thread's natural positions (k_gl's epilogue, planes layout)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        VglSiteInfo si_n;
+        {
+            const VglSiteInfo si_nv = T.sinfo[ls0[h]];
+            si_n.status = __builtin_amdgcn_readfirstlane(si_nv.status); si_n.n_alleles = __builtin_amdgcn_readfirstlane(si_nv.n_alleles);
+            si_n.alleles2acgt = (uint32_t)__builtin_amdgcn_readfirstlane((int)si_nv.alleles2acgt); si_n.acgt2alleles = 0;
+        }
+        const bool live0 = wave_ok[h] && (s0[h] < N);
+        const int nA0 = si_n.n_alleles, nG0 = nA0 * (nA0 + 1) / 2;
+        const bool have0 = (si_n.status == SITE_OK);
+        const int dpn = (int)((a[h] & 0xFFFF) + ((a[h] >> 16) & 0xFFFF) + ((a[h] >> 32) & 0xFFFF) + ((a[h] >> 48) & 0xFFFF));
+        const bool sample_ok = have0 && live0 && dpn > 0;
+        float acc[NG];
+#pragma unroll
+        for (int i = 0; i < NG; ++i) acc[i] = MISS;
+        if (sample_ok) {
+            const uint8_t* const colb = (const uint8_t*)(s_x + pos[h]);
+#pragma unroll
+            for (int idx = 0; idx < NG; ++idx) {
+                const uint32_t c = (uint32_t)(((idx < 8 ? rm_lo[h] : rm_hi[h]) >> (8 * (idx & 7))) & 0xFFu);
+                acc[idx] = __uint_as_float(*(const uint32_t*)(colb + 512u * c));
+            }
+        }
+        const uint32_t nG0u = (uint32_t)__builtin_amdgcn_readfirstlane(nG0), nA0u = (uint32_t)__builtin_amdgcn_readfirstlane(nA0);
+        const int lsh = ls0[h], sbh = sb0[h];
+#define VGL2_ROWS(BASE_, KMAX, EXPR)                                                                     \
+    do {                                                                                                 \
+        vgl_gu32* rp_ = (vgl_gu32*)((BASE_) + ((size_t)lsh * (KMAX)) * N + (size_t)sbh);                 \
+        _Pragma("unroll") for (int i = 0; i < (KMAX); ++i) {                                             \
+            asm volatile("" : "+s"(rp_));                                                                \
+            rp_[(uint32_t)lane] = (EXPR);                                                                \
+            rp_ += N;                                                                                    \
+        }                                                                                                \
+    } while (0)
+#define VGL2_PUT(BASE, KMAX, EXPR) do { uint32_t* const base_ = (uint32_t*)(BASE); if (base_ && live0) VGL2_ROWS(base_, KMAX, EXPR); } while (0)
+        if (T.gl && nG0u == (uint32_t)NG) { if (live0) VGL2_ROWS((uint32_t*)T.gl, NG, __float_as_uint(acc[i])); }
+        else VGL2_PUT(T.gl, NG, __float_as_uint((sample_ok && i < nG0) ? acc[i] : MISS));
+        VGL2_PUT(T.pl, NG, pl_of(acc[i], sample_ok && i < nG0));
+        if (T.pl_u8 && live0) {
+            typedef __attribute__((address_space(1))) uint8_t gu8;
+            gu8* rp = (gu8*)(T.pl_u8 + ((size_t)lsh * NG) * N + (size_t)sbh);
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                const uint32_t v = pl_of(acc[i], sample_ok && i < nG0);
+                asm volatile("" : "+s"(rp));
+                rp[(uint32_t)lane] = (uint8_t)(v > 255u ? 255u : v);
+                rp += N;
+            }
+        }
+        if (T.gp) {
+            float sum_gps = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                const bool valid = sample_ok && i < nG0;
+                acc[i] = valid ? (float)exp10_nonpos((double)acc[i]) : 0.0f;
+                if (valid) sum_gps += acc[i];
+            }
+            VGL2_PUT(T.gp, NG, __float_as_uint((sample_ok && i < nG0) ? acc[i] / sum_gps : MISS));
+        }
+        if (T.fmt_ad || T.fmt_adf || T.fmt_adr) {
+            const uint64_t adf4 = (P.need_adf && live0) ? T.adf4[(size_t)lsh * N + (size_t)sbh + (size_t)lane] : a[h];
+            VGL2_PUT(T.fmt_ad, A, (uint32_t)cnt_of(a[h], (have0 && i < nA0) ? nib(si_n.alleles2acgt, i) : 0xF));
+            VGL2_PUT(T.fmt_adf, A, (uint32_t)cnt_of(adf4, (have0 && i < nA0) ? nib(si_n.alleles2acgt, i) : 0xF));
+            VGL2_PUT(T.fmt_adr, A, (uint32_t)(cnt_of(a[h], (have0 && i < nA0) ? nib(si_n.alleles2acgt, i) : 0xF) - cnt_of(adf4, (have0 && i < nA0) ? nib(si_n.alleles2acgt, i) : 0xF)));
+        }
+        (void)nA0u;
+#undef VGL2_PUT
+#undef VGL2_ROWS
+    }
+}
 
 // ------------------------------------------------------------------------------------
 // INFO/QS and INFO/I16 (vcfgl.cpp:845-898, 982-1074): float32 sums over a site's samples IN SAMPLE ORDER, which a tree reduction would not
@@ -1225,6 +1576,18 @@ extern "C" int vgl_launch_gl(const VglDevParams* p, const VglTilePtrs* t, void* 
     // at C3 / fixed-q / C4: 4 -> 8 wavefronts -7 / -6 / -10 % of the kernel's time, 16 is slower again; equal at depth 5)
     // (GL model 1 with per-read scores, round 4: 8 wavefronts per workgroup measured 5.80 against 5.29 ms per C3-shaped launch -- its per-lane
     //  histograms take 4 KB of LDS per wavefront either way and the larger workgroup only adds barrier waiting; it keeps 4)
+    if (p->gl2x) {
+        if (p->gl_model != 2 || p->precise_gl || !p->gl_sort || p->out_layout != 0 || !t->rowmap8 || !t->gl2_redo || !t->gl2_redo_list || !t->gl2_redo_count) return (int)hipErrorInvalidValue;
+        const unsigned blocks2 = (unsigned)((waves + 15) / 16);
+        hipStream_t s2 = (hipStream_t)stream;
+        if (hipMemsetAsync(t->gl2_redo_count, 0, sizeof(uint32_t), s2) != hipSuccess) return (int)hipGetLastError();
+        if (p->A == 5) hipLaunchKernelGGL((k_gl2<5>), dim3(blocks2), dim3(512), 0, s2, *p, *t);
+        else hipLaunchKernelGGL((k_gl2<4>), dim3(blocks2), dim3(512), 0, s2, *p, *t);
+        hipLaunchKernelGGL(k_gl2_scan, dim3(1), dim3(256), 0, s2, *t, (blocks2 + 31u) / 32u);
+        if (p->A == 5) hipLaunchKernelGGL((k_gl_redo<5>), dim3(1024), dim3(512), 0, s2, *p, *t);
+        else hipLaunchKernelGGL((k_gl_redo<4>), dim3(1024), dim3(512), 0, s2, *p, *t);
+        return (int)hipGetLastError();
+    }
     const int wpb = (p->gl_model == 2 && p->gl_wpb == 8) ? 8 : 4;
     const unsigned blocks = (unsigned)((waves + wpb - 1) / wpb);
     const size_t lds = 0;

@@ -188,7 +188,7 @@ struct vgl_ctx {
     double* d_q2gl = nullptr; double* d_gamma_ln = nullptr; double* d_gl1_fk = nullptr; double* d_gl1_beta = nullptr; double* d_gl1_bsum = nullptr; double* d_gl1_lhet = nullptr;
     // workspace
     uint8_t* d_reads = nullptr; double* d_errp = nullptr; uint64_t* d_ad4 = nullptr; uint64_t* d_adf4 = nullptr;
-    uint32_t* d_qsum = nullptr; uint32_t* d_qsumsq = nullptr; int32_t* d_acc = nullptr; VglSiteInfo* d_sinfo = nullptr; uint64_t* d_rowmap = nullptr;
+    uint32_t* d_qsum = nullptr; uint32_t* d_qsumsq = nullptr; int32_t* d_acc = nullptr; VglSiteInfo* d_sinfo = nullptr; uint64_t* d_rowmap = nullptr; uint64_t* d_rowmap8 = nullptr; uint32_t* d_gl2_redo = nullptr; uint32_t* d_gl2_list = nullptr; uint32_t* d_gl2_count = nullptr; size_t gl2_redo_words = 0;
     uint32_t* d_errflag = nullptr;
     unsigned long long* d_redo_list = nullptr; uint32_t* d_redo_count = nullptr; uint32_t redo_cap = 0; uint32_t* d_redo_bits = nullptr;   // k_sample<2, deferred> -> k_redo
     // beta chain of VGL_RNG_SERIAL with --error-qs 2 and the std beta sampler (vgl_betachain.hip); grow-only buffers
@@ -325,7 +325,7 @@ extern "C" int vgl_ctx_destroy(vgl_ctx* c) {
     if (!c) return VGL_OK;
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_fslot, c->d_gl2_run, c->d_pois_zt, c->d_gl1_fk, c->d_gl1_beta, c->d_gamma_ln, c->d_samp_tab, c->d_qs_read_tab, c->d_pois, c->d_q2gl, c->d_gl1_bsum, c->d_gl1_lhet, c->d_reads, c->d_errp, c->d_ad4,
-                    c->d_adf4, c->d_qsum, c->d_qsumsq, c->d_acc, c->d_sinfo, c->d_rowmap, c->d_errflag, c->d_dbg, c->d_redo_list, c->d_redo_count, c->d_redo_bits,
+                    c->d_adf4, c->d_qsum, c->d_qsumsq, c->d_acc, c->d_sinfo, c->d_rowmap, c->d_rowmap8, c->d_gl2_redo, c->d_gl2_list, c->d_gl2_count, c->d_errflag, c->d_dbg, c->d_redo_list, c->d_redo_count, c->d_redo_bits,
                     c->d_serial, c->d_sst, c->d_site_thresh, c->d_scout_dp, c->d_site_tail, c->d_sdp, c->d_step_tab,
                     c->d_depth_tab, c->d_site_base, c->d_site_hash, c->d_dp_pre, c->d_hts_off, c->d_hts_base, c->d_roff, c->d_rtotal, c->d_errp_lin, c->d_cw, c->d_ccons, c->d_cexit,
                     c->d_ccnt, c->d_centry, c->d_cbase, c->d_cpos, c->d_csnap, c->d_csnapw, c->d_cctl};
@@ -664,6 +664,26 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     TRY(dmalloc(&c->d_acc, (size_t)max_sites * VGL_ACC_STRIDE));
     TRY(dmalloc(&c->d_sinfo, (size_t)max_sites));
     if (p->gl_model == 2) TRY(dmalloc(&c->d_rowmap, (size_t)max_sites * 16));
+    {
+        // GL model 2, three-kernel path: k_gl2 (two evaluations per thread: vgl_gl.hip) where it measured faster than k_gl -- one fixed score
+        // (the light half of its sorted order is table lookups: fixed-q k_gl 2.24 -> 1.91 ms per 65536 x 1000 tile) and per-read scores
+        // from depth 25 (depth 30: 6.27 -> 5.78; depth 20: 2.44 -> 2.49, where it is not used).  Planes layout, sort on, no --precise-gl 1
+        double dsum = 0.0;
+        for (int i = 0; i < N; i++) dsum += p->depths ? p->depths[i] : p->depth;
+        const bool can = p->gl_model == 2 && !p->precise_gl && D.gl_sort != 0 && D.gl_wpb == 8 && p->out_layout == VGL_LAYOUT_PLANES && !D.fused;
+        const bool want = (p->error_qs != 2) || (dsum / (double)N >= 25.0);
+        D.gl2x = (can && hook_int("VGL_GL2X", want ? 1 : 0)) ? 1 : 0;
+        D.dbg_gl2_ovc = hook_int("VGL_DEBUG_GL2_OVC", 0);
+    }
+    if (D.gl2x) {
+        const size_t wg2 = (size_t)max_sites * D.chunks / 16 + 1;
+        TRY(dmalloc(&c->d_rowmap8, (size_t)max_sites * 32));
+        c->gl2_redo_words = (wg2 + 31) / 32;
+        TRY(dmalloc(&c->d_gl2_redo, c->gl2_redo_words));
+        TRYHIP(hipMemset(c->d_gl2_redo, 0, c->gl2_redo_words * sizeof(uint32_t)));
+        TRY(dmalloc(&c->d_gl2_list, c->gl2_redo_words * 32));
+        TRY(dmalloc(&c->d_gl2_count, (size_t)1));
+    }
     TRY(dmalloc(&c->d_errflag, (size_t)1));
     if (D.fused && D.fused_split > 1) TRY(dmalloc(&c->d_fslot, (size_t)max_sites * D.fused_split * 2));
     if (D.defer_ok) {
@@ -729,7 +749,7 @@ extern "C" int vgl_ctx_info(const vgl_ctx* c, vgl_ctx_info_t* out) {
     r.depth_mode = D.serial ? VGL_DEPTH_SERIAL_SCOUT : D.depth_pre;
     r.fused = D.fused; r.fused_split = D.fused ? (D.fused_split > 0 ? D.fused_split : 1) : 0;
     r.sample_lean = D.serial ? 0 : (D.lean_ok ? ((D.error_qs == 2 && D.defer_ok) ? 2 : 1) : ((D.error_qs == 2 && D.defer_ok) ? 3 : 0));
-    r.gl_sort = D.gl_sort; r.gl_wpb = (D.gl_model == 2 && D.gl_wpb == 8) ? 8 : 4;
+    r.gl_sort = D.gl_sort; r.gl_wpb = D.gl2x ? 16 : ((D.gl_model == 2 && D.gl_wpb == 8) ? 8 : 4);   // 16: k_gl2 (sixteen natural wavefronts, two evaluations per thread)
     r.read_cap = D.read_cap; r.pool_cap = D.error_qs == 2 ? D.pool_cap : 0; r.pool_lds_bytes = D.error_qs == 2 ? D.pool_lds_bytes : 0;
 #ifdef VGL_TEST_HOOKS
     r.test_hooks = 1;
@@ -815,7 +835,7 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     memset(&T, 0, sizeof T);
     T.site0 = site0; T.n_sites = n_sites; T.gt = gt;
     T.reads = c->d_reads; T.errp = c->d_errp; T.ad4 = c->d_ad4; T.adf4 = c->d_adf4; T.qsum = c->d_qsum; T.qsumsq = c->d_qsumsq;
-    T.acc = c->d_acc; T.sinfo = c->d_sinfo; T.rowmap = c->d_rowmap; T.errflag = c->d_errflag; T.dbg = c->d_dbg; T.dp_pre = c->d_dp_pre;
+    T.acc = c->d_acc; T.sinfo = c->d_sinfo; T.rowmap = c->d_rowmap; T.rowmap8 = c->d_rowmap8; T.gl2_redo = c->d_gl2_redo; T.gl2_redo_list = c->d_gl2_list; T.gl2_redo_count = c->d_gl2_count; T.errflag = c->d_errflag; T.dbg = c->d_dbg; T.dp_pre = c->d_dp_pre;
     T.site_base = c->d_site_base; T.site_hash = c->d_site_hash; T.fslot = c->d_fslot;
     T.redo_list = c->d_redo_list; T.redo_count = c->d_redo_count; T.redo_cap = c->redo_cap; T.redo_bits = c->d_redo_bits;
     if (D.serial) {
