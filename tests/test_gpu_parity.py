@@ -231,7 +231,7 @@ def test_gl2_two_evaluations_per_thread(oracle, kw, N, n_sites, ovc, monkeypatch
     its default, at 1 (nearly every workgroup goes through k_gl_redo) and at 40.  Equal to the oracle, every tag."""
     args = VcfglArgs(seed=31, **kw, **ALLTAGS, **STRAND)
     gt = synth.acgt_sites(n_sites, N, seed=N + n_sites, missing=0.03)
-    monkeypatch.setenv("VGL_GL2X", "1")
+    monkeypatch.setenv("VGL_GL2X", "2")                             # (2: also with GP and FORMAT/AD*, which the shipped choice leaves to k_gl)
     if ovc:
         monkeypatch.setenv("VGL_DEBUG_GL2_OVC", str(ovc))
     args.rng_mode, args.beta_sampler = _abi.VGL_RNG_TILE, _abi.VGL_BETA_RAND48

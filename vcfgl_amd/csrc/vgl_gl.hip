@@ -122,14 +122,15 @@ __device__ __forceinline__ void site_outputs(const VglDevParams& P, const VglTil
 // k_gl2's compact accumulator array (below): the rows an evaluation leaves depend on how many bases its reads show -- 3 / 6 / 10 / 15 for
 // 1 .. 4 -- so the rows are kept in THAT order (physical row: 0, 10, 14 | 1, 2, 11 | 3, 4, 5, 12 | 6, 7, 8, 9, 13 of k_gl's numbering):
 // the first six, which all but a few per cent of the evaluations stop at, as full rows of the workgroup's 1024 columns (4096 bytes each),
-// the other nine as rows of VGL_GL2_OVC columns (512 bytes each) for the evaluations at the head of the sorted order, which are the ones
-// with three or four bases.  Code of a row = its offset in units of 512 bytes: 8 phys for the first six, 42 + phys for the rest.
-#define VGL_GL2_OVC 128
+// the other nine as rows of VGL_GL2_OVC columns (1024 bytes each) for the evaluations at the head of the sorted order, which are the ones
+// with three or four bases.  Code of a row = its offset in units of 512 bytes: 8 phys for the first six, 36 + 2 phys for the rest.
+#define VGL_GL2_OVC 256
 __device__ __forceinline__ constexpr int gl2_row_phys(const int row) {
     constexpr int ph[15] = {0, 3, 4, 6, 7, 8, 10, 11, 12, 13, 1, 5, 9, 14, 2};
     return ph[row];
 }
-__device__ __forceinline__ constexpr int gl2_row_code(const int row) { return gl2_row_phys(row) < 6 ? 8 * gl2_row_phys(row) : 42 + gl2_row_phys(row); }
+__device__ __forceinline__ constexpr int gl2_row_code(const int row) { return gl2_row_phys(row) < 6 ? 8 * gl2_row_phys(row) : 36 + 2 * gl2_row_phys(row); }
+static_assert(VGL_GL2_OVC * 4 == 2 * 512 && 36 + 2 * 14 < 256, "row codes: full rows of 1024 columns = 8 units, pool rows of VGL_GL2_OVC columns = 2 units of 512 bytes");
 
 // one lane per site.  With the row table of k_gl (T.rowmap, GL model 2) SIXTEEN lanes per site: all work out the site (a few hundred
 // instructions), lane `pm` writes table entry `pm`, lane 0 everything else
@@ -1031,7 +1032,7 @@ __global__ __launch_bounds__(512) void k_gl_redo(const VglDevParams P, const Vgl
 // evaluations in flight.  Here a workgroup of 512 threads takes 1024 evaluations (sixteen natural wavefronts: thread t the positions t and
 // t + 512) -- one counting sort over all of them; thread t works on sorted position q = (t + rotation) mod 512 of the heavy half and on
 // 1023 - q of the light half, so that every wavefront has loop work -- and the accumulators lie in the compact array described at
-// gl2_row_code(): 6 full rows + 9 rows of VGL_GL2_OVC columns = 29 KB for 1024 evaluations (k_gl: 30 KB for 512).  Column = the
+// gl2_row_code(): 6 full rows + 9 rows of VGL_GL2_OVC columns = 33 KB for 1024 evaluations (k_gl: 30 KB for 512).  Column = the
 // evaluation's sorted position (the natural thread knows it from its insertion).  A workgroup with more than VGL_GL2_OVC three- or
 // four-base evaluations cannot keep their upper rows: it sets its bit in T.gl2_redo and k_gl (REDO instantiation) works on it again.
 // Planes layout, no --precise-gl 1, sort on: everything else stays with k_gl.
@@ -1576,7 +1577,7 @@ extern "C" int vgl_launch_gl(const VglDevParams* p, const VglTilePtrs* t, void* 
     // at C3 / fixed-q / C4: 4 -> 8 wavefronts -7 / -6 / -10 % of the kernel's time, 16 is slower again; equal at depth 5)
     // (GL model 1 with per-read scores, round 4: 8 wavefronts per workgroup measured 5.80 against 5.29 ms per C3-shaped launch -- its per-lane
     //  histograms take 4 KB of LDS per wavefront either way and the larger workgroup only adds barrier waiting; it keeps 4)
-    if (p->gl2x) {
+    if (p->gl2x == 2 || (p->gl2x && !t->gp && !t->fmt_ad && !t->fmt_adf && !t->fmt_adr)) {      // (vgl_ctx_create's choice; tiles with GP or FORMAT/AD* stay with k_gl -- 2: test hook, every tile)
         if (p->gl_model != 2 || p->precise_gl || !p->gl_sort || p->out_layout != 0 || !t->rowmap8 || !t->gl2_redo || !t->gl2_redo_list || !t->gl2_redo_count) return (int)hipErrorInvalidValue;
         const unsigned blocks2 = (unsigned)((waves + 15) / 16);
         hipStream_t s2 = (hipStream_t)stream;

@@ -665,14 +665,19 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     TRY(dmalloc(&c->d_sinfo, (size_t)max_sites));
     if (p->gl_model == 2) TRY(dmalloc(&c->d_rowmap, (size_t)max_sites * 16));
     {
-        // GL model 2, three-kernel path: k_gl2 (two evaluations per thread: vgl_gl.hip) where it measured faster than k_gl -- one fixed score
-        // (the light half of its sorted order is table lookups: fixed-q k_gl 2.24 -> 1.91 ms per 65536 x 1000 tile) and per-read scores
-        // from depth 25 (depth 30: 6.27 -> 5.78; depth 20: 2.44 -> 2.49, where it is not used).  Planes layout, sort on, no --precise-gl 1
+        // GL model 2, three-kernel path: k_gl2 (two evaluations per thread: vgl_gl.hip) where it measured faster than k_gl (tools/gl2x_sweep.py,
+        // k_gl's time per tile with k_gl2 / with k_gl): one fixed score 0.77 - 0.85 at depths 12 ... 60, per-read scores 0.99 at depth 16, 0.95 at
+        // 20, 0.91 at 30, 0.87 at 40.  Its pool holds the upper accumulator rows of 256 three- / four-base evaluations of a workgroup's 1024:
+        // beyond ~0.8 expected base-call errors per evaluation workgroups start to overflow into k_gl_redo, and k_gl is the better choice.
+        // Planes layout, sort on, no --precise-gl 1
         double dsum = 0.0;
         for (int i = 0; i < N; i++) dsum += p->depths ? p->depths[i] : p->depth;
         const bool can = p->gl_model == 2 && !p->precise_gl && D.gl_sort != 0 && D.gl_wpb == 8 && p->out_layout == VGL_LAYOUT_PLANES && !D.fused;
-        const bool want = (p->error_qs != 2) || (dsum / (double)N >= 25.0);
-        D.gl2x = (can && hook_int("VGL_GL2X", want ? 1 : 0)) ? 1 : 0;
+        const double dmean = dsum / (double)N, errs = dmean * p->error_rate;      // expected base-call errors per evaluation: what makes three- and four-base evaluations
+        // (at the bench's full tile size per-read scores at depth 20 measured equal, 2.40-2.43 ms either way, depth 30 -6.5 %: from depth 23; and with
+        //  GP or the AD-type FORMAT tags k_gl2's two epilogues per thread cost more than they hide -- all tags: 4.9 -> 5.7 ms: vgl_launch_gl looks at the tile)
+        const bool want = dmean >= (p->error_qs != 2 ? 12.0 : 23.0) && errs <= 0.8;
+        D.gl2x = can ? hook_int("VGL_GL2X", want ? 1 : 0) : 0;                    // (VGL_GL2X=2: also for tiles with GP / FORMAT/AD*)
         D.dbg_gl2_ovc = hook_int("VGL_DEBUG_GL2_OVC", 0);
     }
     if (D.gl2x) {
