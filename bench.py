@@ -411,11 +411,13 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
         evals_per_launch = float(S) * N * steps / max(klaunch[dom], 1)     # average over the launches, partial last tile included
         achieved = b_eval * evals_per_launch / (avg_ms * 1e-3) / 1e9
         prof = profile_entry(name)
-        kprof = prof.get("kernels", {}).get(KERNELS[dom], {})
+        kern = prof.get("kernels", {})
+        two_per_thread = KERNELS[dom] == "k_gl" and "k_gl" not in kern and "k_gl2" in kern     # the k_gl bucket is k_gl2 (+ k_gl2_scan, k_gl_redo): half the wavefronts
+        kprof = kern.get("k_gl2" if two_per_thread else KERNELS[dom], {})
         fresh = bool(prof) and prof.get("src_sha") == source_sha()   # the committed counters describe THIS build
         # wavefronts per launch of the dominant kernel (launch geometry of vgl_sample.hip / vgl_gl.hip)
         sites_per_launch = float(S) * steps / max(klaunch[dom], 1)
-        waves = sites_per_launch * N / 1024.0 if KERNELS[dom] == "k_depth" else sites_per_launch * ((N + 63) // 64)
+        waves = sites_per_launch * N / 1024.0 if KERNELS[dom] == "k_depth" else sites_per_launch * ((N + 63) // 64) * (0.5 if two_per_thread else 1.0)
         scale = sites_per_launch / float(kprof.get("sites_per_launch", sites_per_launch) or sites_per_launch)   # profile launches -> this run's
         src = f"profiles/{prof.get('source')}_pmc_summary.json (committed counters of {'this build' if fresh else 'an EARLIER build: stale'}, not measured by this run)"
         valu = None
