@@ -273,8 +273,16 @@ __device__ __forceinline__ uint64_t fused_sample_eval(const VglDevParams& P, con
 #define VGL_FUSED_SPIN_LIMIT 2048
 
 // (the kernel's body: hw_block = the hardware workgroup index of a grid of hw_grid, or -- hw_grid 0 -- the logical index itself: k_gl_redo)
-template <int A, int GLM, bool PREC, int WPB, int FUSEDW = 0>
+template <int A, int GLM, bool PREC, int WPB, int FUSEDW_ = 0>
 __device__ __forceinline__ void k_gl_body(const VglDevParams& P, const VglTilePtrs& T, const uint32_t hw_block, const uint32_t hw_grid) {
+    // FUSEDW_: the staged words of the fused build (4 / 8), + 16 for its GENERAL build.  The plain fused build is the one the depth-5 configuration
+    // runs -- one workgroup per site, planes layout, GL / PL / DP only -- and carries nothing else: the exchange of a split site's depth sums with
+    // its polling loop and the fallback that samples an absent neighbour's depths, the sample-major stores and the GP / FORMAT-AD epilogue are
+    // several hundred instructions such a tile never runs, and their mere presence cost the kernel its scalar registers (49 scalar spills) and
+    // C5 11 % (round 5, second session: 1.17-1.19 -> 1.04-1.06 ms, same box; vgl_launch_fused picks the build per tile)
+    constexpr int FUSEDW = FUSEDW_ & 15;
+    constexpr bool GEN = (FUSEDW_ & 16) != 0;
+    constexpr bool SPLIT = GEN, SMB = GEN;
     constexpr bool FUSED = FUSEDW != 0;
     static_assert(!FUSED || (GLM == 2 && !PREC), "the fused build exists for GL model 2 with the score table");
     static_assert(FUSEDW == 0 || FUSEDW == 4 || FUSEDW == 8, "staged words per evaluation of the fused build");
@@ -313,12 +321,13 @@ __device__ __forceinline__ void k_gl_body(const VglDevParams& P, const VglTilePt
             if (!P.gl_sort) __syncthreads();                            // (with the sort, its barriers stand between these stores and the loop)
         }
     }
-    const uint32_t chunks_k = FUSED ? (uint32_t)(WPB * P.fused_split) : (uint32_t)P.chunks;   // FUSED: a site takes fused_split whole workgroups (wavefronts beyond its samples idle)
+    const int fsplit = SPLIT ? P.fused_split : 1;
+    const uint32_t chunks_k = FUSED ? (uint32_t)(WPB * fsplit) : (uint32_t)P.chunks;   // FUSED: a site takes fused_split whole workgroups (wavefronts beyond its samples idle)
     const uint32_t nwaves = (uint32_t)T.n_sites * chunks_k;                             // < 2^31 (checked by the launcher)
     // logical workgroup: XCD-contiguous (xcd_block) -- except for the fused build with one workgroup per site, whose workgroups share
     // nothing: there the dispatch order measured 1 % faster (C5 k_gl 1.062 / 1.068 against 1.073 / 1.081 ms; the three-kernel k_gl loses
     // 4 % without the mapping)
-    const uint32_t bx = (hw_grid != 0u && P.xcd_map && !(FUSED && P.fused_split == 1)) ? xcd_block(hw_block, hw_grid) : hw_block;
+    const uint32_t bx = (hw_grid != 0u && P.xcd_map && !(FUSED && fsplit == 1)) ? xcd_block(hw_block, hw_grid) : hw_block;
     uint64_t f_a = 0;                                                   // FUSED: this thread's per-base depths
     // wave k of this workgroup is wave 4 bx + k of the tile = (site, 64-sample chunk).  One scalar division per workgroup; a lane
     // then finds the site of ANY of the four waves with three compares (a per-lane 64-bit division was 60+ vector instructions,
@@ -394,7 +403,7 @@ __device__ __forceinline__ void k_gl_body(const VglDevParams& P, const VglTilePt
     int key = 0;
     int f_status = SITE_OK, f_nall = 0;                                 // FUSED: the site's status and allele count (site_status_nall)
     if constexpr (FUSED) {
-        const int S = P.fused_split;                                    // workgroups of this site
+        const int S = fsplit;                                           // workgroups of this site
         const int site = (int)(bx / (uint32_t)S), part = (int)bx - site * S;
         const int samp = part * WG + tid;
         if (tid < 16) s_lds.f_acc[tid] = 0;
@@ -423,7 +432,7 @@ __device__ __forceinline__ void k_gl_body(const VglDevParams& P, const VglTilePt
             for (int k = 1; k < 5; ++k) if (v[k]) atomicAdd(&s_lds.f_acc[k], v[k]);
         }
         if (P.gl_sort) { natural_setup(); key = sort_key(); atomicAdd(&s_hist[key], 1u); }
-        if (S > 1) {
+        if constexpr (SPLIT) if (S > 1) {
             // ---- the other workgroups' shares.  Every part publishes its four sums as TWO flagged 8-byte words (system-scope stores: A | C << 32
             // and G | T << 32, bit 63 = valid; the slots are zero at the start of the tile) and lane q of the first wavefront polls part q's
             // words with system-scope loads -- one store and, when the neighbour is already there, one load round trip (the first version's
@@ -847,7 +856,7 @@ __device__ __forceinline__ void k_gl_body(const VglDevParams& P, const VglTilePt
         const int w_light = (WPB - 1 - (int)(bx & (WPB - 1))) & (WPB - 1);
         const int m = tid - 64 * w_light;
         if (m >= 0 && m < 16) {
-            const int S = P.fused_split;
+            const int S = fsplit;
             const int site = (int)(bx / (uint32_t)S), part = (int)bx - site * S;
             int32_t acc9[9];
 #pragma unroll
@@ -898,7 +907,7 @@ __device__ __forceinline__ void k_gl_body(const VglDevParams& P, const VglTilePt
     // contiguous run of the slab, so they pass through the wavefront's own columns of s_x (free once every lane has read its
     // accumulators: columns 64 wv .. 64 wv + 63 of every row belong to this wavefront alone) in linear order and leave as
     // nK fully coalesced stores of 256 bytes.
-    const bool sm = P.out_layout == 1;                                   // VGL_LAYOUT_SAMPLE_MAJOR
+    const bool sm = (FUSED && !SMB) ? false : (P.out_layout == 1);        // VGL_LAYOUT_SAMPLE_MAJOR
     const int wv = tid >> 6;
     const uint32_t wb = 64u * (uint32_t)wv;
     const int ls_w = ls0, sb_w = sb0;                                    // (scalar: the natural-order wavefront's site and first sample)
@@ -978,7 +987,7 @@ __device__ __forceinline__ void k_gl_body(const VglDevParams& P, const VglTilePt
             VGL_WAVE_LDS_SYNC();
         }
     }
-    if (T.gp) {                                                          // GP = 10^GL normalised by its float32 sum in genotype order
+    if ((!FUSED || GEN) && T.gp) {                                       // GP = 10^GL normalised by its float32 sum in genotype order
         float sum_gps = 0.0f;
 #pragma unroll
         for (int i = 0; i < NG; ++i) {                                   // (the likelihoods are not needed any more: reuse their registers)
@@ -988,7 +997,7 @@ __device__ __forceinline__ void k_gl_body(const VglDevParams& P, const VglTilePt
         }
         VGL_PUT(T.gp, NG, nG0u, __float_as_uint((sample_ok && i < nG0) ? acc[i] / sum_gps : MISS));
     }
-    if (T.fmt_ad || T.fmt_adf || T.fmt_adr) {
+    if ((!FUSED || GEN) && (T.fmt_ad || T.fmt_adf || T.fmt_adr)) {
         const uint64_t adf4 = (P.need_adf && live0) ? T.adf4[(size_t)ls0 * N + (size_t)sb0 + (size_t)lane] : a;
         VGL_PUT(T.fmt_ad, A, nA0u, (uint32_t)cnt_of(a, (have0 && i < nA0) ? nib(si_n.alleles2acgt, i) : 0xF));
         VGL_PUT(T.fmt_adf, A, nA0u, (uint32_t)cnt_of(adf4, (have0 && i < nA0) ? nib(si_n.alleles2acgt, i) : 0xF));
@@ -998,9 +1007,9 @@ __device__ __forceinline__ void k_gl_body(const VglDevParams& P, const VglTilePt
 #undef VGL_PUT
 #undef VGL_ROWS
 }
-template <int A, int GLM, bool PREC, int WPB, int FUSEDW = 0>
+template <int A, int GLM, bool PREC, int WPB, int FUSEDW_ = 0>
 __global__ __launch_bounds__(64 * WPB) void k_gl(const VglDevParams P, const VglTilePtrs T) {
-    k_gl_body<A, GLM, PREC, WPB, FUSEDW>(P, T, blockIdx.x, gridDim.x);
+    k_gl_body<A, GLM, PREC, WPB, FUSEDW_>(P, T, blockIdx.x, gridDim.x);
 }
 // k_gl2's workgroups that could not keep their accumulators (their bit in T.gl2_redo): k_gl2_scan lists them, k_gl_redo runs k_gl's body on
 // the two 512-evaluation halves of each listed workgroup -- every tag of those evaluations is written again
@@ -1042,6 +1051,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     constexpr int QL = 96;
     constexpr int NG = A * (A + 1) / 2;
     constexpr int OVC = VGL_GL2_OVC;
+#ifdef VGL_TEST_HOOKS
+    constexpr bool RICH = true;                                        // (VGL_GL2X=2: every tag, for the tests)
+#else
+    constexpr bool RICH = false;                                       // vgl_launch_gl keeps tiles with GP or FORMAT/AD* on k_gl: the shipped kernel does not carry their epilogue
+#endif
     struct Lds {
         double q2gl[3 * QL];
         uint32_t x[6 * WGE + 9 * OVC];
@@ -1305,7 +1319,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 rp += N;
             }
         }
-        if (T.gp) {
+        if (RICH && T.gp) {
             float sum_gps = 0.0f;
 #pragma unroll
             for (int i = 0; i < NG; ++i) {
@@ -1315,7 +1329,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             }
             VGL2_PUT(T.gp, NG, __float_as_uint((sample_ok && i < nG0) ? acc[i] / sum_gps : MISS));
         }
-        if (T.fmt_ad || T.fmt_adf || T.fmt_adr) {
+        if (RICH && (T.fmt_ad || T.fmt_adf || T.fmt_adr)) {
             const uint64_t adf4 = (P.need_adf && live0) ? T.adf4[(size_t)lsh * N + (size_t)sbh + (size_t)lane] : a[h];
             VGL2_PUT(T.fmt_ad, A, (uint32_t)cnt_of(a[h], (have0 && i < nA0) ? nib(si_n.alleles2acgt, i) : 0xF));
             VGL2_PUT(T.fmt_adf, A, (uint32_t)cnt_of(adf4, (have0 && i < nA0) ? nib(si_n.alleles2acgt, i) : 0xF));
@@ -1618,8 +1632,13 @@ extern "C" int vgl_launch_fused(const VglDevParams* p, const VglTilePtrs* t, voi
 #define VGL_LAUNCH_FUSED(WPB, FW) \
     do { if (p->A == 5) hipLaunchKernelGGL((k_gl<5, 2, false, WPB, FW>), g, dim3(64 * WPB), 0, s, *p, *t); \
          else hipLaunchKernelGGL((k_gl<4, 2, false, WPB, FW>), g, dim3(64 * WPB), 0, s, *p, *t); } while (0)
-    if (p->read_cap <= 64) { if (wg == 256) VGL_LAUNCH_FUSED(4, 4); else VGL_LAUNCH_FUSED(8, 4); }
-    else { if (wg == 256) VGL_LAUNCH_FUSED(4, 8); else VGL_LAUNCH_FUSED(8, 8); }
+    if (S == 1 && p->out_layout == 0 && !t->gp && !t->fmt_ad && !t->fmt_adf && !t->fmt_adr) {      // the plain build (k_gl_body)
+        if (p->read_cap <= 64) { if (wg == 256) VGL_LAUNCH_FUSED(4, 4); else VGL_LAUNCH_FUSED(8, 4); }
+        else { if (wg == 256) VGL_LAUNCH_FUSED(4, 8); else VGL_LAUNCH_FUSED(8, 8); }
+    } else {                                                             // + 16: the general build
+        if (p->read_cap <= 64) { if (wg == 256) VGL_LAUNCH_FUSED(4, 20); else VGL_LAUNCH_FUSED(8, 20); }
+        else { if (wg == 256) VGL_LAUNCH_FUSED(4, 24); else VGL_LAUNCH_FUSED(8, 24); }
+    }
 #undef VGL_LAUNCH_FUSED
     return (int)hipGetLastError();
 }
