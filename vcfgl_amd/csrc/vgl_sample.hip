@@ -156,9 +156,11 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
     unsigned long long c_t0 = 0, c_pois = 0, c_owner = 0, c_pool = 0, c_flush = 0, c_iter = 0, c_items = 0, c_tmp = 0;
     if (DBG) c_t0 = clock64();
     uint64_t err_thresh = P.err_thresh;
-    const bool k_strand = SLIM ? false : (P.sample_strand != 0);
-    const bool k_qsum = SLIM ? false : (P.need_qsum != 0);
-    const int k_adj = SLIM ? 0 : P.adjust_qs;
+    // LEAN 4 (round 5, second session) = LEAN 3 for the common optional-tag surface -- strand draws AND quality sums, no --adjust-qs (-addQS / -addI16 with
+    // the strand tags: alltags, qsi16) -- with the three options as constants: 9.85 -> 9.40 ms per 65536 x 1000 tile (vgl_launch_sample picks it)
+    const bool k_strand = SLIM ? false : (LEAN == 4 ? true : (P.sample_strand != 0));
+    const bool k_qsum = SLIM ? false : (LEAN == 4 ? true : (P.need_qsum != 0));
+    const int k_adj = (SLIM || LEAN == 4) ? 0 : P.adjust_qs;
 
     // ---- stream states of this evaluation: J^(off_k) . J^(block*s) . J^(block*N*H(site)) (x0); the site factor comes from k_sitebase
     const uint64_t xb = T.site_base[ls];
@@ -275,7 +277,7 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
         // LEAN 3, P.qsum_lds: the owners' per-base quality sums are gathered by the dense pass with one LDS atomic per read, into 32-bit
         // words (sum of squares << 13 | sum: at most 130 reads of a score <= 63 each, 130 x 63 = 8190 < 2^13) -- bases A, C of owner o at l_stq[o] (free between
         // the pool loop and the next segment), bases G, T in 512 bytes behind the pool
-        const bool qfast = (LEAN == 3) && (P.qsum_lds != 0);
+        const bool qfast = (LEAN >= 3) && (P.qsum_lds != 0);
         uint32_t* l_accB = (uint32_t*)(wl + ((576 + 4 * ((size_t)cap + 2) + (size_t)cap + 7) & ~(size_t)7));
         // the pool loop reads l_stq by LDS byte offsets taken from the item slots: the dynamic LDS block must start at 0
         // (this kernel has no static LDS)
@@ -306,7 +308,7 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                 l_lut[qv] = (uint8_t)b;
             }
         }
-        if (P16 && LEAN == 3) { if (P.qsum_lds) { ((uint64_t*)l_qs)[2 * lane] = 0ULL; ((uint64_t*)l_qs)[2 * lane + 1] = 0ULL; } }
+        if (P16 && LEAN >= 3) { if (P.qsum_lds) { ((uint64_t*)l_qs)[2 * lane] = 0ULL; ((uint64_t*)l_qs)[2 * lane + 1] = 0ULL; } }
         if (lane == 0) {
             if (!P16) l_it[cap] = 0u;
             if (F32) {
@@ -422,7 +424,7 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                         if (P16) { *(lds_u16o*)(uintptr_t)ka = (uint16_t)(sv | (uint32_t)r_base); sv += 4u; ka += 2u; }
                         else {
                             *(lds_u32o*)(uintptr_t)ka = sv;
-                            *(lds_u8o*)(uintptr_t)pa = (uint8_t)((LEAN == 3) ? (lane4 | (uint32_t)r_base) : (uint32_t)r_base);   // (LEAN 3: the dense pass finds the item's owner here)
+                            *(lds_u8o*)(uintptr_t)pa = (uint8_t)((LEAN >= 3) ? (lane4 | (uint32_t)r_base) : (uint32_t)r_base);   // (LEAN 3: the dense pass finds the item's owner here)
                             sv += 16u; ka += 4u; pa += 1u;
                         }
                     }
@@ -959,7 +961,7 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
         };
         // (measured, same box: the two-instance form -3.6 % for LEAN 3 -- 10.25 -> 9.89 ms at qsi16 -- and +2.7 % for LEAN 2, whose single instance
         //  at 64 VGPRs the allocator already serves best: profiles/r05_ab/ab_single.txt)
-        if (LEAN == 3 && nseg <= 1) { if (total > 0) { if (run_segment(std::true_type{}, 0)) return; } }
+        if (LEAN >= 3 && nseg <= 1) { if (total > 0) { if (run_segment(std::true_type{}, 0)) return; } }
         else for (int seg0 = 0; seg0 < total; seg0 += seglen) { if (run_segment(std::false_type{}, seg0)) return; }
     }
 
@@ -1019,7 +1021,7 @@ template <int EQS, bool DBG, int DM, bool PREC, int LEAN>
 #ifndef VGL_SAMPLE_WAVES_L3
 #define VGL_SAMPLE_WAVES_L3 7
 #endif
-#define VGL_SAMPLE_WAVES(EQS, PREC, LEAN) ((EQS) == 2 ? ((LEAN) == 2 && !(PREC) ? VGL_SAMPLE_WAVES_F32 : ((LEAN) == 3 && !(PREC) ? VGL_SAMPLE_WAVES_L3 : ((LEAN) >= 2 ? 5 : 4))) : 8)
+#define VGL_SAMPLE_WAVES(EQS, PREC, LEAN) ((EQS) == 2 ? ((LEAN) == 2 && !(PREC) ? VGL_SAMPLE_WAVES_F32 : ((LEAN) >= 3 && !(PREC) ? VGL_SAMPLE_WAVES_L3 : ((LEAN) >= 2 ? 5 : 4))) : 8)
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? VGL_SAMPLE_WAVES(EQS, PREC, LEAN) : 1, VGL_SAMPLE_WAVES(EQS, PREC, LEAN)))) void k_sample(const VglDevParams P, const VglTilePtrs T) {
     // (one 64-sample chunk per launched wavefront: several chunks per wavefront, one after the other, measured slower -- docs/tried.md)
@@ -1165,6 +1167,7 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
             VGL_STATIC_LDS(false, 0, false, 0) VGL_STATIC_LDS(false, 1, false, 0) VGL_STATIC_LDS(false, 2, false, 0)
             VGL_STATIC_LDS(false, 0, false, 3) VGL_STATIC_LDS(false, 1, false, 3) VGL_STATIC_LDS(false, 2, false, 3)
             VGL_STATIC_LDS(false, 0, true, 3) VGL_STATIC_LDS(false, 1, true, 3) VGL_STATIC_LDS(false, 2, true, 3)
+            VGL_STATIC_LDS(false, 0, false, 4) VGL_STATIC_LDS(false, 1, false, 4) VGL_STATIC_LDS(false, 2, false, 4)
 #undef VGL_STATIC_LDS
             return worst == 0;
         }();
@@ -1174,7 +1177,11 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
 #endif
         if (t->errp && sample_deferred(p, t)) { if (lean) VGL_LAUNCH_SAMPLE(2, false, true, 2, lds); else VGL_LAUNCH_SAMPLE(2, false, true, 3, lds); }   // --precise-gl 1: the deferred builds, k_redo (vgl_launch_redo) also rewrites errp
         else if (t->errp) { if (lean) VGL_LAUNCH_SAMPLE(2, false, true, 1, lds); else VGL_LAUNCH_SAMPLE(2, false, true, 0, lds); }   // --precise-gl 1, or the deviates were asked for
-        else if (sample_deferred(p, t)) { if (lean) VGL_LAUNCH_SAMPLE(2, false, false, 2, lds16); else VGL_LAUNCH_SAMPLE(2, false, false, 3, lds16x); }
+        else if (sample_deferred(p, t)) {
+            if (lean) VGL_LAUNCH_SAMPLE(2, false, false, 2, lds16);
+            else if (p->adjust_qs == 0 && p->sample_strand && p->need_qsum) VGL_LAUNCH_SAMPLE(2, false, false, 4, lds16x);      // LEAN 3 with its three options fixed
+            else VGL_LAUNCH_SAMPLE(2, false, false, 3, lds16x);
+        }
         else { if (lean) VGL_LAUNCH_SAMPLE(2, false, false, 1, lds); else VGL_LAUNCH_SAMPLE(2, false, false, 0, lds); }
     }
     // fixed quality score: the LEAN build (no strand draws, forward-strand depths, quality sums or per-read dump) keeps those
