@@ -674,9 +674,10 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
         for (int i = 0; i < N; i++) dsum += p->depths ? p->depths[i] : p->depth;
         const bool can = p->gl_model == 2 && !p->precise_gl && D.gl_sort != 0 && D.gl_wpb == 8 && p->out_layout == VGL_LAYOUT_PLANES && !D.fused;
         const double dmean = dsum / (double)N, errs = dmean * p->error_rate;      // expected base-call errors per evaluation: what makes three- and four-base evaluations
-        // (at the bench's full tile size per-read scores at depth 20 measured equal, 2.40-2.43 ms either way, depth 30 -6.5 %: from depth 23; and with
+        // (at the bench's full tile size per-read scores at depth 20 measured equal with the first version, 2.40-2.43 ms either way, depth 30 -6.5 %; and with
         //  GP or the AD-type FORMAT tags k_gl2's two epilogues per thread cost more than they hide -- all tags: 4.9 -> 5.7 ms: vgl_launch_gl looks at the tile)
-        const bool want = dmean >= (p->error_qs != 2 ? 12.0 : 23.0) && errs <= 0.8;
+        // (... and without the GP / AD epilogue in the shipped k_gl2, depth 20 measures 2.355-2.388 against 2.397-2.413 ms: from depth 18)
+        const bool want = dmean >= (p->error_qs != 2 ? 12.0 : 18.0) && errs <= 0.8;
         D.gl2x = can ? hook_int("VGL_GL2X", want ? 1 : 0) : 0;                    // (VGL_GL2X=2: also for tiles with GP / FORMAT/AD*)
         D.dbg_gl2_ovc = hook_int("VGL_DEBUG_GL2_OVC", 0);
     }
