@@ -123,6 +123,7 @@ struct VglDevParams {
     int32_t dbg_phase;       // diagnostic (VGL_DEBUG_PHASE=n): k_sample returns after phase n; 0 = off
     int32_t dbg_qs_exact;    // test hook (VGL_DEBUG_QS_EXACT=1): k_sample<2> treats every read as undecided in float32
     int32_t dbg_redo_every;  // test hook (VGL_DEBUG_REDO_EVERY=k): the deferred build sends every k-th read and slow-test lane to k_redo
+    int32_t dbg_stamps;      // diagnostic (VGL_DEBUG_STAMPS): 1 = the stamped inline-fallback build of k_sample<2> (LEAN 0), 2 = the stamped float32 build of the default tag surface (LEAN 2)
     int32_t qsum_lds;        // k_sample<2, LEAN 3>: the owners' quality sums are gathered in LDS by the dense pass (one atomic per read) -- --adjust-qs 0 or 3
                              // (one score for likelihoods and sums) and at most 130 staged reads (sum of squares << 13 | sum: 130 x 63 = 8190 < 2^13, 130 x 63^2 < 2^19)
     int32_t defer_ok;        // the flag set allows the deferred build of k_sample<2> (vgl_ctx_create; VGL_NO_DEFER=1 turns it off)

@@ -430,6 +430,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     if (D.slow_period_n < 1) D.slow_period_n = 1;
     D.xcd_map = hook_int("VGL_XCD_MAP", 1);
     D.dbg_phase = hook_int("VGL_DEBUG_PHASE", 0);
+    D.dbg_stamps = hook_int("VGL_DEBUG_STAMPS", 0);
     D.dbg_fuse_alone = hook_int("VGL_DEBUG_FUSE_ALONE", 0);
     D.dbg_depth_chunk = hook_int("VGL_DEPTH_CHUNK", 0);
     D.dbg_qs_exact = hook_int("VGL_DEBUG_QS_EXACT", 0);

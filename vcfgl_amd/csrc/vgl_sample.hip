@@ -154,6 +154,7 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
     uint64_t st_hap = 0, st_base = 0, st_qs = 0;
     // DBG only: per-phase cycle stamps
     unsigned long long c_t0 = 0, c_pois = 0, c_owner = 0, c_pool = 0, c_flush = 0, c_iter = 0, c_items = 0, c_tmp = 0;
+    unsigned long long c_ntest = 0, c_gtest = 0, c_finb = 0, c_lhave = 0, c_lfin = 0, c_lhold = 0;   // float32 pool loop: block executions and lane counts per iteration
     if (DBG) c_t0 = clock64();
     uint64_t err_thresh = P.err_thresh;
     // LEAN 4 (round 5, second session) = LEAN 3 for the common optional-tag surface -- strand draws AND quality sums, no --adjust-qs (-addQS / -addI16 with
@@ -508,6 +509,7 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                     uint32_t s_lo = (uint32_t)st, s_hi = (uint32_t)(st >> 32);
                     float gxf = 0.0f;
                     do {
+                        if (DBG) { c_iter++; c_lhave += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(have)); }
                         const bool full = (--slow_cnt == 0);
                         if (full) slow_cnt = P.slow_period;
                         const bool full_n = (--slow_cnt_n == 0);
@@ -531,6 +533,7 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                         bool redo = false;
                         if (full_n && __builtin_amdgcn_ballot_w64(n_amb)) {
                             bool und;
+                            if (DBG) c_ntest++;
                             slow_n = pool32_normal_slow(svA * __builtin_amdgcn_rcpf(ufA), ufA, qA, n_amb, und);
                             redo = und || (n_amb && dbg_redo_every && (l1 >> 8) % (uint32_t)(dbg_redo_every | (dbg_redo_every == 0)) == 0u);
                         }
@@ -586,6 +589,7 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                         bool slow_g = false;
                         if (full && __builtin_amdgcn_ballot_w64(g_amb)) {
                             bool und;
+                            if (DBG) c_gtest++;
                             slow_g = pool32_gamma_slow(u2f, ga2 * xn, ga1, x4, g_amb, und);
                             redo = redo || und || (g_amb && dbg_redo_every && (l3 >> 8) % (uint32_t)(dbg_redo_every | (dbg_redo_every == 0)) == 1u);
                         }
@@ -607,6 +611,10 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                         const float gx_prev = gxf;
                         gxf = (acc_g && !stage1) ? val : gxf;
                         stage1 = (stage1 != acc_g) && !redo;
+                        if (DBG) {
+                            const uint64_t fm = __builtin_amdgcn_ballot_w64(fin);
+                            c_finb += (fm != 0); c_lfin += (unsigned)__popcll(fm); c_lhold += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(hold));
+                        }
                         if (fin) {
                             const float pf = gx_prev * __builtin_amdgcn_rcpf(gx_prev + val);   // the read's error probability X / (X + Y) (rng.h:438)
                             if (P16) {
@@ -1002,6 +1010,8 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
             atomicAdd(&T.dbg[0], 1ULL); atomicAdd(&T.dbg[1], clock64() - c_t0); atomicAdd(&T.dbg[2], c_pois);
             atomicAdd(&T.dbg[3], c_owner); atomicAdd(&T.dbg[4], c_pool); atomicAdd(&T.dbg[5], c_flush);
             atomicAdd(&T.dbg[6], c_iter); atomicAdd(&T.dbg[7], c_items);
+            atomicAdd(&T.dbg[8], c_ntest); atomicAdd(&T.dbg[9], c_gtest); atomicAdd(&T.dbg[10], c_finb); atomicAdd(&T.dbg[11], c_lhave);
+            atomicAdd(&T.dbg[12], c_lfin); atomicAdd(&T.dbg[13], c_lhold);
         }
     }
 }
@@ -1112,7 +1122,7 @@ __global__ __launch_bounds__(64) void k_redo(const VglDevParams P, const VglTile
 // a deferred build of k_sample<2> (LEAN 2: default tag surface, LEAN 3: optional tags) serves this tile: vgl_launch_sample runs it,
 // vgl_launch_redo runs k_redo behind it
 static bool sample_deferred(const VglDevParams* p, const VglTilePtrs* t) {
-    return !p->serial && p->error_qs == 2 && !t->reads_out && p->defer_ok && t->redo_list && !(t->dbg != nullptr && !t->errp);
+    return !p->serial && p->error_qs == 2 && !t->reads_out && p->defer_ok && t->redo_list && !(t->dbg != nullptr && !t->errp && p->dbg_stamps != 2);
 }
 extern "C" int vgl_launch_redo(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
     if ((int64_t)t->n_sites * p->chunks == 0 || !sample_deferred(p, t)) return 0;
@@ -1158,6 +1168,7 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
             worst = a.sharedSizeBytes > worst ? a.sharedSizeBytes : worst;
 #ifdef VGL_TEST_HOOKS
             VGL_STATIC_LDS(true, 0, false, 0) VGL_STATIC_LDS(true, 1, false, 0) VGL_STATIC_LDS(true, 2, false, 0)
+            VGL_STATIC_LDS(true, 0, false, 2) VGL_STATIC_LDS(true, 1, false, 2) VGL_STATIC_LDS(true, 2, false, 2)
 #endif
             VGL_STATIC_LDS(false, 0, true, 1) VGL_STATIC_LDS(false, 1, true, 1) VGL_STATIC_LDS(false, 2, true, 1)
             VGL_STATIC_LDS(false, 0, true, 0) VGL_STATIC_LDS(false, 1, true, 0) VGL_STATIC_LDS(false, 2, true, 0)
@@ -1173,6 +1184,7 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
         }();
         if (!static_lds_free) return (int)hipErrorInvalidConfiguration;
 #ifdef VGL_TEST_HOOKS
+        if (dbg && !t->errp && p->dbg_stamps == 2 && lean && sample_deferred(p, t)) { VGL_LAUNCH_SAMPLE(2, true, false, 2, lds16); } else   // VGL_DEBUG_STAMPS=2: the stamped float32 build
         if (dbg && !t->errp) { VGL_LAUNCH_SAMPLE(2, true, false, 0, lds); } else   // diagnostic build (VGL_DEBUG_STAMPS / VGL_DEBUG_PHASE): --precise-gl 0 only
 #endif
         if (t->errp && sample_deferred(p, t)) { if (lean) VGL_LAUNCH_SAMPLE(2, false, true, 2, lds); else VGL_LAUNCH_SAMPLE(2, false, true, 3, lds); }   // --precise-gl 1: the deferred builds, k_redo (vgl_launch_redo) also rewrites errp
