@@ -54,7 +54,8 @@ def parse(remarks):
         if m:
             cur = rows.setdefault(m.group(1), {})
             continue
-        m = re.search(r"remark: [^ ]+\s+(TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|SGPRs Spill|VGPRs Spill|LDS Size \[bytes/block\]): (\d+)", l)
+        # ("remark: file:line:col:     VGPRs: 64" with -save-temps, "file:line:col: remark:     VGPRs: 64" without)
+        m = re.search(r"remark:.*?\s(TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|SGPRs Spill|VGPRs Spill|LDS Size \[bytes/block\]): (\d+)", l)
         if m and cur is not None:
             cur[FIELDS[m.group(1)]] = int(m.group(2))
     return rows
