@@ -563,6 +563,26 @@ def test_deferred_reads_are_redrawn_by_k_redo(oracle, monkeypatch, every, cap, d
     assert_parity(want, got, check_gp=False)
 
 
+@pytest.mark.parametrize("limit,pool", [(None, None), (1200, None), (1, None), (None, 640), (900, 1280), (None, 64)])
+@pytest.mark.parametrize("depth,N,bins", [(20, 300, False), (30, 130, True), (20, 1000, False)])
+def test_split_build_of_the_default_tag_surface(oracle, monkeypatch, limit, pool, depth, N, bins):
+    """Round 6: k_sample<2, LEAN 2> runs as two kernels (k_sample_seg) -- <., 1> takes ONE pool segment per wavefront, a wavefront with more reads
+    than the pool holds appends itself to a list and leaves; <., 2> runs the segment loop over the listed wavefronts.  Cases: the library's own
+    limit (nothing listed), VGL_DEBUG_SEG_LIMIT 1200 (about a fifth of depth 20's wavefronts listed, each then served in one segment by the
+    second kernel) and 1 (every wavefront listed), VGL_DEBUG_POOL_CAP 640 / 1280 / 64 with the split forced on (every listed wavefront really takes
+    2 ... 20+ segments; 64: a segment per lane's worth of reads), 1000 samples (16 wavefronts per site, the last one ragged).  Every field equal to
+    the oracle; with the hooks off the same cases run the shipped choice (test_deferred_reads_are_redrawn_by_k_redo)."""
+    if limit is not None:
+        monkeypatch.setenv("VGL_DEBUG_SEG_LIMIT", str(limit))
+    if pool is not None:
+        monkeypatch.setenv("VGL_DEBUG_POOL_CAP", str(pool))
+        monkeypatch.setenv("VGL_SEG_SPLIT", "1")
+    kw = dict(qs_bins=[(0, 2, 2), (3, 14, 12), (15, 30, 23), (31, 40, 37)]) if bins else {}
+    args = VcfglArgs(seed=91, depth=depth, error_rate=0.01, error_qs=2, beta_variance=1e-5, add_pl=1, **kw)
+    want, got = run_both(oracle, args, synth.binary_sites(0, 12, N), hooks=True)
+    assert_parity(want, got, check_gp=False)
+
+
 @pytest.mark.parametrize("every,cap", [(0, None), (3, None), (5, 16), (5, 256)])
 @pytest.mark.parametrize("depth,N,adj,bins", [(20, 300, 0, False), (20, 130, 3, True), (70, 64, 0, False), (70, 64, 3, False), (12, 200, 1, False),
                                               (12, 200, 2, True), (100, 64, 0, False), (100, 70, 2, False)])

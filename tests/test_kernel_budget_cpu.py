@@ -58,7 +58,9 @@ def test_every_shipped_kernel_within_its_budget(current):
 def test_builds_the_round_depends_on(current):
     """the numbers DESIGN.md quotes for the bench configurations' kernels, as hard limits"""
     want = {
-        "k_sample<2, false, 1, false, 2>": dict(vgprs=64, occupancy=8),                   # C3 / C4 / gl1q: eight wavefronts per SIMD
+        "k_sample_seg<1, 1, 2>": dict(vgprs=64, occupancy=8, scratch=0, vgpr_spill=0),     # C3 / C4 / gl1q: eight wavefronts per SIMD, nothing in scratch (round 6)
+        "k_sample_seg<1, 1, 4>": dict(vgprs=64, occupancy=8, scratch=20),                 # qsi16 / alltags
+        "k_sample<2, false, 1, false, 2>": dict(vgprs=64, occupancy=8),                   # the same build with the segment loop inside (pools that do not hold a wavefront's reads)
         "k_gl<5, 2, false, 8, 4>": dict(sgpr_spill=0, vgpr_spill=0, scratch=0),           # C5: the plain fused build spills nothing
         "k_gl<5, 2, false, 4, 4>": dict(sgpr_spill=0, vgpr_spill=0, scratch=0),
         "k_gl2<5>": dict(vgprs=64, scratch=0, occupancy=8),                               # fixed-q / C3 / C4 likelihoods

@@ -127,6 +127,8 @@ struct VglDevParams {
     int32_t qsum_lds;        // k_sample<2, LEAN 3>: the owners' quality sums are gathered in LDS by the dense pass (one atomic per read) -- --adjust-qs 0 or 3
                              // (one score for likelihoods and sums) and at most 130 staged reads (sum of squares << 13 | sum: 130 x 63 = 8190 < 2^13, 130 x 63^2 < 2^19)
     int32_t defer_ok;        // the flag set allows the deferred build of k_sample<2> (vgl_ctx_create; VGL_NO_DEFER=1 turns it off)
+    int32_t seg_split;       // k_sample<2, LEAN 2> without --precise-gl 1 runs as k_sample_seg<., 1> + <., 2>: the pool holds a wavefront's summed depth + 8 sigma (VGL_NO_SEG_SPLIT=1 turns it off)
+    int32_t seg_limit;       // k_sample_seg<., 1>: a wavefront with more reads goes to the list (= pool_cap; test hook VGL_DEBUG_SEG_LIMIT)
     int32_t pre_q, pre_adjq;           // preCalc qScore / adj_qScore (vcfgl.cpp:1697-1702)
     double  adjust_by;
     double  pre_homT, pre_het, pre_homF;
@@ -183,6 +185,7 @@ struct VglTilePtrs {
                              // sampling, set k_sample<2>'s time).  A count may exceed redo_cap: the rest is marked in redo_bits
     uint32_t redo_cap;       // entries per partition
     uint32_t* redo_bits;     // one bit per (evaluation, read) of the tile, all zero between tiles: overflow of the list
+    uint32_t* seg_list;      // k_sample_seg: the wavefronts (index in the tile) whose reads need more than one pool segment; their number is redo_count[1]
     double*  errp;           // [read_cap][n_sites][N]   (precise_gl with error_qs 2)
     uint64_t* ad4;           // [n_sites][N]  4 x u16 ACGT depth
     uint64_t* adf4;          // [n_sites][N]  4 x u16 forward-strand depth

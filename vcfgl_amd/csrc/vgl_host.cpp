@@ -191,6 +191,7 @@ struct vgl_ctx {
     uint32_t* d_qsum = nullptr; uint32_t* d_qsumsq = nullptr; int32_t* d_acc = nullptr; VglSiteInfo* d_sinfo = nullptr; uint64_t* d_rowmap = nullptr; uint64_t* d_rowmap8 = nullptr; uint32_t* d_gl2_redo = nullptr; uint32_t* d_gl2_list = nullptr; uint32_t* d_gl2_count = nullptr; size_t gl2_redo_words = 0;
     uint32_t* d_errflag = nullptr;
     unsigned long long* d_redo_list = nullptr; uint32_t* d_redo_count = nullptr; uint32_t redo_cap = 0; uint32_t* d_redo_bits = nullptr;   // k_sample<2, deferred> -> k_redo
+    uint32_t* d_seg_list = nullptr;                                      // k_sample_seg<., 1> -> k_sample_seg<., 2>
     // beta chain of VGL_RNG_SERIAL with --error-qs 2 and the std beta sampler (vgl_betachain.hip); grow-only buffers
     long long* d_roff = nullptr; long long* d_rtotal = nullptr; double* d_errp_lin = nullptr; size_t errp_lin_cap = 0;
     uint32_t* d_cw = nullptr; uint8_t* d_ccons = nullptr; uint8_t* d_cexit = nullptr; int32_t* d_ccnt = nullptr; uint8_t* d_centry = nullptr;
@@ -325,7 +326,7 @@ extern "C" int vgl_ctx_destroy(vgl_ctx* c) {
     if (!c) return VGL_OK;
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_fslot, c->d_gl2_run, c->d_pois_zt, c->d_gl1_fk, c->d_gl1_beta, c->d_gamma_ln, c->d_samp_tab, c->d_qs_read_tab, c->d_pois, c->d_q2gl, c->d_gl1_bsum, c->d_gl1_lhet, c->d_reads, c->d_errp, c->d_ad4,
-                    c->d_adf4, c->d_qsum, c->d_qsumsq, c->d_acc, c->d_sinfo, c->d_rowmap, c->d_rowmap8, c->d_gl2_redo, c->d_gl2_list, c->d_gl2_count, c->d_errflag, c->d_dbg, c->d_redo_list, c->d_redo_count, c->d_redo_bits,
+                    c->d_adf4, c->d_qsum, c->d_qsumsq, c->d_acc, c->d_sinfo, c->d_rowmap, c->d_rowmap8, c->d_gl2_redo, c->d_gl2_list, c->d_gl2_count, c->d_errflag, c->d_dbg, c->d_redo_list, c->d_redo_count, c->d_redo_bits, c->d_seg_list,
                     c->d_serial, c->d_sst, c->d_site_thresh, c->d_scout_dp, c->d_site_tail, c->d_sdp, c->d_step_tab,
                     c->d_depth_tab, c->d_site_base, c->d_site_hash, c->d_dp_pre, c->d_hts_off, c->d_hts_base, c->d_roff, c->d_rtotal, c->d_errp_lin, c->d_cw, c->d_ccons, c->d_cexit,
                     c->d_ccnt, c->d_centry, c->d_cbase, c->d_cpos, c->d_csnap, c->d_csnapw, c->d_cctl};
@@ -385,6 +386,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     D.read_cap = (cap + 3) & ~3;
     if (hook_env("VGL_DEBUG_READ_CAP")) D.read_cap = (atoi(hook_env("VGL_DEBUG_READ_CAP")) + 3) & ~3;   // test hook: force the overflow path (a multiple of 4: staged reads are packed four per word)
     if (D.read_cap > 1023) { delete c; return fail(VGL_E_ARG, "mean depth too large for the staging layout"); }
+    int pool_want = 0; double pool_lmax = 0.0;
     {   // quality-score pool of one wavefront: the summed depth of its (up to) 64 samples
         double lmax = 0.0;
         for (int c0 = 0; c0 < N; c0 += 64) {
@@ -394,6 +396,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
         }
         int pc = (int)ceil(lmax + 8.0 * sqrt(lmax) + 64.0);
         pc = (pc + 63) & ~63;
+        pool_want = pc; pool_lmax = lmax;              // (the two-byte-item builds below take their own limit from these)
         if (pc > 1920) pc = 1920;                      // 520 + 5 x 1920 B per wavefront: 16 wavefronts (the 4 per SIMD the kernel is
                                                        // built for) fit a CU's 160 KB LDS; larger pools run in several segments
         D.pool_cap = pc;
@@ -505,7 +508,16 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
 #endif
         const int extra16 = (D.qsum_lds ? 1024 : 0) + (p->n_qs_bins ? 256 : 0);
         const int cap_defer = p16 ? ((5120 - 576 - 8 - (D.lean_ok ? (p->n_qs_bins ? 256 : 0) : 0)) / 2 / 64 * 64) : (D.qsum_lds ? 1416 : 1472);
+        // the float32 build of the default tag surface as two kernels (k_sample_seg, vgl_sample.hip) when a wavefront's reads fit one pool up to 8 sigma
+        // (a pool that holds the summed depth + 4.5 sigma: 3e-6 of the wavefronts go through the list)
+        D.seg_split = (p16 && (double)cap_defer >= pool_lmax + 4.5 * sqrt(pool_lmax) && !hook_env("VGL_NO_SEG_SPLIT")) ? 1 : 0;
+        // round 6: the two-byte-item builds take min(summed depth + 8 sigma, what eight wavefronts per SIMD leave) -- the five-byte limit of 1920 above
+        // was still applied first, so that depth 30 (mean 1920 reads per wavefront) ran half of its wavefronts in two segments
+        if (p16) D.pool_cap = pool_want;
         if (D.pool_cap > cap_defer) D.pool_cap = cap_defer;
+        if (hook_env("VGL_DEBUG_POOL_CAP")) { D.pool_cap = std::max(64, std::min(D.pool_cap, atoi(hook_env("VGL_DEBUG_POOL_CAP")) / 64 * 64)); if (hook_int("VGL_SEG_SPLIT", 0)) D.seg_split = p16 ? 1 : 0; }   // test hooks: small pools, the split forced on
+        D.seg_limit = hook_int("VGL_DEBUG_SEG_LIMIT", D.pool_cap);
+        if (D.seg_limit > D.pool_cap) D.seg_limit = D.pool_cap;
         D.pool_lds_bytes = p16 ? (((576 + 2 * (D.pool_cap + 2) + 7) & ~7) + extra16)
                                : (((576 + 4 * (D.pool_cap + 2) + D.pool_cap + 7) & ~7) + (D.qsum_lds ? 512 : 0));   // (vgl_launch_sample sizes the LDS of the build it launches)
     }
@@ -703,6 +715,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
         c->redo_cap /= VGL_REDO_PARTS;                                     // entries per partition (0 with a tiny VGL_DEBUG_REDO_CAP: every entry goes to the bitmap)
         TRY(dmalloc(&c->d_redo_list, std::max<size_t>(1, (size_t)c->redo_cap * VGL_REDO_PARTS)));
         TRY(dmalloc(&c->d_redo_count, (size_t)VGL_REDO_PARTS * VGL_REDO_STRIDE));
+        if (D.seg_split) TRY(dmalloc(&c->d_seg_list, (size_t)max_sites * D.chunks));
         TRYHIP(hipMemset(c->d_redo_count, 0, sizeof(uint32_t) * VGL_REDO_PARTS * VGL_REDO_STRIDE));
     }
     TRYHIP(hipMemset(c->d_errflag, 0, sizeof(uint32_t)));
@@ -845,6 +858,7 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     T.acc = c->d_acc; T.sinfo = c->d_sinfo; T.rowmap = c->d_rowmap; T.rowmap8 = c->d_rowmap8; T.gl2_redo = c->d_gl2_redo; T.gl2_redo_list = c->d_gl2_list; T.gl2_redo_count = c->d_gl2_count; T.errflag = c->d_errflag; T.dbg = c->d_dbg; T.dp_pre = c->d_dp_pre;
     T.site_base = c->d_site_base; T.site_hash = c->d_site_hash; T.fslot = c->d_fslot;
     T.redo_list = c->d_redo_list; T.redo_count = c->d_redo_count; T.redo_cap = c->redo_cap; T.redo_bits = c->d_redo_bits;
+    T.seg_list = c->d_seg_list;
     if (D.serial) {
         const size_t E = (size_t)c->max_sites * D.n_samples;
         T.sst_hap = c->d_sst; T.sst_base = c->d_sst + E; T.sdp = c->d_sdp;

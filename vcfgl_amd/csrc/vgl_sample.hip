@@ -107,7 +107,13 @@ __global__ __launch_bounds__(256) void k_depth(const VglDevParams P, const VglTi
 // score to the evaluation's quality sums and to the site totals, which took a placeholder of 0.  The eight quality sums of an owner
 // live only inside a segment's flush (stored, or added to what earlier segments stored, at its end) instead of across the pool loop.
 // LEAN 0 keeps the inline fallbacks: per-read dumps, beta shapes below 8, VGL_NO_DEFER.
-template <int EQS, bool DBG, int DM, bool PREC, int LEAN>
+// SEG (round 6): how a wavefront whose reads do not fit one pool is served.  0: the segment loop in this kernel (every build but the float32 build
+// of the default tag surface).  1 / 2: that build split in two kernels (k_sample_seg) -- 1 runs ONE segment and nothing else, a wavefront with more
+// reads than the pool holds (8 sigma of the summed depth: never seen at the bench configurations) appends its index to T.seg_list and leaves; 2 is
+// the segment loop, launched behind it over the listed wavefronts.  With the segment loop out of the way nothing of the owners' state (two stream
+// states, thresholds, alleles, per-base depths, pointers) lives across the pool loop, which is what the 64-register build spilled: 76 -> 0 bytes of
+// scratch per lane, 7.6 GB less traffic per 65536 x 1000 tile.
+template <int EQS, bool DBG, int DM, bool PREC, int LEAN, int SEG = 0>
 __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTilePtrs& T, const int64_t wave_index) {
     constexpr bool DEFER = (LEAN >= 2);
     // round 5: the deferred builds without --precise-gl 1 run their pool loop in float32 (vgl_common.hip.h, "the pool loop of k_sample<2>
@@ -144,7 +150,7 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
     const int s = wp.chunk * 64 + lane;
     const bool active = s < N;
     const size_t ev0 = (size_t)ls * N + (size_t)wp.chunk * 64;      // evaluation of lane 0
-    const size_t ev = ev0 + (active ? lane : 0);
+    size_t ev = ev0 + (active ? lane : 0);                          // (SEG 1 forms it again behind the pool loop instead of carrying two registers across it)
     const size_t plane = (size_t)T.n_sites * N;
 
     int dp = 0, a0 = 0, a1 = 0;
@@ -333,7 +339,7 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
         uint8_t* reads_v = T.reads;
         uint8_t* reads_out_v = DUMP ? T.reads_out : nullptr;
         int reads_out_cap_v = (DUMP && T.reads_out) ? T.reads_out_cap : 0;
-        if (!DUMP) asm volatile("" : "+v"(reads_v));
+        if (!DUMP) { if constexpr (SEG != 1) asm volatile("" : "+v"(reads_v)); }
         else asm volatile("" : "+v"(reads_v), "+v"(reads_out_v), "+v"(reads_out_cap_v));
 
         const bool homw = __ballot(active && dp > 0 && a0 != a1) == 0;   // every evaluation of the wavefront with reads is homozygous
@@ -766,6 +772,7 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+            if constexpr (SEG == 1) { uint32_t l2 = (uint32_t)lane; asm volatile("" : "+v"(l2)); ev = ev0 + (active ? (size_t)l2 : 0); }
             if (DBG) { const unsigned long long c = clock64(); c_pool += c - c_tmp; c_tmp = c; }
             if (DBG && P.dbg_phase == 3) return true;
             if (!P16 && qfast && k_qsum) {                              // the pool loop is done with l_stq: zero the 64 x 4 sum words
@@ -851,6 +858,10 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                 // the pool loop has left every read's staged byte in the low byte of its 16-bit slot (bit 8: undecided): two (unaligned)
                 // 32-bit LDS reads per word of four reads, the four bytes picked by one v_perm_b32, masked to the reads of this segment
                 const uint8_t* const it8 = (const uint8_t*)l_it;
+                // (SEG 1: the pointer is taken from the kernel arguments HERE -- pinned in vector registers ahead of the segment it was the one
+                //  value the build still carried across the pool loop in scratch)
+                uint8_t* reads_f = reads_v;
+                if constexpr (SEG == 1) { reads_f = T.reads; asm volatile("" : "+v"(reads_f)); }
                 for (int r0 = rdone & ~3; r0 < r_end; r0 += 4) {
                     uint32_t w_lo, w_hi;
                     __builtin_memcpy(&w_lo, it8 + 2 * (offs + r0 - seg0), 4);   // slots before / after the lane's reads are masked below
@@ -859,7 +870,7 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                     const int lo = rdone > r0 ? rdone - r0 : 0, hi = r_end - r0 < 4 ? r_end - r0 : 4;
                     const uint32_t mask = (0xFFFFFFFFu << (8 * lo)) & (0xFFFFFFFFu >> (8 * (4 - hi)));
                     const uint32_t rw = (w4 & mask) | ((r0 < rdone) ? carry_w : 0u);
-                    ((uint32_t*)reads_v)[(size_t)(r0 >> 2) * plane + ev] = rw;
+                    ((uint32_t*)reads_f)[(size_t)(r0 >> 2) * plane + ev] = rw;
                     carry_w = rw;
                     uint32_t und4 = __builtin_amdgcn_perm(w_hi, w_lo, 0x07050301u) & mask & 0x01010101u;   // the slots' high bytes: bit 0 = undecided
                     if (__builtin_expect(und4 != 0u, 0)) {
@@ -969,10 +980,21 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
         };
         // (measured, same box: the two-instance form -3.6 % for LEAN 3 -- 10.25 -> 9.89 ms at qsi16 -- and +2.7 % for LEAN 2, whose single instance
         //  at 64 VGPRs the allocator already serves best: profiles/r05_ab/ab_single.txt)
+        if constexpr (SEG == 1) {
+            if (total > P.seg_limit) {                                  // (P.seg_limit = the pool's capacity; a test hook lowers it)
+                if (lane == 0) T.seg_list[atomicAdd(T.redo_count + 1, 1u)] = (uint32_t)wave_index;     // redo_count[1]: zeroed with the redo counters before every tile
+                return;
+            }
+            if (total > 0) { if (run_segment(std::true_type{}, 0)) return; }
+        } else if constexpr (SEG == 2) {
+            for (int seg0 = 0; seg0 < total; seg0 += seglen) { if (run_segment(std::false_type{}, seg0)) return; }
+        } else {
         if (LEAN >= 3 && nseg <= 1) { if (total > 0) { if (run_segment(std::true_type{}, 0)) return; } }
         else for (int seg0 = 0; seg0 < total; seg0 += seglen) { if (run_segment(std::false_type{}, seg0)) return; }
+        }
     }
 
+    if constexpr (SEG == 1) { uint32_t l3 = (uint32_t)lane; asm volatile("" : "+v"(l3)); ev = ev0 + (active ? (size_t)l3 : 0); }    // (as behind the pool loop)
     if (active) {
         if (!k_strand) adf4 = ad4;
         if (T.fmt_dp) T.fmt_dp[ev] = dp;
@@ -1036,6 +1058,23 @@ template <int EQS, bool DBG, int DM, bool PREC, int LEAN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? VGL_SAMPLE_WAVES(EQS, PREC, LEAN) : 1, VGL_SAMPLE_WAVES(EQS, PREC, LEAN)))) void k_sample(const VglDevParams P, const VglTilePtrs T) {
     // (one 64-sample chunk per launched wavefront: several chunks per wavefront, one after the other, measured slower -- docs/tried.md)
     k_sample_body<EQS, DBG, DM, PREC, LEAN>(P, T, (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
+}
+
+// the float32 build of the default tag surface (k_sample<2, false, DM, false, 2>) as two kernels: SEG 1 = one pool segment per wavefront, SEG 2 = the
+// segment loop over the wavefronts SEG 1 listed (k_sample_body, SEG)
+// (eight wavefronts per SIMD for the optional-tag builds too: without the segment loop LEAN 3 / 4 need 68-69 registers, and at 64 they measure 2.5-3 % faster
+//  than at 72 -- qsi16 9.40 -> 9.15 ms, alltags 9.58 -> 9.31, same box: profiles/r06_ab/ab_seg_split.txt)
+template <int DM, int SEG, int LEAN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VGL_SAMPLE_WAVES_F32, VGL_SAMPLE_WAVES_F32))) void k_sample_seg(const VglDevParams P, const VglTilePtrs T) {
+    if constexpr (SEG == 1) k_sample_body<2, false, DM, false, LEAN, 1>(P, T, (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
+    else {
+        const uint32_t n = __builtin_amdgcn_readfirstlane(T.redo_count[1]);
+        for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {          // (one wavefront per workgroup)
+            k_sample_body<2, false, DM, false, LEAN, 2>(P, T, (int64_t)T.seg_list[i]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1180,6 +1219,15 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
             VGL_STATIC_LDS(false, 0, true, 3) VGL_STATIC_LDS(false, 1, true, 3) VGL_STATIC_LDS(false, 2, true, 3)
             VGL_STATIC_LDS(false, 0, false, 4) VGL_STATIC_LDS(false, 1, false, 4) VGL_STATIC_LDS(false, 2, false, 4)
 #undef VGL_STATIC_LDS
+#define VGL_STATIC_LDS_SEG(DM, SEG) \
+            if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_sample_seg<DM, SEG, 2>)) != hipSuccess) return false; \
+            worst = a.sharedSizeBytes > worst ? a.sharedSizeBytes : worst; \
+            if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_sample_seg<DM, SEG, 3>)) != hipSuccess) return false; \
+            worst = a.sharedSizeBytes > worst ? a.sharedSizeBytes : worst; \
+            if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_sample_seg<DM, SEG, 4>)) != hipSuccess) return false; \
+            worst = a.sharedSizeBytes > worst ? a.sharedSizeBytes : worst;
+            VGL_STATIC_LDS_SEG(0, 1) VGL_STATIC_LDS_SEG(1, 1) VGL_STATIC_LDS_SEG(2, 1) VGL_STATIC_LDS_SEG(0, 2) VGL_STATIC_LDS_SEG(1, 2) VGL_STATIC_LDS_SEG(2, 2)
+#undef VGL_STATIC_LDS_SEG
             return worst == 0;
         }();
         if (!static_lds_free) return (int)hipErrorInvalidConfiguration;
@@ -1190,7 +1238,17 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
         if (t->errp && sample_deferred(p, t)) { if (lean) VGL_LAUNCH_SAMPLE(2, false, true, 2, lds); else VGL_LAUNCH_SAMPLE(2, false, true, 3, lds); }   // --precise-gl 1: the deferred builds, k_redo (vgl_launch_redo) also rewrites errp
         else if (t->errp) { if (lean) VGL_LAUNCH_SAMPLE(2, false, true, 1, lds); else VGL_LAUNCH_SAMPLE(2, false, true, 0, lds); }   // --precise-gl 1, or the deviates were asked for
         else if (sample_deferred(p, t)) {
-            if (lean) VGL_LAUNCH_SAMPLE(2, false, false, 2, lds16);
+            // one segment per wavefront, then the segment loop over what that kernel listed (nothing, at the bench configurations)
+            const dim3 g2((unsigned)(waves < 1024 ? waves : 1024));
+#define VGL_LAUNCH_SEG(LEAN, LDS) \
+            do { if (dm == 1) { hipLaunchKernelGGL((k_sample_seg<1, 1, LEAN>), g, b, LDS, s, *p, *t); hipLaunchKernelGGL((k_sample_seg<1, 2, LEAN>), g2, b, LDS, s, *p, *t); } \
+                 else if (dm == 2) { hipLaunchKernelGGL((k_sample_seg<2, 1, LEAN>), g, b, LDS, s, *p, *t); hipLaunchKernelGGL((k_sample_seg<2, 2, LEAN>), g2, b, LDS, s, *p, *t); } \
+                 else { hipLaunchKernelGGL((k_sample_seg<0, 1, LEAN>), g, b, LDS, s, *p, *t); hipLaunchKernelGGL((k_sample_seg<0, 2, LEAN>), g2, b, LDS, s, *p, *t); } } while (0)
+            const bool split = p->seg_split && t->seg_list;
+            if (lean && split) VGL_LAUNCH_SEG(2, lds16);
+            else if (!lean && split && p->adjust_qs == 0 && p->sample_strand && p->need_qsum) VGL_LAUNCH_SEG(4, lds16x);
+            else if (!lean && split) VGL_LAUNCH_SEG(3, lds16x);
+            else if (lean) VGL_LAUNCH_SAMPLE(2, false, false, 2, lds16);
             else if (p->adjust_qs == 0 && p->sample_strand && p->need_qsum) VGL_LAUNCH_SAMPLE(2, false, false, 4, lds16x);      // LEAN 3 with its three options fixed
             else VGL_LAUNCH_SAMPLE(2, false, false, 3, lds16x);
         }
