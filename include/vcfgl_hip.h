@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define VGL_ABI_VERSION 5
+#define VGL_ABI_VERSION 6
 /* the library is built with -fvisibility=hidden: these entry points are its whole dynamic symbol table */
 #define VGL_API __attribute__((visibility("default")))
 
@@ -314,6 +314,36 @@ typedef struct vgl_ctx_info_t {
     int64_t rng_tile_max_sites;  /* VGL_RNG_TILE: sites [0, this) are addressable (vgl_rng_tile_max_sites); 0 in serial mode */
 } vgl_ctx_info_t;
 VGL_API int vgl_ctx_info(const vgl_ctx* ctx, vgl_ctx_info_t* out);
+
+/* ---- record packing on the device (ABI 6) ---------------------------------------------------------------------------------
+ * The reference writes one record at a time with bcf_write (vcfgl.cpp:167-206) from the arrays simRecord::add_tags() filled
+ * (bcf_utils.cpp:426-507: of every FORMAT tag only the record's nGenotypes / nAlleles values per sample).  With the sites of a job
+ * sharded over the GPUs of a node, each rank hands the writer its kept sites in that form -- skipped sites (site_status < 0) dropped,
+ * nG(site) = nA (nA + 1) / 2 planes of GL / PL / GP and nA(site) planes of AD / ADF / ADR -- and these two calls are the producer side
+ * of that gather: an exclusive prefix sum over the tile's sites, then coalesced row copies (every byte read once, written once).
+ * Every pointer but `totals` is device memory of `device`; work is enqueued on `hip_stream`.
+ *
+ *   vgl_pack_plan_device     offsets: int32 [3][n_sites + 1] -- row c = exclusive prefix sums of the rows a site contributes to a field of
+ *                            kind c (VGL_PACK_ROW: 1 per kept site; _ROWS_G: nG(site); _ROWS_A: nA(site)), entry [n_sites] = the total.
+ *                            The three totals also come back to the host (the caller sizes the packed arrays from them): synchronises the stream.
+ *   vgl_pack_records_device  index_out: int32 [n_kept][3] = (site index in the tile, site_status, n_alleles) of the kept sites (may be NULL);
+ *                            field f: the rows of src -- [n_sites][planes] rows of row_bytes bytes -- that belong to records, in site order,
+ *                            into dst (sized from the plan: total rows of its kind x row_bytes).  Asynchronous. */
+#define VGL_PACK_ROW    0   /* one row per site: per-site vectors and FORMAT tags with one value per sample (planes = 1) */
+#define VGL_PACK_ROWS_G 1   /* a [site][planes][N] array of which a record keeps its nGenotypes(site) first planes        */
+#define VGL_PACK_ROWS_A 2   /* ... its nAlleles(site) first planes                                                       */
+typedef struct vgl_pack_field {
+    const void* src;
+    void*       dst;
+    int32_t     kind;        /* VGL_PACK_*                                   */
+    int32_t     planes;      /* rows per site in src                         */
+    int64_t     row_bytes;   /* bytes of one row (N x element size, or the per-site vector) */
+} vgl_pack_field;
+typedef struct vgl_pack_plan { int64_t n_kept, rows_g, rows_a; } vgl_pack_plan;
+VGL_API int vgl_pack_plan_device(int32_t device, int32_t n_sites, const int32_t* site_status, const int32_t* n_alleles, int32_t* offsets,
+                                 vgl_pack_plan* totals, void* hip_stream);
+VGL_API int vgl_pack_records_device(int32_t device, int32_t n_sites, const int32_t* site_status, const int32_t* n_alleles, const int32_t* offsets,
+                                    int32_t* index_out, const vgl_pack_field* fields, int32_t n_fields, void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -6,7 +6,7 @@ not been built -- the product path never falls back to a CPU implementation.
 import ctypes as C
 import os
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 VGL_OK = 0
 VGL_E_ARG, VGL_E_NODEVICE, VGL_E_NOMEM, VGL_E_CAPACITY, VGL_E_UNSUPPORTED, VGL_E_QSBIN, VGL_E_ADJQ = -1, -2, -3, -4, -5, -6, -7
@@ -89,7 +89,18 @@ EXPORTS = [
     "vgl_last_error", "vgl_ctx_create", "vgl_ctx_destroy", "vgl_simulate_tile",
     "vgl_simulate_tile_device", "vgl_ctx_check", "vgl_ctx_timing", "vgl_ctx_kernel_ms", "vgl_rng_tile_max_sites", "vgl_rng_tile_site_hash",
     "vgl_simulate_tile_async", "vgl_tile_wait", "vgl_host_alloc", "vgl_host_alloc_on", "vgl_host_free", "vgl_ctx_info",
+    "vgl_pack_plan_device", "vgl_pack_records_device",
 ]
+VGL_PACK_ROW, VGL_PACK_ROWS_G, VGL_PACK_ROWS_A = 0, 1, 2
+
+
+class PackField(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("kind", C.c_int32), ("planes", C.c_int32), ("row_bytes", C.c_int64)]
+
+
+class PackPlan(C.Structure):
+    _fields_ = [("n_kept", C.c_int64), ("rows_g", C.c_int64), ("rows_a", C.c_int64)]
+
 # entry points of the -DVGL_TEST_HOOKS build only (lib/libvcfgl_hip_hooks.so): never in the shipped library
 HOOK_EXPORTS = ["vgl_dbg_bound_sweep", "vgl_dbg_chain", "vgl_dbg_redo_count", "vgl_dbg_site_base", "vgl_dbg_stamps", "vgl_dbg_vlog"]
 
@@ -144,6 +155,8 @@ def load_library(hooks=False):
     lib.vgl_ctx_timing.argtypes = [C.c_void_p, C.c_int32]
     lib.vgl_ctx_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32, C.c_int32]
     lib.vgl_ctx_info.argtypes = [C.c_void_p, C.POINTER(CtxInfo)]
+    lib.vgl_pack_plan_device.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PackPlan), C.c_void_p]
+    lib.vgl_pack_records_device.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PackField), C.c_int32, C.c_void_p]
     if lib.vgl_abi_version() != ABI_VERSION:
         raise RuntimeError("libvcfgl_hip.so ABI version mismatch")
     _LIB[hooks] = lib

@@ -34,6 +34,7 @@ static int hook_int(const char* name, int dflt) { const char* v = hook_env(name)
 
 extern "C" const char* vgl_last_error(void) { return g_err; }
 extern "C" int vgl_abi_version(void) { return VGL_ABI_VERSION; }
+extern "C" int vgl_pack_set_error(int code, const char* msg);      // (vgl_pack.hip reports through vgl_last_error() too; not exported)
 
 // PROGRAM_WILL_ADD_UNOBSERVED (shared.h:151-152): <*> / <NON_REF> appended => 5 alleles
 extern "C" int32_t vgl_max_alleles(const vgl_params* p) {
@@ -754,6 +755,8 @@ extern "C" int vgl_ctx_kernel_ms(vgl_ctx* c, double* ms, int64_t* launches, int3
     if (reset) for (int k = 0; k < VGL_N_TIMING_BUCKETS; k++) { c->ms[k] = 0; c->launches[k] = 0; }
     return VGL_OK;
 }
+
+extern "C" int vgl_pack_set_error(int code, const char* msg) { return fail(code, "%s", msg); }
 
 // what this context launches (include/vcfgl_hip.h: vgl_ctx_info_t)
 extern "C" int vgl_ctx_info(const vgl_ctx* c, vgl_ctx_info_t* out) {

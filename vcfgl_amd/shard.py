@@ -107,10 +107,68 @@ def _rows_per_site(field_name: str, n_alleles: torch.Tensor) -> torch.Tensor:
     return na * (na + 1) // 2 if _KIND[field_name] == "planeG" else na
 
 
+def _pack_records_device(tile: Dict[str, torch.Tensor], site0: int) -> PackedRecords:
+    """pack_records() for a tile in device memory: the library's own kernels (vgl_pack_plan_device + vgl_pack_records_device, csrc/vgl_pack.hip:
+    one prefix sum over the sites, then coalesced row copies) on the current stream of the tile's device.  No fallback: without the library this raises."""
+    import ctypes as C
+    lib = _abi.load_library()
+    status, n_alleles = tile["site_status"], tile["n_alleles"]
+    dev = status.device
+    S = int(status.shape[0])
+    if status.dtype != torch.int32 or n_alleles.dtype != torch.int32 or not status.is_contiguous() or not n_alleles.is_contiguous():
+        raise ValueError("site_status / n_alleles must be contiguous int32 tensors")
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
+
+    def check(rc):
+        if rc != 0:
+            raise RuntimeError(f"libvcfgl_hip: {lib.vgl_last_error().decode(errors='replace')} (code {rc})")
+
+    offsets = torch.empty((3, S + 1), dtype=torch.int32, device=dev)
+    plan = _abi.PackPlan()
+    check(lib.vgl_pack_plan_device(dev_index, S, status.data_ptr(), n_alleles.data_ptr(), offsets.data_ptr(), C.byref(plan), stream))
+    totals = {_abi.VGL_PACK_ROW: int(plan.n_kept), _abi.VGL_PACK_ROWS_G: int(plan.rows_g), _abi.VGL_PACK_ROWS_A: int(plan.rows_a)}
+    index = torch.empty((totals[_abi.VGL_PACK_ROW], 3), dtype=torch.int32, device=dev)
+    p = PackedRecords(site0=int(site0), n_samples=0, index=index)
+    descr = []
+    N = 0
+    for name, t in tile.items():
+        if name in ("site_status", "n_alleles") or t is None:
+            continue
+        if not t.is_contiguous():
+            raise ValueError(f"{name}: the tile's arrays must be contiguous")
+        kind = _KIND[name]
+        if kind in ("site", "site5", "siteA", "site16", "eval"):
+            k, planes, tail = _abi.VGL_PACK_ROW, 1, tuple(t.shape[1:])
+            out = torch.empty((totals[k],) + tail, dtype=t.dtype, device=dev)
+            (p.per_eval if kind == "eval" else p.per_site)[name] = out
+            if kind == "eval":
+                N = int(t.shape[1])
+            row_bytes = (int(t.numel()) // max(S, 1)) * t.element_size()
+        else:                                                    # planeG / planeA: [S, K, N]
+            k = _abi.VGL_PACK_ROWS_G if kind == "planeG" else _abi.VGL_PACK_ROWS_A
+            planes, N = int(t.shape[1]), int(t.shape[2])
+            out = torch.empty((totals[k], N), dtype=t.dtype, device=dev)
+            p.planes[name] = out
+            row_bytes = N * t.element_size()
+        if out.numel() and S:
+            descr.append(_abi.PackField(t.data_ptr(), out.data_ptr(), k, planes, row_bytes))
+    p.n_samples = N
+    if S:
+        arr = (_abi.PackField * max(len(descr), 1))(*descr)
+        check(lib.vgl_pack_records_device(dev_index, S, status.data_ptr(), n_alleles.data_ptr(), offsets.data_ptr(),
+                                          index.data_ptr() if index.numel() else None, arr, len(descr), stream))
+    p._keepalive = (offsets,)                                    # (the kernels read it after this function has returned)
+    return p
+
+
 def pack_records(tile: Dict[str, torch.Tensor], site0: int = 0) -> PackedRecords:
     """`tile`: {field name of vgl_tile_out: tensor} of one simulated tile; site_status and n_alleles are required.
-    Runs on the tensors' device."""
+    A tile in device memory is packed by the library's kernels (_pack_records_device: hand-written HIP behind the C ABI); the torch
+    formulation below serves host tensors only (the CPU rehearsals of the N-rank path, where the oracle stands in for the kernels)."""
     status, n_alleles = tile["site_status"], tile["n_alleles"]
+    if status.is_cuda:
+        return _pack_records_device(tile, site0)
     S = int(status.shape[0])
     kept = status >= 0
     rows = kept.nonzero().squeeze(1)
