@@ -38,6 +38,75 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E vendor peak (MI355X_MICROARCH.md)
 # faster (2.6 measured), so a kernel made of them -- the float32 pool loop of round 5 -- can read ABOVE 1.0 against this peak: the line
 # says so (`valu_peak_note`) instead of pretending a second roof it has not measured.
 VALU_PEAK_WAVE_INST_PER_S = 1024 * 2.4e9 / 4.0
+N_SIMD = 1024                  # 256 CUs x 4
+SCLK_NOMINAL_MHZ = 2400.0
+DTYPE = "f64 (f32-filtered decisions, f64 fallback)"     # every result is the reference's double arithmetic; float32 only DECIDES where an explicit bound says it can
+ORACLE_PIN = {"c2": "n<=3 goldens + model definition", "gl1q": "n<=3 goldens + model definition"}   # GL model 1 = htslib errmod, not in the reference tree
+
+
+class ClockSampler:
+    """sclk / mclk of one GPU sampled from sysfs (pp_dpm_sclk / pp_dpm_mclk of the device's PCI function: the starred level) every 20 ms
+    while the timed steps run -- a box-to-box difference of the headline (round 5: 9 % on the depth-5 configuration) is then visible in the line."""
+
+    def __init__(self, torch_device):
+        self.paths, self.samples, self._stop, self._thr = None, {"sclk": [], "mclk": []}, None, None
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(torch_device)
+            bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            base = os.path.join("/sys/bus/pci/devices", bdf)
+            if os.path.exists(os.path.join(base, "pp_dpm_sclk")):
+                self.paths = {"sclk": os.path.join(base, "pp_dpm_sclk"), "mclk": os.path.join(base, "pp_dpm_mclk")}
+        except Exception:
+            self.paths = None
+
+    @staticmethod
+    def _starred(path):
+        for l in open(path):
+            if "*" in l:
+                return float(l.split(":")[1].strip().split("M")[0])
+        return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            for k, pth in self.paths.items():
+                try:
+                    v = self._starred(pth)
+                    if v:
+                        self.samples[k].append(v)
+                except Exception:
+                    pass
+            self._stop.wait(0.02)
+
+    def start(self):
+        import threading
+        if self.paths:
+            self.samples = {"sclk": [], "mclk": []}
+            self._stop = threading.Event()
+            self._thr = threading.Thread(target=self._run, daemon=True)
+            self._thr.start()
+
+    def stop(self):
+        if self._thr is not None:
+            self._stop.set()
+            self._thr.join(timeout=1.0)
+            self._thr = None
+        out = {"source": os.path.dirname(self.paths["sclk"]) if self.paths else "unavailable"}
+        for k in ("sclk", "mclk"):
+            v = sorted(self.samples[k])
+            out[k + "_mhz"] = v[len(v) // 2] if v else None
+            out[k + "_mhz_min"] = v[0] if v else None
+        out["samples"] = len(self.samples["sclk"])
+        return out
+
+
+def issue_roof_entry(workload):
+    """profiles/issue_roof.json (tools/isa_hist.py + the replay of the kernel's hot loop on the GPU box): SIMD cycles per vector instruction of the
+    dominant kernel's instruction mix"""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "issue_roof.json"))).get(workload, {})
+    except Exception:
+        return {}
 
 RTA3 = [(0, 2, 2), (3, 14, 12), (15, 30, 23), (31, 40, 37)]
 WORKLOADS = {
@@ -235,7 +304,7 @@ class _HostStream:
         pass
 
 
-def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_cpu=False, gather="index", early=None):
+def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_cpu=False, gather="index", early=None, strict=True):
     """K timed passes of the hot path over one workload; returns the result dictionary (rank 0) or None.
     `early(res)`: called on rank 0 as soon as the timed value exists, BEFORE anything that is allowed to fail or stall afterwards
     (the sampled record gather over RCCL): the line is on stdout by then."""
@@ -367,6 +436,9 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
                 log(f"--gather records: the writer needs about {need / 1e9:.1f} GB for the peers' packed tiles but has {free / 1e9:.1f} GB free: "
                     f"use a smaller --tile-sites, fewer --sites, or --gather sample")
             dist.barrier()
+            if not strict:                                         # (the short record-gather leg of a default N-rank run: reported, never fatal)
+                sim.close()
+                raise RuntimeError(f"the writer needs about {need / 1e9:.1f} GB for the peers' packed tiles, {free / 1e9:.1f} GB free")
             sys.exit(3)
 
     def barrier():
@@ -385,11 +457,15 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
     gathered_bytes[0] = 0
     for k in comm:
         comm[k] = 0
+    clocks = ClockSampler(dev) if (on_gpu and rank == 0) else None
+    if clocks:
+        clocks.start()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    clk = clocks.stop() if clocks else None
     sim.check(stream.cuda_stream)
     kms, klaunch = sim.kernel_ms(reset=True)
     sim.timing(False)
@@ -427,10 +503,23 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
                     "valu_insts_per_wave": kprof["valu_insts_per_wave"], "waves_per_launch": waves,
                     "valu_busy_frac_pmc": kprof.get("valu_busy_frac"), "source": src, "profile_matches_build": fresh,
                     "peak_note": "1024 SIMDs x 2.4 GHz / 4 cycles per wavefront instruction (float64 / three-operand class); two-operand 32-bit forms issue in ~2.6, so float32 kernels can exceed 1.0"}
+        # instruction-issue roof (round 6): SIMD cycles the kernel's vector instructions need = instructions per wavefront (committed counters) x the
+        # cycles per instruction of its hot loop's mix, measured by replaying that loop on the box (profiles/issue_roof.json) / (1024 SIMDs x sclk)
+        issue = None
+        ir = issue_roof_entry(name)
+        if kprof.get("valu_insts_per_wave") and ir.get("issue_cycles_per_inst") and ir.get("kernel", KERNELS[dom]).startswith(KERNELS[dom]):
+            sclk_mhz = (clk or {}).get("sclk_mhz") or SCLK_NOMINAL_MHZ
+            bound_ms = waves * kprof["valu_insts_per_wave"] * ir["issue_cycles_per_inst"] / (N_SIMD * sclk_mhz * 1e6) * 1e3
+            issue = {"issue_cycles_per_inst": ir["issue_cycles_per_inst"], "issue_bound_ms": bound_ms, "issue_frac": bound_ms / avg_ms, "sclk_mhz_used": sclk_mhz,
+                     "valu_insts_per_wave": kprof["valu_insts_per_wave"], "waves_per_launch": waves, "method": ir.get("method"), "source": ir.get("source"),
+                     "profile_matches_build": fresh and ir.get("src_sha") == source_sha()}
         traffic = kprof.get("hbm_bytes_per_launch") * scale if kprof.get("hbm_bytes_per_launch") else None
         traffic_frac = (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None
         busy = kprof.get("valu_busy_frac")
-        if traffic_frac is not None and busy is not None:
+        if issue is not None and traffic_frac is not None:
+            bound = "hbm" if traffic_frac >= issue["issue_frac"] else "valu"
+            basis = f"dominant kernel: HBM traffic {traffic_frac:.2f} of peak, instruction issue {issue['issue_frac']:.2f} of its roof"
+        elif traffic_frac is not None and busy is not None:
             bound = "hbm" if traffic_frac >= busy else "valu"
             basis = f"PMC of the dominant kernel: HBM traffic {traffic_frac:.2f} of peak, VALU pipes {busy:.2f} busy"
         else:
@@ -449,7 +538,7 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
                          "traffic_source": src if kprof else None,
                          "step": {"achieved": step_gbs, "frac": step_gbs / HBM_PEAK_GBS, "unit": "GB/s",
                                   "note": "algorithmic bytes of one step / wall time of one step on this GPU"},
-                         "valu": valu, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_eval": b_eval,
+                         "valu": valu, "issue": issue, "clocks": clk, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_eval": b_eval,
                          "kernel_ms_total": dict(zip(KERNELS, kms)), "launches": dict(zip(KERNELS, klaunch))},
         }
         if per_rank is not None:
@@ -476,9 +565,17 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
         # AFTER the timed steps and after rank 0 has printed the line: a failure is reported in `comm`, a stall ends the run with the
         # line already on stdout (the first 8-GPU run is the first time these point-to-point transfers execute over xGMI)
         def stalled():
-            log(f"rank {rank}: sampled record gather stalled for more than {opt.comm_timeout:g} s: ending the run; the line already printed stands")
+            # the line is already on stdout (`early`); rank 0 prints it once more, last, with records_sample "stalled", and every rank ends with a
+            # non-zero code: a hung point-to-point transfer must not read as a clean run
+            log(f"rank {rank}: sampled record gather stalled for more than {opt.comm_timeout:g} s: ending the run (exit 15); the line already printed stands")
+            if res is not None and early is not None:
+                try:
+                    res["comm"]["records_sample"] = "stalled"
+                    early(res)
+                except Exception:
+                    pass
             sys.stdout.flush(); sys.stderr.flush()
-            os._exit(0)
+            os._exit(15)
         dog = threading.Timer(opt.comm_timeout, stalled)
         dog.daemon = True
         dog.start()
@@ -622,16 +719,19 @@ def _r(x, nd=4):
 
 def compact_roofline(rf):
     v = rf.get("valu") or {}
+    iss = rf.get("issue") or {}
     out = {"bound": rf["bound"], "kernel": rf["kernel"], "achieved": _r(rf["achieved"], 5), "peak": rf["peak"], "unit": rf["unit"], "frac": _r(rf["frac"], 4),
            "traffic": _r(rf.get("traffic"), 5), "traffic_frac_of_peak": _r(rf.get("traffic_frac_of_peak")),
            "traffic_source": (rf.get("traffic_source") or "").split(" ")[0] or None,
            "avg_launch_ms": _r(rf["avg_launch_ms"], 5), "algorithmic_bytes_per_eval": rf["algorithmic_bytes_per_eval"],
            "step_frac": _r(rf["step"]["frac"]), "step_GBps": _r(rf["step"]["achieved"], 5),
-           "valu_frac": _r(v.get("frac")),
-           "valu_busy_pmc": _r(v.get("valu_busy_frac_pmc")), "valu_insts_per_wave": _r(v.get("valu_insts_per_wave"), 5),
+           "issue_frac": _r(iss.get("issue_frac")), "issue_cycles_per_inst": _r(iss.get("issue_cycles_per_inst")), "issue_bound_ms": _r(iss.get("issue_bound_ms"), 5),
+           "valu_insts_per_wave": _r(v.get("valu_insts_per_wave"), 5),
+           "sclk_mhz": (rf.get("clocks") or {}).get("sclk_mhz"), "mclk_mhz": (rf.get("clocks") or {}).get("mclk_mhz"), "sclk_mhz_min": (rf.get("clocks") or {}).get("sclk_mhz_min"),
            "profile_matches_build": v.get("profile_matches_build"),
            "kernel_ms_per_launch": {k: _r(rf["kernel_ms_total"][k] / max(rf["launches"][k], 1)) for k in rf["kernel_ms_total"] if rf["launches"][k]},
-           "note": "achieved/frac = algorithmic bytes of the dominant kernel / its HIP-event time; bound valu = instruction issue (valu_frac: of 1024 SIMD x 2.4 GHz / 4 cycles; 32-bit forms issue faster, >1 possible)"}
+           "note": "achieved/frac = algorithmic bytes of the dominant kernel / its HIP-event time; bound valu = instruction issue: issue_frac = (vector instructions per wavefront x "
+                   "cycles per instruction of the kernel's loop, replayed on the box: profiles/issue_roof.json) / (1024 SIMD x sclk) / launch time"}
     if "copy_bw_measured" in rf:
         out["copy_bw_measured"] = _r(rf["copy_bw_measured"], 5)
     return out
@@ -643,7 +743,7 @@ def compact_line(main_res, extra, opt, world, metric, dist_info=None):
     line = {
         "metric": metric, "value": main_res["value"], "unit": main_res["unit"],
         "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": _r(main_res["ms_per_step"], 6),
-        "higher_is_better": True, "scaling": opt.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "higher_is_better": True, "scaling": opt.scaling, "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": main_res["workload"][:200], "tile_sites": opt.tile_sites,
                    "parallelism": f"site-sharded x{world}"},
         "roofline": compact_roofline(main_res["roofline"]),
@@ -669,8 +769,16 @@ def compact_line(main_res, extra, opt, world, metric, dist_info=None):
         line["records_gather"] = {k: _r(v, 5) for k, v in main_res["records_gather"].items()}
     if "record_packing" in main_res:
         line["record_packing_GBps"] = _r(main_res["record_packing"]["GBps"], 5)
+    if "value_with_record_gather" in main_res:
+        line["value_with_record_gather"] = _r(main_res["value_with_record_gather"], 6)
+        line["record_gather_leg"] = {k: (_r(v, 5) if not isinstance(v, str) else v[:200]) for k, v in main_res["record_gather_leg"].items()}
+    elif "record_gather_leg" in main_res:
+        line["record_gather_leg"] = {k: (_r(v, 5) if not isinstance(v, str) else v[:200]) for k, v in main_res["record_gather_leg"].items()}
     if extra:
         line["extra"] = {k: (_r(v.get("value"), 5) if isinstance(v, dict) and "value" in v else "error") for k, v in extra.items() if v is not None}
+        pins = {k: ORACLE_PIN[k] for k in extra if k in ORACLE_PIN}
+        if pins:
+            line["extra_oracle_pin"] = pins
         line["extra_detail"] = "line `bench_extra` above + " + os.path.relpath(detail_path(opt), ROOT)
     return line
 
@@ -686,8 +794,10 @@ def compact_extra(extra):
         elif "roofline" in v:
             rf = v["roofline"]
             out[k] = {"value": _r(v["value"], 5), "ms_per_step": _r(v["ms_per_step"], 5), "steps": v["steps"], "kernel": rf["kernel"], "bound": rf["bound"],
-                      "frac": _r(rf["frac"]), "step_frac": _r(rf["step"]["frac"]), "valu_frac": _r((rf.get("valu") or {}).get("frac")),
-                      "avg_launch_ms": _r(rf["avg_launch_ms"], 5), "B_eval": rf["algorithmic_bytes_per_eval"]}
+                      "frac": _r(rf["frac"]), "step_frac": _r(rf["step"]["frac"]), "issue_frac": _r((rf.get("issue") or {}).get("issue_frac")),
+                      "avg_launch_ms": _r(rf["avg_launch_ms"], 5), "B_eval": rf["algorithmic_bytes_per_eval"], "sclk_mhz": (rf.get("clocks") or {}).get("sclk_mhz")}
+            if k in ORACLE_PIN:
+                out[k]["oracle_pin"] = ORACLE_PIN[k]
         else:
             out[k] = {"value": _r(v.get("value"), 5), "GBps_over_pcie": _r(v.get("GBps_over_pcie")),
                       "sync_pageable": _r((v.get("sync_pageable") or {}).get("value"), 5)}
@@ -810,6 +920,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the other configurations attached as `extra`")
     ap.add_argument("--no-pack-rate", action="store_true")
+    ap.add_argument("--no-records-leg", action="store_true", help="N > 1 with --gather sample: skip the short second leg that gathers every tile's records inside the timed step")
+    ap.add_argument("--records-leg-tiles", type=int, default=4, help="tiles per rank of that leg (a budget the writer's memory and a few seconds hold)")
     ap.add_argument("--detail-file", default=None, help="where the full (unabridged) result goes; default gpurun_out/bench_detail.json")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)     # internal: one shard of the all-cores CPU leg
     ap.add_argument("--cpu-single-worker", action="store_true", help=argparse.SUPPRESS)   # internal: the one-core CPU leg in a process of its own
@@ -884,6 +996,38 @@ def main():
         emit(res, {}, opt, world, metric, dist_info, final=False)
     main_res = run_workload(opt.workload, opt, env, opt.steps, opt.warmup, sites=opt.sites, samples=opt.samples,
                             with_cpu=(not opt.no_cpu_baseline and solo), gather=opt.gather, early=(early if dist is not None else None))
+    if dist is not None and opt.gather == "sample" and not opt.no_records_leg:
+        # north_star's record gather INSIDE the timed region, on a tile budget that fits the writer: `value` above moves no records (sites shard with
+        # nothing exchanged; a full record gather is bound by the writer's links) -- this leg puts the figure WITH the gather beside it.
+        # One warm-up and one timed pass over --records-leg-tiles tiles per rank, every tile's packed records point to point into rank 0.
+        import threading
+        leg_sites = min(opt.sites if opt.sites is not None else WORKLOADS[opt.workload]["sites"], max(1, opt.records_leg_tiles) * opt.tile_sites)
+
+        def leg_stalled():
+            log(f"rank {rank}: the record-gather leg stalled for more than {3 * opt.comm_timeout:g} s: ending the run (exit 15)")
+            if rank == 0 and main_res is not None:
+                try:
+                    main_res["record_gather_leg"] = {"status": "stalled", "sites_per_rank": leg_sites}
+                    emit(main_res, {}, opt, world, metric, dist_info, final=False)
+                except Exception:
+                    pass
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(15)
+        dog = threading.Timer(3 * opt.comm_timeout, leg_stalled)
+        dog.daemon = True
+        dog.start()
+        try:
+            leg = run_workload(opt.workload, opt, env, steps=1, warmup=1, sites=leg_sites, samples=opt.samples, gather="records", strict=False)
+            if rank == 0:
+                rg = leg.get("records_gather", {})
+                main_res["value_with_record_gather"] = leg["value"]
+                main_res["record_gather_leg"] = {"status": "ok", "sites_per_rank": leg_sites, "ms_per_step": leg["ms_per_step"],
+                                                 "GBps_into_writer": rg.get("GBps_into_writer"), "bytes_into_writer": rg.get("bytes_per_step_at_writer"),
+                                                 "note": "every tile's packed records gathered to rank 0 inside the timed step; `value` gathers none"}
+        except Exception as e:
+            if rank == 0 and main_res is not None:
+                main_res["record_gather_leg"] = {"status": "error", "error": repr(e)[:200], "sites_per_rank": leg_sites}
+        dog.cancel()
     cpu_proc = None
     if rank == 0 and solo and not opt.no_cpu_baseline:
         # the one-core CPU leg runs in its own process BESIDE the extra GPU workloads (this thread only enqueues launches and waits);

@@ -303,9 +303,13 @@ typedef struct vgl_ctx_info_t {
     int32_t fused_split;         /* workgroups per site of that kernel (1, or several with the site sums exchanged in HBM)   */
     int32_t sample_lean;         /* build of k_sample a tile without per-read dump gets: 0 every option's state carried, double-precision
                                     fallbacks inline; 1 default tag surface; 2 = 1 with the fallbacks deferred to k_redo; 3 = 0 with the
-                                    fallbacks deferred (optional tags: -addQS / -addI16 / strand tags / --adjust-qs)               */
+                                    fallbacks deferred (optional tags: -addQS / -addI16 / strand tags / --adjust-qs; a tile with the strand
+                                    tags and the quality sums and no --adjust-qs gets that build with its options fixed, "LEAN 4").
+                                    ABI 6: the float32 builds (2, 3) run as two kernels, k_sample_seg<., 1> + <., 2>, when a wavefront's reads
+                                    fit one pool (see pool_cap)                                                                     */
     int32_t gl_sort;             /* k_gl re-deals a workgroup's evaluations in (distinct bases, depth) order                */
-    int32_t gl_wpb;              /* natural wavefronts per k_gl workgroup (4 or 8; 16: k_gl2, two evaluations per thread)   */
+    int32_t gl_wpb;              /* natural wavefronts per k_gl workgroup (4 or 8); 16 = the context is ELIGIBLE for k_gl2 (two evaluations per thread):
+                                    a tile that asks for GP or FORMAT/AD* still runs k_gl with 8 -- the choice is per tile (vgl_launch_gl)              */
     int32_t read_cap;            /* staged reads per (site, sample): a deeper draw is VGL_E_CAPACITY                        */
     int32_t pool_cap;            /* quality-score work items per wavefront and LDS segment (--error-qs 2)                   */
     int32_t pool_lds_bytes;      /* LDS bytes per wavefront of k_sample<2>                                                  */

@@ -98,6 +98,24 @@ def test_no_gpu_fails_loudly():
     assert b"no CPU path" in lib.vgl_last_error() or b"hip" in lib.vgl_last_error().lower()
 
 
+def test_binned_scores_above_63_are_refused_before_any_device_is_touched():
+    """the staged read, the two-byte items and the LDS sum words of k_sample<2> hold a quality score in six bits; the reference accepts
+    --qs-bins values up to 255 (io.cpp:161-163).  Such a run is refused (VGL_E_UNSUPPORTED, with the bin named) instead of cut silently -- the
+    check precedes the device lookup, so it is testable here."""
+    lib = _abi.load_library()
+    for bins, rc in (([(0, 20, 10), (21, 254, 64)], -5), ([(0, 254, 255)], -5), ([(0, 254, -1)], -5), ([(0, 20, 10), (21, 254, 63)], None)):
+        args = VcfglArgs(seed=1, depth=20, error_rate=0.01, error_qs=2, beta_variance=1e-5, qs_bins=bins)
+        p, keep = args.to_struct(8)
+        ctx = C.c_void_p()
+        got = lib.vgl_ctx_create(C.byref(p), 0, 16, C.byref(ctx))
+        if rc is None:
+            assert got in (0, -2)                                  # a valid table: created (GPU box) or "no HIP device" (here)
+            if got == 0:
+                lib.vgl_ctx_destroy(ctx)
+        else:
+            assert got == rc and b"six bits" in lib.vgl_last_error(), (bins, got, lib.vgl_last_error())
+
+
 def test_flag_parser_matches_reference_surface():
     a = VcfglArgs.from_argv("--seed 42 -d 4 -e 0.01 -GL 1 -doUnobserved 2 -addPL 1 -addFormatAD 1 --adjust-qs 1".split()).validate()
     assert (a.seed, a.depth, a.error_rate, a.gl_model, a.do_unobserved, a.add_pl, a.add_fmt_ad) == (42, 4.0, 0.01, 1, 2, 1, 1)

@@ -43,8 +43,10 @@ def test_headline_is_small_strict_and_complete(tmp_path, capsys):
     for k in CONTRACT:
         assert k in line, k
     assert line["value"] == res["value"] and line["n_gpus"] == 1 and line["steps"] == 20 and line["warmup"] == 5
+    assert line["dtype"].startswith("f64") and "f32" in line["dtype"]                 # float64 results; float32 only decides behind explicit bounds
+    assert line["extra_oracle_pin"] == {k: "n<=3 goldens + model definition" for k in ("c2", "gl1q") if k in extra}
     rf = line["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "valu_frac", "step_frac"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "issue_frac", "issue_cycles_per_inst", "sclk_mhz", "mclk_mhz", "step_frac"):
         assert k in rf, k
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
     assert all(not isinstance(v, (dict, list)) or k == "kernel_ms_per_launch" for k, v in rf.items())
@@ -63,11 +65,21 @@ def test_headline_is_small_strict_and_complete(tmp_path, capsys):
 def test_non_finite_numbers_never_reach_the_line(tmp_path, capsys):
     res, extra = _full_result()
     res["roofline"]["traffic"] = float("nan")
-    res["roofline"]["valu"]["frac"] = float("inf")
+    res["roofline"]["issue"] = {"issue_frac": float("inf"), "issue_cycles_per_inst": 3.03, "issue_bound_ms": float("nan")}
     extra["c2"]["value"] = float("nan")
     text = bench.emit(res, extra, _opt(tmp_path), 1, bench.METRIC)
     line = _strict(text)
-    assert line["roofline"]["traffic"] is None and line["roofline"]["valu_frac"] is None
+    assert line["roofline"]["traffic"] is None and line["roofline"]["issue_frac"] is None and line["roofline"]["issue_bound_ms"] is None
+
+
+def test_issue_roof_and_clocks_reach_the_line(tmp_path, capsys):
+    res, extra = _full_result()
+    res["roofline"]["issue"] = {"issue_frac": 0.97, "issue_cycles_per_inst": 3.03, "issue_bound_ms": 7.6, "sclk_mhz_used": 2395.0}
+    res["roofline"]["clocks"] = {"sclk_mhz": 2395.0, "sclk_mhz_min": 2100.0, "mclk_mhz": 2000.0, "samples": 170, "source": "/sys/bus/pci/devices/0000:05:00.0"}
+    line = _strict(bench.emit(res, extra, _opt(tmp_path), 1, bench.METRIC))
+    rf = line["roofline"]
+    assert rf["issue_frac"] == 0.97 and rf["issue_cycles_per_inst"] == 3.03 and rf["sclk_mhz"] == 2395.0 and rf["mclk_mhz"] == 2000.0 and rf["sclk_mhz_min"] == 2100.0
+    assert "valu_frac" not in rf
 
 
 def test_multi_rank_blocks_fit_too(tmp_path, capsys):
@@ -79,9 +91,12 @@ def test_multi_rank_blocks_fit_too(tmp_path, capsys):
                    "records_sample_ms": 40.0, "records_sample_bytes_into_writer": 29e9, "records_sample_GBps": 700.0,
                    "full_record_gather_s_per_step_at_that_rate": 0.65, "records_sample_note": "z" * 400}
     info = {"rccl_world": 8, "backend": "rccl (torch.distributed nccl)", "rccl_version": "2.26.6", "gather": "sample"}
+    res["value_with_record_gather"] = 1.4e10
+    res["record_gather_leg"] = {"status": "ok", "sites_per_rank": 262144, "ms_per_step": 150.0, "GBps_into_writer": 640.0, "bytes_into_writer": 9.6e10, "note": "n" * 300}
     text = bench.emit(res, {}, _opt(tmp_path), 8, bench.METRIC, info)
     line = _strict(text)
     assert len(text) < bench.LINE_LIMIT
+    assert line["value_with_record_gather"] == 1.4e10 and line["record_gather_leg"]["status"] == "ok" and line["record_gather_leg"]["GBps_into_writer"] == 640.0
     assert line["n_gpus"] == 8 and line["config"]["rccl_world"] == 8 and line["config"]["rccl_version"] == "2.26.6"
     assert line["comm"]["records_sample_GBps"] == 700.0 and "records_sample_note" not in line["comm"]
     assert line["ranks"]["evals_per_s_min"] == 4.1e9

@@ -42,6 +42,10 @@ def test_world8_line_schema_with_rccl_fallback(tmp_path):
     # 7 peers x the packed records of their last 32-site tile crossed into the writer: the stub keeps 6/7 of the sites, n_alleles 2..4
     assert comm["records_sample_bytes_into_writer"] > 7 * 20 * 8 * 4 and comm["records_sample_GBps"] > 0
     assert line["ranks"]["evals_per_s_min"] <= line["ranks"]["evals_per_s_max"]
+    # the short second leg: every tile's records gathered inside the timed step, reported beside `value` (which gathers none)
+    leg = line["record_gather_leg"]
+    assert leg["status"] == "ok" and leg["sites_per_rank"] == 64 and leg["bytes_into_writer"] > 0 and line["value_with_record_gather"] > 0
+    assert "value_with_record_gather" not in early
     # value = the units ALL ranks processed / the slowest rank's time
     assert abs(line["value"] - 8 * 64 * 8 * 2 / (line["ms_per_step"] * 2e-3)) / line["value"] < 1e-3
     full = json.load(open(tmp_path / "d.json"))
@@ -53,10 +57,11 @@ def test_a_rank_that_never_arrives_in_the_record_gather_does_not_cost_the_line()
     r = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--comm-timeout", "8", "--backend", "gloo"] + COMMON, env=_env(BENCH_TEST_STALL_RANK="2"),
                        capture_output=True, text=True, timeout=600)
     assert time.time() - t0 < 120
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == 15, (r.returncode, r.stderr[-2000:])      # a stalled transfer is not a clean run ...
     lines = _lines(r.stdout)
-    assert len(lines) == 1 and lines[0]["n_gpus"] == 4 and lines[0]["value"] > 0
+    assert len(lines) == 2 and lines[0]["n_gpus"] == 4 and lines[0]["value"] > 0     # ... but the line is there, printed before the gather was attempted,
     assert lines[0]["comm"]["records_sample"] == "pending"
+    assert lines[1]["comm"]["records_sample"] == "stalled" and lines[1]["value"] == lines[0]["value"]    # and once more, last, saying what happened
     assert "stalled" in r.stderr
 
 

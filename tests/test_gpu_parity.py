@@ -224,7 +224,7 @@ def test_gl2_one_base_run_table(oracle, kw, monkeypatch):
                                           (dict(depth=26.0, error_rate=0.02, error_qs=1, beta_variance=1e-4), 257, 12), (dict(depth=12.0, error_rate=0.0), 640, 4)])
 def test_gl2_two_evaluations_per_thread(oracle, kw, N, n_sites, ovc, monkeypatch):
     """k_gl2 (GL model 2, three-kernel path, planes layout): a workgroup of 512 threads takes 1024 evaluations, the accumulators lie in
-    a compact array (six full rows + nine rows of 128 columns for the three- / four-base evaluations at the head of the sorted order),
+    a compact array (six full rows + nine rows of 256 columns (VGL_GL2_OVC) for the three- / four-base evaluations at the head of the sorted order),
     and a workgroup with more such evaluations than the upper rows hold is worked on again by k_gl's own body (k_gl2_scan, k_gl_redo).
     Forced on (VGL_GL2X=1, hooks build) for one fixed score and per-read scores, N = 1 ... 2500 (workgroups spanning sites, ragged
     ends), error rates that make most evaluations show three or four bases, sites without an absent allele; with the pool's limit at
@@ -560,6 +560,19 @@ def test_deferred_reads_are_redrawn_by_k_redo(oracle, monkeypatch, every, cap, d
     kw = dict(qs_bins=[(0, 2, 2), (3, 14, 12), (15, 30, 23), (31, 40, 37)]) if bins else {}          # the rta3 bins (doc/error_qs.MD)
     args = VcfglArgs(seed=77, depth=depth, error_rate=0.01, error_qs=2, beta_variance=1e-5, add_pl=1, **kw)
     want, got = run_both(oracle, args, synth.binary_sites(0, 10, N), hooks=True)
+    assert_parity(want, got, check_gp=False)
+
+
+@pytest.mark.parametrize("period,period_n", [(3, 5), (1, 7), (5, 2), (8, 8)])
+def test_bounded_tests_run_on_one_period(oracle, monkeypatch, period, period_n):
+    """in the float32 pool loop a lane held for BOTH bounded logarithm tests advanced only when both counters fired -- every lcm of
+    VGL_SLOW_PERIOD and VGL_SLOW_PERIOD_N under the hooks.  The loop now runs both tests on VGL_SLOW_PERIOD; whatever the two values, no candidate
+    forced to k_redo (VGL_DEBUG_REDO_EVERY unset), the result is the oracle's (the A / B attempt bookkeeping -- useB, rejB, hold -- under periods
+    other than the default 4 / 4)."""
+    monkeypatch.setenv("VGL_SLOW_PERIOD", str(period))
+    monkeypatch.setenv("VGL_SLOW_PERIOD_N", str(period_n))
+    args = VcfglArgs(seed=19, depth=25, error_rate=0.01, error_qs=2, beta_variance=1e-5, add_pl=1)
+    want, got = run_both(oracle, args, synth.binary_sites(0, 16, 200), hooks=True)
     assert_parity(want, got, check_gp=False)
 
 

@@ -106,7 +106,7 @@ def price(tok, exact, wild, rates):
 
 def demangle(names):
     out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
-    return [o.replace("void ", "").split("(")[0] for o in out]
+    return [o.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0] for o in out]
 
 
 def function_lines(asm_path, kernel):

@@ -63,7 +63,7 @@ def parse(remarks):
 
 def demangle(names):
     out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
-    return [o.replace("void ", "").split("(")[0] for o in out]
+    return [o.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0] for o in out]
 
 
 def current(outdir=None):

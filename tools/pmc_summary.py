@@ -32,12 +32,20 @@ for f in sorted(glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv"
         for c, vals in v.items():
             out[k][c] = sum(vals) / len(vals)
             out[k]["launches_" + c] = len(vals)
+def bucket(k):
+    """the bench's kernel bucket of a kernel: k_sample_seg<DM, 1, LEAN> (round 6: one pool segment per wavefront) IS k_sample; its follow-up
+    <DM, 2, LEAN> (the segment loop over listed wavefronts: nothing listed at the bench configurations) is kept under its own name"""
+    if k.startswith("k_sample_seg<"):
+        return "k_sample" if k.split(",")[1].strip() == "1" else "k_sample_seg_list"
+    return k.split("<")[0]
+
+
 traffic = {}
 for k, v in out.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         v["hbm_bytes_per_launch"] = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
         v["hbm_bytes_per_launch_raw_fetch"] = (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
-        traffic.setdefault(k.split("<")[0], {}).update({"hbm_bytes_per_launch": v["hbm_bytes_per_launch"],
+        traffic.setdefault(bucket(k), {}).update({"hbm_bytes_per_launch": v["hbm_bytes_per_launch"],
                                                         "raw_fetch_variant": v["hbm_bytes_per_launch_raw_fetch"]})
     if "SQ_ACTIVE_INST_VALU" in v and v.get("GRBM_GUI_ACTIVE"):
         # VALU pipes busy: SQ_ACTIVE_INST_VALU counts 4-cycle quads summed over the chip's 1024 SIMDs (256 CUs x 4);
@@ -51,14 +59,14 @@ for k, v in out.items():
         # k_sample) reads above 1: the raw value is kept, the fraction is capped at 1.
         v["valu_issue_slots_at_4_cycles"] = 4.0 * v["SQ_ACTIVE_INST_VALU"] / (128.0 * v["GRBM_GUI_ACTIVE"])
         v["valu_busy_frac"] = min(1.0, v["valu_issue_slots_at_4_cycles"])
-        traffic.setdefault(k.split("<")[0], {}).update({"valu_busy_frac": v["valu_busy_frac"], "valu_issue_slots_at_4_cycles": v["valu_issue_slots_at_4_cycles"]})
+        traffic.setdefault(bucket(k), {}).update({"valu_busy_frac": v["valu_busy_frac"], "valu_issue_slots_at_4_cycles": v["valu_issue_slots_at_4_cycles"]})
     if "SQ_ACTIVE_INST_VALU" in v and v.get("SQ_WAVE_CYCLES"):
         # the kernel's own denominator: share of its wavefronts' resident cycles in which a VALU instruction of theirs was executing
         v["valu_active_share_of_wave_cycles"] = v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"]
     if "SQ_INSTS_VALU" in v and "SQ_WAVES" in v:
         v["valu_insts_per_wave"] = v["SQ_INSTS_VALU"] / v["SQ_WAVES"]
         v["active_lanes_per_valu_inst"] = v.get("SQ_THREAD_CYCLES_VALU", 0) / v["SQ_INSTS_VALU"]
-        traffic.setdefault(k.split("<")[0], {}).update({"valu_insts_per_wave": v["valu_insts_per_wave"],
+        traffic.setdefault(bucket(k), {}).update({"valu_insts_per_wave": v["valu_insts_per_wave"],
                                                         "active_lanes_per_valu_inst": v["active_lanes_per_valu_inst"]})
 here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 json.dump(out, open(os.path.join(here, "profiles", f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)

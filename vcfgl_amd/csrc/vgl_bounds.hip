@@ -23,8 +23,8 @@ enum {
     VGL_BOUND_QUOT = 9,         // quot_int24 == IEEE float32 quotient of integers q <= sum <= 2^24 (k_siteagg; count = pairs)
     VGL_BOUND_DIV10 = 10,       // div10_f32(x) == (float)((double)x / 10.0) for every float32 bit pattern of the sweep (k_gl, GL model 1)
     VGL_BOUND_POISSON = 11,     // poisson_fast == poisson_exact wherever it does not call the attempt ambiguous (param = mean depth; count = attempts)
-    VGL_BOUND_QS_FIX = 13,      // qs_decide_fix: every float32 p it decides has ONE score over the whole interval its true value can lie in (param = adjust_by, 0 = none)
     VGL_BOUND_POOL32 = 12,      // the float32 pool loop of k_sample<2>: every decision it takes equals the float64 one, values within their bounds (param = shape alpha >= 8; count = attempts)
+    VGL_BOUND_QS_FIX = 13,      // qs_decide_fix: every float32 p it decides has ONE score over the whole interval its true value can lie in (param = adjust_by, 0 = none)
     VGL_BOUND_N
 };
 

@@ -1062,7 +1062,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         uint16_t perm[WGE];
         int32_t ws[2 * NW];
         int32_t n3p;
+        // the epilogue reads accumulator row c of an evaluation at x + 4 pos + 512 c for every genotype of the site, also for an evaluation whose pool rows
+        // (codes 48 ... 64) do not exist because its sorted position is beyond VGL_GL2_OVC -- such a workgroup has set its redo bit and k_gl_redo writes all of
+        // its tags again, so the value is never used; the pad keeps even that read (at most 4092 + 512 x 64 bytes from x) inside this structure
+        uint32_t guard[224];
     };
+    static_assert(sizeof(Lds) - offsetof(Lds, x) >= 4092 + 512 * 64 + 4, "k_gl2: every accumulator address of the epilogue lies inside the LDS block");
     __shared__ Lds s_lds;
     double* const s_q2gl = s_lds.q2gl;
     uint32_t* const s_x = s_lds.x;

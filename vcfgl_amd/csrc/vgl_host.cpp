@@ -360,6 +360,12 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     if (p->do_unobserved < 0 || p->do_unobserved > 5) return fail(VGL_E_ARG, "[Bad argument value: '-doUnobserved %d'] Allowed range is [0,5]", p->do_unobserved);
     if (!(p->error_rate >= 0.0 && p->error_rate < 1.0)) return fail(VGL_E_ARG, "[Bad argument value: '--error-rate %f'] Allowed range is [0,1)", p->error_rate);
     if (p->n_qs_bins < 0 || p->n_qs_bins > VGL_MAX_QS_BINS) return fail(VGL_E_ARG, "at most %d qs bins are supported", VGL_MAX_QS_BINS);
+    // a staged read is one byte, score << 2 | base, and the two-byte items / LDS sum words of k_sample<2> give a score six bits too: a binned score above
+    // 63 (the reference takes --qs-bins values up to 255, io.cpp:161-163; its own default scores stop at CAP_BASEQ = 63) would be cut, so such a run is refused
+    if (p->n_qs_bins > 0 && !p->qs_bins) return fail(VGL_E_ARG, "n_qs_bins > 0 without qs_bins");
+    for (int i = 0; i < p->n_qs_bins; ++i)
+        if (p->qs_bins[3 * i + 2] < 0 || p->qs_bins[3 * i + 2] > 63)
+            return fail(VGL_E_UNSUPPORTED, "--qs-bins: bin %d maps to quality score %d; the device path stages quality scores in six bits (0 ... 63)", i, p->qs_bins[3 * i + 2]);
     if (p->gl_model == 1 && p->precise_gl) return fail(VGL_E_ARG, "Precise genotype likelihood error (--precise-gl 1) is not supported with genotype likelihood model 1 (--gl-model 1).");
     if (p->rng_mode != VGL_RNG_TILE && p->rng_mode != VGL_RNG_SERIAL) return fail(VGL_E_ARG, "rng_mode must be VGL_RNG_TILE or VGL_RNG_SERIAL");
     if (p->out_layout != VGL_LAYOUT_PLANES && p->out_layout != VGL_LAYOUT_SAMPLE_MAJOR) return fail(VGL_E_ARG, "out_layout must be VGL_LAYOUT_PLANES or VGL_LAYOUT_SAMPLE_MAJOR");

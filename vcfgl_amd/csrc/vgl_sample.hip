@@ -516,10 +516,12 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                     float gxf = 0.0f;
                     do {
                         if (DBG) { c_iter++; c_lhave += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(have)); }
+                        // ONE period for both bounded tests: a lane held for the normal attempt's logarithm test AND for the gamma test advances only
+                        // in an iteration that runs both; with two counters (VGL_SLOW_PERIOD != VGL_SLOW_PERIOD_N under the hooks) that was every lcm of the periods,
+                        // all 64 lanes spinning meanwhile.  P.slow_period_n is the float64 loop's alone now
                         const bool full = (--slow_cnt == 0);
                         if (full) slow_cnt = P.slow_period;
-                        const bool full_n = (--slow_cnt_n == 0);
-                        if (full_n) slow_cnt_n = P.slow_period_n;
+                        const bool full_n = full;
                         uint32_t goff = stage1 ? 528u : 512u;                       // this stage's four constants: LDS bytes 512 / 528 (the dynamic LDS block starts at 0)
                         asm volatile("" : "+v"(goff));
                         const lds_f32* const gc = (const lds_f32*)(uintptr_t)goff;
