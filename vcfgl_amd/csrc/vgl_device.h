@@ -58,6 +58,14 @@ __device__ __forceinline__ size_t vgl_read_byte(const int r, const size_t plane,
     return ((((size_t)(r >> 2)) * plane + ev) << 2) | (size_t)(r & 3);
 }
 #endif
+// Staged error probabilities (VglTilePtrs::errp, --precise-gl 1 and the deviate dumps): EVALUATION-major since round 6 -- read r of evaluation ev at
+// [ev * read_cap + r].  The lane of k_sample<2> that finishes a read stores its probability; the reads of one evaluation are neighbours in the
+// wavefront's pool and are finished within a few iterations of one another, so their 8-byte stores now fall into the same one or two cache lines
+// while those are still in L2 (read-major, [r][site][N], the sixteen stores of a line were spread over the whole pool loop: the partial-line
+// write-backs cost k_sample<2, PREC> a third of its time).  k_gl reads 8 bytes per lane and read, consecutive reads from the same line.
+#if defined(__HIPCC__)
+__device__ __forceinline__ size_t vgl_errp_index(const int r, const size_t ev, const int read_cap) { return ev * (size_t)read_cap + (size_t)r; }
+#endif
 #define VGL_REDO_PARTS 64
 #define VGL_REDO_STRIDE 32
 #define VGL_DEVERR_CAPACITY 1u
@@ -186,7 +194,7 @@ struct VglTilePtrs {
     uint32_t redo_cap;       // entries per partition
     uint32_t* redo_bits;     // one bit per (evaluation, read) of the tile, all zero between tiles: overflow of the list
     uint32_t* seg_list;      // k_sample_seg: the wavefronts (index in the tile) whose reads need more than one pool segment; their number is redo_count[1]
-    double*  errp;           // [read_cap][n_sites][N]   (precise_gl with error_qs 2)
+    double*  errp;           // [n_sites][N][read_cap] evaluation-major (vgl_errp_index): --precise-gl 1 with error_qs 2, and the deviate dumps
     uint64_t* ad4;           // [n_sites][N]  4 x u16 ACGT depth
     uint64_t* adf4;          // [n_sites][N]  4 x u16 forward-strand depth
     uint32_t* qsum;          // [n_sites][4][N]
@@ -257,6 +265,7 @@ extern "C" {
 int vgl_launch_sitebase(const VglDevParams* p, const VglTilePtrs* t, void* stream);
 int vgl_launch_depth(const VglDevParams* p, const VglTilePtrs* t, void* stream);
 int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, void* stream);
+int vgl_launch_errp_dump(const VglDevParams* p, const double* errp, double* out, size_t n_eval, int rows, void* stream);   // read_errp = [read][site][N] from the evaluation-major planes
 int vgl_launch_redo(const VglDevParams* p, const VglTilePtrs* t, void* stream);      // k_redo, when vgl_launch_sample ran the deferred build (else nothing)
 int vgl_launch_site(const VglDevParams* p, const VglTilePtrs* t, void* stream);
 int vgl_launch_gl(const VglDevParams* p, const VglTilePtrs* t, void* stream);

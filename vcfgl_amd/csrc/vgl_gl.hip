@@ -581,7 +581,13 @@ __device__ __forceinline__ void k_gl_body(const VglDevParams& P, const VglTilePt
                 const int lastw = (dp - 1) >> 2;
                 uint32_t w0 = 0, w1 = 0, w2 = 0;
                 if constexpr (!FUSED) { w0 = colw[0]; w1 = colw[(size_t)(1 < lastw ? 1 : lastw) * plane]; w2 = colw[(size_t)(2 < lastw ? 2 : lastw) * plane]; }
-                auto one_read = [&](const uint32_t rb, const int r) {
+                // --precise-gl 1: the trip's four error probabilities (evaluation-major planes, vgl_errp_index: 32 contiguous, 32-byte aligned bytes per lane -- read_cap is
+                // a multiple of four) as two 16-byte loads, asked for one trip ahead like the staged words
+                typedef double v2d __attribute__((ext_vector_type(2)));
+                const v2d* const ecol = (PREC && per_read) ? (const v2d*)(T.errp + vgl_errp_index(0, ev, P.read_cap)) : nullptr;
+                v2d en0 = {0.0, 0.0}, en1 = {0.0, 0.0};
+                if constexpr (PREC && !FUSED) { if (per_read) { en0 = ecol[0]; en1 = ecol[1]; } }
+                auto one_read = [&](const uint32_t rb, const int r, const double e_r) {
                     const int ci = (int)((cmap >> ((rb & 3) * 2)) & 3);                           // the read's base among the present ones
                     if (per_read) {
                         if (!PREC) {
@@ -589,7 +595,7 @@ __device__ __forceinline__ void k_gl_body(const VglDevParams& P, const VglTilePt
                             if (__builtin_expect(q < QL, 1)) { homT = s_q2gl[q]; het = s_q2gl[QL + q]; homF = s_q2gl[2 * QL + q]; }
                             else { homT = P.q2gl[q]; het = P.q2gl[257 + q]; homF = P.q2gl[514 + q]; }
                         } else {
-                            const double e = T.errp[(size_t)r * plane + ev];
+                            const double e = e_r;
                             if (0.0 == e) { homT = 0.0; het = -0.30103; homF = -INFINITY; }
                             else {
                                 // e / 3.0 and e / 6.0 correctly rounded, as the reference's divisions are: q0 = e RN(1/3), one residual and one
@@ -641,7 +647,7 @@ __device__ __forceinline__ void k_gl_body(const VglDevParams& P, const VglTilePt
                         const uint32_t cur = curw >> ((r0 & 15) * 2);
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            if (r0 + j < dp) one_read((cur >> (2 * j)) & 3u, r0 + j);
+                            if (r0 + j < dp) one_read((cur >> (2 * j)) & 3u, r0 + j, 0.0);
                     }
                 } else
                 for (int r0 = 0; r0 < dp; r0 += 4) {                                          // (r0 is the same in every active lane)
@@ -649,9 +655,17 @@ __device__ __forceinline__ void k_gl_body(const VglDevParams& P, const VglTilePt
                     w0 = w1; w1 = w2;
                     const int nw = (r0 >> 2) + 3;
                     w2 = colw[(size_t)(nw < lastw ? nw : lastw) * plane];
+#ifndef VGL_ERRP_NOT_AHEAD
+                    const v2d ec0 = en0, ec1 = en1;
+                    if constexpr (PREC) { if (per_read) { const int nt = (r0 >> 2) + 1; const int t = nt < lastw ? nt : lastw; en0 = ecol[2 * t]; en1 = ecol[2 * t + 1]; } }
+#else
+                    v2d ec0 = en0, ec1 = en1;
+                    if constexpr (PREC) { if (per_read) { ec0 = ecol[2 * (r0 >> 2)]; ec1 = ecol[2 * (r0 >> 2) + 1]; } }
+#endif
+                    const double e4[4] = {ec0.x, ec0.y, ec1.x, ec1.y};
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (r0 + j < dp) one_read((cur >> (8 * j)) & 0xFFu, r0 + j);
+                        if (r0 + j < dp) one_read((cur >> (8 * j)) & 0xFFu, r0 + j, e4[j]);
                 }
                 // deposit: column otid (= the evaluation's natural position in the workgroup), rows = genotype index over (present
                 // base ranks 0..3, 4 = absent) whatever KK this wavefront ran with, so that the reader needs no KK

@@ -489,7 +489,11 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     D.lean_ok = (!D.need_qsum && !D.sample_strand && !D.need_adf && p->adjust_qs == 0 && !hook_env("VGL_NO_LEAN")) ? 1 : 0;
     D.defer_ok = (!D.serial && p->error_qs == 2 &&
                   !D.gx.changed && !D.gy.changed && D.gx.alpha0 >= 8.0 && D.gy.alpha0 >= 8.0 && !hook_env("VGL_NO_DEFER") && !hook_env("VGL_DEBUG_QS_EXACT") && !hook_env("VGL_NO_LEAN") &&
+#ifdef VGL_PREC_F64
                   !(!p->precise_gl && (D.read_cap > 256 || !bins_below_255))) ? 1 : 0;   // (the two-byte items of the float32 builds hold a read index of 8 bits
+#else
+                  !(D.read_cap > 256 || !bins_below_255)) ? 1 : 0;                       // (the two-byte items of the float32 builds hold a read index of 8 bits
+#endif
                                                                              // and look binned scores up in a 256-entry table: other runs take the inline build)
     // one workgroup per site does everything (k_gl<.., FUSED>, vgl_gl.hip): sampling with one fixed score, the site's allele order and the
     // likelihoods, with nothing staged in HBM between them
@@ -508,12 +512,14 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
         // quality-sum words with qsum_lds, + 256 B of binned scores with --qs-bins) -- 2240 items (depth 30 in one segment) leave LDS for the eight
         // wavefronts per SIMD k_sample<2, LEAN 2> is built for (32 x 5.1 KB in a CU's 160 KB).  With --precise-gl 1 (float64 loop): five bytes, 1472
         // items = 5 wavefronts per SIMD (1416 with the 512 B of sum words)
-#ifndef VGL_POOL_F64
+#if !defined(VGL_POOL_F64) && !defined(VGL_PREC_F64)
+        const bool p16 = true;                                   // (round 6: --precise-gl 1 runs the float32 loop too, + 32 bytes of double constants)
+#elif !defined(VGL_POOL_F64)
         const bool p16 = !p->precise_gl;
 #else
         const bool p16 = false;
 #endif
-        const int extra16 = (D.qsum_lds ? 1024 : 0) + (p->n_qs_bins ? 256 : 0);
+        const int extra16 = (D.qsum_lds ? 1024 : 0) + (p->n_qs_bins ? 256 : 0) + (p->precise_gl ? 32 : 0);
         const int cap_defer = p16 ? ((5120 - 576 - 8 - (D.lean_ok ? (p->n_qs_bins ? 256 : 0) : 0)) / 2 / 64 * 64) : (D.qsum_lds ? 1416 : 1472);
         // the float32 build of the default tag surface as two kernels (k_sample_seg, vgl_sample.hip) when a wavefront's reads fit one pool up to 8 sigma
         // (a pool that holds the summed depth + 4.5 sigma: 3e-6 of the wavefronts go through the list)
@@ -937,7 +943,7 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     if (dump_errp) {
         const size_t row = (size_t)n_sites * D.n_samples;
         const size_t rows = (size_t)(o->read_capacity < D.read_cap ? o->read_capacity : D.read_cap);
-        HIPCHK(hipMemcpyAsync(o->read_errp, c->d_errp, rows * row * sizeof(double), hipMemcpyDeviceToDevice, st));
+        if (vgl_launch_errp_dump(&D, c->d_errp, o->read_errp, row, (int)rows, st)) return fail(VGL_E_NODEVICE, "k_errp_dump launch failed");
         if ((size_t)o->read_capacity > rows)
             HIPCHK(hipMemsetAsync(o->read_errp + rows * row, 0xFF, ((size_t)o->read_capacity - rows) * row * sizeof(double), st));
     }

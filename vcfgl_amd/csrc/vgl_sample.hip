@@ -127,7 +127,14 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
 #ifdef VGL_POOL_F64
     constexpr bool F32 = false;
 #else
-    constexpr bool F32 = DEFER && !PREC;
+#ifdef VGL_PREC_F64
+    constexpr bool F32 = DEFER && !PREC;                             // (A/B: --precise-gl 1 on the float64 loop, as until round 5)
+#else
+    // round 6: --precise-gl 1 too.  The DECISIONS of the rejection loops come from the float32 loop exactly as without the flag; what k_gl needs beyond
+    // the score -- the read's error probability X / (X + Y) as the reference's double -- is evaluated in double for the ACCEPTED attempts only (PREC blocks
+    // below: the attempt's two uniforms rebuilt from its generator states, v / u, w, a1 w^3 as rng.h:72-78,139-145 do), twice per read instead of once per attempt
+    constexpr bool F32 = DEFER;
+#endif
 #endif
     // P16 (round 5): the float32 loop of the default tag surface keeps an item in TWO bytes -- owner << 10 | read << 2 | base until it is
     // finished, then the read's staged byte (score << 2 | base; bit 8: undecided, k_redo draws the read) written by the lane that finishes
@@ -306,6 +313,9 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
         // the lane that finishes a read, read and cleared by the owner when it stages its reads
         uint8_t* const l_lut = wl + ((576 + 2 * ((size_t)cap + 2) + 7) & ~(size_t)7);
         uint32_t* const l_qs = (uint32_t*)(l_lut + (P.n_qs_bins != 0 ? 256 : 0));
+        // PREC with the float32 loop: a1, a2 of the first and of the second gamma sampler as doubles, 32 bytes behind the sum words (vgl_launch_sample adds them)
+        double* const l_gcd = (double*)((uint8_t*)l_qs + ((LEAN >= 3 && P.qsum_lds) ? 1024 : 0));
+        if (F32 && PREC) { if (lane == 0) { l_gcd[0] = P.gx.a1; l_gcd[1] = P.gx.a2; l_gcd[2] = P.gy.a1; l_gcd[3] = P.gy.a2; } }
         if (P16 && P.n_qs_bins != 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -514,6 +524,7 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                     typedef __attribute__((address_space(3))) float lds_f32;
                     uint32_t s_lo = (uint32_t)st, s_hi = (uint32_t)(st >> 32);
                     float gxf = 0.0f;
+                    double gxd = 0.0;                                           // PREC: the first gamma deviate of the lane's read, in double
                     do {
                         if (DBG) { c_iter++; c_lhave += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(have)); }
                         // ONE period for both bounded tests: a lane held for the normal attempt's logarithm test AND for the gamma test advances only
@@ -617,6 +628,40 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                         const float val = ga1 * vv;
                         const bool fin = (acc_g && stage1) || redo;
                         const float gx_prev = gxf;
+                        if constexpr (PREC) {
+                            // the accepted attempt again, in double (rng.h:72-78: u, v = 1.7156 (u' - 0.5), x = v / u; :139-145: w = 1 + a2 x, a1 w^3): its two
+                            // uniforms are the generator states the float32 attempt was formed from (A: outputs one and two, B: three and four); every decision
+                            // has been taken, only the value is wanted.  For the second deviate of a read the error probability X / (X + Y) (rng.h:438) goes to
+                            // the staging plane k_gl reads (a read the float32 loop hands to k_redo gets its probability there).
+#ifdef VGL_EXP_NO_CHAIN
+                            if (false) {
+#else
+                            if (acc_g) {
+#endif
+#if VGL_POOL_ATTEMPTS == 2
+                                const uint32_t ulo = useB ? l3 : l1, uhi = useB ? h3 : h1, vlo = useB ? l4 : l2, vhi = useB ? h4 : h2;
+#else
+                                const uint32_t ulo = l1, uhi = h1, vlo = l2, vhi = h2;
+#endif
+                                const double ud = bits_1xxx_52r(((uint64_t)uhi << 32) | ulo, k3ff) - 1.0;
+                                const double vd = 1.7156 * (bits_1xxx_52r(((uint64_t)vhi << 32) | vlo, k3ff) - 1.5);
+                                const __attribute__((address_space(3))) double* const gd = (const __attribute__((address_space(3))) double*)(uintptr_t)((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)l_gcd + (stage1 ? 16u : 0u));
+                                const double a1d = gd[0], a2d = gd[1];
+                                const double xd = div_inrange(vd, ud);
+                                const double wd = 1.0 + a2d * xd;
+                                const double vald = a1d * (wd * wd * wd);
+                                if (stage1) {
+                                    if (!redo) {
+                                        const size_t ei = vgl_errp_index((int)((sk >> 2) & 0xFFu), ev0 + (sk >> 10), P.read_cap);
+#ifdef VGL_EXP_NO_ERRP_STORE
+                                        const double epx = div_inrange(gxd, gxd + vald); if (epx > 2.0) T.errp[ei] = epx;      // (timing experiment: the value computed, never stored)
+#else
+                                        T.errp[ei] = div_inrange(gxd, gxd + vald);
+#endif
+                                    }
+                                } else gxd = vald;
+                            }
+                        }
                         gxf = (acc_g && !stage1) ? val : gxf;
                         stage1 = (stage1 != acc_g) && !redo;
                         if (DBG) {
@@ -755,7 +800,7 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                         if (DEFER) { if (redo) *(lds_u32*)(uintptr_t)(576u + (uint32_t)k) = 0x7FC00000u; }        // NaN: undecided for the dense pass
                         if (PREC) {
                             // read index x plane as ONE 32 x 32 -> 64-bit multiply-add (the tile has fewer than 2^32 evaluations: vgl_launch_sample)
-                            const uint64_t ei = (uint64_t)((it_m & 0xFFFFu) >> 4) * (uint64_t)(uint32_t)plane + (uint64_t)(ev0 + (it_m >> 19));
+                            const size_t ei = vgl_errp_index((int)((it_m & 0xFFFFu) >> 4), ev0 + (it_m >> 19), P.read_cap);
                             T.errp[ei] = (DEFER ? div_inrange(gx_prev, gx_prev + val) : gx_prev / (gx_prev + val));   // DEFER: both shape parameters >= 8, the operands are far from the exponent limits
                             it_m = m_n;
                         }
@@ -1055,7 +1100,10 @@ template <int EQS, bool DBG, int DM, bool PREC, int LEAN>
 #ifndef VGL_SAMPLE_WAVES_L3
 #define VGL_SAMPLE_WAVES_L3 7
 #endif
-#define VGL_SAMPLE_WAVES(EQS, PREC, LEAN) ((EQS) == 2 ? ((LEAN) == 2 && !(PREC) ? VGL_SAMPLE_WAVES_F32 : ((LEAN) >= 3 && !(PREC) ? VGL_SAMPLE_WAVES_L3 : ((LEAN) >= 2 ? 5 : 4))) : 8)
+#ifndef VGL_SAMPLE_WAVES_PREC
+#define VGL_SAMPLE_WAVES_PREC 5
+#endif
+#define VGL_SAMPLE_WAVES(EQS, PREC, LEAN) ((EQS) == 2 ? ((LEAN) == 2 && !(PREC) ? VGL_SAMPLE_WAVES_F32 : ((LEAN) >= 3 && !(PREC) ? VGL_SAMPLE_WAVES_L3 : ((LEAN) >= 2 ? VGL_SAMPLE_WAVES_PREC : 4))) : 8)
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? VGL_SAMPLE_WAVES(EQS, PREC, LEAN) : 1, VGL_SAMPLE_WAVES(EQS, PREC, LEAN)))) void k_sample(const VglDevParams P, const VglTilePtrs T) {
     // (one 64-sample chunk per launched wavefront: several chunks per wavefront, one after the other, measured slower -- docs/tried.md)
@@ -1077,6 +1125,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VGL_SAMPLE_
             __builtin_amdgcn_wave_barrier();
         }
     }
+}
+
+// the deviate dump (vgl_tile_out.read_errp, [read][site][N] as the ABI documents it) from the evaluation-major staging planes: one lane per evaluation
+__global__ __launch_bounds__(256) void k_errp_dump(const double* __restrict__ errp, double* __restrict__ out, const size_t n_eval, const int rows, const int read_cap) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_eval) return;
+    for (int r = 0; r < rows; ++r) out[(size_t)r * n_eval + e] = errp[vgl_errp_index(r, e, read_cap)];
+}
+extern "C" int vgl_launch_errp_dump(const VglDevParams* p, const double* errp, double* out, size_t n_eval, int rows, void* stream) {
+    if (n_eval == 0 || rows <= 0) return 0;
+    hipLaunchKernelGGL(k_errp_dump, dim3((unsigned)((n_eval + 255) / 256)), dim3(256), 0, (hipStream_t)stream, errp, out, n_eval, rows, (int)p->read_cap);
+    return (int)hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------
@@ -1117,7 +1177,7 @@ __device__ __forceinline__ void redo_read(const VglDevParams& P, const VglTilePt
     errprob_raw(P, ep, q, aq);
     if (aq < 0 && (P.adjust_qs & 3)) atomicOr(T.errflag, VGL_DEVERR_ADJQ);   // vcfgl.cpp:558, gl_methods.cpp:101
     qs_finish(P, q, aq, T.errflag, true);
-    if (T.errp) T.errp[(size_t)r * plane + ev] = ep;                     // --precise-gl 1 / the deviate dump: the read's exact error probability
+    if (T.errp) T.errp[vgl_errp_index(r, ev, P.read_cap)] = ep;                     // --precise-gl 1 / the deviate dump: the read's exact error probability
     uint8_t* const p = T.reads + vgl_read_byte(r, plane, ev);
     const uint32_t base = *p & 3u;
     const int q_gl = (P.adjust_qs & 1) ? aq : q;                         // vcfgl.cpp:525-531
@@ -1237,7 +1297,11 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
         if (dbg && !t->errp && p->dbg_stamps == 2 && lean && sample_deferred(p, t)) { VGL_LAUNCH_SAMPLE(2, true, false, 2, lds16); } else   // VGL_DEBUG_STAMPS=2: the stamped float32 build
         if (dbg && !t->errp) { VGL_LAUNCH_SAMPLE(2, true, false, 0, lds); } else   // diagnostic build (VGL_DEBUG_STAMPS / VGL_DEBUG_PHASE): --precise-gl 0 only
 #endif
+#if defined(VGL_POOL_F64) || defined(VGL_PREC_F64)
         if (t->errp && sample_deferred(p, t)) { if (lean) VGL_LAUNCH_SAMPLE(2, false, true, 2, lds); else VGL_LAUNCH_SAMPLE(2, false, true, 3, lds); }   // --precise-gl 1: the deferred builds, k_redo (vgl_launch_redo) also rewrites errp
+#else
+        if (t->errp && sample_deferred(p, t)) { if (lean) VGL_LAUNCH_SAMPLE(2, false, true, 2, lds16 + 32); else VGL_LAUNCH_SAMPLE(2, false, true, 3, lds16x + 32); }   // --precise-gl 1: the float32 loop + the double value chain (two-byte items)
+#endif
         else if (t->errp) { if (lean) VGL_LAUNCH_SAMPLE(2, false, true, 1, lds); else VGL_LAUNCH_SAMPLE(2, false, true, 0, lds); }   // --precise-gl 1, or the deviates were asked for
         else if (sample_deferred(p, t)) {
             // one segment per wavefront, then the segment loop over what that kernel listed (nothing, at the bench configurations)

@@ -83,7 +83,6 @@ __device__ int glibc_rand(VglSerialState* S) {
 __global__ __launch_bounds__(64) void k_scout(const VglDevParams P, const VglTilePtrs T, VglSerialState* S) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int N = P.n_samples;
-    const size_t plane = (size_t)T.n_sites * N;
     uint64_t st0 = S->st0, st1 = S->st1;
     for (int ls = 0; ls < T.n_sites; ++ls) {
         const size_t e0 = (size_t)ls * N;
@@ -119,7 +118,7 @@ __global__ __launch_bounds__(64) void k_scout(const VglDevParams P, const VglTil
             for (int r = 0; r < dp; ++r) {                          // vcfgl.cpp:469-613
                 bool fwd;
                 last_base = sample_read_base(st1, st0, a0, a1, thresh, P.sample_strand != 0, fwd);
-                if (P.error_qs == 2) T.errp[(size_t)r * plane + e0 + s] = serial_beta(P, S);
+                if (P.error_qs == 2) T.errp[vgl_errp_index(r, (size_t)e0 + s, P.read_cap)] = serial_beta(P, S);
             }
         }
         if (P.add_i16 && T.site_tail) {                             // vcfgl.cpp:647-663
@@ -371,8 +370,8 @@ __global__ __launch_bounds__(256) void k_sample_serial(const VglDevParams P, con
             int q_i = P.pre_q, aq_i = P.pre_adjq;
             if (P.error_qs == 2) {
                 double e;
-                if (T.errp_lin) { e = T.errp_lin[T.roff[ev] + r]; if (T.errp) T.errp[(size_t)r * plane + ev] = e; }   // k_gl reads the planes
-                else e = T.errp[(size_t)r * plane + ev];
+                if (T.errp_lin) { e = T.errp_lin[T.roff[ev] + r]; if (T.errp) T.errp[vgl_errp_index(r, ev, P.read_cap)] = e; }   // k_gl reads the planes
+                else e = T.errp[vgl_errp_index(r, ev, P.read_cap)];
                 errprob_to_qs(P, e, q_i, aq_i, T.errflag);
                 if (aq_i < 0 && (P.adjust_qs & 3)) atomicOr(T.errflag, VGL_DEVERR_ADJQ);               // vcfgl.cpp:558, gl_methods.cpp:101
             }
