@@ -570,7 +570,11 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
         const VglAffine jr = aff_pow(lay.qs_read_stride);
         VglAffine cur = {1, 0};
         for (int r = 0; r < D.read_cap; r++) { rt[r] = cur; rt[r].c <<= 4; cur = aff_compose(jr, cur); }   // constants scaled by 16: the pool loop's states are (aff52)
-        TRY(dmalloc(&c->d_qs_read_tab, (size_t)D.read_cap));
+        // at least 256 entries (zeros behind the reads'): the two-byte-item pool loop prefetches the table entry of a lane's NEXT item from the item's 8-bit
+        // read index without asking whether there is a next item -- a lane past the end of its items reads an arbitrary slot and never uses what comes back
+        const size_t rt_n = std::max<size_t>(256, (size_t)D.read_cap);
+        TRY(dmalloc(&c->d_qs_read_tab, rt_n));
+        TRYHIP(hipMemset(c->d_qs_read_tab, 0, sizeof(VglAffine) * rt_n));
         TRYHIP(hipMemcpy(c->d_qs_read_tab, rt.data(), sizeof(VglAffine) * D.read_cap, hipMemcpyHostToDevice));
         D.qs_read_tab = c->d_qs_read_tab;
     }

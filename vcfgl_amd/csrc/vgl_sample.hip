@@ -210,6 +210,9 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
         a0 = g & 0xF; a1 = (g >> 4) & 0xF;
         dp = (a0 == 0xF || a1 == 0xF) ? 0 : n;
         if (dp > P.read_cap) { atomicOr(T.errflag, VGL_DEVERR_CAPACITY); dp = P.read_cap; }
+#ifdef VGL_EXP_FIXED_DP
+        if (EQS != 2 && dp > 0) dp = VGL_EXP_FIXED_DP;                // (timing experiment, round 6: no spread of the 64 depths of a wavefront = the most lane pairing could give)
+#endif
     }
 
     if (DBG) c_pois = clock64() - c_t0;
@@ -579,7 +582,14 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
 #endif
                         // operands of this lane's next item (as in the float64 loop)
                         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kn));
+#ifdef VGL_POOL_CLAMP_NEXT
                         const uint32_t kc = (uint32_t)(kn < segT4 ? kn : segT * ISZ);   // l_it[segT] = 0 stands for "none" (a quarter's own limit is another quarter's live item)
+#else
+                        // (round 6: no clamp.  A lane whose claim lies past its items reads whatever 16 bits are there -- another quarter's slot, the table, or
+                        //  beyond the block, which LDS answers with zeros -- and forms a table address of at most 255 x 16 bytes (the table has 256 entries) and an
+                        //  LDS address below 512: nothing of it is used, the lane has no item any more (`have`).  Three vector instructions per iteration less.)
+                        const uint32_t kc = P16 ? (uint32_t)kn : (uint32_t)(kn < segT4 ? kn : segT * ISZ);
+#endif
                         uint32_t rd16, ow8, skn = 0;
                         if (P16) {
                             skn = *(const lds_u16*)(uintptr_t)(576u + kc);                                // owner << 10 | read << 2 | base
