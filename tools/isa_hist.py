@@ -306,6 +306,42 @@ def emit_replay(o, loop_blocks, weights, rows):
         f.write(src)
     return {"file": o.emit_replay, "blocks": used_blocks, "valu": n_valu, "salu": n_salu, "vgprs_of_body": nv}
 
+
+def auto_weights(loop_blocks, freq, bins):
+    """k_sample<2>'s float32 pool loop: which of its blocks run how often per iteration, from what the blocks contain and the frequencies the stamped
+    build counted (tools/stamps.py 2).  Returns ({label: weight}, {label: why})."""
+    w, why = {}, {}
+    period = 0.25                                                    # VGL_SLOW_PERIOD 4: the ballot that asks whether any lane needs a bounded test
+    region = None                                                    # inside a bounded test's blocks until the join block (starts with s_or_b64 exec)
+    for lab, ins in loop_blocks:
+        toks = [x.split()[0] for x in ins if not x.startswith(";;#")]
+        valu = [t for t in toks if t.startswith("v_")]
+        text = " ".join(ins)
+        if region and toks and toks[0] == "s_or_b64" and "exec" in ins[0]:
+            region = None
+        if region:
+            w[lab], why[lab] = freq[region], f"inside the bounded {region.split('_')[0]} test ({freq[region]:.3f} per iteration, measured)"
+            continue
+        if "global_atomic" in text or (valu and all(t.startswith("v_readlane") or t.startswith("v_mov") for t in valu) and "v_readlane_b32" in toks):
+            w[lab], why[lab] = 0.0, "error flag (never at the bench configurations)"
+        elif len(valu) == 2 and toks[-1].startswith("s_cbranch_vcc") and valu[0].startswith("v_cndmask") and valu[1].startswith("v_cmp_ne_u32"):
+            w[lab], why[lab] = period, "does any lane need a bounded test? (every fourth iteration)"
+        elif sum(t.startswith("v_fma_f32") for t in valu) >= 8:
+            region = "gamma_test"
+            w[lab], why[lab] = freq[region], f"bounded gamma test ({freq[region]:.3f} per iteration, measured)"
+        elif "v_log_f32_e32" in toks and any(t.startswith("v_rcp_f32") for t in toks) and "v_cvt_i32_f32_e32" not in toks and len(valu) <= 16:
+            region = "normal_test"
+            w[lab], why[lab] = freq[region], f"bounded normal-deviate test ({freq[region]:.3f} per iteration, measured)"
+        elif "ds_read_u8" in toks:
+            w[lab], why[lab] = (freq["finish"] if bins else 0.0), "finish path, --qs-bins table lookup"
+        elif len(valu) <= 2 and any(t.startswith("v_min_i32_sdwa") for t in toks) and toks[-1] == "s_branch":
+            w[lab], why[lab] = (0.0 if bins else freq["finish"]), "finish path without --qs-bins (cap at 63)"
+        elif len(valu) <= 2 and valu and all(t.startswith(("v_cndmask", "v_and_b32")) for t in valu) and toks[-1] == "s_branch":
+            w[lab], why[lab] = (freq["finish"] if bins else 0.0), "finish path, --qs-bins (no bin -> 0)"
+        elif "v_cvt_i32_f32_e32" in toks or "ds_add_rtn_u32" in toks or "ds_write_b16" in toks:
+            w[lab], why[lab] = freq["finish"], f"a lane finishes a read ({freq['finish']:.3f} per iteration, measured)"
+    return w, why
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--asm", required=True)
@@ -314,6 +350,9 @@ def main():
     ap.add_argument("--rates", required=True)
     ap.add_argument("--weight", action="append", default=[], help="LABEL=w: how often the block runs per iteration (default 1)")
     ap.add_argument("--note", action="append", default=[], help="LABEL=why (printed with the weight)")
+    ap.add_argument("--auto", default=None, help="JSON written by tools/stamps.py 2 (per_iteration: normal_test, gamma_test, finish): classify the pool loop's blocks of "
+                                                 "k_sample<2> by what they contain and weigh them with the measured frequencies (printed; --weight still overrides)")
+    ap.add_argument("--bins", type=int, default=0, help="--auto: 1 = the workload has --qs-bins (the table-lookup block of the finish path runs), 0 = it has not")
     ap.add_argument("--list", action="store_true", help="print the loop's blocks with their first instructions (to choose the weights)")
     ap.add_argument("--json", default=None)
     ap.add_argument("--emit-replay", default=None, help="write a HIP program that replays the loop's vector (and scalar ALU) instructions of the blocks with "
@@ -331,8 +370,13 @@ def main():
     lines, sym = function_lines(o.asm, o.kernel)
     blocks = blocks_of(lines)
     a, b = find_loop(blocks, o.loop_with)
-    weights = {k: float(v) for k, v in (w.split("=") for w in o.weight)}
     notes = dict(n.split("=", 1) for n in o.note)
+    weights = {}
+    if o.auto:
+        weights, auto_notes = auto_weights(blocks[a:b + 1], json.load(open(o.auto))["per_iteration"], o.bins)
+        for k, v in auto_notes.items():
+            notes.setdefault(k, v)
+    weights.update({k: float(v) for k, v in (w.split("=") for w in o.weight)})
     unknown_labels = [k for k in weights if k not in [lab for lab, _ in blocks[a:b + 1]]]
     if unknown_labels:
         sys.exit(f"--weight names blocks that are not in the loop: {unknown_labels}")

@@ -63,7 +63,7 @@ for k, v in out.items():
     if "SQ_ACTIVE_INST_VALU" in v and v.get("SQ_WAVE_CYCLES"):
         # the kernel's own denominator: share of its wavefronts' resident cycles in which a VALU instruction of theirs was executing
         v["valu_active_share_of_wave_cycles"] = v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"]
-    if "SQ_INSTS_VALU" in v and "SQ_WAVES" in v:
+    if v.get("SQ_INSTS_VALU") and v.get("SQ_WAVES"):            # (a kernel whose wavefronts leave at once -- k_sample_seg<., 2, .> with nothing listed -- has no vector instruction)
         v["valu_insts_per_wave"] = v["SQ_INSTS_VALU"] / v["SQ_WAVES"]
         v["active_lanes_per_valu_inst"] = v.get("SQ_THREAD_CYCLES_VALU", 0) / v["SQ_INSTS_VALU"]
         traffic.setdefault(bucket(k), {}).update({"valu_insts_per_wave": v["valu_insts_per_wave"],

@@ -522,8 +522,8 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
         const int extra16 = (D.qsum_lds ? 1024 : 0) + (p->n_qs_bins ? 256 : 0) + (p->precise_gl ? 32 : 0);
         const int cap_defer = p16 ? ((5120 - 576 - 8 - (D.lean_ok ? (p->n_qs_bins ? 256 : 0) : 0)) / 2 / 64 * 64) : (D.qsum_lds ? 1416 : 1472);
         // the float32 build of the default tag surface as two kernels (k_sample_seg, vgl_sample.hip) when a wavefront's reads fit one pool up to 8 sigma
-        // (a pool that holds the summed depth + 4.5 sigma: 3e-6 of the wavefronts go through the list)
-        D.seg_split = (p16 && (double)cap_defer >= pool_lmax + 4.5 * sqrt(pool_lmax) && !hook_env("VGL_NO_SEG_SPLIT")) ? 1 : 0;
+        // (a pool that holds the summed depth + 4 sigma: 3e-5 of the wavefronts go through the list -- depth 30 with --qs-bins: 2112 items for 1920 + 4 x 43.8)
+        D.seg_split = (p16 && (double)cap_defer >= pool_lmax + 4.0 * sqrt(pool_lmax) && !hook_env("VGL_NO_SEG_SPLIT")) ? 1 : 0;
         // round 6: the two-byte-item builds take min(summed depth + 8 sigma, what eight wavefronts per SIMD leave) -- the five-byte limit of 1920 above
         // was still applied first, so that depth 30 (mean 1920 reads per wavefront) ran half of its wavefronts in two segments
         if (p16) D.pool_cap = pool_want;
