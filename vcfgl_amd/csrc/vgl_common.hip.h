@@ -728,8 +728,9 @@ __device__ __forceinline__ int sample_read_base16(uint64_t& st_hap, uint64_t& st
 // stream is the evaluation's own window, read by nobody else.
 // emit(trip, bases): bases = the trip's reads, two bits each (read 4 trip + j at bits 2j); entries beyond dp are a0's bits.
 // Returns the per-base depths (A | C << 16 | G << 32 | T << 48).
+// (the 64-bit-state form with 16-bit depth fields: evaluations of up to 65535 reads -- what a run with a staging capacity beyond 255 reads uses)
 template <bool HOM, class Emit>
-__device__ __forceinline__ uint64_t sample_reads_fixed(uint64_t st_hap16, uint64_t st_base16, const int a0, const int a1, const int dp,
+__device__ __forceinline__ uint64_t sample_reads_fixed_wide(uint64_t st_hap16, uint64_t st_base16, const int a0, const int a1, const int dp,
                                                        const uint64_t err_thresh16, Emit&& emit) {
     const uint32_t dx = (uint32_t)(a0 ^ a1);
     const uint32_t rep0 = (uint32_t)a0 * 0x55u;                       // a0 in four 2-bit fields
@@ -766,6 +767,57 @@ __device__ __forceinline__ uint64_t sample_reads_fixed(uint64_t st_hap16, uint64
         emit(r0 >> 2, bases);
     }
     return (((uint64_t)((uint32_t)dp - n1)) << (16 * (a0 & 3))) + (((uint64_t)n1) << (16 * (a1 & 3))) + adfix;   // (dp = 0 for a missing genotype, alleles 0xF)
+}
+// Round 6: the same reads on the raw 52-bit form of the two states (x 16, as lcg52_step carries them: the low product and the constant in one
+// v_mad_u64_u32, the two cross terms through the 24-bit multiply-add -- three instructions a step instead of four, and no 64-bit pair to shuffle).
+// Of the high word only bits 0-19 are valid: the haplotype pick is bit 19 (u >= 0.5), a wrong base bits 18-19 (floor(4 u)), and the base-call error test
+// u < e is taken in two steps -- high 20 bits <= the threshold's (one 32-bit compare on the common path; true for e + 2^-20 of the reads), then the exact
+// 52-bit comparison inside the rare block.  The errors' corrections to the per-base depths are kept in four 8-bit fields of one register (modulo 2^32;
+// every final depth is below 256: the caller's read_cap <= 255, else sample_reads_fixed_wide) and spread to 16-bit fields once at the end.
+template <bool HOM, class Emit>
+__device__ __forceinline__ uint64_t sample_reads_fixed(const uint64_t st_hap16, const uint64_t st_base16, const int a0, const int a1, const int dp,
+                                                       const uint64_t err_thresh16, Emit&& emit) {
+    uint32_t hl = (uint32_t)(st_hap16 >> 12), hh = (uint32_t)(st_hap16 >> 44);          // state x 16 = (state x 2^16) >> 12
+    uint32_t bl = (uint32_t)(st_base16 >> 12), bh = (uint32_t)(st_base16 >> 44);
+    // threshold x 16; sample_thresh16 saturates e >= 1 to 2^64 - 1, whose top 52 bits compare above every state as well
+    const uint32_t t_lo = (uint32_t)(err_thresh16 >> 12), t_hi = (uint32_t)(err_thresh16 >> 44);
+    const uint32_t dx = (uint32_t)(a0 ^ a1);
+    const uint32_t rep0 = (uint32_t)a0 * 0x55u;                       // a0 in four 2-bit fields
+    uint32_t n1 = 0;                                                  // reads that picked the second haplotype
+    uint32_t adfix8 = 0;                                              // the errors' corrections to the per-base depths, 8 bits per base (modulo 2^32)
+    for (int r0 = 0; r0 < dp; r0 += 4) {
+        uint32_t hb = 0, fix = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (r0 + j < dp) {
+                if (!HOM) {
+                    lcg52_step(hl, hh, hl, hh);
+                    hb = ((hh >> (19 - j)) & (1u << j)) | hb;             // u >= 0.5: the second allele (vcfgl.cpp:473)
+                }
+                lcg52_step(bl, bh, bl, bh);
+                if (__builtin_expect((bh & 0xFFFFFu) <= t_hi, 0)) {       // may be a base-call error (vcfgl.cpp:486-488): settle it on all 52 bits
+                    if ((bh & 0xFFFFFu) < t_hi || bl < t_lo) {
+                        const uint32_t tb = HOM ? (uint32_t)a0 : (((hb >> j) & 1u) ? (uint32_t)a1 : (uint32_t)a0);
+                        uint32_t rb;
+                        do { lcg52_step(bl, bh, bl, bh); rb = (bh >> 18) & 3u; } while (rb == tb);
+                        fix |= (tb ^ rb) << (2 * j);
+                        adfix8 += (1u << (8 * rb)) - (1u << (8 * tb));
+                    }
+                }
+            }
+        }
+        uint32_t bases = rep0 ^ fix;
+        if (!HOM) {
+            uint32_t sp = (hb | (hb << 2)) & 0x33u;                   // bit j -> bit 2j
+            sp = (sp | (sp << 1)) & 0x55u;
+            bases ^= sp * dx;                                         // dx <= 3: no carries between the fields
+            n1 += (uint32_t)__builtin_popcount(hb);
+        }
+        emit(r0 >> 2, bases);
+    }
+    // per-base depths in 8-bit fields: picks + corrections (each final field is the count of reads that show the base: 0 ... dp < 256), then 16 bits a field
+    const uint32_t d8 = (((uint32_t)dp - n1) << (8 * (a0 & 3))) + (n1 << (8 * (a1 & 3))) + adfix8;      // (dp = 0 for a missing genotype, alleles 0xF)
+    return (uint64_t)(d8 & 0xFFu) | ((uint64_t)(d8 & 0xFF00u) << 8) | ((uint64_t)(d8 & 0xFF0000u) << 16) | ((uint64_t)(d8 & 0xFF000000u) << 24);
 }
 // the trip's staged word, one byte per read (score << 2 | base), from its 2-bit bases; qrep = (score << 2) in every byte
 __device__ __forceinline__ uint32_t staged_word_of(const uint32_t bases, const uint32_t qrep) {

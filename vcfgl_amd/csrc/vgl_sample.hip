@@ -249,8 +249,18 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
             const uint32_t qrep = (q_gl << 2) * 0x01010101u;
             uint32_t* const col = reads_w + ev;
             auto emit = [&](const int trip, const uint32_t bases) { if (stage) col[(size_t)trip * plane] = staged_word_of(bases, qrep); };
-            if (__ballot(active && dp > 0 && a0 != a1) == 0) ad4 = sample_reads_fixed<true>(st_hap16, st_base16, a0, a1, dp, err_thresh16, emit);
-            else ad4 = sample_reads_fixed<false>(st_hap16, st_base16, a0, a1, dp, err_thresh16, emit);
+#ifdef VGL_FIXED_READS_V1
+            const bool narrow = false;
+#else
+            const bool narrow = P.read_cap <= 255;                       // (8-bit depth fields: sample_reads_fixed; deeper runs keep the 16-bit form)
+#endif
+            if (narrow) {
+                if (__ballot(active && dp > 0 && a0 != a1) == 0) ad4 = sample_reads_fixed<true>(st_hap16, st_base16, a0, a1, dp, err_thresh16, emit);
+                else ad4 = sample_reads_fixed<false>(st_hap16, st_base16, a0, a1, dp, err_thresh16, emit);
+            } else {
+                if (__ballot(active && dp > 0 && a0 != a1) == 0) ad4 = sample_reads_fixed_wide<true>(st_hap16, st_base16, a0, a1, dp, err_thresh16, emit);
+                else ad4 = sample_reads_fixed_wide<false>(st_hap16, st_base16, a0, a1, dp, err_thresh16, emit);
+            }
         } else
         for (int r0 = 0; r0 < dp; r0 += 4) {
             uint32_t rw = 0;
@@ -386,6 +396,35 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                         // (as sample_reads_fixed) instead of a 64-bit shift-and-add per read
                         uint32_t n1 = 0;
                         const uint32_t nrd = (sv_end > sv) ? ((sv_end - sv) >> (P16 ? 2 : 4)) : 0u;
+#ifdef VGL_OWNER_READS_V2     // (built and measured in round 6: +1.5 % on C3 / C4 -- the loop is 5 % of the kernel and the change costs the pool loop its register allocation; not used)
+                        // the two states on their raw 52-bit form for the loop (lcg52_step: three instructions a step; pick = bit 19 of the high word, a
+                        // wrong base its bits 18-19, the error test first on the high 20 bits and exactly inside the rare block -- as sample_reads_fixed)
+                        uint32_t hl = (uint32_t)(st_hap16 >> 12), hh = (uint32_t)(st_hap16 >> 44), bl = (uint32_t)(st_base16 >> 12), bh = (uint32_t)(st_base16 >> 44);
+                        const uint32_t t_lo = (uint32_t)(err_thresh16 >> 12), t_hi = (uint32_t)(err_thresh16 >> 44);
+                        while (sv < sv_end) {
+                            uint32_t rb = (uint32_t)a0;
+                            if (!HOMW) {
+                                lcg52_step(hl, hh, hl, hh);
+                                const uint32_t h = (hh >> 19) & 1u;                       // u >= 0.5: the second allele (vcfgl.cpp:473)
+                                n1 += h;
+                                rb = h ? (uint32_t)a1 : (uint32_t)a0;
+                            }
+                            lcg52_step(bl, bh, bl, bh);
+                            if (__builtin_expect((bh & 0xFFFFFu) <= t_hi, 0)) {
+                                if ((bh & 0xFFFFFu) < t_hi || bl < t_lo) {                  // vcfgl.cpp:486-488
+                                    const uint32_t tb = rb;
+                                    do { lcg52_step(bl, bh, bl, bh); rb = (bh >> 18) & 3u; } while (rb == tb);
+                                    ad4 += (1ULL << (16 * rb)) - (1ULL << (16 * tb));
+                                }
+                            }
+                            if (P16) { *(lds_u16o*)(uintptr_t)ka = (uint16_t)(sv | rb); sv += 4u; ka += 2u; }
+                            else { *(lds_u32o*)(uintptr_t)ka = sv; *(lds_u8o*)(uintptr_t)pa = (uint8_t)rb; sv += 16u; ka += 4u; pa += 1u; }
+                        }
+                        if constexpr (SEG != 1) {                                         // (another segment may follow: the states back on the form the rest of the kernel carries)
+                            st_hap16 = ((((uint64_t)(hh & 0xFFFFFu)) << 32) | hl) << 12;
+                            st_base16 = ((((uint64_t)(bh & 0xFFFFFu)) << 32) | bl) << 12;
+                        }
+#else
                         while (sv < sv_end) {
                             uint32_t rb = (uint32_t)a0;
                             if (!HOMW) {
@@ -403,6 +442,7 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
                             if (P16) { *(lds_u16o*)(uintptr_t)ka = (uint16_t)(sv | rb); sv += 4u; ka += 2u; }
                             else { *(lds_u32o*)(uintptr_t)ka = sv; *(lds_u8o*)(uintptr_t)pa = (uint8_t)rb; sv += 16u; ka += 4u; pa += 1u; }
                         }
+#endif
                         ad4 += (((uint64_t)(nrd - n1)) << (16 * (a0 & 3))) + (((uint64_t)n1) << (16 * (a1 & 3)));
                     } else if constexpr (P16) {
                         // LEAN 3, float32 build: the same counting with the strand draws (vcfgl.cpp:581-586: one more output of the base
