@@ -57,11 +57,11 @@ def test_a_rank_that_never_arrives_in_the_record_gather_does_not_cost_the_line()
     r = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--comm-timeout", "8", "--backend", "gloo"] + COMMON, env=_env(BENCH_TEST_STALL_RANK="2"),
                        capture_output=True, text=True, timeout=600)
     assert time.time() - t0 < 120
-    assert r.returncode == 15, (r.returncode, r.stderr[-2000:])      # a stalled transfer is not a clean run ...
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])       # `value` is complete: the run is not failed by a transfer reported beside it ...
     lines = _lines(r.stdout)
-    assert len(lines) == 2 and lines[0]["n_gpus"] == 4 and lines[0]["value"] > 0     # ... but the line is there, printed before the gather was attempted,
+    assert len(lines) == 2 and lines[0]["n_gpus"] == 4 and lines[0]["value"] > 0     # ... the line is there, printed before the gather was attempted,
     assert lines[0]["comm"]["records_sample"] == "pending"
-    assert lines[1]["comm"]["records_sample"] == "stalled" and lines[1]["value"] == lines[0]["value"]    # and once more, last, saying what happened
+    assert lines[1]["comm"]["records_sample"] == "stalled" and lines[1]["value"] == lines[0]["value"]    # and once more, last, SAYING that the transfer stalled
     assert "stalled" in r.stderr
 
 
