@@ -509,8 +509,16 @@ def run_workload(name, opt, env, steps, warmup, sites=None, samples=None, with_c
         ir = issue_roof_entry(name)
         if kprof.get("valu_insts_per_wave") and ir.get("issue_cycles_per_inst") and ir.get("kernel", KERNELS[dom]).startswith(KERNELS[dom]):
             sclk_mhz = (clk or {}).get("sclk_mhz") or SCLK_NOMINAL_MHZ
-            bound_ms = waves * kprof["valu_insts_per_wave"] * ir["issue_cycles_per_inst"] / (N_SIMD * sclk_mhz * 1e6) * 1e3
-            issue = {"issue_cycles_per_inst": ir["issue_cycles_per_inst"], "issue_bound_ms": bound_ms, "issue_frac": bound_ms / avg_ms, "sclk_mhz_used": sclk_mhz,
+            lp = ir.get("loop") or {}
+            it, vpw = lp.get("iterations_per_wave"), kprof["valu_insts_per_wave"]
+            loop_valu = (it or 0) * (lp.get("valu_per_iteration_main_path", 0) + lp.get("rare_blocks_valu_per_iteration", 0))
+            if it and lp.get("floor_cycles_per_inst_outside_the_loop") and 0 < loop_valu <= vpw:
+                # iterations x (the loop's replayed every-iteration path + its rare blocks) + what is outside the loop at the part's cheapest rate: a lower bound
+                cyc_wave = it * (lp["simd_cycles_per_iteration_main_path"] + lp.get("rare_blocks_cycles_per_iteration", 0.0)) + (vpw - loop_valu) * lp["floor_cycles_per_inst_outside_the_loop"]
+            else:
+                cyc_wave = vpw * ir["issue_cycles_per_inst"]
+            bound_ms = waves * cyc_wave / (N_SIMD * sclk_mhz * 1e6) * 1e3
+            issue = {"issue_cycles_per_inst": ir["issue_cycles_per_inst"], "issue_cycles_per_wave": cyc_wave, "issue_bound_ms": bound_ms, "issue_frac": bound_ms / avg_ms, "sclk_mhz_used": sclk_mhz,
                      "valu_insts_per_wave": kprof["valu_insts_per_wave"], "waves_per_launch": waves, "method": ir.get("method"), "source": ir.get("source"),
                      "profile_matches_build": fresh and ir.get("src_sha") == source_sha()}
         traffic = kprof.get("hbm_bytes_per_launch") * scale if kprof.get("hbm_bytes_per_launch") else None

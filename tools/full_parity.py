@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off: a bench configuration at its FULL size against the CPU oracle, site by site and field by field (the suite's
 tests/test_gpu_scale_oracle.py does 1e8 of C3's 1e9 evaluations).  The oracle is test infrastructure; this script is a checker.
-usage (GPU box): python tools/full_parity.py [c3|c4|c5|alltags|qsi16|fq20|c5wide] [sites]      -- prints a progress line per 100 000 sites"""
+usage (GPU box): python tools/full_parity.py [c3|c4|c5|alltags|qsi16|fq20|c5wide|precise|fixedq|gl1q] [sites]      -- prints a progress line per 100 000 sites"""
 import dataclasses
 import os
 import sys
@@ -15,7 +15,7 @@ import oracle_pool
 import test_gpu_scale_oracle as T
 
 name = sys.argv[1] if len(sys.argv) > 1 else "c3"
-full = {"c3": 1_000_000, "c4": 1_250_000, "c5": 2_000_000, "alltags": 262_144, "qsi16": 262_144, "fq20": 1_000_000, "c5wide": 1_000_000}[name]
+full = {"c3": 1_000_000, "c4": 1_250_000, "c5": 2_000_000, "alltags": 262_144, "qsi16": 262_144, "fq20": 1_000_000, "c5wide": 1_000_000, "precise": 262_144, "fixedq": 1_000_000, "gl1q": 262_144}[name]
 case = dict(T.CASES[name], S=int(sys.argv[2]) if len(sys.argv) > 2 else full, site0=0)
 t0 = time.time()
 got, sim = T._gpu_checksums(case)

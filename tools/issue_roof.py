@@ -10,16 +10,22 @@ import bench
 wls, hist, rep, st = sys.argv[1].split(","), json.load(open(sys.argv[2])), json.load(open(sys.argv[3])), json.load(open(sys.argv[4]))
 bucket = sys.argv[5] if len(sys.argv) > 5 else "k_sample"
 rare = sum(b["weight"] * b["cycles"] for b in hist["blocks"] if 0 < b["weight"] < 0.5)        # the bounded tests: priced by the class rates, scaled like the main path
+rare_valu = sum(b["weight"] * b["valu"] for b in hist["blocks"] if 0 < b["weight"] < 0.5)
+# the cheapest a vector instruction can be on this part (v_fma_f32 / v_mov_b32 / v_add_u32 at eight wavefronts per SIMD: tools/valu_rates.hip): what the
+# kernel's instructions OUTSIDE the replayed loop are priced at, so that the sum stays a lower bound of the time
+floor = min(float(l.split()[3]) for l in open(os.path.join(ROOT, "profiles", "r06_valu_rates.txt")) if l.startswith(("k_fma_f32 ", "k_mov ", "k_add_u32 ")) and "waves/SIMD 8" in l)
 main_valu = rep["valu_per_iteration"]
 scale = rep["simd_cycles_per_iteration_grbm"] / max(1e-9, sum(b["cycles"] for b in hist["blocks"] if b["weight"] >= 0.5))
 entry = {"kernel": bucket, "kernel_build": hist["kernel"], "src_sha": bench.source_sha(),
          "issue_cycles_per_inst": rep["cycles_per_valu_inst_grbm"],
          "loop": {"valu_per_iteration_main_path": main_valu, "simd_cycles_per_iteration_main_path": rep["simd_cycles_per_iteration_grbm"],
-                  "rare_blocks_cycles_per_iteration": rare * scale, "class_sum_cycles_main_path": sum(b["cycles"] for b in hist["blocks"] if b["weight"] >= 0.5),
+                  "rare_blocks_cycles_per_iteration": rare * scale, "rare_blocks_valu_per_iteration": rare_valu, "floor_cycles_per_inst_outside_the_loop": floor,
+                  "class_sum_cycles_main_path": sum(b["cycles"] for b in hist["blocks"] if b["weight"] >= 0.5),
                   "iterations_per_wave": st.get("pool iterations"), "lanes_with_item": st.get("per_iteration", {}).get("lanes_with_item")},
          "replay": {k: rep[k] for k in ("waves_per_simd", "iterations", "effective_clock_ghz", "simd_cycles_per_iteration_slowest_wave", "grbm_gui_active", "dispatch_ms")},
-         "method": "cycles per vector instruction of the kernel's pool loop (main path), measured by replaying its instruction sequence on the box (tools/isa_hist.py --emit-replay, "
-                   "GRBM_GUI_ACTIVE cycles); bench.py multiplies by the kernel's vector instructions per wavefront (committed counters)",
+         "method": "SIMD cycles the kernel's vector instructions need, per wavefront = pool iterations (stamped build) x [the loop's every-iteration path, replayed on the box "
+                   "with its own instruction sequence (tools/isa_hist.py --emit-replay, GRBM_GUI_ACTIVE cycles) + its rarely-run blocks at class rates] + the instructions "
+                   "outside the loop (counters' total minus the loop's) x the cheapest issue rate of the part: a LOWER bound of the kernel's time",
          "source": "profiles/" + os.path.basename(sys.argv[3])}
 path = os.path.join(ROOT, "profiles", "issue_roof.json")
 try:
