@@ -740,8 +740,9 @@ def compact_roofline(rf):
            "sclk_mhz": (rf.get("clocks") or {}).get("sclk_mhz"), "mclk_mhz": (rf.get("clocks") or {}).get("mclk_mhz"), "sclk_mhz_min": (rf.get("clocks") or {}).get("sclk_mhz_min"),
            "profile_matches_build": v.get("profile_matches_build"),
            "kernel_ms_per_launch": {k: _r(rf["kernel_ms_total"][k] / max(rf["launches"][k], 1)) for k in rf["kernel_ms_total"] if rf["launches"][k]},
-           "note": "achieved/frac = algorithmic bytes of the dominant kernel / its HIP-event time; bound valu = instruction issue: issue_frac = (vector instructions per wavefront x "
-                   "cycles per instruction of the kernel's loop, replayed on the box: profiles/issue_roof.json) / (1024 SIMD x sclk) / launch time"}
+           "note": "achieved/frac = algorithmic bytes of the dominant kernel / its HIP-event time; bound valu = instruction issue: issue_frac = [pool iterations x (the loop's "
+                   "instruction sequence replayed on the box, counted cycles, + its rare blocks) + instructions outside the loop x the part's cheapest rate] / (1024 SIMD x sclk) "
+                   "/ launch time: a lower bound of the kernel's time (profiles/issue_roof.json, DESIGN.md section 5)"}
     if "copy_bw_measured" in rf:
         out["copy_bw_measured"] = _r(rf["copy_bw_measured"], 5)
     return out
