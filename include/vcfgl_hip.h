@@ -101,7 +101,13 @@ extern "C" {
  * Stream 3 is further divided per read: the beta deviate of read r starts at
  * e*block + off[3] + r*qs_read_stride, so the quality scores of one wavefront's reads are
  * independent work items that the device balances across lanes.  With --error-qs 1 the single
- * per-site beta deviate uses stream 3 of sample 0, read 0. */
+ * per-site beta deviate uses stream 3 of sample 0, read 0.
+ * I16 tail distances (-addI16; vcfgl.cpp:647-663): the reference draws one per read from libc rand(), never seeded -- one serial
+ * stream, which VGL_RNG_SERIAL follows.  VGL_RNG_TILE takes them from a SECOND rand48 sequence, X0 = 0x7A11D157A11D (no --seed
+ * produces that state), addressed like the first: evaluation e owns draws [e*block, (e+1)*block) of it and read r uses draw r
+ * as a 31-bit integer x (the state's top 31 bits, as lrand48()): tail = min(1 + x / (RAND_MAX / 50 + 1), 25)  (rng.h:12,
+ * CAP_TAIL_DIST), credited -- as in the reference -- to the base of the site's last simulated read, float32 sums in (sample,
+ * read) order.  (ABI 6, round 6: until then fields 13-16 of INFO/I16 were 0 in VGL_RNG_TILE.) */
 typedef struct vgl_rng_layout {
     uint64_t block;
     uint64_t off[4];
@@ -171,9 +177,9 @@ typedef struct vgl_tile_out {
     int32_t* info_adf;       /* [n_sites][A]                                                   */
     int32_t* info_adr;       /* [n_sites][A]                                                   */
     float*   qs;             /* [n_sites][A]   INFO/QS                                         */
-    float*   i16;            /* [n_sites][16]  INFO/I16; fields 12-15 (tail distance: the reference draws
-                                               them from the never-seeded libc rand()) are produced in
-                                               VGL_RNG_SERIAL mode and are 0 in VGL_RNG_TILE mode */
+    float*   i16;            /* [n_sites][16]  INFO/I16; fields 12-15 (tail distance): the reference's own
+                                               libc rand() draws in VGL_RNG_SERIAL, a counter-addressed rand48
+                                               sequence in VGL_RNG_TILE (see vgl_rng_layout)                */
     /* per (site, sample) */
     int32_t* fmt_dp;         /* [n_sites][n_samples]          FORMAT/DP                        */
     float*   gl;             /* [n_sites][G][n_samples]       FORMAT/GL, VCF genotype order;

@@ -341,6 +341,9 @@ static int cmp_u16(const void* a, const void* b) {
 #define HTS_RAND48_X0 0x1234ABCD330EULL
 /* draws of that stream one evaluation owns in VGL_RNG_TILE mode: evaluation e starts at draw e * VGL_HTS_TILE_STRIDE */
 #define VGL_HTS_TILE_STRIDE 1024ULL
+/* VGL_RNG_TILE, -addI16: the tail distances' own rand48 sequence (the reference: libc rand(), one serial stream); evaluation e owns draws
+ * [e block, (e + 1) block) of it, as of the main sequence (include/vcfgl_hip.h) */
+#define VGL_TAIL_RAND48_X0 0x7A11D157A11DULL
 
 /* ks_shuffle(uint16_t, n, a) of htslib's ksort.h: for (i = n; i > 1; --i) { j = (int)(hts_drand48() * i); swap(a[j], a[i-1]); } */
 static void ks_shuffle_u16(int n, uint16_t* a, uint64_t* st) {
@@ -786,13 +789,25 @@ static int simulate_site(vgl_oracle* o, int64_t site_abs, int32_t ls, int32_t n_
     }
 
     if (p->add_i16) {                                                                /* :647-663 */
-        for (int s = 0; s < N; s++)
+        for (int s = 0; s < N; s++) {
+            /* VGL_RNG_TILE (include/vcfgl_hip.h, "I16 tail distances"): the never-seeded libc rand() of the reference is one serial stream; tile mode
+             * draws instead from a second rand48 sequence (X0 = VGL_TAIL_RAND48_X0) of which evaluation e owns draws [e block, (e + 1) block), exactly
+             * as of the main one: read r takes draw r of that window as a 31-bit integer (the state's top 31 bits, as lrand48) through the
+             * reference's own range formula */
+            uint64_t st_tail = 0;
+            if (tile) {
+                const uint64_t e = vgl_oracle_site_hash((uint64_t)site_abs, o->hash_bits) * (uint64_t)N + (uint64_t)s;
+                st_tail = vgl_oracle_rand48_jump(VGL_TAIL_RAND48_X0, e * o->lay.block);
+            }
             for (int r = 0; r < dp[s]; r++) {
-                int td = 1 + rand() / (RAND_MAX / (50 - 1 + 1) + 1);                 /* rng.h:12 */
-                o->n_draw_rand++;
+                int rv;
+                if (tile) { st_tail = (st_tail * LCG_A + LCG_C) & MASK48; rv = (int)(st_tail >> 17); }
+                else { rv = rand(); o->n_draw_rand++; }
+                int td = 1 + rv / (2147483647 / (50 - 1 + 1) + 1);                   /* rng.h:12 (RAND_MAX = 2^31 - 1) */
                 if (td > 25) td = 25;                                                /* CAP_TAIL_DIST */
                 taild[r_base] += td; taild_sq[r_base] += (td * td);                  /* stale r_base: reference quirk */
             }
+        }
     }
 
     {

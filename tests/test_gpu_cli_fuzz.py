@@ -128,7 +128,7 @@ def test_random_cli_runs_against_the_oracle(oracle, chunk, tmp_path):
                 # a device log10 / pow feeds these floats (1e-6): one unit of the sixth printed digit
                 gu.close6 = lambda x, y: strict(x, y) or (np.isfinite(x) and np.isfinite(y) and abs(x - y) <= 2e-5 * max(abs(x), abs(y), 1e-30))
             try:
-                errs = gu.compare_with_golden(args, sites, tile, got, check_i16_tail=(mode == _abi.VGL_RNG_SERIAL))
+                errs = gu.compare_with_golden(args, sites, tile, got, check_i16_tail=True)
             finally:
                 gu.close6 = strict
             assert not errs, (tag, errs[:10])

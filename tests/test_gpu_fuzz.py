@@ -70,7 +70,7 @@ def compare(want, got, tol_gl, tag):
     if "qs" in got.arrays:
         assert np.array_equal(want.numpy("qs").view(np.uint32), got.numpy("qs").view(np.uint32)), (tag, "qs")
     if "i16" in got.arrays:
-        assert np.array_equal(want.numpy("i16")[:, :12], got.numpy("i16")[:, :12]), (tag, "i16")
+        assert np.array_equal(want.numpy("i16").view(np.uint32), got.numpy("i16").view(np.uint32)), (tag, "i16")
 
 
 # VGL_FUZZ_CHUNKS / VGL_FUZZ_SEED: longer one-off runs (10 configurations x 2 RNG modes per chunk)
@@ -106,8 +106,6 @@ def test_random_configurations(oracle, chunk):
             got = sim.simulate(0, gt, fields=fields)
             sim.close()
             compare(want, got, tol_gl=bool(args.precise_gl), tag=tag)
-            if mode == _abi.VGL_RNG_SERIAL and args.add_i16:
-                assert np.array_equal(want.numpy("i16"), got.numpy("i16")), (tag, "i16 tail")
         done += 1
 
 

@@ -75,7 +75,7 @@ def assert_parity(want, got, exact_gl=True, i16=False, qs=True, check_gp=True):
     if qs and "qs" in got.arrays:
         assert np.array_equal(want.numpy("qs").view(np.uint32), got.numpy("qs").view(np.uint32)), "QS"
     if i16 and "i16" in got.arrays:
-        assert np.array_equal(want.numpy("i16")[:, :12], got.numpy("i16")[:, :12]), "I16[0..11]"
+        assert np.array_equal(want.numpy("i16").view(np.uint32), got.numpy("i16").view(np.uint32)), "I16"      # all sixteen fields, both RNG modes (round 6: k_tail)
 
 
 ALLTAGS = dict(add_gp=1, add_pl=1, add_qs=1, add_info_dp=1, add_fmt_ad=1, add_info_ad=1)
@@ -253,6 +253,32 @@ def test_siteagg_sixteen_sites_per_wavefront(oracle, N, n_sites, eqs):
     assert_parity(want, got, i16=True)
 
 
+@pytest.mark.parametrize("kw,N,depth", [(dict(), 1, 4.0), (dict(), 63, 20.0), (dict(gl_model=1), 130, 9.0), (dict(error_qs=2, beta_variance=1e-5), 200, 20.0),
+                                        (dict(error_qs=2, beta_variance=1e-5, precise_gl=1), 65, 14.0), (dict(error_qs=1, beta_variance=1e-5), 257, 3.0),
+                                        (dict(gl_model=1, error_qs=2, beta_variance=1e-5, add_qs=1), 100, 30.0), (dict(depth=300.0, gl_model=1), 40, 300.0)])
+def test_i16_tail_distances_in_tile_mode(oracle, kw, N, depth):
+    """INFO/I16 fields 13-16 (vcfgl.cpp:647-663, 1029-1071) in VGL_RNG_TILE: one draw per read from the second rand48 sequence (k_tail, k_tail_fin) -- every
+    sampler build that can run with -addI16 (fixed score with GL model 1: reads staged only for this; per-read scores; --precise-gl 1; a capacity beyond
+    255 reads), all sixteen fields equal to the oracle, not zero, and independent of the tiling and of site0"""
+    kw = dict(kw); kw.pop("depth", None)
+    args = VcfglArgs(seed=11, depth=depth, error_rate=0.01, **kw, **STRAND)
+    gt = synth.acgt_sites(24, N, seed=4, missing=0.1)
+    gt[3] = 0xFF                                                # a site without reads: no draw, no base
+    want, got = run_both(oracle, args, gt, site0=7)
+    assert_parity(want, got, i16=True, qs=False, check_gp=False, exact_gl=not args.precise_gl)
+    tail = got.numpy("i16")[:, 12:].astype(np.float64)
+    ok = tail.sum(axis=1) > 0                                   # (I16 is written for sites with reads and more than one allele)
+    assert ok.sum() >= 12 and (tail[3] == 0).all()
+    # every draw of a site goes to ONE base (the last read's): fields 13 + 15 hold the site's sum; mean tail distance (1 + ... + 24 + 26 x 25) / 50 = 19
+    nread = got.numpy("info_dp")[ok].sum()
+    assert abs(tail[ok][:, [0, 2]].sum() / nread - 19.0) < 4 * 8.0 / np.sqrt(nread) + 0.05
+    args.rng_mode, args.beta_sampler = _abi.VGL_RNG_TILE, _abi.VGL_BETA_RAND48
+    sim = Simulator(args, N, device=0, max_sites_per_tile=5)
+    parts = [sim.simulate(7 + s0, gt[s0:s0 + 5]).numpy("i16") for s0 in range(0, 24, 5)]
+    sim.close()
+    assert np.array_equal(np.concatenate(parts).view(np.uint32), got.numpy("i16").view(np.uint32))
+
+
 @pytest.mark.parametrize("kw,N,depth", [(dict(error_rate=1e-7), 300, 20), (dict(error_rate=0.01, i16_mapq=37), 700, 20), (dict(error_rate=0.01, i16_mapq=59), 400, 60),
                                         (dict(error_rate=0.01, i16_mapq=0), 100, 5), (dict(error_rate=0.01, i16_mapq=60), 2000, 30)])
 def test_siteagg_beyond_the_exact_range_of_float32(oracle, kw, N, depth):
@@ -268,7 +294,7 @@ def test_siteagg_beyond_the_exact_range_of_float32(oracle, kw, N, depth):
     for f in ("site_status", "fmt_dp", "info_dp", "info_adf"):
         assert np.array_equal(want.numpy(f), got.numpy(f)), f
     assert np.array_equal(want.numpy("qs").view(np.uint32), got.numpy("qs").view(np.uint32)), "QS"
-    assert np.array_equal(want.numpy("i16")[:, :12].view(np.uint32), got.numpy("i16")[:, :12].view(np.uint32)), "I16[0..11]"
+    assert np.array_equal(want.numpy("i16").view(np.uint32), got.numpy("i16").view(np.uint32)), "I16"
 
 
 @pytest.mark.parametrize("precise", [0, 1])

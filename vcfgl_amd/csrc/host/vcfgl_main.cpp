@@ -935,7 +935,7 @@ int main(int argc, char** argv) {
         if (a.add_pl) hdr.push_back("##FORMAT=<ID=PL,Number=G,Type=Integer,Description=\"Phred-scaled genotype likelihoods\">");
         if (a.add_gp) hdr.push_back("##FORMAT=<ID=GP,Number=G,Type=Float,Description=\"Genotype probabilities\">");
         if (a.add_qs) hdr.push_back("##INFO=<ID=QS,Number=R,Type=Float,Description=\"Normalised per-allele base quality sum\">");
-        if (a.add_i16) hdr.push_back("##INFO=<ID=I16,Number=16,Type=Float,Description=\"bcftools call auxiliary tag (fields 13-16 only in --rng-mode 1)\">");
+        if (a.add_i16) hdr.push_back("##INFO=<ID=I16,Number=16,Type=Float,Description=\"bcftools call auxiliary tag\">");
         if (a.add_fmt_ad) hdr.push_back("##FORMAT=<ID=AD,Number=R,Type=Integer,Description=\"Allelic depths\">");
         if (a.add_fmt_adf) hdr.push_back("##FORMAT=<ID=ADF,Number=R,Type=Integer,Description=\"Allelic depths, forward strand\">");
         if (a.add_fmt_adr) hdr.push_back("##FORMAT=<ID=ADR,Number=R,Type=Integer,Description=\"Allelic depths, reverse strand\">");

@@ -15,6 +15,16 @@
 // (hts_drand48: never seeded by its callers, state {0x330e, 0xabcd, 0x1234}); GL model 1 reaches it with --depth > ~200
 #define VGL_HTS_RAND48_X0 0x1234ABCD330EULL
 #define VGL_HTS_TILE_STRIDE 1024ULL   // VGL_RNG_TILE: evaluation e owns draws [e * 1024, (e + 1) * 1024) of that stream
+// -addI16 in VGL_RNG_TILE: the reference draws the tail distances (vcfgl.cpp:647-663) from the never-seeded libc rand(), one serial stream; tile mode
+// takes them from a SECOND rand48 sequence (started at VGL_TAIL_RAND48_X0 -- not a state any --seed produces: those end in 0x330E) addressed exactly as
+// the first: evaluation e = H(site) N + sample owns draws [e block, (e + 1) block) of it, read r = draw r of the window, as a 31-bit integer (the
+// state's top 31 bits, as lrand48) through the reference's range formula (rng.h:12).  block >= read_cap, and the windows fill at most one period (W).
+#define VGL_TAIL_RAND48_X0 0x7A11D157A11DULL
+// per-site accumulators of those draws (int32 slots of VglTilePtrs::acc): [9] sum of the tail distances, [10..11] sum of their squares (one 64-bit word),
+// [12] max over the site's evaluations with reads of (sample + 1) << 2 | base of the evaluation's last read -- the reference's stale r_base
+#define VGL_ACC_TAIL 9
+#define VGL_ACC_TAILSQ 10
+#define VGL_ACC_TAILKEY 12
 
 // x -> a*x + c (mod 2^48): a power of the rand48 step
 struct VglAffine { uint64_t a, c; };
@@ -105,6 +115,7 @@ struct VglDevParams {
     int32_t add_i16;
     int32_t gl1_deep;        // GL model 1 and the staging capacity exceeds 255 reads: reads are staged (also with one fixed
                              // quality score) so that k_gl can subsample a deep evaluation the way errmod_cal() does
+    int32_t stage_fixed;     // k_sample<0 / 1> stages its reads: GL model 2, gl1_deep, or -addI16 in tile mode (k_tail reads the last read's base)
     int32_t serial;          // VGL_RNG_SERIAL
     int32_t scout_lds_bytes; // dynamic LDS of k_scout_wave (9 bytes per sample when the site fits)
     int32_t beta_std;        // VGL_BETA_STD (serial only)
@@ -211,6 +222,7 @@ struct VglTilePtrs {
     int32_t*  dp_pre;        // [n_sites][N] depth draws of k_depth (tile mode)
     uint64_t* site_base;     // [n_sites] tile mode: J^(block N H(site)) (x0), the generator state in front of the site's windows (k_sitebase)
     uint64_t* site_hash;     // [n_sites] tile mode: H(site) (GL model 1 deeper than 255 reads addresses htslib's stream by it)
+    uint64_t* tail_base;     // [n_sites] tile mode with an I16 output: the second sequence's state in front of the site's windows, J^(block N H(site)) (VGL_TAIL_RAND48_X0) (k_sitebase); else null
     unsigned long long* fslot;   // [n_sites][fused_split][2] split fused sites: each workgroup's flagged per-base depth sums (zero at the start of a tile)
     // outputs (caller owned device memory; may be null)
     int32_t* site_status; int32_t* n_alleles; int32_t* n_alleles_obs; int8_t* alleles2acgt;
@@ -226,7 +238,7 @@ struct VglTilePtrs {
     int32_t*  sdp;           // [n_sites][N] depth draws of the scout
     uint64_t* site_thresh;   // [n_sites] per-site base-pick error threshold (error_qs 1)
     int32_t*  scout_off;     // [N] scratch of the scout: first read index of each sample
-    VglSiteTail* site_tail;  // [n_sites] (serial mode with -addI16)
+    VglSiteTail* site_tail;  // [n_sites] with -addI16: written by the scout in serial mode, by k_tail_fin in tile mode
     const long long* hts_off; // [n_sites][N] serial mode, GL model 1 deeper than 255: first draw of an evaluation's shuffle in htslib's stream
     const uint64_t* hts_base; // [1] state of that stream at the start of the tile (serial mode)
     const long long* roff;   // [n_sites][N] index of an evaluation's first read in draw order (serial --error-qs 2, std beta)
@@ -270,6 +282,7 @@ int vgl_launch_redo(const VglDevParams* p, const VglTilePtrs* t, void* stream); 
 int vgl_launch_site(const VglDevParams* p, const VglTilePtrs* t, void* stream);
 int vgl_launch_gl(const VglDevParams* p, const VglTilePtrs* t, void* stream);
 int vgl_launch_siteagg(const VglDevParams* p, const VglTilePtrs* t, void* stream);
+int vgl_launch_tail(const VglDevParams* p, const VglTilePtrs* t, void* stream);      // k_tail + k_tail_fin: T.site_tail in tile mode (ahead of k_siteagg)
 int vgl_launch_fused(const VglDevParams* p, const VglTilePtrs* t, void* stream);
 int vgl_launch_hts_offsets(const VglDevParams* p, const VglTilePtrs* t, struct VglSerialState* st, long long* hts_off, uint64_t* hts_base, void* stream);
 int vgl_launch_scout(const VglDevParams* p, const VglTilePtrs* t, struct VglSerialState* st, void* stream);

@@ -1375,7 +1375,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 //     (every partial sum is a multiple of 2^tz(c)); beyond that the remaining additions are performed one by one (no memory traffic).
 //     A site whose integer totals leave the exact range is walked sample by sample by one lane, as the reference does (rare: more than
 //     2^24 / q^2 reads of one base at a site).
-// fields 1-4: per-base strand depths of the site (acc); fields 13-16: tail distances, drawn from libc rand() in serial mode, 0 in tile mode.
+// fields 1-4: per-base strand depths of the site (acc); fields 13-16: tail distances (T.site_tail: the scout's libc rand() draws in serial mode, k_tail's in tile mode).
 #define VGL_AGG_SITES 16
 #define VGL_AGG_ROW 65                                                 // 64 samples + 1 word of padding: the chain lanes' reads fall on distinct banks
 // the reference's K-fold `acc += c` (acc starts at 0; c a positive integer-valued float): jump over the exact range, walk the rest
@@ -1495,7 +1495,7 @@ __global__ __launch_bounds__(64) void k_siteagg(const VglDevParams P, const VglT
             // one addition of the mapping quality (and of its square) per read, reference allele / the others (vcfgl.cpp:1003-1024)
             v[8] = repeated_add(mq, k_ref); v[9] = repeated_add(mq2, k_ref);
             v[10] = repeated_add(mq, k_non); v[11] = repeated_add(mq2, k_non);
-            // tail distance (vcfgl.cpp:1029-1071): drawn from libc rand() by the serial-mode scout; zero in tile mode
+            // tail distance (vcfgl.cpp:1029-1071): from the serial-mode scout (libc rand()) or from k_tail / k_tail_fin (tile mode)
             if (T.site_tail) {
                 const VglSiteTail tl = T.site_tail[ls];
                 if (tl.base == refb) { v[12] = tl.sum; v[13] = tl.sumsq; }
@@ -1659,6 +1659,98 @@ extern "C" int vgl_launch_fused(const VglDevParams* p, const VglTilePtrs* t, voi
         else { if (wg == 256) VGL_LAUNCH_FUSED(4, 24); else VGL_LAUNCH_FUSED(8, 24); }
     }
 #undef VGL_LAUNCH_FUSED
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// INFO/I16 fields 13-16 in VGL_RNG_TILE (vcfgl.cpp:647-663, 1029-1071): one tail distance per read of the site, min(1 + rand() / (RAND_MAX / 50 + 1), 25)
+// (rng.h:12, CAP_TAIL_DIST), all credited to the base of the site's LAST simulated read (the reference's r_base is stale by then), summed and
+// square-summed as float32 in (sample, read) order.  The reference's rand() is one serial never-seeded stream (VGL_RNG_SERIAL follows it, vgl_serial.hip);
+// tile mode draws from a second rand48 sequence (VGL_TAIL_RAND48_X0) addressed like the first: evaluation e = H(site) N + sample owns draws
+// [e block, (e + 1) block), read r takes draw r (include/vcfgl_hip.h) -- the site's state from k_sitebase, the sample's jump from P.samp_tab.
+//   k_tail      one wavefront per (site, 64 samples): each lane its evaluation's draws, integer sums by DPP scans into the site's accumulators
+//               (acc[9], acc[10..11], acc[12]: VGL_ACC_TAIL*), the last read's base from the staged reads.
+//   k_tail_fin  one lane per site: while the sum of squares stays at or below 2^24 every partial sum of the reference's float32 chains is an integer the
+//               format holds -- the chains' results ARE the integer totals; beyond that (more than ~40 000 reads at a site) the lane walks the site's reads
+//               in the reference's order and adds in float32 as the reference does.
+// T = the top 32 bits of the 48-bit state (lcg52_top32); the reference's 1 + rand() / (RAND_MAX / 50 + 1) on x = T >> 1, capped at CAP_TAIL_DIST
+__device__ __forceinline__ uint32_t tail_dist_of(const uint32_t T) {
+    const uint32_t q = (T >> 1) / 42949673u;                           // (a 31-bit dividend: one multiply-high and a shift)
+    return q >= 24u ? 25u : q + 1u;
+}
+// the evaluation's draws: its window's state on the raw 52-bit form (x 16: lcg52_step, three instructions a step), sum and sum of squares of dp distances
+__device__ __forceinline__ void tail_sums(const uint64_t st48, const int dp, uint32_t& s1, uint32_t& s2) {
+    const uint64_t x = st48 << 4;
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    for (int r = 0; r < dp; ++r) {
+        lcg52_step(lo, hi, lo, hi);
+        const uint32_t td = tail_dist_of(lcg52_top32(lo, hi));
+        s1 += td; s2 += td * td;                                       // (at most 1023 reads: 25 x 1023, 625 x 1023)
+    }
+}
+__device__ __forceinline__ int dp_of_ad4(const uint64_t a) { return (int)((a & 0xFFFF) + ((a >> 16) & 0xFFFF) + ((a >> 32) & 0xFFFF) + ((a >> 48) & 0xFFFF)); }
+
+__global__ __launch_bounds__(256) void k_tail(const VglDevParams P, const VglTilePtrs T) {
+    const int lane = threadIdx.x & 63;
+    const int N = P.n_samples;
+    const int64_t w = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (w >= (int64_t)T.n_sites * P.chunks) return;
+    const int ls = (int)(w / P.chunks), s = (int)(w - (int64_t)ls * P.chunks) * 64 + lane;
+    uint32_t s1 = 0, s2 = 0, key = 0;
+    if (s < N) {
+        const size_t ev = (size_t)ls * N + (size_t)s;
+        const int dp = dp_of_ad4(T.ad4[ev]);
+        if (dp > 0) {
+            const size_t plane = (size_t)T.n_sites * N;
+            const uint8_t last = T.reads[vgl_read_byte(dp - 1, plane, ev)];
+            key = ((uint32_t)(s + 1) << 2) | (uint32_t)(last & 3u);
+            tail_sums(aff(P.samp_tab[s], T.tail_base[ls]), dp, s1, s2);
+        }
+    }
+    const uint32_t t1 = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(s1), 63);
+    const uint32_t t2 = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(s2), 63);      // (64 x 625 x 1023 < 2^32)
+    uint32_t km = key;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)km, m, 64); km = o > km ? o : km; }
+    if (lane == 0 && km) {
+        int32_t* const acc = T.acc + (size_t)ls * VGL_ACC_STRIDE;
+        atomicAdd((unsigned int*)&acc[VGL_ACC_TAIL], t1);
+        atomicAdd((unsigned long long*)&acc[VGL_ACC_TAILSQ], (unsigned long long)t2);
+        atomicMax((unsigned int*)&acc[VGL_ACC_TAILKEY], km);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_tail_fin(const VglDevParams P, const VglTilePtrs T) {
+    const int ls = blockIdx.x * 64 + threadIdx.x;
+    if (ls >= T.n_sites) return;
+    const int N = P.n_samples;
+    const int32_t* const acc = T.acc + (size_t)ls * VGL_ACC_STRIDE;
+    const uint32_t t1 = (uint32_t)acc[VGL_ACC_TAIL], key = (uint32_t)acc[VGL_ACC_TAILKEY];
+    const unsigned long long t2 = *(const unsigned long long*)&acc[VGL_ACC_TAILSQ];
+    VglSiteTail t; t.sum = (float)t1; t.sumsq = (float)t2; t.base = key ? (int32_t)(key & 3u) : -1; t.pad = 0;
+    if (t2 > (1ULL << 24)) {                                           // (t1 <= t2: every distance is at least 1)
+        float f1 = 0.0f, f2 = 0.0f;
+        const uint64_t xb = T.tail_base[ls];
+        for (int s = 0; s < N; ++s) {
+            const int dp = dp_of_ad4(T.ad4[(size_t)ls * N + (size_t)s]);
+            const uint64_t x = aff(P.samp_tab[s], xb) << 4;
+            uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+            for (int r = 0; r < dp; ++r) {
+                lcg52_step(lo, hi, lo, hi);
+                const uint32_t td = tail_dist_of(lcg52_top32(lo, hi));
+                f1 += (float)td; f2 += (float)(td * td);
+            }
+        }
+        t.sum = f1; t.sumsq = f2;
+    }
+    T.site_tail[ls] = t;
+}
+
+extern "C" int vgl_launch_tail(const VglDevParams* p, const VglTilePtrs* t, void* stream) {
+    if (t->n_sites == 0 || !t->site_tail || !t->tail_base) return 0;
+    const int64_t waves = (int64_t)t->n_sites * p->chunks;
+    hipLaunchKernelGGL(k_tail, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *p, *t);
+    hipLaunchKernelGGL(k_tail_fin, dim3((t->n_sites + 63) / 64), dim3(64), 0, (hipStream_t)stream, *p, *t);
     return (int)hipGetLastError();
 }
 

@@ -202,6 +202,7 @@ struct vgl_ctx {
     // VGL_RNG_SERIAL
     long long* d_hts_off = nullptr; uint64_t* d_hts_base = nullptr;
     VglSerialState* d_serial = nullptr; uint64_t* d_sst = nullptr; uint64_t* d_site_thresh = nullptr; int32_t* d_scout_dp = nullptr; int32_t* d_sdp = nullptr; VglAffine* d_step_tab = nullptr; VglSiteTail* d_site_tail = nullptr;
+    uint64_t* d_tail_base = nullptr;   // VGL_RNG_TILE with -addI16 (k_tail)
     int64_t serial_next_site = 0;   // VGL_DEBUG_STAMPS=1 diagnostic counters
     // host variant (vgl_simulate_tile / _async): two slots of device mirrors, so that the copies of one tile's tags back to the
     // host (copy stream) run beside the kernels of the next tile (compute stream) -- SURVEY H8
@@ -328,7 +329,7 @@ extern "C" int vgl_ctx_destroy(vgl_ctx* c) {
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_fslot, c->d_gl2_run, c->d_pois_zt, c->d_gl1_fk, c->d_gl1_beta, c->d_gamma_ln, c->d_samp_tab, c->d_qs_read_tab, c->d_pois, c->d_q2gl, c->d_gl1_bsum, c->d_gl1_lhet, c->d_reads, c->d_errp, c->d_ad4,
                     c->d_adf4, c->d_qsum, c->d_qsumsq, c->d_acc, c->d_sinfo, c->d_rowmap, c->d_rowmap8, c->d_gl2_redo, c->d_gl2_list, c->d_gl2_count, c->d_errflag, c->d_dbg, c->d_redo_list, c->d_redo_count, c->d_redo_bits, c->d_seg_list,
-                    c->d_serial, c->d_sst, c->d_site_thresh, c->d_scout_dp, c->d_site_tail, c->d_sdp, c->d_step_tab,
+                    c->d_serial, c->d_sst, c->d_site_thresh, c->d_scout_dp, c->d_site_tail, c->d_sdp, c->d_step_tab, c->d_tail_base,
                     c->d_depth_tab, c->d_site_base, c->d_site_hash, c->d_dp_pre, c->d_hts_off, c->d_hts_base, c->d_roff, c->d_rtotal, c->d_errp_lin, c->d_cw, c->d_ccons, c->d_cexit,
                     c->d_ccnt, c->d_centry, c->d_cbase, c->d_cpos, c->d_csnap, c->d_csnapw, c->d_cctl};
     for (void* q : ptrs) if (q) (void)hipFree(q);
@@ -420,6 +421,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     D.adjust_by = p->adjust_by;
     D.serial = (p->rng_mode == VGL_RNG_SERIAL) ? 1 : 0;
     D.gl1_deep = (p->gl_model == 1 && D.read_cap > 255) ? 1 : 0;
+    D.stage_fixed = (p->gl_model != 1 || D.gl1_deep || (p->add_i16 && !D.serial)) ? 1 : 0;
     D.scout_lds_bytes = ((size_t)p->n_samples * 9 <= 144 * 1024) ? (int32_t)(((size_t)p->n_samples * 9 + 15) & ~(size_t)15) : 0;
     D.beta_std = (p->beta_sampler == VGL_BETA_STD) ? 1 : 0;
     D.beta_chain = (D.serial && D.beta_std && p->error_qs == 2 && !hook_env("VGL_NO_BETA_CHAIN")) ? 1 : 0;
@@ -560,6 +562,10 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
         TRYHIP(hipMemcpy(c->d_depth_tab, dt.data(), sizeof(VglAffine) * N, hipMemcpyHostToDevice));
         D.depth_tab = c->d_depth_tab;
         TRY(dmalloc(&c->d_site_base, (size_t)max_sites)); TRY(dmalloc(&c->d_site_hash, (size_t)max_sites));
+        if (p->add_i16) {    // INFO/I16 fields 13-16 (k_tail, vgl_gl.hip): the same windows of a second rand48 sequence; the staging capacity fits a window
+            if ((uint64_t)D.read_cap > lay.block) { vgl_ctx_destroy(c); return fail(VGL_E_ARG, "-addI16: layout.block (%llu) is smaller than the staging capacity of %d reads", (unsigned long long)lay.block, D.read_cap); }
+            TRY(dmalloc(&c->d_tail_base, (size_t)max_sites)); TRY(dmalloc(&c->d_site_tail, (size_t)max_sites));
+        }
     }
     TRY(dmalloc(&c->d_samp_tab, (size_t)N));
     TRYHIP(hipMemcpy(c->d_samp_tab, samp.data(), sizeof(VglAffine) * N, hipMemcpyHostToDevice));
@@ -878,6 +884,7 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     T.site_base = c->d_site_base; T.site_hash = c->d_site_hash; T.fslot = c->d_fslot;
     T.redo_list = c->d_redo_list; T.redo_count = c->d_redo_count; T.redo_cap = c->redo_cap; T.redo_bits = c->d_redo_bits;
     T.seg_list = c->d_seg_list;
+    if (!D.serial && o->i16 && c->d_tail_base) { T.tail_base = c->d_tail_base; T.site_tail = c->d_site_tail; }   // (k_sitebase, k_tail; a tile without an I16 output skips both)
     if (D.serial) {
         const size_t E = (size_t)c->max_sites * D.n_samples;
         T.sst_hap = c->d_sst; T.sst_base = c->d_sst + E; T.sdp = c->d_sdp;
@@ -933,6 +940,9 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     if (!fused && vgl_launch_sample(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_sample launch failed: %s", hipGetErrorString(hipGetLastError()));
     if (c->timing) HIPCHK(hipEventRecord(e[VGL_T_REDO], st));
     if (!fused && vgl_launch_redo(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_redo launch failed");
+    // INFO/I16 tail distances in tile mode (k_tail wants the LAST read's base): with the other site aggregates, behind k_gl -- unless k_gl's GL model 1
+    // path may shuffle a deep evaluation's staged reads in place (gl1_deep), then ahead of it
+    if (T.tail_base && D.gl1_deep && vgl_launch_tail(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_tail launch failed");
     if (c->timing) HIPCHK(hipEventRecord(e[VGL_T_SITE], st));
     if (!fused && vgl_launch_site(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_site launch failed");
     if (c->timing) HIPCHK(hipEventRecord(e[VGL_T_GL], st));
@@ -943,6 +953,7 @@ extern "C" int vgl_simulate_tile_device(vgl_ctx* c, int64_t site0, int32_t n_sit
     if (fused) { if (vgl_launch_fused(&D, &T, st)) return fail(VGL_E_NODEVICE, "fused k_gl launch failed"); }
     else if (vgl_launch_gl(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_gl launch failed");
     if (c->timing) HIPCHK(hipEventRecord(e[VGL_T_SITEAGG], st));
+    if (T.tail_base && !D.gl1_deep && vgl_launch_tail(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_tail launch failed");
     if (o->qs || o->i16) if (vgl_launch_siteagg(&D, &T, st)) return fail(VGL_E_NODEVICE, "k_siteagg launch failed");
     if (dump_errp) {
         const size_t row = (size_t)n_sites * D.n_samples;

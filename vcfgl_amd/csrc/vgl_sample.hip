@@ -31,6 +31,13 @@ __global__ __launch_bounds__(256) void k_sitebase(const VglDevParams P, const Vg
         if ((h >> b) & 1) xb = aff(P.site_pow[b], xb);
     T.site_base[ls] = xb;
     T.site_hash[ls] = h;
+    if (T.tail_base) {                                                 // -addI16: the same windows of the tail distances' sequence (k_tail, vgl_gl.hip)
+        uint64_t xt = VGL_TAIL_RAND48_X0;
+#pragma unroll 1
+        for (int b = 0; b < 40; ++b)
+            if ((h >> b) & 1) xt = aff(P.site_pow[b], xt);
+        T.tail_base[ls] = xt;
+    }
 }
 
 // Depth draws of a tile (vcfgl.cpp:364-389; rng.h:284-351), ahead of k_sample.  The rejection sampler
@@ -237,8 +244,8 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
         const uint32_t q_gl = (uint32_t)((P.adjust_qs & 1) ? aq_i : q_i);
         const uint32_t qq = (uint32_t)((P.adjust_qs & 2) ? aq_i : q_i);
         const uint32_t q2 = (uint32_t)qs_to_qssq((int)qq);
-        const bool stage = (P.gl_model != 1) || P.gl1_deep;   // GL model 1 with one fixed qScore needs only the per-base depths, unless
-                                                              // an evaluation may exceed 255 reads (k_gl then subsamples the staged reads)
+        const bool stage = P.stage_fixed != 0;                // GL model 1 with one fixed qScore needs only the per-base depths, unless an evaluation may exceed
+                                                              // 255 reads (k_gl then subsamples the staged reads) or k_tail wants the last read's base (I16, tile mode)
         uint64_t st_hap16 = st_hap << 16, st_base16 = st_base << 16;      // sample_read_base16: states carried shifted by 16
         const uint64_t err_thresh16 = sample_thresh16(err_thresh);
         // four reads per trip: one 32-bit store of the staged word (vgl_read_byte) instead of four byte stores
