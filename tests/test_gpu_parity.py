@@ -502,17 +502,62 @@ def test_capacity_sized_from_largest_mean(oracle):
     sim.close()
 
 
-@pytest.mark.parametrize("eqs", [0, 2])
-def test_capacity_overflow_is_reported(oracle, eqs, monkeypatch):
-    """a depth beyond the staging capacity must surface as VGL_E_CAPACITY, never as wrong data
-    (VGL_DEBUG_READ_CAP shrinks the capacity so the path can be exercised)"""
+@pytest.mark.parametrize("kw,N,S", [(dict(), 100, 8), (dict(error_qs=2, beta_variance=1e-5), 100, 8), (dict(gl_model=1), 70, 5),
+                                    (dict(error_qs=2, beta_variance=1e-5, precise_gl=1, add_pl=1), 65, 3), (dict(depths=1), 130, 4),
+                                    (dict(error_qs=2, beta_variance=1e-5, add_qs=1, add_i16=1, add_fmt_adf=1, add_gp=1, add_fmt_ad=1), 90, 6),
+                                    (dict(layout="sm"), 300, 2500)])
+def test_a_draw_deeper_than_the_staging_capacity_runs_the_tile_again(oracle, kw, N, S, monkeypatch):
+    """vcfgl grows its read buffers (bcf_utils.cpp:618-648); the library stages a fixed number of reads per sample (mean + 8 sigma + 16) and flags a tile
+    with a deeper draw.  The host entry points then run that tile again on a sibling context with the staging layout's largest capacity, in sub-tiles
+    -- VGL_DEBUG_READ_CAP=8 at depth 20 makes every tile such a tile: equal to the oracle, through vgl_simulate_tile and through the async pair
+    (S = 2500: two sub-tiles of the sibling, sample-major slabs)"""
+    import ctypes as C
+    monkeypatch.setenv("VGL_DEBUG_READ_CAP", "8")
+    kw = dict(kw)
+    depths = [20.0 + (i % 7) for i in range(N)] if kw.pop("depths", 0) else None
+    sm = kw.pop("layout", None) == "sm"
+    args = VcfglArgs(seed=42, depth=20, depths=depths, error_rate=0.01, **kw)
+    args.rng_mode, args.beta_sampler = _abi.VGL_RNG_TILE, _abi.VGL_BETA_RAND48
+    if sm:
+        args.out_layout = _abi.VGL_LAYOUT_SAMPLE_MAJOR
+    gt = synth.acgt_sites(S, N, seed=S, missing=0.03)
+    sim = Simulator(args, N, max_sites_per_tile=S, hooks=True)
+    assert sim.info()["read_cap"] == 8 and sim.info()["test_hooks"] == 1
+    got = sim.simulate(3, gt)
+    want = oracle.Oracle(args, N).simulate(3, gt, fields=sim.default_fields())
+    assert int(want.numpy("fmt_dp").max()) > 8
+    assert_parity(want, got, i16=True, exact_gl=not args.precise_gl)
+    # the async pair: the rerun happens in vgl_tile_wait, the other slot's tile is untouched
+    t0, t1 = sim.new_tile(S), sim.new_tile(S)
+    k0, k1 = C.c_int32(), C.c_int32()
+    sim._check(sim.lib.vgl_simulate_tile_async(sim.ctx, 3, S, gt.ctypes.data, t0.byref(), C.byref(k0)))
+    sim._check(sim.lib.vgl_simulate_tile_async(sim.ctx, 3, S, gt.ctypes.data, t1.byref(), C.byref(k1)))
+    sim._check(sim.lib.vgl_tile_wait(sim.ctx, k0)); sim._check(sim.lib.vgl_tile_wait(sim.ctx, k1))
+    for t in (t0, t1):
+        for f in ("fmt_dp", "gl", "site_status", "n_alleles"):
+            assert np.array_equal(bits(t.numpy(f)), bits(got.numpy(f))), f
+    sim.close()
+
+
+@pytest.mark.parametrize("how", ["device", "serial", "dump"])
+def test_capacity_overflow_is_reported_where_the_tile_cannot_be_run_again(oracle, how, monkeypatch):
+    """... and where that cannot be done a depth beyond the staging capacity surfaces as VGL_E_CAPACITY, never as wrong data: the device-buffer entry
+    point (the flags are read by vgl_ctx_check, which does not know the tile), VGL_RNG_SERIAL (the streams have moved on), a per-read dump (planes of the
+    caller's own capacity)"""
+    import torch
     from vcfgl_amd import VglError
     monkeypatch.setenv("VGL_DEBUG_READ_CAP", "8")
-    args = VcfglArgs(seed=42, depth=20, error_rate=0.01, error_qs=eqs, beta_variance=1e-5 if eqs else -1.0)
+    args = VcfglArgs(seed=42, depth=20, error_rate=0.01)
+    args.rng_mode = _abi.VGL_RNG_SERIAL if how == "serial" else _abi.VGL_RNG_TILE
     sim = Simulator(args, 100, max_sites_per_tile=8, hooks=True)
-    assert sim.info()["read_cap"] == 8 and sim.info()["test_hooks"] == 1
+    gt = synth.binary_sites(0, 8, 100)
     with pytest.raises(VglError) as ei:
-        sim.simulate(0, synth.binary_sites(0, 8, 100))
+        if how == "device":
+            tile = sim.new_tile(8, fields=["fmt_dp", "gl"], device="cuda:0")
+            sim.simulate_device(0, torch.from_numpy(gt).to("cuda:0"), tile)
+            sim.check()
+        else:
+            sim.simulate(0, gt, read_capacity=8 if how == "dump" else 0)
     assert ei.value.code == _abi.VGL_E_CAPACITY
     sim.close()
 

@@ -178,7 +178,8 @@ static void build_gl1_tables(double depcorr, int q, std::vector<double>& bsum, s
 
 // ---- context ---------------------------------------------------------------------------
 struct vgl_ctx {
-    vgl_params p;
+    vgl_params p;                                                   // (depths / qs_bins: the copies below)
+    std::vector<double> depths_copy; std::vector<int32_t> bins_copy;
     int device;
     int max_sites;
     VglDevParams dp;
@@ -215,7 +216,13 @@ struct vgl_ctx {
         uint32_t* h_flag = nullptr;                                 // pinned: the tile's device error flags
         hipEvent_t ev_kernels = nullptr, ev_copied = nullptr;
         bool busy = false; int rc = VGL_OK;
+        int64_t site0 = 0; int32_t n_sites = 0; vgl_tile_out o;     // the tile in flight (vgl_tile_wait may run it again through `deep`)
     } slot[2];
+    // a draw deeper than the staging capacity (vcfgl grows its read buffers, bcf_utils.cpp:618-648): the host entry points run such a tile again on
+    // this sibling context, created on first need with the staging layout's largest capacity (VGL_READ_CAP_MAX reads) and tiles of at most
+    // VGL_DEEP_TILE_SITES sites.  VGL_RNG_TILE only (a value depends on (seed, site, sample) alone, so the second run is the same tile)
+    vgl_ctx* deep = nullptr;
+    int32_t deep_runs = 0;
     hipStream_t s_compute = nullptr, s_copy = nullptr;
     int next_slot = 0;
     // timing
@@ -326,6 +333,7 @@ template <typename T> static int dmalloc(T** p, size_t n) {
 
 extern "C" int vgl_ctx_destroy(vgl_ctx* c) {
     if (!c) return VGL_OK;
+    if (c->deep) { (void)vgl_ctx_destroy(c->deep); c->deep = nullptr; }
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_fslot, c->d_gl2_run, c->d_pois_zt, c->d_gl1_fk, c->d_gl1_beta, c->d_gamma_ln, c->d_samp_tab, c->d_qs_read_tab, c->d_pois, c->d_q2gl, c->d_gl1_bsum, c->d_gl1_lhet, c->d_reads, c->d_errp, c->d_ad4,
                     c->d_adf4, c->d_qsum, c->d_qsumsq, c->d_acc, c->d_sinfo, c->d_rowmap, c->d_rowmap8, c->d_gl2_redo, c->d_gl2_list, c->d_gl2_count, c->d_errflag, c->d_dbg, c->d_redo_list, c->d_redo_count, c->d_redo_bits, c->d_seg_list,
@@ -350,7 +358,11 @@ extern "C" int vgl_ctx_destroy(vgl_ctx* c) {
     return VGL_OK;
 }
 
-extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_sites, vgl_ctx** out) {
+#define VGL_READ_CAP_MAX 1020          // the staging layout's largest capacity (four reads per word, below 1024)
+#define VGL_DEEP_TILE_SITES 2048       // tiles of the sibling context that takes over a tile with a deeper draw
+static int ctx_create_cap(const vgl_params* p, int32_t device, int32_t max_sites, vgl_ctx** out, int cap_override);
+extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_sites, vgl_ctx** out) { return ctx_create_cap(p, device, max_sites, out, 0); }
+static int ctx_create_cap(const vgl_params* p, int32_t device, int32_t max_sites, vgl_ctx** out, const int cap_override) {
     if (!p || !out) return fail(VGL_E_ARG, "null argument");
     *out = nullptr;
     if (p->abi_version != VGL_ABI_VERSION) return fail(VGL_E_ARG, "abi version mismatch");
@@ -384,6 +396,8 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     vgl_ctx* c = new vgl_ctx();
     AcctScope acct(c);
     c->p = *p; c->p.depths = nullptr; c->p.qs_bins = nullptr;
+    if (p->depths) c->depths_copy.assign(p->depths, p->depths + p->n_samples);
+    if (p->n_qs_bins > 0 && p->qs_bins) c->bins_copy.assign(p->qs_bins, p->qs_bins + 3 * (size_t)p->n_qs_bins);
     c->device = device; c->max_sites = max_sites;
     VglDevParams& D = c->dp;
     memset(&D, 0, sizeof D);
@@ -393,6 +407,7 @@ extern "C" int vgl_ctx_create(const vgl_params* p, int32_t device, int32_t max_s
     int cap = (int)ceil(dmax + 8.0 * sqrt(dmax) + 16.0);
     D.read_cap = (cap + 3) & ~3;
     if (hook_env("VGL_DEBUG_READ_CAP")) D.read_cap = (atoi(hook_env("VGL_DEBUG_READ_CAP")) + 3) & ~3;   // test hook: force the overflow path (a multiple of 4: staged reads are packed four per word)
+    if (cap_override) D.read_cap = cap_override;                  // the sibling context of a tile with a deeper draw (vgl_tile_wait)
     if (D.read_cap > 1023) { delete c; return fail(VGL_E_ARG, "mean depth too large for the staging layout"); }
     int pool_want = 0; double pool_lmax = 0.0;
     {   // quality-score pool of one wavefront: the summed depth of its (up to) 64 samples
@@ -1167,6 +1182,7 @@ extern "C" int vgl_simulate_tile_async(vgl_ctx* c, int64_t site0, int32_t n_site
     if (!S.h_gt) HIPCHK(hipHostMalloc((void**)&S.h_gt, (size_t)c->max_sites * N, hipHostMallocDefault));
     if (!S.h_flag) HIPCHK(hipHostMalloc((void**)&S.h_flag, sizeof(uint32_t), hipHostMallocDefault));
     S.rc = VGL_OK; *S.h_flag = 0;
+    S.site0 = site0; S.n_sites = n_sites; S.o = *o;
     if (n_sites == 0) HIPCHK(hipEventRecord(S.ev_copied, c->s_copy));
     else {
         const int rc = enqueue_host_tile(c, S, site0, n_sites, gt, o);
@@ -1185,6 +1201,39 @@ extern "C" int vgl_simulate_tile_async(vgl_ctx* c, int64_t site0, int32_t n_site
     return VGL_OK;
 }
 
+// A tile whose device flags report a draw deeper than the staging capacity, run again through the sibling context (host buffers: the slot's own copy of
+// the genotypes, the caller's output arrays), VGL_DEEP_TILE_SITES sites at a time -- every tag array of a tile is site-major, so a sub-tile is a slice of
+// it.  Returns VGL_E_CAPACITY (quietly) where that cannot be done: serial mode (the streams have moved on), a per-read dump (read-major planes of the
+// caller's own capacity), a capacity already at the layout's maximum, or no memory for the sibling.
+static int deep_rerun(vgl_ctx* c, vgl_ctx::HostSlot& S) {
+    const VglDevParams& D = c->dp;
+    if (D.serial || D.read_cap >= VGL_READ_CAP_MAX || (S.o.read_capacity > 0 && (S.o.reads || S.o.read_errp))) return VGL_E_CAPACITY;
+    if (!c->deep) {
+        vgl_params p = c->p;
+        std::vector<double> depths; std::vector<int32_t> bins;
+        if (c->depths_copy.size()) { depths = c->depths_copy; p.depths = depths.data(); }
+        if (c->bins_copy.size()) { bins = c->bins_copy; p.qs_bins = bins.data(); }
+        char keep[sizeof g_err];
+        memcpy(keep, g_err, sizeof keep);
+        const int rc = ctx_create_cap(&p, c->device, c->max_sites < VGL_DEEP_TILE_SITES ? c->max_sites : VGL_DEEP_TILE_SITES, &c->deep, VGL_READ_CAP_MAX);
+        if (rc != VGL_OK) { c->deep = nullptr; memcpy(g_err, keep, sizeof keep); return VGL_E_CAPACITY; }
+    }
+    const size_t N = (size_t)D.n_samples;
+    for (int32_t k = 0; k < S.n_sites; k += c->deep->max_sites) {
+        const int32_t n = (S.n_sites - k < c->deep->max_sites) ? (S.n_sites - k) : c->deep->max_sites;
+        vgl_tile_out o = S.o;
+        for (int f = 0; f < N_FIELDS; f++) {
+            char* host = *(char**)((char*)&S.o + FIELDS[f].off);
+            if (host) *(char**)((char*)&o + FIELDS[f].off) = host + field_count(c, FIELDS[f].kind, (size_t)k) * FIELDS[f].esz;
+        }
+        if (o.site_pick_err) o.site_pick_err += k;
+        const int rc = vgl_simulate_tile(c->deep, S.site0 + k, n, S.h_gt + (size_t)k * N, &o);
+        if (rc != VGL_OK) return rc;                                 // (a draw beyond VGL_READ_CAP_MAX reads: VGL_E_CAPACITY after all)
+    }
+    c->deep_runs++;
+    return VGL_OK;
+}
+
 extern "C" int vgl_tile_wait(vgl_ctx* c, int32_t ticket) {
     if (!c || ticket < 0 || ticket > 1) return fail(VGL_E_ARG, "bad ticket");
     vgl_ctx::HostSlot& S = c->slot[ticket];
@@ -1192,6 +1241,10 @@ extern "C" int vgl_tile_wait(vgl_ctx* c, int32_t ticket) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipEventSynchronize(S.ev_copied));
     S.busy = false;
+    if ((*S.h_flag & VGL_DEVERR_CAPACITY) && S.n_sites > 0) {
+        const int rc = deep_rerun(c, S);
+        if (rc != VGL_E_CAPACITY) return rc;                         // done (or failed for another reason, reported as such)
+    }
     return flags_to_rc(c, *S.h_flag);
 }
 
