@@ -48,7 +48,10 @@ extern "C" {
 #define VGL_E_ARG          (-1)  /* bad parameter value (reference: io.cpp:757-1000 range checks) */
 #define VGL_E_NODEVICE     (-2)  /* no HIP device / HIP runtime error                            */
 #define VGL_E_NOMEM        (-3)  /* allocation failure                                           */
-#define VGL_E_CAPACITY     (-4)  /* a per-sample read depth exceeded the staging capacity        */
+#define VGL_E_CAPACITY     (-4)  /* a per-sample read depth exceeded the staging capacity (mean + 8 sigma + 16 reads) where the tile could not be run
+                                    again: the host-buffer entry points (vgl_simulate_tile, vgl_tile_wait) run such a tile once more on an internal
+                                    context with the layout's largest capacity, 1020 reads (the reference grows its buffers, bcf_utils.cpp:618-648), so
+                                    this code is left to vgl_ctx_check() (device buffers), VGL_RNG_SERIAL, per-read dumps and draws beyond 1020 reads */
 #define VGL_E_UNSUPPORTED  (-5)  /* flag combination not implemented on the device path (the mt19937 beta sampler in VGL_RNG_TILE) */
 #define VGL_E_QSBIN        (-6)  /* "Could not find a range for qs value" (vcfgl.cpp:63)         */
 #define VGL_E_ADJQ         (-7)  /* --adjust-qs 1|2 met a read without a valid adjusted quality score: error probability
@@ -316,7 +319,7 @@ typedef struct vgl_ctx_info_t {
     int32_t gl_sort;             /* k_gl re-deals a workgroup's evaluations in (distinct bases, depth) order                */
     int32_t gl_wpb;              /* natural wavefronts per k_gl workgroup (4 or 8); 16 = the context is ELIGIBLE for k_gl2 (two evaluations per thread):
                                     a tile that asks for GP or FORMAT/AD* still runs k_gl with 8 -- the choice is per tile (vgl_launch_gl)              */
-    int32_t read_cap;            /* staged reads per (site, sample): a deeper draw is VGL_E_CAPACITY                        */
+    int32_t read_cap;            /* staged reads per (site, sample); a deeper draw: see VGL_E_CAPACITY                       */
     int32_t pool_cap;            /* quality-score work items per wavefront and LDS segment (--error-qs 2)                   */
     int32_t pool_lds_bytes;      /* LDS bytes per wavefront of k_sample<2>                                                  */
     int32_t test_hooks;          /* 1: this library was built with -DVGL_TEST_HOOKS (environment overrides, vgl_dbg_*)      */
