@@ -273,6 +273,60 @@ __device__ __forceinline__ uint64_t fused_sample_eval(const VglDevParams& P, con
 #define VGL_FUSED_SPIN_LIMIT 2048
 
 // (the kernel's body: hw_block = the hardware workgroup index of a grid of hw_grid, or -- hw_grid 0 -- the logical index itself: k_gl_redo)
+// The fused build's split sites (more than 512 samples: up to four consecutive workgroups per site): the exchange of the parts' per-base depth sums.
+// Its own device function since round 6: only the GENERAL fused build (FUSEDW_ + 16) calls it -- the plain build the depth-5
+// configuration runs does not carry it (round 5: its mere presence cost that kernel 51 scalar spills).  f_acc[1..4]: this part's sums in, the site's out.
+template <int WG>
+__device__ __forceinline__ void fused_split_exchange(const VglDevParams& P, const VglTilePtrs& T, const int site, const int S, const int part, const int tid, const int N, int32_t* const f_acc) {
+    // ---- the other workgroups' shares.  Every part publishes its four sums as TWO flagged 8-byte words (system-scope stores: A | C << 32
+    // and G | T << 32, bit 63 = valid; the slots are zero at the start of the tile) and lane q of the first wavefront polls part q's
+    // words with system-scope loads -- one store and, when the neighbour is already there, one load round trip (the first version's
+    // four returning atomics + counter + polls + four reads by one lane cost about 8 us per workgroup with seven wavefronts waiting)
+    __syncthreads();
+    unsigned long long* const slots = T.fslot + (size_t)site * (size_t)S * 2;
+    __shared__ int s_alone;
+    if (tid == 0) {
+        s_alone = 0;
+        const unsigned long long V = 1ULL << 63;
+        __hip_atomic_store(&slots[part * 2], (unsigned long long)(uint32_t)f_acc[1] | ((unsigned long long)(uint32_t)f_acc[2] << 32) | V, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&slots[part * 2 + 1], (unsigned long long)(uint32_t)f_acc[3] | ((unsigned long long)(uint32_t)f_acc[4] << 32) | V, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();                                            // (s_alone cleared; f_acc still holds this part's own sums)
+    if (tid < S && tid != part) {
+        const unsigned long long V = 1ULL << 63;
+        unsigned long long w0 = 0, w1 = 0;
+        const bool absent = (P.dbg_fuse_alone >> tid) & 1;     // test hook: part `tid` is treated as one that never arrives
+        for (int spin = 0; spin < VGL_FUSED_SPIN_LIMIT && !absent; ++spin) {
+            w0 = __hip_atomic_load(&slots[tid * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            w1 = __hip_atomic_load(&slots[tid * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((w0 & w1 & V) != 0) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if ((w0 & w1 & V) != 0 && !absent) {
+            atomicAdd(&f_acc[1], (int)(uint32_t)w0); atomicAdd(&f_acc[2], (int)(uint32_t)((w0 & ~V) >> 32));
+            atomicAdd(&f_acc[3], (int)(uint32_t)w1); atomicAdd(&f_acc[4], (int)(uint32_t)((w1 & ~V) >> 32));
+        } else atomicOr(&s_alone, 1 << tid);
+    }
+    __syncthreads();
+    const int alone_m = s_alone;
+    if (alone_m) {
+        // those neighbours did not show up in time (nothing promises that they run beside this workgroup): their evaluations' depths are
+        // sampled here as well, counts only -- same streams, same sums
+        for (int p2 = 0; p2 < S; ++p2) {
+            if (!((alone_m >> p2) & 1)) continue;
+            const int s2 = p2 * WG + tid;
+            uint64_t ad2 = 0;
+            if (s2 < N) { int d2; ad2 = fused_sample_eval<false>(P, T, site, s2, N, d2, [](const int, const uint32_t) {}); }
+            int v2[4];
+            wave_sum_ad4(ad2, v2);
+            if ((tid & 63) == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (v2[k]) atomicAdd(&f_acc[1 + k], v2[k]);
+            }
+        }
+    }
+}
+
 template <int A, int GLM, bool PREC, int WPB, int FUSEDW_ = 0>
 __device__ __forceinline__ void k_gl_body(const VglDevParams& P, const VglTilePtrs& T, const uint32_t hw_block, const uint32_t hw_grid) {
     // FUSEDW_: the staged words of the fused build (4 / 8), + 16 for its GENERAL build.  The plain fused build is the one the depth-5 configuration
@@ -432,55 +486,7 @@ __device__ __forceinline__ void k_gl_body(const VglDevParams& P, const VglTilePt
             for (int k = 1; k < 5; ++k) if (v[k]) atomicAdd(&s_lds.f_acc[k], v[k]);
         }
         if (P.gl_sort) { natural_setup(); key = sort_key(); atomicAdd(&s_hist[key], 1u); }
-        if constexpr (SPLIT) if (S > 1) {
-            // ---- the other workgroups' shares.  Every part publishes its four sums as TWO flagged 8-byte words (system-scope stores: A | C << 32
-            // and G | T << 32, bit 63 = valid; the slots are zero at the start of the tile) and lane q of the first wavefront polls part q's
-            // words with system-scope loads -- one store and, when the neighbour is already there, one load round trip (the first version's
-            // four returning atomics + counter + polls + four reads by one lane cost about 8 us per workgroup with seven wavefronts waiting)
-            __syncthreads();
-            unsigned long long* const slots = T.fslot + (size_t)site * (size_t)S * 2;
-            __shared__ int s_alone;
-            if (tid == 0) {
-                s_alone = 0;
-                const unsigned long long V = 1ULL << 63;
-                __hip_atomic_store(&slots[part * 2], (unsigned long long)(uint32_t)s_lds.f_acc[1] | ((unsigned long long)(uint32_t)s_lds.f_acc[2] << 32) | V, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(&slots[part * 2 + 1], (unsigned long long)(uint32_t)s_lds.f_acc[3] | ((unsigned long long)(uint32_t)s_lds.f_acc[4] << 32) | V, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            __syncthreads();                                            // (s_alone cleared; f_acc still holds this part's own sums)
-            if (tid < S && tid != part) {
-                const unsigned long long V = 1ULL << 63;
-                unsigned long long w0 = 0, w1 = 0;
-                const bool absent = (P.dbg_fuse_alone >> tid) & 1;     // test hook: part `tid` is treated as one that never arrives
-                for (int spin = 0; spin < VGL_FUSED_SPIN_LIMIT && !absent; ++spin) {
-                    w0 = __hip_atomic_load(&slots[tid * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    w1 = __hip_atomic_load(&slots[tid * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    if ((w0 & w1 & V) != 0) break;
-                    __builtin_amdgcn_s_sleep(4);
-                }
-                if ((w0 & w1 & V) != 0 && !absent) {
-                    atomicAdd(&s_lds.f_acc[1], (int)(uint32_t)w0); atomicAdd(&s_lds.f_acc[2], (int)(uint32_t)((w0 & ~V) >> 32));
-                    atomicAdd(&s_lds.f_acc[3], (int)(uint32_t)w1); atomicAdd(&s_lds.f_acc[4], (int)(uint32_t)((w1 & ~V) >> 32));
-                } else atomicOr(&s_alone, 1 << tid);
-            }
-            __syncthreads();
-            const int alone_m = s_alone;
-            if (alone_m) {
-                // those neighbours did not show up in time (nothing promises that they run beside this workgroup): their evaluations' depths are
-                // sampled here as well, counts only -- same streams, same sums
-                for (int p2 = 0; p2 < S; ++p2) {
-                    if (!((alone_m >> p2) & 1)) continue;
-                    const int s2 = p2 * WG + tid;
-                    uint64_t ad2 = 0;
-                    if (s2 < N) { int d2; ad2 = fused_sample_eval<false>(P, T, site, s2, N, d2, [](const int, const uint32_t) {}); }
-                    int v2[4];
-                    wave_sum_ad4(ad2, v2);
-                    if ((tid & 63) == 0) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) if (v2[k]) atomicAdd(&s_lds.f_acc[1 + k], v2[k]);
-                    }
-                }
-            }
-        }
+        if constexpr (SPLIT) if (S > 1) fused_split_exchange<WG>(P, T, site, S, part, tid, N, s_lds.f_acc);
         __syncthreads();
         // ---- the site's sums are complete.  The likelihood loops need the site's status and allele COUNT only: every thread works them
         // out itself (a dozen instructions); the allele ORDER, the row table and the site's outputs (k_site's code, sixteen threads) are
