@@ -38,9 +38,18 @@ def makefile_flags():
     return hipcc, flags, kernels
 
 
+def extra_flags(kernel):
+    """per-file options of the Makefile (SEGFLAGS: vgl_sample_seg.hip is compiled with scheduler options of its own)"""
+    if kernel != "vgl_sample_seg":
+        return []
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    m = re.search(r"^SEGFLAGS\s*\?=[ \t]*(.*)$", mk, re.M)
+    return m.group(1).split() if m else []
+
+
 def remarks_of(hipcc, flags, kernel, outdir):
     os.makedirs(outdir, exist_ok=True)
-    cmd = [hipcc] + flags + ["-c", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o", os.path.join(outdir, kernel + ".o"), kernel + ".hip"]
+    cmd = [hipcc] + flags + extra_flags(kernel) + ["-c", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o", os.path.join(outdir, kernel + ".o"), kernel + ".hip"]
     r = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"{' '.join(cmd)} failed:\n{r.stderr[-2000:]}")

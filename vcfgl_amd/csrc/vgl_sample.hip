@@ -21,6 +21,7 @@
 // H(site) (vgl_site_hash, vgl_device.h) and the generator state J^(block N H(site)) (x0) in front of the site's N evaluation
 // blocks from the 40-entry power table.  k_depth, k_sample and k_redo start from that state (one load per wavefront / lane);
 // samples and reads stay additive inside a site.
+#ifndef VGL_SAMPLE_SEG_TU
 __global__ __launch_bounds__(256) void k_sitebase(const VglDevParams P, const VglTilePtrs T) {
     const int ls = blockIdx.x * 256 + threadIdx.x;
     if (ls >= T.n_sites) return;
@@ -94,6 +95,8 @@ __global__ __launch_bounds__(256) void k_depth(const VglDevParams P, const VglTi
         i = i_n; busy = busy_n;
     }
 }
+
+#endif  // !VGL_SAMPLE_SEG_TU
 
 // DBG: diagnostic instantiation (VGL_DEBUG_STAMPS / VGL_DEBUG_PHASE), never used in a timed run
 // DM (depth mode): 1 = depths come from k_depth, 2 = every sample uses the product method (mean depth < 12), drawn
@@ -1142,7 +1145,6 @@ __device__ __forceinline__ void k_sample_body(const VglDevParams& P, const VglTi
     }
 }
 
-template <int EQS, bool DBG, int DM, bool PREC, int LEAN>
 // wavefronts per SIMD the register allocator is asked for.  The float32 pool loop of the default tag surface (LEAN 2 without --precise-gl 1) runs at
 // EIGHT (64 VGPRs; two-byte items, pools of 2240: vgl_host.cpp): with the redo list's counter out of the way more resident wavefronts pay (round 5,
 // A/B on one box: 5 -> 8 wavefronts at depth 20 9.9 -> 9.4 ms with five-byte items in two segments, 8.5 with two-byte items in one); the
@@ -1162,11 +1164,20 @@ template <int EQS, bool DBG, int DM, bool PREC, int LEAN>
 #endif
 #define VGL_SAMPLE_WAVES(EQS, PREC, LEAN) ((EQS) == 2 ? ((LEAN) == 2 && !(PREC) ? VGL_SAMPLE_WAVES_F32 : ((LEAN) >= 3 && !(PREC) ? VGL_SAMPLE_WAVES_L3 : ((LEAN) >= 2 ? VGL_SAMPLE_WAVES_PREC : 4))) : 8)
 #endif
+#ifndef VGL_SAMPLE_SEG_TU
+template <int EQS, bool DBG, int DM, bool PREC, int LEAN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQS == 2 ? VGL_SAMPLE_WAVES(EQS, PREC, LEAN) : 1, VGL_SAMPLE_WAVES(EQS, PREC, LEAN)))) void k_sample(const VglDevParams P, const VglTilePtrs T) {
     // (one 64-sample chunk per launched wavefront: several chunks per wavefront, one after the other, measured slower -- docs/tried.md)
     k_sample_body<EQS, DBG, DM, PREC, LEAN>(P, T, (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
 }
+#endif
 
+// Translation units (round 6, second session): the k_sample_seg kernels are built from vgl_sample_seg.hip (= this file with VGL_SAMPLE_SEG_TU: the body
+// template, the kernels below and their launcher, nothing else), so that they can be compiled with their own scheduler options (Makefile: SEGFLAGS) --
+// an LLVM scheduling strategy is a property of the whole module, and no setting held across ALL kernels of this file (docs/tried.md, round 6).
+extern "C" int vgl_sample_seg_launch(int dm, int lean, unsigned grid1, unsigned grid2, size_t lds, void* stream, const VglDevParams* p, const VglTilePtrs* t);
+extern "C" size_t vgl_sample_seg_static_lds(void);           // the largest static LDS of the seg kernels (must be 0), (size_t)-1 on a query error
+#ifdef VGL_SAMPLE_SEG_TU
 // the float32 build of the default tag surface (k_sample<2, false, DM, false, 2>) as two kernels: SEG 1 = one pool segment per wavefront, SEG 2 = the
 // segment loop over the wavefronts SEG 1 listed (k_sample_body, SEG)
 // (eight wavefronts per SIMD for the optional-tag builds too: without the segment loop LEAN 3 / 4 need 68-69 registers, and at 64 they measure 2.5-3 % faster
@@ -1183,6 +1194,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VGL_SAMPLE_
         }
     }
 }
+
+extern "C" int vgl_sample_seg_launch(const int dm, const int lean, const unsigned grid1, const unsigned grid2, const size_t lds, void* stream, const VglDevParams* p, const VglTilePtrs* t) {
+    const dim3 g(grid1), g2(grid2), b(64);
+    hipStream_t s = (hipStream_t)stream;
+#define VGL_LAUNCH_SEG_DM(DM, LEAN) do { hipLaunchKernelGGL((k_sample_seg<DM, 1, LEAN>), g, b, lds, s, *p, *t); hipLaunchKernelGGL((k_sample_seg<DM, 2, LEAN>), g2, b, lds, s, *p, *t); } while (0)
+#define VGL_LAUNCH_SEG(LEAN) do { if (dm == 1) VGL_LAUNCH_SEG_DM(1, LEAN); else if (dm == 2) VGL_LAUNCH_SEG_DM(2, LEAN); else VGL_LAUNCH_SEG_DM(0, LEAN); } while (0)
+    if (lean == 2) VGL_LAUNCH_SEG(2); else if (lean == 3) VGL_LAUNCH_SEG(3); else if (lean == 4) VGL_LAUNCH_SEG(4); else return (int)hipErrorInvalidValue;
+#undef VGL_LAUNCH_SEG
+#undef VGL_LAUNCH_SEG_DM
+    return (int)hipGetLastError();
+}
+extern "C" size_t vgl_sample_seg_static_lds(void) {
+    size_t worst = 0;
+    hipFuncAttributes a;
+#define VGL_STATIC_LDS_SEG(DM, SEG, LEAN) \
+    if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_sample_seg<DM, SEG, LEAN>)) != hipSuccess) return (size_t)-1; \
+    worst = a.sharedSizeBytes > worst ? a.sharedSizeBytes : worst;
+#define VGL_STATIC_LDS_SEG3(DM, SEG) VGL_STATIC_LDS_SEG(DM, SEG, 2) VGL_STATIC_LDS_SEG(DM, SEG, 3) VGL_STATIC_LDS_SEG(DM, SEG, 4)
+    VGL_STATIC_LDS_SEG3(0, 1) VGL_STATIC_LDS_SEG3(1, 1) VGL_STATIC_LDS_SEG3(2, 1) VGL_STATIC_LDS_SEG3(0, 2) VGL_STATIC_LDS_SEG3(1, 2) VGL_STATIC_LDS_SEG3(2, 2)
+#undef VGL_STATIC_LDS_SEG3
+#undef VGL_STATIC_LDS_SEG
+    return worst;
+}
+#else  // !VGL_SAMPLE_SEG_TU: everything else of this file
 
 // the deviate dump (vgl_tile_out.read_errp, [read][site][N] as the ABI documents it) from the evaluation-major staging planes: one lane per evaluation
 __global__ __launch_bounds__(256) void k_errp_dump(const double* __restrict__ errp, double* __restrict__ out, const size_t n_eval, const int rows, const int read_cap) {
@@ -1338,15 +1373,7 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
             VGL_STATIC_LDS(false, 0, true, 3) VGL_STATIC_LDS(false, 1, true, 3) VGL_STATIC_LDS(false, 2, true, 3)
             VGL_STATIC_LDS(false, 0, false, 4) VGL_STATIC_LDS(false, 1, false, 4) VGL_STATIC_LDS(false, 2, false, 4)
 #undef VGL_STATIC_LDS
-#define VGL_STATIC_LDS_SEG(DM, SEG) \
-            if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_sample_seg<DM, SEG, 2>)) != hipSuccess) return false; \
-            worst = a.sharedSizeBytes > worst ? a.sharedSizeBytes : worst; \
-            if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_sample_seg<DM, SEG, 3>)) != hipSuccess) return false; \
-            worst = a.sharedSizeBytes > worst ? a.sharedSizeBytes : worst; \
-            if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_sample_seg<DM, SEG, 4>)) != hipSuccess) return false; \
-            worst = a.sharedSizeBytes > worst ? a.sharedSizeBytes : worst;
-            VGL_STATIC_LDS_SEG(0, 1) VGL_STATIC_LDS_SEG(1, 1) VGL_STATIC_LDS_SEG(2, 1) VGL_STATIC_LDS_SEG(0, 2) VGL_STATIC_LDS_SEG(1, 2) VGL_STATIC_LDS_SEG(2, 2)
-#undef VGL_STATIC_LDS_SEG
+            { const size_t ws = vgl_sample_seg_static_lds(); if (ws == (size_t)-1) return false; worst = ws > worst ? ws : worst; }
             return worst == 0;
         }();
         if (!static_lds_free) return (int)hipErrorInvalidConfiguration;
@@ -1363,10 +1390,7 @@ extern "C" int vgl_launch_sample(const VglDevParams* p, const VglTilePtrs* t, vo
         else if (sample_deferred(p, t)) {
             // one segment per wavefront, then the segment loop over what that kernel listed (nothing, at the bench configurations)
             const dim3 g2((unsigned)(waves < 1024 ? waves : 1024));
-#define VGL_LAUNCH_SEG(LEAN, LDS) \
-            do { if (dm == 1) { hipLaunchKernelGGL((k_sample_seg<1, 1, LEAN>), g, b, LDS, s, *p, *t); hipLaunchKernelGGL((k_sample_seg<1, 2, LEAN>), g2, b, LDS, s, *p, *t); } \
-                 else if (dm == 2) { hipLaunchKernelGGL((k_sample_seg<2, 1, LEAN>), g, b, LDS, s, *p, *t); hipLaunchKernelGGL((k_sample_seg<2, 2, LEAN>), g2, b, LDS, s, *p, *t); } \
-                 else { hipLaunchKernelGGL((k_sample_seg<0, 1, LEAN>), g, b, LDS, s, *p, *t); hipLaunchKernelGGL((k_sample_seg<0, 2, LEAN>), g2, b, LDS, s, *p, *t); } } while (0)
+#define VGL_LAUNCH_SEG(LEAN, LDS) do { const int rc_ = vgl_sample_seg_launch(dm, LEAN, g.x, g2.x, LDS, stream, p, t); if (rc_) return rc_; } while (0)
             const bool split = p->seg_split && t->seg_list;
             if (lean && split) VGL_LAUNCH_SEG(2, lds16);
             else if (!lean && split && p->adjust_qs == 0 && p->sample_strand && p->need_qsum) VGL_LAUNCH_SEG(4, lds16x);
@@ -1404,3 +1428,4 @@ extern "C" __attribute__((visibility("default"))) int vgl_dbg_vlog(const float* 
     return (int)hipDeviceSynchronize();
 }
 #endif
+#endif  // !VGL_SAMPLE_SEG_TU
