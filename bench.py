@@ -281,7 +281,7 @@ def source_sha():
     h = hashlib.sha1()
     d = os.path.join(ROOT, "vcfgl_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h", ".cpp")):
+        if f.endswith((".hip", ".h", ".cpp")) or f == "Makefile":             # (the Makefile: per-file compiler options are part of the build)
             h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
