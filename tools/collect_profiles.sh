@@ -5,7 +5,7 @@ set -eu
 tag=${1:?tag}; shift
 wls=${*:-c3 c5 c5u8 c4 fixedq c2 gl1q precise alltags qsi16}
 for wl in $wls; do
-    f=$(ls gpurun_out/$tag/$wl/kt/*/*kernel_stats.csv | head -1)
+    f=$(ls -t gpurun_out/$tag/$wl/kt/*/*kernel_stats.csv | head -1)       # the newest (an earlier call's files under the same tag stay beside it)
     cp "$f" profiles/${tag}_${wl}_kernel_stats.csv
     [ -f gpurun_out/$tag/$wl/kernel_timed_stats.csv ] && cp gpurun_out/$tag/$wl/kernel_timed_stats.csv profiles/${tag}_${wl}_kernel_timed_stats.csv
     [ -n "${KTONLY:-}" ] && continue

@@ -20,7 +20,14 @@ root, tag = sys.argv[1], sys.argv[2]
 workload = sys.argv[3] if len(sys.argv) > 3 else "c3"
 sites_per_launch = int(sys.argv[4]) if len(sys.argv) > 4 else 65536
 out = collections.defaultdict(dict)
-for f in sorted(glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")), key=lambda f: (os.sep + "SQ" + os.sep in f, f)):
+# one file per counter group: the NEWEST (gpurun merges a call's files into gpurun_out/ beside those of an earlier call under the same tag -- round 6: a
+# stale pass of the previous build sorted last and overrode the new one)
+_newest = {}
+for f in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")):
+    g = os.path.dirname(f)
+    if g not in _newest or os.path.getmtime(f) > os.path.getmtime(_newest[g]):
+        _newest[g] = f
+for f in sorted(_newest.values(), key=lambda f: (os.sep + "SQ" + os.sep in f, f)):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
